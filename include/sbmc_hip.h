@@ -1,0 +1,165 @@
+/*
+ * sbmc_hip.h -- C ABI of libsbmc_hip.so, the MI355X (gfx950) implementation of
+ * SBMC's per-sample kernel-splatting operators.
+ *
+ * This is the drop-in boundary.  In the reference the boundary is the
+ * Halide-generated extension module `sbmc.halide_ops` (setup.py:65-90), whose
+ * pybind wrapper (halide_pytorch/halide_pytorch/extension.py:149-175) exposes,
+ * per operator, `<op>_{cpu,cuda}_float32(inputs..., preallocated outputs...)`
+ * in generator Input<>/Output<> declaration order.  Every function below
+ * replaces one of those entry points (cited) or fuses the Python composition
+ * that sits directly on top of them (sbmc/modules.py:376-473).
+ *
+ * Conventions (same contract as the reference wrapper):
+ *   - all tensors are contiguous float32 (int32 where stated) DEVICE pointers
+ *     in torch index order:
+ *         data     [bs, c,  h, w]
+ *         weights  [bs, kh, kw, h, w]   (kh, kw odd or even; pad = (k-1)/2)
+ *         sum_w    [bs, h, w]
+ *   - the caller allocates every output; the kernels write every element of
+ *     every output (buffers may arrive uninitialised); inputs are read-only;
+ *     outputs must not alias inputs;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *     Launches are asynchronous on it; no device synchronisation, allocation or
+ *     global scratch inside the library => re-entrant from any host thread;
+ *   - return value: 0 on success; SBMC_HIP_EINVAL for bad arguments; otherwise
+ *     the hipError_t of the failed launch.  Nothing throws across this ABI.
+ */
+#ifndef SBMC_HIP_H
+#define SBMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define SBMC_API __attribute__((visibility("default")))
+#else
+#define SBMC_API
+#endif
+
+#define SBMC_HIP_ABI_VERSION 1
+#define SBMC_HIP_EINVAL (-1)
+/* largest channel count the fused/plain kernels take in one call */
+#define SBMC_HIP_MAX_CHANNELS 8
+
+/* Returns SBMC_HIP_ABI_VERSION. */
+SBMC_API int sbmc_hip_abi_version(void);
+
+/* Human-readable text for a non-zero return code (static storage). */
+SBMC_API const char *sbmc_hip_strerror(int code);
+
+/*
+ * scatter2gather -- replaces `scatter2gather_cuda_float32(weights, output)`
+ * (reference: src/scatter2gather.cpp:29-52, called at sbmc/functions.py:56-59
+ * and, as its own adjoint, :67-70).
+ *   output[n,dy,dx,y,x] = Wz[n, kh-1-dy, kw-1-dx, y+dy-ph, x+dx-pw]   (z: 0 outside)
+ */
+SBMC_API int sbmc_scatter2gather_f32(const float *weights, float *output,
+                            int bs, int h, int w, int kh, int kw,
+                            void *stream);
+
+/*
+ * kernel_weighting forward -- replaces
+ * `kernel_weighting_cuda_float32(data, weights, output, sum_w)`
+ * (reference: src/kernel_weighting.cpp:28-64, called at sbmc/functions.py:95-98).
+ *   output[n,c,y,x] = sum_{ry,rx} W[n,ry,rx,y,x] * Dz[n,c,y+ry-ph,x+rx-pw]
+ *   sum_w[n,y,x]    = sum_{ry,rx} W[n,ry,rx,y,x]          (not boundary-masked)
+ * c is unrestricted (processed in groups of SBMC_HIP_MAX_CHANNELS).
+ */
+SBMC_API int sbmc_kernel_weighting_fwd_f32(const float *data, const float *weights,
+                                  float *output, float *sum_w,
+                                  int bs, int c, int h, int w, int kh, int kw,
+                                  void *stream);
+
+/*
+ * kernel_weighting backward -- replaces
+ * `kernel_weighting_grad_cuda_float32(data, weights, sum_w, d_output, d_sum_w,
+ *                                     d_data, d_weights)`
+ * (reference: src/kernel_weighting.cpp:68-124, called at sbmc/functions.py:109-114).
+ *   d_data[n,c,y,x]       = sum_{ry,rx} Wz[n,kh-1-ry,kw-1-rx,y+ry-ph,x+rx-pw]
+ *                                       * dOz[n,c,y+ry-ph,x+rx-pw]
+ *   d_weights[n,dy,dx,y,x] = d_sum_w[n,y,x] + sum_c Dz[n,c,y+dy-ph,x+dx-pw] * dO[n,c,y,x]
+ * `sum_w` is accepted for signature parity and ignored (as in the reference).
+ */
+SBMC_API int sbmc_kernel_weighting_bwd_f32(const float *data, const float *weights,
+                                  const float *sum_w, const float *d_output,
+                                  const float *d_sum_w, float *d_data,
+                                  float *d_weights,
+                                  int bs, int c, int h, int w, int kh, int kw,
+                                  void *stream);
+
+/*
+ * 1 if sbmc_splat_update_{fwd,bwd}_f32 accept this (channels, kernel size): k odd,
+ * 1 <= c <= SBMC_HIP_MAX_CHANNELS and the LDS halo tiles fit; 0 otherwise (the
+ * caller then composes scatter2gather + kernel_weighting instead).
+ */
+SBMC_API int sbmc_splat_update_supported(int c, int k);
+
+/*
+ * Fused progressive splat update, forward -- one call replaces the whole body of
+ * `ProgressiveKernelApply.forward` for splat=True (sbmc/modules.py:422-471):
+ * Scatter2Gather -> max over taps -> running-max merge -> sub_/exp_ ->
+ * KernelWeighting -> running sums, in ONE pass over the [k*k,h,w] logits.
+ *
+ *   kernels   [bs, k*k, h, w]  sample-centred (splat) logits, k odd
+ *   data      [bs, c, h, w]    sample radiance, 1 <= c <= SBMC_HIP_MAX_CHANNELS
+ *   sum_r_in  [bs, c, h, w] | sum_w_in [bs, h, w] | max_w_in [bs, h, w]
+ *             running state, or all three NULL for the initialisation call
+ *             (modules.py:431-447); a mix of NULL / non-NULL is SBMC_HIP_EINVAL
+ *   sum_r_out, sum_w_out, max_w_out   updated state (same shapes)
+ *   kmax_out  [bs, h, w]       max over this sample's gather taps (modules.py:429)
+ *   arow_out  [bs, h, w] int32 gather-kernel row dy of the first tap attaining kmax
+ *             (kmax_out / arow_out are saved for backward: autograd routes the
+ *             gradient of the max to that tap)
+ * With g[t] the gather-layout logits of destination pixel q (0 where the source
+ * pixel lies outside the image) and M = max(kmax, max_w_in):
+ *   sum_r_out = sum_r_in * exp(max_w_in - M) + sum_t exp(g[t]-M) * Dz[src(t)]
+ *   sum_w_out = sum_w_in * exp(max_w_in - M) + sum_t exp(g[t]-M)
+ */
+SBMC_API int sbmc_splat_update_fwd_f32(const float *data, const float *kernels,
+                              const float *sum_r_in, const float *sum_w_in,
+                              const float *max_w_in,
+                              float *sum_r_out, float *sum_w_out,
+                              float *max_w_out, float *kmax_out,
+                              int32_t *arow_out,
+                              int bs, int c, int h, int w, int k,
+                              void *stream);
+
+/*
+ * Fused progressive splat update, backward -- the adjoint of the call above,
+ * i.e. what torch autograd computes through modules.py:422-471 +
+ * functions.py:62-71,102-115 (KernelWeighting.backward, exp/sub/max backward,
+ * Scatter2Gather.backward), in one read of the logits and one write of their
+ * gradient.
+ *
+ *   inputs saved from forward: data, kernels, sum_r_in/sum_w_in/max_w_in (or all
+ *       NULL), sum_r_out, sum_w_out, max_w_out, kmax, arow
+ *   upstream gradients: d_sum_r_out [bs,c,h,w], d_sum_w_out [bs,h,w],
+ *       d_max_w_out [bs,h,w]   (all required; pass zeros where unused)
+ *   outputs: d_data [bs,c,h,w], d_kernels [bs,k*k,h,w] (splat layout), and --
+ *       unless this was the initialisation call -- d_sum_r_in, d_sum_w_in,
+ *       d_max_w_in (pass NULL for all three on the initialisation call)
+ *   scratch: d_kmax_scratch [bs,h,w] caller-provided workspace (the library
+ *       holds no global state); contents undefined on return.
+ */
+SBMC_API int sbmc_splat_update_bwd_f32(const float *data, const float *kernels,
+                              const float *sum_r_in, const float *sum_w_in,
+                              const float *max_w_in,
+                              const float *sum_r_out, const float *sum_w_out,
+                              const float *max_w_out, const float *kmax,
+                              const int32_t *arow,
+                              const float *d_sum_r_out, const float *d_sum_w_out,
+                              const float *d_max_w_out,
+                              float *d_data, float *d_kernels,
+                              float *d_sum_r_in, float *d_sum_w_in,
+                              float *d_max_w_in, float *d_kmax_scratch,
+                              int bs, int c, int h, int w, int k,
+                              void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBMC_HIP_H */

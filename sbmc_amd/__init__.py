@@ -1,0 +1,10 @@
+"""sbmc_amd -- MI355X-native hot path of Sample-Based Monte Carlo denoising.
+
+Hand-written gfx950 HIP kernels behind a C ABI (include/sbmc_hip.h) for the
+per-sample kernel-splatting operators, exposed through the reference's own
+``sbmc.functions`` / ``sbmc.modules`` / ``sbmc.models`` API.
+"""
+from .models import Multisteps, KPCN  # noqa: F401
+from . import functions, modules, models, losses  # noqa: F401
+
+__version__ = "0.1.0"

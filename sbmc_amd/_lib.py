@@ -1,0 +1,79 @@
+"""ctypes binding of libsbmc_hip.so (C ABI: include/sbmc_hip.h).
+
+The library must exist: there is no fallback of any kind.  If it is missing or
+does not export every symbol of the header, importing this module's ``lib()``
+raises -- loudly -- instead of degrading to a slow path.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be loaded first: brings in the HIP runtime the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsbmc_hip.so")
+
+#: every extern "C" symbol include/sbmc_hip.h declares
+SYMBOLS = (
+    "sbmc_hip_abi_version",
+    "sbmc_hip_strerror",
+    "sbmc_scatter2gather_f32",
+    "sbmc_kernel_weighting_fwd_f32",
+    "sbmc_kernel_weighting_bwd_f32",
+    "sbmc_splat_update_supported",
+    "sbmc_splat_update_fwd_f32",
+    "sbmc_splat_update_bwd_f32",
+)
+ABI_VERSION = 1
+MAX_CHANNELS = 8
+
+_LIB = None
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads (once) and returns the ctypes handle; raises if unavailable."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            "%s not found: build it with `python -m sbmc_amd.build` (hipcc, gfx950). "
+            "sbmc_amd has no CPU or PyTorch fallback for its operators." % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name in SYMBOLS:
+        if not hasattr(handle, name):
+            raise HipExtensionMissing("%s does not export %s" % (LIB_PATH, name))
+    p, i = ctypes.c_void_p, ctypes.c_int
+    handle.sbmc_hip_abi_version.restype = i
+    handle.sbmc_hip_strerror.restype = ctypes.c_char_p
+    handle.sbmc_hip_strerror.argtypes = [i]
+    handle.sbmc_scatter2gather_f32.argtypes = [p, p, i, i, i, i, i, p]
+    handle.sbmc_kernel_weighting_fwd_f32.argtypes = [p] * 4 + [i] * 6 + [p]
+    handle.sbmc_kernel_weighting_bwd_f32.argtypes = [p] * 7 + [i] * 6 + [p]
+    handle.sbmc_splat_update_supported.argtypes = [i, i]
+    handle.sbmc_splat_update_fwd_f32.argtypes = [p] * 10 + [i] * 5 + [p]
+    handle.sbmc_splat_update_bwd_f32.argtypes = [p] * 19 + [i] * 5 + [p]
+    for name in SYMBOLS[2:]:
+        getattr(handle, name).restype = i
+    if handle.sbmc_hip_abi_version() != ABI_VERSION:
+        raise HipExtensionMissing("ABI version mismatch: rebuild with `python -m sbmc_amd.build --force`")
+    _LIB = handle
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().sbmc_hip_strerror(rc)
+        raise RuntimeError("%s failed: %s (code %d)" % (what, msg.decode() if msg else "?", rc))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

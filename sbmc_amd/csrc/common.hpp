@@ -1,0 +1,93 @@
+// Shared device/host helpers for the gfx950 SBMC splat kernels.
+//
+// Tiling model used by every kernel in this library (wave64, CDNA4):
+//   * a workgroup owns a tile of TX = 64 pixels (one per lane) by TY rows, one
+//     wavefront per row, so every global access of the big [k*k, H, W] tensors
+//     is a 256-byte contiguous segment per wave instruction;
+//   * the small [C, H, W] operand that is read at a per-tap *offset* (sample
+//     radiance in the forward, upstream gradients in the backward) is staged
+//     once per workgroup in LDS with a (k-1)/2 halo, struct-of-arrays, so the
+//     per-tap LDS reads are lane-consecutive (conflict-free ds_read_b32);
+//   * workgroups are numbered so that each XCD (blockIdx % 8 on MI355X) walks a
+//     contiguous band of image rows: x-adjacent tiles, which share the cache
+//     lines that a misaligned 256-byte segment straddles, land in the same
+//     XCD-private L2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sbmc {
+
+constexpr int TX = 64;             // pixels per tile row == wavefront width
+constexpr int NUM_XCD = 8;         // MI355X: 8 XCDs, block b is placed on XCD b % 8
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr float OUTSIDE_MAX = 1.0e30f;  // "max" of an out-of-image destination: exp(s - it) == 0
+
+struct TileCoord {
+    int n;   // batch index
+    int y0;  // first row of the tile
+    int x0;  // first column of the tile
+};
+
+// Host side: number of tiles for one [H, W] image plane.
+static inline int tiles_x(int w) { return (w + TX - 1) / TX; }
+static inline int tiles_y(int h, int ty) { return (h + ty - 1) / ty; }
+
+// Device side: XCD-aware decode of the linear workgroup id.
+// Physical block b runs on XCD b % 8 (observed placement -- used for speed only,
+// correctness does not depend on it).  XCD x receives the logical tile range
+// [x*q + min(x, r), ...) so that it walks consecutive tiles (x fastest, then y).
+__device__ __forceinline__ TileCoord decode_tile(int ntx, int nty, int ty_rows) {
+    const unsigned nb = gridDim.x;
+    const unsigned b = blockIdx.x;
+    const unsigned q = nb / NUM_XCD, r = nb % NUM_XCD;
+    const unsigned xcd = b % NUM_XCD, i = b / NUM_XCD;
+    const unsigned logical = xcd * q + (xcd < r ? xcd : r) + i;
+    TileCoord t;
+    const unsigned per_img = (unsigned)ntx * (unsigned)nty;
+    t.n = (int)(logical / per_img);
+    const unsigned rem = logical % per_img;
+    t.y0 = (int)(rem / (unsigned)ntx) * ty_rows;
+    t.x0 = (int)(rem % (unsigned)ntx) * TX;
+    return t;
+}
+
+// Cooperative load of a haloed tile of one [H, W] plane into LDS.
+//   dst[r * tw + cc] = inside ? src[(ys0 + r) * W + xs0 + cc] : fill
+__device__ __forceinline__ void stage_plane(float* __restrict__ dst,
+                                            const float* __restrict__ src,
+                                            int h, int w, int ys0, int xs0,
+                                            int th, int tw, float fill) {
+    const int nthreads = blockDim.x;
+    for (int r = threadIdx.x / TX; r < th; r += nthreads / TX) {
+        const int ys = ys0 + r;
+        const bool yin = (ys >= 0) && (ys < h);
+        const float* row = src + (size_t)(yin ? ys : 0) * w;
+        for (int cc = threadIdx.x % TX; cc < tw; cc += TX) {
+            const int xs = xs0 + cc;
+            const bool in = yin && (xs >= 0) && (xs < w);
+            dst[r * tw + cc] = in ? row[xs] : fill;
+        }
+    }
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ int wave_id() {
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
+}  // namespace sbmc
+
+#define SBMC_DISPATCH_C(CVAL, ...)                                   \
+    switch (CVAL) {                                                  \
+        case 1: { constexpr int C = 1; __VA_ARGS__; } break;         \
+        case 2: { constexpr int C = 2; __VA_ARGS__; } break;         \
+        case 3: { constexpr int C = 3; __VA_ARGS__; } break;         \
+        case 4: { constexpr int C = 4; __VA_ARGS__; } break;         \
+        case 5: { constexpr int C = 5; __VA_ARGS__; } break;         \
+        case 6: { constexpr int C = 6; __VA_ARGS__; } break;         \
+        case 7: { constexpr int C = 7; __VA_ARGS__; } break;         \
+        case 8: { constexpr int C = 8; __VA_ARGS__; } break;         \
+        default: return SBMC_HIP_EINVAL;                             \
+    }

@@ -1,0 +1,205 @@
+"""Autograd operators of the SBMC splat path, MI355X-native.
+
+API mirror of the reference's ``sbmc/functions.py`` (:39-115): the classes
+``Scatter2Gather`` and ``KernelWeighting`` keep their names, argument order,
+returned shapes and dispatch rule (``_is_cuda`` -> ``*_cuda_float32``, else
+``*_cpu_float32``).  ``SplatUpdate`` is new: a single autograd operator for the
+body of ``ProgressiveKernelApply.forward`` (sbmc/modules.py:422-471) backed by the
+fused gfx950 kernels of ``csrc/splat_fused.hip``.
+"""
+import torch as th
+
+from . import _lib
+from . import halide_ops as ops
+
+__all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported"]
+
+
+def _is_cuda(*args):
+    """True if any argument lives on a GPU (reference functions.py:30-36)."""
+    for arg in args:
+        if arg.is_cuda:
+            return True
+    return False
+
+
+class Scatter2Gather(th.autograd.Function):
+    """Converts (transposes) scatter kernels into gather kernels.
+
+    Kernel weights at (x, y) for offset (dx, dy) (i.e. scatter[., dy, dx, y, x])
+    are put at gather[., -dy, -dx, y+dy, x+dx]  (reference functions.py:39-71).
+
+    Args:
+      data(th.Tensor)[bs, k_h, k_w, h, w]: scatter kernel weights.
+    Returns:
+      (th.Tensor)[bs, k_h, k_w, h, w]: gather kernel weights.
+    """
+
+    @staticmethod
+    def forward(ctx, data):
+        assert len(data.shape) == 5, "data should be 5d"
+        data = data.contiguous()
+        output = th.empty_like(data)
+        if _is_cuda(data):
+            ops.scatter2gather_cuda_float32(data, output)
+        else:
+            ops.scatter2gather_cpu_float32(data, output)
+        return output
+
+    @staticmethod
+    def backward(ctx, d_output):
+        # the operator is its own adjoint (reference functions.py:62-71)
+        d_output = d_output.contiguous()
+        d_data = th.empty_like(d_output)
+        if _is_cuda(d_output):
+            ops.scatter2gather_cuda_float32(d_output, d_data)
+        else:
+            ops.scatter2gather_cpu_float32(d_output, d_data)
+        return d_data
+
+
+class KernelWeighting(th.autograd.Function):
+    """Locally-weighted sum of the input values using kernel weights.
+
+    Args:
+      data(th.Tensor)[bs, c, h, w]: input values to be locally averaged.
+      weights(th.Tensor)[bs, k_h, k_w, h, w]: kernel weights.  Channels are
+        filtered independently.
+    Returns:
+      output(th.Tensor)[bs, c, h, w]:
+        output[., c, y, x] = sum_{dx, dy} weights[., dy, dx, y, x] * data[., c, y+dy, x+dx].
+      sum_w(th.Tensor)[bs, h, w]: sum of weights per pixel.
+    (reference functions.py:74-115)
+    """
+
+    @staticmethod
+    def forward(ctx, data, weights):
+        bs, c, h, w = data.shape
+        data = data.contiguous()
+        weights = weights.contiguous()
+        output = th.empty_like(data)
+        sum_w = data.new_empty(bs, h, w)
+        if _is_cuda(data, weights):
+            ops.kernel_weighting_cuda_float32(data, weights, output, sum_w)
+        else:
+            ops.kernel_weighting_cpu_float32(data, weights, output, sum_w)
+        ctx.save_for_backward(data, weights, sum_w)
+        return output, sum_w
+
+    @staticmethod
+    def backward(ctx, d_output, d_sum_w):
+        data, weights, sum_w = ctx.saved_tensors
+        d_output = d_output.contiguous()
+        d_sum_w = d_sum_w.contiguous()
+        d_data = th.empty_like(data)
+        d_weights = th.empty_like(weights)
+        if _is_cuda(d_output, d_sum_w):
+            ops.kernel_weighting_grad_cuda_float32(
+                data, weights, sum_w, d_output, d_sum_w, d_data, d_weights)
+        else:
+            ops.kernel_weighting_grad_cpu_float32(
+                data, weights, sum_w, d_output, d_sum_w, d_data, d_weights)
+        return d_data, d_weights
+
+
+def splat_update_supported(data, kernels):
+    """True when the fused kernels can take these operands (GPU, fp32, odd k, <= 8 channels)."""
+    if not (data.is_cuda and kernels.is_cuda):
+        return False
+    if data.dtype != th.float32 or kernels.dtype != th.float32:
+        return False
+    k2 = kernels.shape[1]
+    k = int(round(k2 ** 0.5))
+    if k * k != k2:
+        return False
+    return bool(_lib.lib().sbmc_splat_update_supported(int(data.shape[1]), k))
+
+
+class SplatUpdate(th.autograd.Function):
+    """One progressive splat update, fused (forward AND backward).
+
+    Same inputs / outputs as ``ProgressiveKernelApply(splat=True).forward``
+    (reference sbmc/modules.py:376-473):
+
+    Args:
+      data(th.Tensor)[bs, c, h, w]: sample radiance.
+      kernels(th.Tensor)[bs, k*k, h, w]: sample-centred (splat) kernel logits.
+      sum_r(None or th.Tensor)[bs, c, h, w], sum_w, max_w(None or th.Tensor)[bs, 1, h, w]:
+        running state; all None on the initialisation call.
+    Returns:
+      sum_r[bs, c, h, w], sum_w[bs, 1, h, w], max_w[bs, 1, h, w]: updated state.
+
+    Unlike the reference composition it does not modify ``kernels`` and keeps only
+    the logits (not the 1.6 GB of exponentiated gather weights) for backward.
+    """
+
+    @staticmethod
+    def forward(ctx, data, kernels, sum_r, sum_w, max_w):
+        if sum_r is None:
+            if sum_w is not None or max_w is not None:
+                raise RuntimeError("all of sum_r, sum_w, max_w should be none")
+        elif sum_w is None or max_w is None:
+            raise RuntimeError("all of sum_r, sum_w, max_w should be provided")
+        bs, k2, h, w = kernels.shape
+        k = int(round(k2 ** 0.5))
+        c = data.shape[1]
+        if tuple(data.shape) != (bs, c, h, w):
+            raise RuntimeError("data should be [bs, c, h, w] matching kernels [bs, k*k, h, w]")
+        data = data.contiguous()
+        kernels = kernels.contiguous()
+        first = sum_r is None
+        if not first:
+            sum_r, sum_w, max_w = sum_r.contiguous(), sum_w.contiguous(), max_w.contiguous()
+            if (tuple(sum_r.shape) != (bs, c, h, w) or sum_w.numel() != bs * h * w
+                    or max_w.numel() != bs * h * w):
+                raise RuntimeError("running state has the wrong shape")
+        new_r = th.empty_like(data)
+        new_w = data.new_empty(bs, 1, h, w)
+        new_m = data.new_empty(bs, 1, h, w)
+        kmax = data.new_empty(bs, h, w)
+        arow = th.empty(bs, h, w, dtype=th.int32, device=data.device)
+        dev = data.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_splat_update_fwd_f32(
+                _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
+                _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(arow),
+                bs, c, h, w, k, _lib.current_stream(dev))
+        _lib.check(rc, "splat_update_fwd")
+        ctx.first = first
+        ctx.k = k
+        if first:
+            ctx.save_for_backward(data, kernels, new_r, new_w, new_m, kmax, arow)
+        else:
+            ctx.save_for_backward(data, kernels, new_r, new_w, new_m, kmax, arow, sum_r, sum_w, max_w)
+        return new_r, new_w, new_m
+
+    @staticmethod
+    def backward(ctx, d_r, d_w, d_m):
+        saved = ctx.saved_tensors
+        data, kernels, new_r, new_w, new_m, kmax, arow = saved[:7]
+        sum_r = sum_w = max_w = None
+        if not ctx.first:
+            sum_r, sum_w, max_w = saved[7:]
+        bs, c, h, w = data.shape
+        d_r = th.zeros_like(new_r) if d_r is None else d_r.contiguous()
+        d_w = th.zeros_like(new_w) if d_w is None else d_w.contiguous()
+        d_m = th.zeros_like(new_m) if d_m is None else d_m.contiguous()
+        d_data = th.empty_like(data)
+        d_kernels = th.empty_like(kernels)
+        scratch = data.new_empty(bs, h, w)
+        d_sum_r = d_sum_w = d_max_w = None
+        if not ctx.first:
+            d_sum_r = th.empty_like(sum_r)
+            d_sum_w = th.empty_like(sum_w)
+            d_max_w = th.empty_like(max_w)
+        dev = data.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_splat_update_bwd_f32(
+                _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
+                _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(arow),
+                _lib.ptr(d_r), _lib.ptr(d_w), _lib.ptr(d_m),
+                _lib.ptr(d_data), _lib.ptr(d_kernels),
+                _lib.ptr(d_sum_r), _lib.ptr(d_sum_w), _lib.ptr(d_max_w), _lib.ptr(scratch),
+                bs, c, h, w, ctx.k, _lib.current_stream(dev))
+        _lib.check(rc, "splat_update_bwd")
+        return d_data, d_kernels, d_sum_r, d_sum_w, d_max_w

@@ -1,0 +1,160 @@
+"""The SBMC kernel-splatting denoiser, device-resident on MI355X.
+
+``Multisteps`` has the constructor, sub-module names (``embedding_XX``,
+``propagation_XX``, ``kernel_regressor``, ``kernel_update``) and numerics of the
+reference's ``sbmc/models.py:35-218``; a reference state-dict loads unchanged.
+
+What differs is *where the tensors live*.  The reference's eval path parks the
+per-sample embeddings in host memory and calls ``empty_cache()`` after every
+sample (models.py:136-169,195-209) to fit 11 GB GPUs; with 288 GB of HBM3E the
+whole [bs, spp, C, H, W] working set stays on the device and both modes share one
+batched path.  ``sample_chunk`` bounds the number of samples embedded per
+convolution call for very large frames.
+"""
+import logging
+
+import torch as th
+import torch.nn as nn
+
+from . import modules as ops
+from .utils import crop_like
+
+__all__ = ["Multisteps", "KPCN"]
+
+LOG = logging.getLogger(__name__)
+
+
+class Multisteps(nn.Module):
+    """Sample-based Monte Carlo denoiser [Gharbi 2019].
+
+    Args:
+        n_features(int): per-sample input features.
+        n_global_features(int): global (per-image) features.
+        width(int): channels of the conv layers.
+        embedding_width(int): channels of the per-sample embedding.
+        ksize(int): splat kernel size (odd, >= 3).
+        splat(bool): predict splat kernels (True) or gather kernels (ablation).
+        nsteps(int): sample/pixel coordination steps.
+        pixel(bool): average the samples first and treat the result as 1 spp (ablation).
+        sample_chunk(int or None): embed at most this many samples per conv call
+            (None: all at once).  Not a reference argument; does not change results.
+    """
+
+    def __init__(self, n_features, n_global_features, width=128,
+                 embedding_width=128, ksize=21, splat=True, nsteps=3,
+                 pixel=False, sample_chunk=None):
+        super(Multisteps, self).__init__()
+        if ksize < 3 or (ksize % 2 == 0):
+            LOG.error("Kernel size should be odd and > 3.")
+            raise ValueError("Kernel size should be odd and > 3.")
+        if nsteps < 1:
+            LOG.error("Multisteps requires at least one sample/pixel step.")
+            raise ValueError("Multisteps requires at least one sample/pixel step.")
+
+        self.ksize = ksize
+        self.splat = splat
+        self.pixel = pixel
+        self.width = width
+        self.embedding_width = embedding_width
+        self.eps = 1e-8  # kernel normalisation (reference models.py:75)
+        self.nsteps = nsteps
+        self.sample_chunk = sample_chunk
+
+        for step in range(nsteps):
+            n_in = n_features + n_global_features if step == 0 else embedding_width + width
+            # per-sample transformation: 1x1 convolutions
+            self.add_module("embedding_{:02d}".format(step), ops.ConvChain(
+                n_in, embedding_width, width=width, depth=3, ksize=1, pad=False))
+            # pixel-space propagation: U-net
+            self.add_module("propagation_{:02d}".format(step), ops.Autoencoder(
+                embedding_width, width, num_levels=3, increase_factor=2.0,
+                num_convs=3, width=width, ksize=3, output_type="leaky_relu",
+                pooling="max"))
+
+        self.kernel_regressor = ops.ConvChain(
+            width + embedding_width, ksize * ksize, depth=3, width=width, ksize=1,
+            activation="leaky_relu", pad=False, output_type="linear")
+        self.kernel_update = ops.ProgressiveKernelApply(splat=splat)
+
+    def _embed(self, module, per_sample, per_pixel):
+        """Runs a 1x1 ConvChain on cat(per_sample[:, s], per_pixel) for every sample s.
+
+        per_sample [bs, spp, c, h, w], per_pixel [bs, c', h, w] -> [bs, spp, e, h, w]
+        """
+        bs, spp, c, h, w = per_sample.shape
+        chunk = self.sample_chunk or spp
+        outs = []
+        for s0 in range(0, spp, chunk):
+            part = per_sample[:, s0:s0 + chunk]
+            n = part.shape[1]
+            ctx = per_pixel.unsqueeze(1).expand(bs, n, per_pixel.shape[1], h, w)
+            flat = th.cat([part, ctx], 2).reshape(bs * n, c + per_pixel.shape[1], h, w)
+            outs.append(module(flat).view(bs, n, -1, h, w))
+        return outs[0] if len(outs) == 1 else th.cat(outs, 1)
+
+    def forward(self, samples):
+        """
+        Args:
+            samples(dict): "radiance" [bs, spp, 3, h, w], "features" [bs, spp, nf, h, w],
+                "global_features" [bs, ngf, 1, 1].
+        Returns:
+            dict: "radiance" [bs, 3, h - (ksize-1), w - (ksize-1)] denoised radiance.
+        """
+        radiance = samples["radiance"]
+        features = samples["features"].to(radiance.device)
+        gfeatures = samples["global_features"].to(radiance.device)
+
+        if self.pixel:
+            radiance = radiance.mean(1, keepdim=True)
+            features = features.mean(1, keepdim=True)
+
+        bs, spp, nf, h, w = features.shape
+
+        # -- alternate per-sample embedding and per-pixel propagation --------------
+        # step 0 sees the global features, later steps the propagated pixel context
+        # (reference models.py:142-189; batch elements are paired correctly for
+        # bs > 1, where the reference's train path mis-tiles them).
+        context = gfeatures.expand(bs, gfeatures.shape[1], h, w)
+        for step in range(self.nsteps):
+            features = self._embed(getattr(self, "embedding_{:02d}".format(step)),
+                                   features, context)
+            reduced = features.mean(1)
+            context = getattr(self, "propagation_{:02d}".format(step))(reduced)
+
+        # -- per-sample kernel prediction + progressive splat ----------------------
+        sum_r, sum_w, max_w = None, None, None
+        for sp in range(spp):
+            f = th.cat([features[:, sp], context], 1)
+            kernels = self.kernel_regressor(f)
+            r = crop_like(radiance[:, sp], kernels)
+            sum_r, sum_w, max_w = self.kernel_update(r, kernels, sum_r, sum_w, max_w)
+
+        output = sum_r / (sum_w + self.eps)
+        crop = (self.ksize - 1) // 2
+        output = output[..., crop:-crop, crop:-crop]
+        return {"radiance": output}
+
+
+class KPCN(nn.Module):
+    """Kernel-predicting baseline [Bako 2017] (reference models.py:221-291): two 5x5
+    ConvChains predict per-pixel gather kernels applied with a softmax KernelApply."""
+
+    def __init__(self, n_in, ksize=21, depth=9, width=100):
+        super(KPCN, self).__init__()
+        self.ksize = ksize
+        chain = dict(depth=depth, width=width, ksize=5, activation="relu",
+                     weight_norm=False, pad=False, output_type="linear")
+        self.diffuse = ops.ConvChain(n_in, ksize * ksize, **chain)
+        self.specular = ops.ConvChain(n_in, ksize * ksize, **chain)
+        self.kernel_apply = ops.KernelApply(softmax=True, splat=False)
+
+    def forward(self, data):
+        k_diffuse = self.diffuse(data["kpcn_diffuse_in"])
+        k_specular = self.specular(data["kpcn_specular_in"])
+        b_diffuse = crop_like(data["kpcn_diffuse_buffer"], k_diffuse).contiguous()
+        b_specular = crop_like(data["kpcn_specular_buffer"], k_specular).contiguous()
+        r_diffuse, _ = self.kernel_apply(b_diffuse, k_diffuse)
+        r_specular, _ = self.kernel_apply(b_specular, k_specular)
+        albedo = crop_like(data["kpcn_albedo"], r_diffuse)
+        radiance = albedo * r_diffuse + (th.exp(r_specular) - 1)
+        return dict(radiance=radiance, diffuse=r_diffuse, specular=r_specular)

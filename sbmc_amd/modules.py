@@ -1,0 +1,313 @@
+"""Building blocks of the SBMC denoiser on MI355X.
+
+Public API, constructor signatures, sub-module names and therefore state-dict
+keys are those of the reference's ``sbmc/modules.py`` (``__all__`` at :29), so a
+reference checkpoint loads unchanged:
+
+* ``ConvChain`` (:34-192) and ``Autoencoder`` (:195-320): the kernel-predicting
+  backbone.  Plain ``torch.nn`` convolutions -- on ROCm these run on MIOpen
+  (MFMA); nothing here is hand-written.
+* ``KernelApply`` (:323-361) and ``ProgressiveKernelApply`` (:364-473): the splat
+  path.  On GPU tensors ``ProgressiveKernelApply(splat=True)`` is ONE fused HIP
+  operator (``functions.SplatUpdate``); every other case composes the
+  boundary-level operators ``Scatter2Gather`` / ``KernelWeighting`` exactly like
+  the reference does.
+"""
+import logging
+import warnings
+
+import numpy as np
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functions as funcs
+
+__all__ = ["ConvChain", "Autoencoder", "KernelApply", "ProgressiveKernelApply"]
+
+LOG = logging.getLogger(__name__)
+
+_ACTIVATIONS = {
+    "relu": nn.ReLU,
+    "leaky_relu": nn.LeakyReLU,
+    "tanh": nn.Tanh,
+    "elu": nn.ELU,
+}
+
+
+def _weight_norm(conv):
+    # Old-style weight norm on purpose: it registers `weight_g` / `weight_v`, the
+    # parameter names found in reference checkpoints.
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)
+        return nn.utils.weight_norm(conv)
+
+
+def _init_conv(conv, nonlinearity):
+    # Reference behaviour (modules.py:85-94,178-188): zero bias, Xavier-uniform on
+    # `conv.weight`.  With weight norm `conv.weight` is a derived tensor, so the
+    # Xavier call does not touch the trainable weight_g / weight_v -- kept as is so
+    # that a seeded init reproduces the reference's parameters bit for bit.
+    conv.bias.data.zero_()
+    gain_of = "relu" if nonlinearity in ("elu", "softplus") else nonlinearity
+    nn.init.xavier_uniform_(conv.weight.data, nn.init.calculate_gain(gain_of))
+
+
+class ConvChain(nn.Module):
+    """A stack of ``depth`` convolutions: (depth-1) x [conv, (norm), activation] + conv.
+
+    Args (same as the reference):
+        ninputs(int), noutputs(int): input / output channels.
+        ksize(int): size of all the convolution kernels.
+        width(int): channels of the intermediate layers.
+        depth(int): number of conv layers (> 0).
+        stride(int): stride of the intermediate convolutions.
+        pad(bool): zero-pad to keep the resolution, else 'valid' convolutions.
+        normalize(bool), normalization_type(str): optional batch / instance norm.
+        output_type(str): linear, relu, leaky_relu, sigmoid, tanh, elu, softplus.
+        activation(str): relu, leaky_relu, tanh, elu.
+        weight_norm(bool): weight-normalised convolutions.
+    """
+
+    def __init__(self, ninputs, noutputs, ksize=3, width=64, depth=3, stride=1,
+                 pad=True, normalize=False, normalization_type="batch",
+                 output_type="linear", activation="relu", weight_norm=True):
+        super(ConvChain, self).__init__()
+        if depth <= 0:
+            LOG.error("ConvChain should have non-negative depth.")
+            raise ValueError("negative network depth.")
+        padding = ksize // 2 if pad else 0
+
+        nin = ninputs
+        for d in range(depth - 1):
+            self.add_module("layer_{}".format(d), ConvChain._ConvBNRelu(
+                nin, ksize, width, normalize=normalize,
+                normalization_type=normalization_type, padding=padding,
+                stride=stride, activation=activation, weight_norm=weight_norm))
+            nin = width
+
+        head = nn.Conv2d(nin, noutputs, ksize, bias=True, padding=padding)
+        if weight_norm:
+            head = _weight_norm(head)
+        if output_type not in ("linear", "relu", "leaky_relu", "sigmoid", "tanh",
+                               "elu", "softplus"):
+            raise ValueError("Unknon output type '{}'".format(output_type))
+        _init_conv(head, output_type)
+        self.add_module("prediction", head)
+
+        out_act = {
+            "relu": lambda: nn.ReLU(inplace=True),
+            "leaky_relu": lambda: nn.LeakyReLU(inplace=True),
+            "sigmoid": nn.Sigmoid,
+            "tanh": nn.Tanh,
+            "elu": nn.ELU,
+            "softplus": nn.Softplus,
+        }.get(output_type)
+        if out_act is not None:
+            self.add_module("output_activation", out_act())
+
+    def forward(self, x):
+        for m in self.children():
+            x = m(x)
+        return x
+
+    class _ConvBNRelu(nn.Module):
+        """conv -> (norm) -> activation, stored as ``self.layer`` (an nn.Sequential)."""
+
+        def __init__(self, ninputs, ksize, noutputs, normalize=False,
+                     normalization_type="batch", stride=1, padding=0,
+                     activation="relu", weight_norm=True):
+            super(ConvChain._ConvBNRelu, self).__init__()
+            if activation not in _ACTIVATIONS:
+                LOG.error("Incorrect activation %s", activation)
+                raise ValueError("activation should be one of: relu, leaky_relu, tanh, elu")
+            act = _ACTIVATIONS[activation]
+            if normalize:
+                conv = nn.Conv2d(ninputs, noutputs, ksize, stride=stride,
+                                 padding=padding, bias=False)
+                if normalization_type == "batch":
+                    nrm = nn.BatchNorm2d(noutputs)
+                elif normalization_type == "instance":
+                    nrm = nn.InstanceNorm2d(noutputs, affine=True)
+                else:
+                    LOG.error("Incorrect normalization %s", normalization_type)
+                    raise ValueError("Unkown normalization type {}".format(normalization_type))
+                nrm.bias.data.zero_()
+                nrm.weight.data.fill_(1.0)
+                self.layer = nn.Sequential(conv, nrm, act())
+                gain_of = "relu" if activation == "elu" else activation
+                nn.init.xavier_uniform_(conv.weight.data, nn.init.calculate_gain(gain_of))
+            else:
+                conv = nn.Conv2d(ninputs, noutputs, ksize, stride=stride, padding=padding)
+                if weight_norm:
+                    conv = _weight_norm(conv)
+                self.layer = nn.Sequential(conv, act())
+                _init_conv(conv, activation)
+
+        def forward(self, x):
+            return self.layer(x)
+
+
+class Autoencoder(nn.Module):
+    """U-net: per level [left ConvChain] -> pool -> coarser level -> bilinear up ->
+    concat(skip) -> [right ConvChain].  Arguments as in the reference (:195-245)."""
+
+    def __init__(self, ninputs, noutputs, ksize=3, width=64, num_levels=3,
+                 num_convs=2, max_width=512, increase_factor=1.0,
+                 normalize=False, normalization_type="batch",
+                 output_type="linear", activation="relu", pooling="max"):
+        super(Autoencoder, self).__init__()
+
+        def level_width(lvl):
+            return min(int(width * increase_factor ** lvl), max_width)
+
+        coarser = None
+        for lvl in reversed(range(num_levels)):
+            n_in, n_out, o_type = level_width(lvl - 1), level_width(lvl), activation
+            n_us = level_width(lvl + 1)
+            if lvl == 0:
+                n_in, n_out, o_type = ninputs, noutputs, output_type
+            elif lvl == num_levels - 1:
+                n_us = None
+            coarser = Autoencoder._Level(
+                n_in, n_out, next_level=coarser, num_us=n_us, ksize=ksize,
+                width=level_width(lvl), num_convs=num_convs, output_type=o_type,
+                normalize=normalize, normalization_type=normalization_type,
+                activation=activation, pooling=pooling)
+        self.add_module("net", coarser)
+
+    def forward(self, x):
+        return self.net(x)
+
+    class _Level(nn.Module):
+        """One resolution of the U-net (reference :247-320)."""
+
+        def __init__(self, num_inputs, num_outputs, next_level=None, num_us=None,
+                     ksize=3, width=64, num_convs=2, output_type="linear",
+                     normalize=True, normalization_type="batch", pooling="max",
+                     activation="relu"):
+            super(Autoencoder._Level, self).__init__()
+            self.is_last = next_level is None
+            common = dict(ksize=ksize, width=width, depth=num_convs, stride=1, pad=True,
+                          normalize=normalize, normalization_type=normalization_type)
+            if self.is_last:
+                # (the reference does not forward `activation` here either)
+                self.left = ConvChain(num_inputs, num_outputs, output_type=output_type, **common)
+                return
+            assert num_us is not None
+            self.left = ConvChain(num_inputs, width, output_type=activation,
+                                  activation=activation, **common)
+            if pooling == "max":
+                self.downsample = nn.MaxPool2d(2, 2)
+            elif pooling == "average":
+                self.downsample = nn.AvgPool2d(2, 2)
+            elif pooling == "conv":
+                self.downsample = nn.Conv2d(width, width, 2, stride=2)
+            else:
+                raise ValueError("unknown pooling'{}'".format(pooling))
+            self.next_level = next_level
+            self.right = ConvChain(num_us + width, num_outputs, output_type=output_type, **common)
+
+        def forward(self, x):
+            left = self.left(x)
+            if self.is_last:
+                return left
+            coarse = self.next_level(self.downsample(left))
+            up = F.interpolate(coarse, size=left.shape[-2:], mode="bilinear",
+                               align_corners=False)
+            return self.right(th.cat([up, left], 1))
+
+
+def _ksize_of(kernels):
+    k2 = kernels.shape[1]
+    return int(np.sqrt(k2))
+
+
+class KernelApply(nn.Module):
+    """Applies kernel-based averaging to the input (reference :323-361).
+
+    Args:
+        softmax(bool): softmax-normalise the kernels over the taps of each output pixel.
+        splat(bool): kernels are sample-centred (splat); they are transposed to the
+            gather layout first.
+    """
+
+    def __init__(self, softmax=True, splat=True):
+        super(KernelApply, self).__init__()
+        self.softmax = softmax
+        self.splat = splat
+
+    def forward(self, data, kernels):
+        """data [bs, c, h, w], kernels [bs, k*k, h, w] -> (output [bs, c, h, w], sum_w [bs, 1, h, w])."""
+        bs, k2, h, w = kernels.shape
+        k = _ksize_of(kernels)
+        kernels = kernels.view(bs, k, k, h, w)
+        if self.splat:
+            kernels = funcs.Scatter2Gather.apply(kernels)
+        if self.softmax:
+            kernels = F.softmax(kernels.view(bs, k * k, h, w), dim=1).view(bs, k, k, h, w)
+        output, sum_w = funcs.KernelWeighting.apply(data, kernels)
+        return output, sum_w.unsqueeze(1)
+
+
+class ProgressiveKernelApply(nn.Module):
+    """Accumulates one sample's kernel-weighted contribution into running sums
+    with a numerically-stable running softmax (reference :364-473).
+
+    ``sum_r / sum_w`` is the normalised reconstruction after any number of calls:
+        sum_r = sum_i sum_taps exp(kernels_i - max_w) * data_i
+        sum_w = sum_i sum_taps exp(kernels_i - max_w)
+    with ``max_w`` the running per-pixel maximum of the (gather-layout) logits.
+
+    Args:
+        splat(bool): kernels are sample-centred (splat) rather than gather kernels.
+        fused(bool): allow the single-kernel HIP path when the operands qualify
+            (ROCm tensors, fp32, splat=True).  ``False`` forces the reference
+            composition of the boundary-level operators (used by the tests to check
+            one against the other on the GPU).
+    """
+
+    def __init__(self, splat=False, fused=True):
+        super(ProgressiveKernelApply, self).__init__()
+        self.splat = splat
+        self.fused = fused
+
+    def forward(self, data, kernels, sum_r, sum_w, max_w):
+        """
+        Args:
+            data [bs, c, h, w]; kernels [bs, k*k, h, w];
+            sum_r [bs, c, h, w] | sum_w [bs, 1, h, w] | max_w [bs, 1, h, w], or all None
+            for the initialisation call.
+        Returns:
+            (sum_r, sum_w, max_w) updated.
+        """
+        if sum_r is None and (sum_w is not None or max_w is not None):
+            LOG.error("sum_r is None, this is the initialization step: "
+                      "sum_w and max_w should be None as well.")
+            raise RuntimeError("all of sum_r, sum_w, max_w should be none")
+
+        if self.splat and self.fused and funcs.splat_update_supported(data, kernels):
+            return funcs.SplatUpdate.apply(data, kernels, sum_r, sum_w, max_w)
+        return self._composed(data, kernels, sum_r, sum_w, max_w)
+
+    def _composed(self, data, kernels, sum_r, sum_w, max_w):
+        # Reference sequence, out of place (the reference mutates the gather tensor
+        # with sub_/exp_; values and gradients are identical).
+        bs, k2, h, w = kernels.shape
+        k = _ksize_of(kernels)
+        kernels = kernels.view(bs, k, k, h, w)
+        if self.splat:
+            kernels = funcs.Scatter2Gather.apply(kernels)
+        kmax = kernels.reshape(bs, k * k, h, w).max(1, keepdim=True)[0]
+
+        if sum_r is None:
+            max_w = kmax
+            weights = th.exp(kernels - max_w.unsqueeze(1))
+            sum_r, sum_w = funcs.KernelWeighting.apply(data.contiguous(), weights.contiguous())
+            return sum_r, sum_w.unsqueeze(1), max_w
+
+        new_max = th.max(kmax, max_w)
+        scaler = th.exp(max_w - new_max)
+        weights = th.exp(kernels - new_max.unsqueeze(1))
+        new_r, new_w = funcs.KernelWeighting.apply(data.contiguous(), weights.contiguous())
+        return sum_r * scaler + new_r, sum_w * scaler + new_w.unsqueeze(1), new_max

@@ -1,0 +1,23 @@
+"""Small host-side helpers (stand-ins for the two torch-tools symbols the hot path uses)."""
+import logging
+
+
+def get_logger(name):
+    return logging.getLogger(name)
+
+
+def crop_like(src, tgt):
+    """Centre-crops the last two dims of ``src`` to those of ``tgt``.
+
+    Stand-in for ``ttools.modules.image_operators.crop_like`` (torch-tools 0.0.36,
+    not in the reference tree -- parity of this helper is unpinned; in Multisteps
+    the call is an identity, reference models.py:98-102,206).
+    """
+    sh, sw = src.shape[-2:]
+    th_, tw = tgt.shape[-2:]
+    if (sh, sw) == (th_, tw):
+        return src
+    dy, dx = (sh - th_) // 2, (sw - tw) // 2
+    if dy < 0 or dx < 0:
+        raise ValueError("crop_like: source is smaller than the target")
+    return src[..., dy:dy + th_, dx:dx + tw]

@@ -1,0 +1,30 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture
+def oracle():
+    """The CPU oracle (test infrastructure, see oracle/sbmc_oracle.py)."""
+    from oracle import sbmc_oracle
+    sbmc_oracle.lib()
+    return sbmc_oracle
+
+
+@pytest.fixture
+def cpu_ops(oracle):
+    """Installs the oracle behind sbmc_amd's `*_cpu_float32` names for the duration of a
+    test, so that the Python host logic above the operators can run on host tensors."""
+    from sbmc_amd import halide_ops
+    halide_ops.register_cpu_ops_for_testing(oracle)
+    yield oracle
+    halide_ops.register_cpu_ops_for_testing(None)

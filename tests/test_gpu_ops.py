@@ -1,0 +1,180 @@
+"""GPU parity: the gfx950 kernels (called through the C ABI) vs the CPU oracle.
+
+Tolerance: north_star asks for 1e-5 relative fp32.  Sums of up to 441 mixed-sign
+products are compared with an abs-scaled bound: |a - b| <= 1e-5 * max|b| + 1e-5 * |b|
+(hard part 2).
+"""
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def close(a, b, rtol=RTOL, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, what
+    scale = b.abs().max().item() if b.numel() else 0.0
+    err = (a - b).abs()
+    bound = rtol * scale + rtol * b.abs()
+    bad = err > bound
+    assert not bad.any(), "%s: max err %.3e (scale %.3e), %d bad" % (
+        what, err.max().item(), scale, int(bad.sum()))
+
+
+SHAPES = [
+    # bs, c, h, w, k
+    (1, 3, 16, 16, 3),
+    (2, 3, 19, 70, 5),      # ragged: w % 64 != 0, h % 4 != 0
+    (1, 5, 9, 130, 7),
+    (2, 1, 33, 65, 9),
+    (1, 3, 40, 150, 21),    # the tuned K=21 instantiation, border + interior tiles
+    (1, 9, 12, 20, 3),      # more channels than one kernel pass takes (groups of 8)
+    (1, 3, 5, 7, 21),       # image smaller than the kernel
+]
+
+
+@pytest.mark.parametrize("bs,c,h,w,k", SHAPES)
+def test_scatter2gather(oracle, bs, c, h, w, k):
+    from sbmc_amd import functions as F
+    th.manual_seed(1)
+    x = th.randn(bs, k, k, h, w)
+    ref = oracle.Scatter2Gather.apply(x)
+    out = F.Scatter2Gather.apply(x.cuda())
+    assert th.equal(out.cpu(), ref)  # pure permutation: bit exact
+
+
+def test_scatter2gather_rectangular(oracle):
+    from sbmc_amd import functions as F
+    th.manual_seed(2)
+    x = th.randn(2, 3, 7, 11, 80)
+    assert th.equal(F.Scatter2Gather.apply(x.cuda()).cpu(), oracle.Scatter2Gather.apply(x))
+    x = th.randn(1, 4, 6, 11, 30)  # even sizes: pad = (k-1)//2
+    assert th.equal(F.Scatter2Gather.apply(x.cuda()).cpu(), oracle.Scatter2Gather.apply(x))
+
+
+@pytest.mark.parametrize("bs,c,h,w,k", SHAPES)
+def test_kernel_weighting_fwd_bwd(oracle, bs, c, h, w, k):
+    from sbmc_amd import functions as F
+    th.manual_seed(3)
+    data = (2 * th.randn(bs, c, h, w)).requires_grad_()
+    wts = th.randn(bs, k, k, h, w).requires_grad_()
+    go = th.randn(bs, c, h, w)
+    gs = th.randn(bs, h, w)
+    o_ref, s_ref = oracle.KernelWeighting.apply(data, wts)
+    th.autograd.backward([o_ref, s_ref], [go, gs])
+    dg, wg = data.grad.clone(), wts.grad.clone()
+
+    data_g = data.detach().cuda().requires_grad_()
+    wts_g = wts.detach().cuda().requires_grad_()
+    o, s = F.KernelWeighting.apply(data_g, wts_g)
+    th.autograd.backward([o, s], [go.cuda(), gs.cuda()])
+    close(o, o_ref, what="output")
+    close(s, s_ref, what="sum_w")
+    close(data_g.grad, dg, what="d_data")
+    close(wts_g.grad, wg, what="d_weights")
+
+
+def test_kernel_weighting_rectangular(oracle):
+    from sbmc_amd import functions as F
+    th.manual_seed(4)
+    data = th.randn(1, 3, 20, 90)
+    wts = th.randn(1, 3, 5, 20, 90)
+    o_ref, s_ref = oracle.KernelWeighting.apply(data, wts)
+    o, s = F.KernelWeighting.apply(data.cuda(), wts.cuda())
+    close(o, o_ref)
+    close(s, s_ref)
+
+
+def _progressive(mod_fn, data_list, kern_list, grads, device):
+    """Runs S progressive updates, then backward with upstream grads on all 3 outputs."""
+    datas = [d.detach().to(device).requires_grad_() for d in data_list]
+    kerns = [k.detach().to(device).requires_grad_() for k in kern_list]
+    sr = sw = mw = None
+    for d, k in zip(datas, kerns):
+        sr, sw, mw = mod_fn(d, k, sr, sw, mw)
+    th.autograd.backward([sr, sw, mw], [g.to(device) for g in grads])
+    return (sr, sw, mw), [d.grad for d in datas], [k.grad for k in kerns]
+
+
+@pytest.mark.parametrize("bs,c,h,w,k,spp", [
+    (1, 3, 16, 16, 3, 3),
+    (2, 3, 19, 70, 5, 2),
+    (1, 5, 9, 130, 7, 2),
+    (1, 3, 40, 150, 21, 3),
+    (1, 3, 5, 7, 21, 2),
+    (1, 8, 12, 66, 3, 2),
+])
+def test_fused_splat_update_vs_oracle(oracle, bs, c, h, w, k, spp):
+    """Fused fwd+bwd == the reference composition (oracle ops + torch autograd), with
+    non-trivial upstream gradients on sum_r, sum_w AND max_w so that the arg-max
+    routing of the running max is exercised."""
+    from sbmc_amd import modules
+    th.manual_seed(5)
+    datas = [th.rand(bs, c, h, w) * 2 for _ in range(spp)]
+    kerns = [th.randn(bs, k * k, h, w) * 2 for _ in range(spp)]
+    grads = [th.randn(bs, c, h, w), th.randn(bs, 1, h, w), th.randn(bs, 1, h, w)]
+
+    ref_out, ref_dd, ref_dk = _progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=True),
+        datas, kerns, grads, "cpu")
+    fused = modules.ProgressiveKernelApply(splat=True)
+    out, dd, dk = _progressive(fused, datas, kerns, grads, "cuda")
+    for a, b, n in zip(out, ref_out, ("sum_r", "sum_w", "max_w")):
+        close(a, b, what=n)
+    for s in range(spp):
+        close(dd[s], ref_dd[s], what="d_data[%d]" % s)
+        close(dk[s], ref_dk[s], what="d_kernels[%d]" % s)
+
+
+@pytest.mark.parametrize("splat", [True, False])
+def test_composed_path_on_gpu_vs_oracle(oracle, splat):
+    """The non-fused composition (Scatter2Gather + KernelWeighting HIP ops + torch) on GPU."""
+    from sbmc_amd import modules
+    th.manual_seed(6)
+    bs, c, h, w, k, spp = 1, 3, 21, 77, 5, 2
+    datas = [th.rand(bs, c, h, w) for _ in range(spp)]
+    kerns = [th.randn(bs, k * k, h, w) for _ in range(spp)]
+    grads = [th.randn(bs, c, h, w), th.randn(bs, 1, h, w), th.randn(bs, 1, h, w)]
+    ref_out, ref_dd, ref_dk = _progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=splat),
+        datas, kerns, grads, "cpu")
+    mod = modules.ProgressiveKernelApply(splat=splat, fused=False)
+    out, dd, dk = _progressive(mod, datas, kerns, grads, "cuda")
+    for a, b in zip(out, ref_out):
+        close(a, b)
+    for s in range(spp):
+        close(dd[s], ref_dd[s])
+        close(dk[s], ref_dk[s])
+
+
+def test_fused_forces_running_max_branches(oracle):
+    """Data-dependent branches need their own test: sample 2 raises the max everywhere
+    (spike), sample 3 nowhere, and exact ties between kmax and the running max."""
+    from sbmc_amd import modules
+    th.manual_seed(7)
+    bs, c, h, w, k = 1, 3, 12, 70, 5
+    base = th.randn(bs, k * k, h, w)
+    spike = base.clone()
+    spike[:, 7] += 30.0
+    low = base - 50.0
+    datas = [th.rand(bs, c, h, w) for _ in range(4)]
+    kerns = [base, spike, low, spike.clone()]  # last one ties exactly with the running max
+    grads = [th.randn(bs, c, h, w), th.randn(bs, 1, h, w), th.randn(bs, 1, h, w)]
+    ref_out, ref_dd, ref_dk = _progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=True),
+        datas, kerns, grads, "cpu")
+    out, dd, dk = _progressive(modules.ProgressiveKernelApply(splat=True), datas, kerns, grads, "cuda")
+    for a, b in zip(out, ref_out):
+        close(a, b)
+    for s in range(4):
+        close(dd[s], ref_dd[s], what="d_data[%d]" % s)
+        close(dk[s], ref_dk[s], what="d_kernels[%d]" % s)
+
+
+def test_cpu_tensors_are_refused():
+    from sbmc_amd import functions as F
+    with pytest.raises(RuntimeError):
+        F.KernelWeighting.apply(th.zeros(1, 3, 8, 8), th.zeros(1, 3, 3, 8, 8))
