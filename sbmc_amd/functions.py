@@ -15,6 +15,35 @@ from . import halide_ops as ops
 __all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported"]
 
 
+# Optional per-call device timing (used by bench.py for the roofline figure): when a list
+# is installed, every fused call appends (name, start_event, end_event), recorded on the
+# stream the kernels are launched on (torch's current stream).
+_KERNEL_TIMINGS = None
+
+
+def enable_kernel_timing(store):
+    """store: a list to append (name, start, end) event triples to, or None to disable."""
+    global _KERNEL_TIMINGS
+    _KERNEL_TIMINGS = store
+
+
+class _timed(object):
+    def __init__(self, name, device):
+        self.name, self.device = name, device
+
+    def __enter__(self):
+        if _KERNEL_TIMINGS is not None:
+            self.start = th.cuda.Event(enable_timing=True)
+            self.end = th.cuda.Event(enable_timing=True)
+            self.start.record(th.cuda.current_stream(self.device))
+
+    def __exit__(self, *exc):
+        if _KERNEL_TIMINGS is not None:
+            self.end.record(th.cuda.current_stream(self.device))
+            _KERNEL_TIMINGS.append((self.name, self.start, self.end))
+        return False
+
+
 def _is_cuda(*args):
     """True if any argument lives on a GPU (reference functions.py:30-36)."""
     for arg in args:
@@ -159,7 +188,7 @@ class SplatUpdate(th.autograd.Function):
         kmax = data.new_empty(bs, h, w)
         arow = th.empty(bs, h, w, dtype=th.int32, device=data.device)
         dev = data.device
-        with th.cuda.device(dev):
+        with th.cuda.device(dev), _timed("splat_update_fwd", dev):
             rc = _lib.lib().sbmc_splat_update_fwd_f32(
                 _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
                 _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(arow),
@@ -193,7 +222,7 @@ class SplatUpdate(th.autograd.Function):
             d_sum_w = th.empty_like(sum_w)
             d_max_w = th.empty_like(max_w)
         dev = data.device
-        with th.cuda.device(dev):
+        with th.cuda.device(dev), _timed("splat_update_bwd", dev):
             rc = _lib.lib().sbmc_splat_update_bwd_f32(
                 _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
                 _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(arow),
