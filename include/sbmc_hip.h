@@ -28,6 +28,7 @@
 #ifndef SBMC_HIP_H
 #define SBMC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -111,8 +112,8 @@ SBMC_API int sbmc_splat_update_supported(int c, int k);
  *             (modules.py:431-447); a mix of NULL / non-NULL is SBMC_HIP_EINVAL
  *   sum_r_out, sum_w_out, max_w_out   updated state (same shapes)
  *   kmax_out  [bs, h, w]       max over this sample's gather taps (modules.py:429)
- *   arow_out  [bs, h, w] int32 gather-kernel row dy of the first tap attaining kmax
- *             (kmax_out / arow_out are saved for backward: autograd routes the
+ *   atap_out  [bs, h, w] int32 gather tap index dy*k+dx of the first tap attaining kmax
+ *             (kmax_out / atap_out are saved for backward: autograd routes the
  *             gradient of the max to that tap)
  * With g[t] the gather-layout logits of destination pixel q (0 where the source
  * pixel lies outside the image) and M = max(kmax, max_w_in):
@@ -124,9 +125,12 @@ SBMC_API int sbmc_splat_update_fwd_f32(const float *data, const float *kernels,
                               const float *max_w_in,
                               float *sum_r_out, float *sum_w_out,
                               float *max_w_out, float *kmax_out,
-                              int32_t *arow_out,
+                              int32_t *atap_out,
                               int bs, int c, int h, int w, int k,
                               void *stream);
+
+/* Size in bytes of the workspace sbmc_splat_update_bwd_f32 needs for these dimensions. */
+SBMC_API size_t sbmc_splat_update_bwd_scratch_bytes(int bs, int c, int h, int w, int k);
 
 /*
  * Fused progressive splat update, backward -- the adjoint of the call above,
@@ -136,26 +140,27 @@ SBMC_API int sbmc_splat_update_fwd_f32(const float *data, const float *kernels,
  * gradient.
  *
  *   inputs saved from forward: data, kernels, sum_r_in/sum_w_in/max_w_in (or all
- *       NULL), sum_r_out, sum_w_out, max_w_out, kmax, arow
+ *       NULL), sum_r_out, sum_w_out, max_w_out, kmax, atap
  *   upstream gradients: d_sum_r_out [bs,c,h,w], d_sum_w_out [bs,h,w],
  *       d_max_w_out [bs,h,w]   (all required; pass zeros where unused)
  *   outputs: d_data [bs,c,h,w], d_kernels [bs,k*k,h,w] (splat layout), and --
  *       unless this was the initialisation call -- d_sum_r_in, d_sum_w_in,
  *       d_max_w_in (pass NULL for all three on the initialisation call)
- *   scratch: d_kmax_scratch [bs,h,w] caller-provided workspace (the library
- *       holds no global state); contents undefined on return.
+ *   scratch: caller-provided device workspace of
+ *       sbmc_splat_update_bwd_scratch_bytes(bs, c, h, w, k) bytes (the library holds
+ *       no global state and never allocates); contents undefined on return.
  */
 SBMC_API int sbmc_splat_update_bwd_f32(const float *data, const float *kernels,
                               const float *sum_r_in, const float *sum_w_in,
                               const float *max_w_in,
                               const float *sum_r_out, const float *sum_w_out,
                               const float *max_w_out, const float *kmax,
-                              const int32_t *arow,
+                              const int32_t *atap,
                               const float *d_sum_r_out, const float *d_sum_w_out,
                               const float *d_max_w_out,
                               float *d_data, float *d_kernels,
                               float *d_sum_r_in, float *d_sum_w_in,
-                              float *d_max_w_in, float *d_kmax_scratch,
+                              float *d_max_w_in, float *scratch,
                               int bs, int c, int h, int w, int k,
                               void *stream);
 

@@ -20,6 +20,7 @@ SYMBOLS = (
     "sbmc_kernel_weighting_fwd_f32",
     "sbmc_kernel_weighting_bwd_f32",
     "sbmc_splat_update_supported",
+    "sbmc_splat_update_bwd_scratch_bytes",
     "sbmc_splat_update_fwd_f32",
     "sbmc_splat_update_bwd_f32",
 )
@@ -56,8 +57,10 @@ def lib():
     handle.sbmc_splat_update_supported.argtypes = [i, i]
     handle.sbmc_splat_update_fwd_f32.argtypes = [p] * 10 + [i] * 5 + [p]
     handle.sbmc_splat_update_bwd_f32.argtypes = [p] * 19 + [i] * 5 + [p]
+    handle.sbmc_splat_update_bwd_scratch_bytes.argtypes = [i] * 5
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
+    handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t
     if handle.sbmc_hip_abi_version() != ABI_VERSION:
         raise HipExtensionMissing("ABI version mismatch: rebuild with `python -m sbmc_amd.build --force`")
     _LIB = handle

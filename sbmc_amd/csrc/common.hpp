@@ -37,12 +37,16 @@ static inline int tiles_y(int h, int ty) { return (h + ty - 1) / ty; }
 // Physical block b runs on XCD b % 8 (observed placement -- used for speed only,
 // correctness does not depend on it).  XCD x receives the logical tile range
 // [x*q + min(x, r), ...) so that it walks consecutive tiles (x fastest, then y).
-__device__ __forceinline__ TileCoord decode_tile(int ntx, int nty, int ty_rows) {
+__device__ __forceinline__ unsigned logical_block_id() {
     const unsigned nb = gridDim.x;
     const unsigned b = blockIdx.x;
     const unsigned q = nb / NUM_XCD, r = nb % NUM_XCD;
     const unsigned xcd = b % NUM_XCD, i = b / NUM_XCD;
-    const unsigned logical = xcd * q + (xcd < r ? xcd : r) + i;
+    return xcd * q + (xcd < r ? xcd : r) + i;
+}
+
+__device__ __forceinline__ TileCoord decode_tile(int ntx, int nty, int ty_rows) {
+    const unsigned logical = logical_block_id();
     TileCoord t;
     const unsigned per_img = (unsigned)ntx * (unsigned)nty;
     t.n = (int)(logical / per_img);
@@ -71,7 +75,35 @@ __device__ __forceinline__ void stage_plane(float* __restrict__ dst,
     }
 }
 
+// Raw buffer access (SRSRC descriptor in SGPRs): address = base + soffset(SGPR) + voffset(VGPR).
+// All per-tap address arithmetic is scalar; the one per-lane offset register is shared by
+// every load/store of a strip.  The hardware bounds check runs on voffset only, so a lane
+// is switched off by giving it BUF_OOB: its loads return 0 and its stores are dropped.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned BUF_RANGE = 0x80000000u;  // num_records: valid voffsets are below this
+constexpr unsigned BUF_OOB = 0x80000000u;    // voffset of a switched-off lane
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* uniform_base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_base), /*stride*/ 0,
+                                             BUF_RANGE, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Orders this wave's LDS traffic: LDS operations of one wavefront execute in issue
+// order, so lanes of a wave may exchange data through LDS without s_barrier -- but the
+// compiler must be told not to move LDS accesses across the hand-off point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ int wave_id() {
     return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -89,5 +121,14 @@ __device__ __forceinline__ int wave_id() {
         case 6: { constexpr int C = 6; __VA_ARGS__; } break;         \
         case 7: { constexpr int C = 7; __VA_ARGS__; } break;         \
         case 8: { constexpr int C = 8; __VA_ARGS__; } break;         \
+        default: return SBMC_HIP_EINVAL;                             \
+    }
+
+#define SBMC_DISPATCH_C4(CVAL, ...)                                  \
+    switch (CVAL) {                                                  \
+        case 1: { constexpr int C = 1; __VA_ARGS__; } break;         \
+        case 2: { constexpr int C = 2; __VA_ARGS__; } break;         \
+        case 3: { constexpr int C = 3; __VA_ARGS__; } break;         \
+        case 4: { constexpr int C = 4; __VA_ARGS__; } break;         \
         default: return SBMC_HIP_EINVAL;                             \
     }

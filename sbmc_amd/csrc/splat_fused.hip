@@ -14,28 +14,44 @@
 //   (2p-dy, 2p-dx):  g = S[(2p-dy)*k + (2p-dx)][Y+dy-p][X+dx-p]   (0 if outside).
 //   A wave therefore reads, per tap, one contiguous 256-byte row segment of one
 //   tap plane, shifted by (dx-p) floats: coalesced, merely misaligned.  Radiance
-//   of the contributing sample comes from an LDS halo tile.  The softmax over the
-//   441 taps (and the merge with the running state of earlier samples) is an
-//   online softmax with one rescale per kernel row (21 taps), all in registers.
+//   of the contributing sample comes from LDS.  The softmax over the k*k taps (and
+//   the merge with the running state of earlier samples) is an online softmax in
+//   registers with one rescale per kernel row.
 //
 // Backward (sample-centred, "scatter" view):
 //   lane = sample pixel (ys,xs).  Tap (ky,kx) lands on destination
 //   (ys+ky-p, xs+kx-p).  Reads of S and writes of dS are *aligned* 256-byte
 //   segments of plane (ky,kx); the per-destination quantities (final max M,
-//   upstream dR[c], dW) come from an LDS halo tile:
+//   upstream dR[c], dW, and the gradient of the max with its arg-max tap) come
+//   from LDS:
 //       e  = exp(S - M[q]);  dS = e * (dW[q] + sum_c dR[q][c] * D[c]);  dD[c] += e * dR[q][c]
+//       dS += d_kmax[q]  where this tap is q's arg-max  (torch routes max() that way)
 //   Destinations outside the image carry M = +1e30 => e = 0 (Scatter2Gather's
-//   zero fill and its adjoint).  The dependence of the outputs on the running
-//   max itself (torch routes it to the arg-max tap, modules.py:429,450) is
-//   handled exactly by two small per-pixel kernels around the main one.
+//   zero fill and its adjoint).
+//
+// Two generations of kernels live here:
+//   v1  "tile" kernels: a workgroup owns a 64 x TY pixel tile and stages a haloed
+//       tile of the small operand in LDS.  Any odd k, up to 8 channels.  This is
+//       the generic path.
+//   v2  "strip" kernels (k = 21, <= 4 channels -- the SBMC configuration): a
+//       wavefront owns one 64-pixel row strip; the 4 waves of a workgroup are
+//       x-adjacent so that the cache lines their misaligned segments share are
+//       requested from one CU at nearly the same time; the small operand is staged
+//       per wave, one kernel row at a time, in a 1-2 KB LDS ring (no s_barrier
+//       anywhere); the big streams go through raw buffer loads/stores whose per-tap
+//       offsets are scalar, so a strip needs one VGPR of addressing in total.
 #include "common.hpp"
 #include "../../include/sbmc_hip.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace sbmc {
 
-constexpr int FWD_TY = 4;   // forward : 4 waves, LDS tile [C][TY+k-1][64+k-1]
-constexpr int BWD_TY = 8;   // backward: 8 waves, LDS tile [C+2][TY+k-1][64+k-1]
+constexpr int FWD_TY = 4;   // v1 forward : 4 waves, LDS tile [C][TY+k-1][64+k-1]
+constexpr int BWD_TY = 8;   // v1 backward: 8 waves, LDS tile [C+2][TY+k-1][64+k-1]
+constexpr int V2_WAVES = 4; // v2: 4 x-adjacent strips per workgroup
+constexpr int V2_ROW = 96;  // v2: staged positions per strip (>= 64 + k - 1)
+constexpr int REC = 8;      // v2 backward: floats per destination record
 
 struct SplatFwdParams {
     const float* data;       // [bs, c, h, w]
@@ -47,43 +63,16 @@ struct SplatFwdParams {
     float* sum_w_out;
     float* max_w_out;
     float* kmax_out;
-    int32_t* arow_out;
+    int32_t* atap_out;
     int bs, h, w, k;
     int ntx, nty;
 };
 
-// One kernel row (K taps) of the online softmax for one destination pixel.
-//   v[dx]    : the K gather logits of this row
-//   drow     : LDS pointer to Dtile[0][wave+dy][lane]; channel stride cstride
-template <int K, int C>
-__device__ __forceinline__ void fwd_row_update(const float (&v)[K], const float* drow, int cstride,
-                                               int dy, float& m, float& kmax, int& arow,
-                                               float (&acc)[C], float& accw) {
-    float rmax = v[0];
-#pragma unroll
-    for (int dx = 1; dx < K; ++dx) rmax = fmaxf(rmax, v[dx]);
-    if (rmax > kmax) { kmax = rmax; arow = dy; }
-    const float mn = fmaxf(m, rmax);
-    const float sc = fast_exp2((m - mn) * LOG2E);  // m == -inf on the first row of an init call -> 0
-    m = mn;
-    accw *= sc;
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] *= sc;
-#pragma unroll
-    for (int dx = 0; dx < K; ++dx) {
-        const float e = fast_exp2((v[dx] - mn) * LOG2E);
-        accw += e;
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = fmaf(e, drow[c * cstride + dx], acc[c]);
-    }
-}
-
-// K > 0: compile-time kernel size (row-buffered online softmax, unrolled taps).
-// K == 0: any odd runtime k (tap-at-a-time online softmax; correctness path).
-template <int K, int C>
-__global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_kernel(SplatFwdParams p) {
+// ------------------------------------------------------------------ v1 forward
+template <int C>
+__global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_tile_kernel(SplatFwdParams p) {
     extern __shared__ float lds[];  // [C][th][tw] radiance halo tile, zero outside the image
-    const int k = K > 0 ? K : p.k;
+    const int k = p.k;
     const int pad = (k - 1) / 2;
     const int th = FWD_TY + k - 1, tw = TX + k - 1;
     const TileCoord t = decode_tile(p.ntx, p.nty, FWD_TY);
@@ -113,11 +102,9 @@ __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_kernel(SplatFwdParams p
         for (int c = 0; c < C; ++c) acc[c] = p.sum_r_in[((size_t)t.n * C + c) * hw + pix];
     }
     float kmax = -INFINITY;
-    int arow = 0;
+    int atap = 0;
 
     const float* S = p.kernels + (size_t)t.n * k * k * hw;
-    // wave-uniform: every lane's source column is inside the image for every dx
-    const bool interior_x = (t.x0 - pad >= 0) && (t.x0 + TX - 1 + pad < p.w);
     const int cstride = th * tw;
 
     for (int dy = 0; dy < k; ++dy) {
@@ -127,44 +114,22 @@ __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_kernel(SplatFwdParams p
         // plane (2p-dy, 2p-dx), row ys, column X+dx-p  ==  rowbase - dx*(hw-1) + lane
         const float* rowbase = S + ((long)((2 * pad - dy) * k + 2 * pad) * (long)hw +
                                     (long)(yin ? ys : 0) * p.w + (long)(t.x0 - pad));
-        if constexpr (K > 0) {
-            float v[K];
-            if (!yin) {
+        for (int dx = 0; dx < k; ++dx) {
+            const int xs = X + dx - pad;
+            const float* q = rowbase - (long)dx * (long)(hw - 1);
+            const float v = (yin && xs >= 0 && xs < p.w) ? q[lane] : 0.f;
+            if (v > kmax) { kmax = v; atap = dy * k + dx; }
+            if (v > m) {
+                const float sc = fast_exp2((m - v) * LOG2E);
+                accw *= sc;
 #pragma unroll
-                for (int dx = 0; dx < K; ++dx) v[dx] = 0.f;
-            } else if (interior_x) {
-#pragma unroll
-                for (int dx = 0; dx < K; ++dx) {
-                    const float* q = rowbase - (long)dx * (long)(hw - 1);  // uniform base
-                    v[dx] = q[lane];
-                }
-            } else {
-#pragma unroll
-                for (int dx = 0; dx < K; ++dx) {
-                    const int xs = X + dx - pad;
-                    const float* q = rowbase - (long)dx * (long)(hw - 1);
-                    v[dx] = (xs >= 0 && xs < p.w) ? q[lane] : 0.f;
-                }
+                for (int c = 0; c < C; ++c) acc[c] *= sc;
+                m = v;
             }
-            fwd_row_update<K, C>(v, drow, cstride, dy, m, kmax, arow, acc, accw);
-        } else {
-            for (int dx = 0; dx < k; ++dx) {
-                const int xs = X + dx - pad;
-                const float* q = rowbase - (long)dx * (long)(hw - 1);
-                const float v = (yin && xs >= 0 && xs < p.w) ? q[lane] : 0.f;
-                if (v > kmax) { kmax = v; arow = dy; }
-                if (v > m) {
-                    const float sc = fast_exp2((m - v) * LOG2E);
-                    accw *= sc;
+            const float e = fast_exp2((v - m) * LOG2E);
+            accw += e;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) acc[c] *= sc;
-                    m = v;
-                }
-                const float e = fast_exp2((v - m) * LOG2E);
-                accw += e;
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] = fmaf(e, drow[c * cstride + dx], acc[c]);
-            }
+            for (int c = 0; c < C; ++c) acc[c] = fmaf(e, drow[c * cstride + dx], acc[c]);
         }
     }
 
@@ -173,9 +138,157 @@ __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_kernel(SplatFwdParams p
         p.sum_w_out[o] = accw;
         p.max_w_out[o] = m;
         p.kmax_out[o] = kmax;
-        p.arow_out[o] = arow;
+        p.atap_out[o] = atap;
 #pragma unroll
         for (int c = 0; c < C; ++c) p.sum_r_out[((size_t)t.n * C + c) * hw + pix] = acc[c];
+    }
+}
+
+// ------------------------------------------------------------------ v2 forward
+// One kernel row (K taps) of the online softmax for one destination pixel.
+//   v[dx] : the K gather logits of this row;  srow : LDS, staged radiance positions
+template <int K, int C>
+__device__ __forceinline__ void fwd_row_update(const float (&v)[K], const float* srow, int dy,
+                                               float& m, float& kmax, int& atap,
+                                               float (&acc)[C], float& accw) {
+    float rmax = v[0];
+#pragma unroll
+    for (int dx = 1; dx < K; ++dx) rmax = fmaxf(rmax, v[dx]);
+    if (rmax > kmax) {  // strict: the first row attaining the max wins
+        kmax = rmax;
+        int idx = K - 1;
+#pragma unroll
+        for (int dx = K - 2; dx >= 0; --dx) idx = (v[dx] == rmax) ? dx : idx;  // first tap in the row
+        atap = dy * K + idx;
+    }
+    const float mn = fmaxf(m, rmax);
+    const float sc = fast_exp2((m - mn) * LOG2E);  // m == -inf on the first row of an init call -> 0
+    m = mn;
+    accw *= sc;
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] *= sc;
+    // taps in groups of G: the scheduling barrier keeps the compiler from hoisting all
+    // K*C LDS reads of the row to the top (which costs >100 VGPRs and the occupancy)
+    constexpr int G = 7;
+#pragma unroll
+    for (int g = 0; g < K; g += G) {
+#pragma unroll
+        for (int dx = g; dx < (g + G < K ? g + G : K); ++dx) {
+            const float e = fast_exp2((v[dx] - mn) * LOG2E);
+            accw += e;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = fmaf(e, srow[c * V2_ROW + dx], acc[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int K, int C>
+__global__ __launch_bounds__(V2_WAVES * TX, 7) void splat_fwd_strip_kernel(SplatFwdParams p) {
+    static_assert(TX + K - 1 <= V2_ROW, "staged row too short");
+    constexpr int P = (K - 1) / 2;
+    __shared__ float lds[V2_WAVES * C * V2_ROW];  // per wave: [C][V2_ROW] radiance of one source row
+    const int wv = wave_id();
+    const int lane = threadIdx.x & 63;
+    const long item = (long)logical_block_id() * V2_WAVES + wv;
+    const int nseg = p.ntx;
+    const long per_img = (long)p.h * nseg;
+    if (item >= per_img * p.bs) return;  // whole wave; no block-level barrier is used below
+    // readfirstlane: the divisions run on the VALU; force the (uniform) results back to
+    // SGPRs so that every address below is "SGPR base + lane" (global_load saddr form)
+    const int n = __builtin_amdgcn_readfirstlane((int)(item / per_img));
+    const int rem = __builtin_amdgcn_readfirstlane((int)(item % per_img));
+    const int Y = __builtin_amdgcn_readfirstlane(rem / nseg);
+    const int X0 = __builtin_amdgcn_readfirstlane((rem % nseg) * TX);
+    const int X = X0 + lane;
+    const bool xact = X < p.w;
+    const size_t hw = (size_t)p.h * p.w;
+    const size_t pix = (size_t)Y * p.w + (xact ? X : p.w - 1);
+    const bool first = (p.sum_r_in == nullptr);
+    float* buf = lds + wv * (C * V2_ROW);
+
+    float m = -INFINITY, accw = 0.f, acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    if (!first) {
+        m = p.max_w_in[(size_t)n * hw + pix];
+        accw = p.sum_w_in[(size_t)n * hw + pix];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = p.sum_r_in[((size_t)n * C + c) * hw + pix];
+    }
+    float kmax = -INFINITY;
+    int atap = 0;
+
+    const float* S = p.kernels + (size_t)n * K * K * hw;
+    const float* data = p.data + (size_t)n * C * hw;
+    const bool interior_x = (X0 - P >= 0) && (X0 + TX - 1 + P < p.w);  // wave-uniform
+    // staged source columns: positions 0..63 by every lane, 64..64+K-2 by the first K-1 lanes
+    const int colA = X0 - P + lane, colB = colA + TX;
+    const bool inA = (colA >= 0) && (colA < p.w);
+    const bool inB = (lane < K - 1) && (colB < p.w);
+    const unsigned voff = (unsigned)lane * 4u;
+    const unsigned tap_stride = (unsigned)(hw - 1) * 4u;  // bytes between taps dx+1 -> dx
+    // border strips: lane's source column X+dx-P is inside the image for dx in [dx_lo, dx_hi)
+    const int dx_lo = P - X, dx_hi = p.w + P - X;
+
+    auto load_row = [&](int dy, float (&v)[K], float (&s)[2 * C]) {
+        const int ys = Y + dy - P;
+        const bool yin = (ys >= 0) && (ys < p.h);  // wave-uniform
+        if (!yin) {
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) v[dx] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * C; ++j) s[j] = 0.f;
+            return;
+        }
+        // tap dx of this row: plane (2P-dy)*K + (K-1-dx), row ys, column X0-P+dx+lane
+        //   = rowmin + (K-1-dx) * (hw-1) + lane,  rowmin = address of tap K-1, lane 0
+        const rsrc_t rs = make_rsrc(S + ((long)((2 * P - dy) * K) * (long)hw + (long)ys * p.w + (long)(X0 + P)));
+        if (interior_x) {
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) v[dx] = buf_load(rs, voff, (unsigned)(K - 1 - dx) * tap_stride);
+        } else {
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const unsigned vo = (dx >= dx_lo && dx < dx_hi) ? voff : BUF_OOB;  // OOB lanes read 0
+                v[dx] = buf_load(rs, vo, (unsigned)(K - 1 - dx) * tap_stride);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float* dr = data + c * hw + (size_t)ys * p.w;
+            s[2 * c] = inA ? dr[colA] : 0.f;
+            s[2 * c + 1] = inB ? dr[colB] : 0.f;
+        }
+    };
+    auto step = [&](int dy, const float (&v)[K], const float (&s)[2 * C]) {
+        wave_lds_sync();  // previous row's reads are done before its slots are overwritten
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            buf[c * V2_ROW + lane] = s[2 * c];
+            if (lane < K - 1) buf[c * V2_ROW + TX + lane] = s[2 * c + 1];
+        }
+        wave_lds_sync();
+        fwd_row_update<K, C>(v, buf + lane, dy, m, kmax, atap, acc, accw);
+    };
+
+    // (A register double-buffer that prefetches row dy+1 while row dy is reduced was tried:
+    // it costs ~40 VGPRs, i.e. 2-3 waves/SIMD of occupancy, and measured slower.)
+    float v[K], s[2 * C];
+#pragma unroll 1
+    for (int dy = 0; dy < K; ++dy) {
+        load_row(dy, v, s);
+        step(dy, v, s);
+    }
+
+    if (xact) {
+        const size_t o = (size_t)n * hw + pix;
+        p.sum_w_out[o] = accw;
+        p.max_w_out[o] = m;
+        p.kmax_out[o] = kmax;
+        p.atap_out[o] = atap;
+#pragma unroll
+        for (int c = 0; c < C; ++c) p.sum_r_out[((size_t)n * C + c) * hw + pix] = acc[c];
     }
 }
 
@@ -190,7 +303,7 @@ struct SplatBwdParams {
     const float* sum_w_out;
     const float* max_w_out;
     const float* kmax;
-    const int32_t* arow;
+    const int32_t* atap;
     const float* d_sum_r_out;
     const float* d_sum_w_out;
     const float* d_max_w_out;
@@ -199,7 +312,7 @@ struct SplatBwdParams {
     float* d_sum_r_in;         // or null
     float* d_sum_w_in;
     float* d_max_w_in;
-    float* d_kmax;             // scratch [bs, h, w]
+    float* scratch;            // v1: d_kmax [bs, h, w];  v2: destination records [bs, h, w, REC]
     int bs, c, h, w, k;
     int ntx, nty;
 };
@@ -211,7 +324,9 @@ struct SplatBwdParams {
 //   d_max_in   = sigma * (dR . sum_r_in + dW * sum_w_in) + dM_total * [max_in >  kmax] (1/2 on ties)
 //   d_kmax     =                                           dM_total * [kmax   >  max_in] (1/2 on ties)
 // (torch.max(a, b) splits the gradient evenly on ties.)
-template <int C>
+// RECORDS = false: writes d_kmax to scratch[bs,h,w]                          (v1)
+// RECORDS = true : writes {M, dW, d_kmax, atap | dR0..dR3} to scratch[bs,h,w,8] (v2)
+template <int C, bool RECORDS>
 __global__ __launch_bounds__(256) void splat_bwd_state_kernel(SplatBwdParams p) {
     const size_t hw = (size_t)p.h * p.w;
     const size_t total = (size_t)p.bs * hw;
@@ -228,10 +343,10 @@ __global__ __launch_bounds__(256) void splat_bwd_state_kernel(SplatBwdParams p) 
             dot_out = fmaf(dR[c], p.sum_r_out[(n * C + c) * hw + pix], dot_out);
         }
         const float dMtot = p.d_max_w_out[i] - dot_out;
-        if (first) {
-            p.d_kmax[i] = dMtot;
-        } else {
-            const float M = p.max_w_out[i], Mp = p.max_w_in[i], km = p.kmax[i];
+        const float M = p.max_w_out[i];
+        float dkmax = dMtot;
+        if (!first) {
+            const float Mp = p.max_w_in[i], km = p.kmax[i];
             const float sigma = expf(Mp - M);
             float dot_in = dW * p.sum_w_in[i];
 #pragma unroll
@@ -242,15 +357,30 @@ __global__ __launch_bounds__(256) void splat_bwd_state_kernel(SplatBwdParams p) 
             p.d_sum_w_in[i] = dW * sigma;
             const float sel_prev = Mp > km ? 1.f : (Mp == km ? 0.5f : 0.f);
             p.d_max_w_in[i] = sigma * dot_in + dMtot * sel_prev;
-            p.d_kmax[i] = dMtot * (1.f - sel_prev);
+            dkmax = dMtot * (1.f - sel_prev);
+        }
+        if constexpr (RECORDS) {
+            static_assert(C <= 4, "records hold up to 4 channels");
+            float4 r0, r1;
+            r0.x = M; r0.y = dW; r0.z = dkmax; r0.w = __int_as_float(p.atap[i]);
+            r1.x = dR[0];
+            r1.y = C > 1 ? dR[C > 1 ? 1 : 0] : 0.f;
+            r1.z = C > 2 ? dR[C > 2 ? 2 : 0] : 0.f;
+            r1.w = C > 3 ? dR[C > 3 ? 3 : 0] : 0.f;
+            float4* rec = reinterpret_cast<float4*>(p.scratch) + i * 2;
+            rec[0] = r0;
+            rec[1] = r1;
+        } else {
+            p.scratch[i] = dkmax;
         }
     }
 }
 
-template <int K, int C>
-__global__ __launch_bounds__(BWD_TY * TX) void splat_bwd_main_kernel(SplatBwdParams p) {
+// v1 main: tile kernel, any odd k, up to 8 channels.
+template <int C>
+__global__ __launch_bounds__(BWD_TY * TX) void splat_bwd_tile_kernel(SplatBwdParams p) {
     extern __shared__ float lds[];  // [C+2][th][tw]: M (1e30 outside), dR[0..C) (0 outside), dW (0 outside)
-    const int k = K > 0 ? K : p.k;
+    const int k = p.k;
     const int pad = (k - 1) / 2;
     const int th = BWD_TY + k - 1, tw = TX + k - 1;
     const int fstride = th * tw;
@@ -284,114 +414,220 @@ __global__ __launch_bounds__(BWD_TY * TX) void splat_bwd_main_kernel(SplatBwdPar
 
     for (int ky = 0; ky < k; ++ky) {
         const float* trow = lds + (wv + ky) * tw + lane;
-        if constexpr (K > 0) {
-            float s[K];
+        for (int kx = 0; kx < k; ++kx) {
+            const float s = (S + (size_t)(ky * k + kx) * hw)[lane];
+            const float e = fast_exp2((s - trow[kx]) * LOG2E);
+            float g = trow[(1 + C) * fstride + kx];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) s[kx] = (S + (size_t)(ky * K + kx) * hw)[lane];
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const float e = fast_exp2((s[kx] - trow[kx]) * LOG2E);
-                float g = trow[(1 + C) * fstride + kx];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float a = trow[(1 + c) * fstride + kx];
-                    g = fmaf(a, D[c], g);
-                    dD[c] = fmaf(e, a, dD[c]);
-                }
-                (dS + (size_t)(ky * K + kx) * hw)[lane] = e * g;
+            for (int c = 0; c < C; ++c) {
+                const float a = trow[(1 + c) * fstride + kx];
+                g = fmaf(a, D[c], g);
+                dD[c] = fmaf(e, a, dD[c]);
             }
-        } else {
-            for (int kx = 0; kx < k; ++kx) {
-                const float s = (S + (size_t)(ky * k + kx) * hw)[lane];
-                const float e = fast_exp2((s - trow[kx]) * LOG2E);
-                float g = trow[(1 + C) * fstride + kx];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float a = trow[(1 + c) * fstride + kx];
-                    g = fmaf(a, D[c], g);
-                    dD[c] = fmaf(e, a, dD[c]);
-                }
-                (dS + (size_t)(ky * k + kx) * hw)[lane] = e * g;
-            }
+            (dS + (size_t)(ky * k + kx) * hw)[lane] = e * g;
         }
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) p.d_data[((size_t)t.n * C + c) * hw + pix] = dD[c];
 }
 
-// Routes d_kmax to the arg-max tap (torch: kernels_view.max(1) backward scatters to
-// one index, modules.py:429).  One lane per destination pixel; only the K taps of the
-// recorded arg-max row are scanned, and only where d_kmax != 0.  Distinct
+// v1 routing: adds d_kmax to the arg-max tap recorded by the forward (torch:
+// kernels_view.max(1) backward scatters to one index, modules.py:429).  Distinct
 // destinations map to distinct (tap, sample) elements of d_kernels, so plain
-// read-modify-write is race free.  Must run after splat_bwd_main_kernel.
+// read-modify-write is race free.  Must run after splat_bwd_tile_kernel.
 __global__ __launch_bounds__(256) void splat_bwd_route_kernel(SplatBwdParams p) {
     const int k = p.k, pad = (k - 1) / 2;
     const size_t hw = (size_t)p.h * p.w;
     const size_t total = (size_t)p.bs * hw;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
-        const float dk = p.d_kmax[i];
+        const float dk = p.scratch[i];
         if (dk == 0.f) continue;
         const size_t n = i / hw, pix = i % hw;
         const int Y = (int)(pix / p.w), X = (int)(pix % p.w);
-        const int dy = p.arow[i];
-        const int ys = Y + dy - pad;
-        if (ys < 0 || ys >= p.h) continue;  // arg-max is a zero-filled tap: gradient dropped
-        const float km = p.kmax[i];
-        const size_t base = n * (size_t)k * k * hw;
-        for (int dx = 0; dx < k; ++dx) {
-            const int xs = X + dx - pad;
-            const bool in = (xs >= 0) && (xs < p.w);
-            const size_t idx = base + ((size_t)((2 * pad - dy) * k + (2 * pad - dx))) * hw +
-                               (size_t)ys * p.w + (in ? xs : 0);
-            const float v = in ? p.kernels[idx] : 0.f;
-            if (v == km) {
-                if (in) p.d_kernels[idx] += dk;
-                break;
-            }
-        }
+        const int t = p.atap[i];
+        const int dy = t / k, dx = t % k;
+        const int ys = Y + dy - pad, xs = X + dx - pad;
+        if (ys < 0 || ys >= p.h || xs < 0 || xs >= p.w) continue;  // arg-max is a zero-filled tap
+        const size_t idx = n * (size_t)k * k * hw + ((size_t)((2 * pad - dy) * k + (2 * pad - dx))) * hw +
+                           (size_t)ys * p.w + xs;
+        p.d_kernels[idx] += dk;
     }
 }
 
-static inline size_t fwd_lds_bytes(int c, int k) {
+// v2 main: strip kernel (one wave = one 64-sample row strip).  Destination records
+// {M, dW, d_kmax, atap | dR0..3} of one destination row at a time are staged per wave
+// in LDS as two float4 arrays, so each tap costs two conflict-free ds_read_b128.
+template <int K, int C>
+__global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(SplatBwdParams p) {
+    static_assert(TX + K - 1 <= V2_ROW, "staged row too short");
+    static_assert(C <= 4, "records hold up to 4 channels");
+    constexpr int P = (K - 1) / 2;
+    __shared__ float4 lds[V2_WAVES * 2 * V2_ROW];  // per wave: [2][V2_ROW] record halves
+    const int wv = wave_id();
+    const int lane = threadIdx.x & 63;
+    const long item = (long)logical_block_id() * V2_WAVES + wv;
+    const int nseg = p.ntx;
+    const long per_img = (long)p.h * nseg;
+    if (item >= per_img * p.bs) return;  // whole wave
+    const int n = __builtin_amdgcn_readfirstlane((int)(item / per_img));
+    const int rem = __builtin_amdgcn_readfirstlane((int)(item % per_img));
+    const int ys = __builtin_amdgcn_readfirstlane(rem / nseg);
+    const int X0 = __builtin_amdgcn_readfirstlane((rem % nseg) * TX);
+    const int xs = X0 + lane;
+    const bool active = xs < p.w;
+    const size_t hw = (size_t)p.h * p.w;
+    const size_t pix = (size_t)ys * p.w + (active ? xs : p.w - 1);
+    float4* h0 = lds + wv * (2 * V2_ROW);
+    float4* h1 = h0 + V2_ROW;
+
+    float D[C], dD[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        D[c] = p.data[((size_t)n * C + c) * hw + pix];
+        dD[c] = 0.f;
+    }
+    const float* S = p.kernels + (size_t)n * K * K * hw + (size_t)ys * p.w + X0;
+    float* dS = p.d_kernels + (size_t)n * K * K * hw + (size_t)ys * p.w + X0;
+    const float4* rec = reinterpret_cast<const float4*>(p.scratch) + (size_t)n * hw * 2;
+    const unsigned voff = active ? (unsigned)lane * 4u : BUF_OOB;  // sample-less lanes: loads 0, stores dropped
+    const unsigned plane_stride = (unsigned)hw * 4u;
+
+    // staged destination columns: positions 0..63 by every lane, 64..64+K-2 by the first K-1 lanes
+    const int colA = X0 - P + lane, colB = colA + TX;
+    const bool inA = (colA >= 0) && (colA < p.w);
+    const bool inB = (lane < K - 1) && (colB < p.w);
+    const float4 fill0 = make_float4(OUTSIDE_MAX, 0.f, 0.f, __int_as_float(-1));
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_logits = [&](int ky, float (&s)[K]) {
+        const rsrc_t rs = make_rsrc(S + (size_t)(ky * K) * hw);  // tap (ky, 0); tap kx is kx planes further
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) s[kx] = buf_load(rs, voff, (unsigned)kx * plane_stride);
+    };
+    auto step = [&](int ky, const float (&s)[K]) {
+        const int yd = ys + ky - P;
+        const bool yin = (yd >= 0) && (yd < p.h);  // wave-uniform
+        float4 a0 = fill0, a1 = zero4, b0 = fill0, b1 = zero4;
+        if (yin) {
+            const float4* rrow = rec + (size_t)yd * p.w * 2;
+            if (inA) { a0 = rrow[(size_t)colA * 2]; a1 = rrow[(size_t)colA * 2 + 1]; }
+            if (inB) { b0 = rrow[(size_t)colB * 2]; b1 = rrow[(size_t)colB * 2 + 1]; }
+        }
+        wave_lds_sync();  // previous row's reads are done before its slots are overwritten
+        h0[lane] = a0;
+        h1[lane] = a1;
+        if (lane < K - 1) { h0[TX + lane] = b0; h1[TX + lane] = b1; }
+        wave_lds_sync();
+        const rsrc_t ws = make_rsrc(dS + (size_t)(ky * K) * hw);
+        const int tg0 = K * K - 1 - ky * K;  // gather tap index of (ky, kx) is tg0 - kx
+        constexpr int G = 3;  // taps per scheduling group (bounds the live LDS values)
+#pragma unroll
+        for (int g = 0; g < K; g += G) {
+#pragma unroll
+        for (int kx = g; kx < (g + G < K ? g + G : K); ++kx) {
+            const float4 q0 = h0[lane + kx];  // M, dW, d_kmax, atap
+            const float4 q1 = h1[lane + kx];  // dR0..3
+            const float e = fast_exp2((s[kx] - q0.x) * LOG2E);
+            float g = q0.y;
+            g = fmaf(q1.x, D[0], g);
+            dD[0] = fmaf(e, q1.x, dD[0]);
+            if constexpr (C > 1) { g = fmaf(q1.y, D[C > 1 ? 1 : 0], g); dD[C > 1 ? 1 : 0] = fmaf(e, q1.y, dD[C > 1 ? 1 : 0]); }
+            if constexpr (C > 2) { g = fmaf(q1.z, D[C > 2 ? 2 : 0], g); dD[C > 2 ? 2 : 0] = fmaf(e, q1.z, dD[C > 2 ? 2 : 0]); }
+            if constexpr (C > 3) { g = fmaf(q1.w, D[C > 3 ? 3 : 0], g); dD[C > 3 ? 3 : 0] = fmaf(e, q1.w, dD[C > 3 ? 3 : 0]); }
+            float ds = e * g;
+            ds += (__float_as_int(q0.w) == tg0 - kx) ? q0.z : 0.f;
+            buf_store(ds, ws, voff, (unsigned)kx * plane_stride);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    float s[K];
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+        load_logits(ky, s);
+        step(ky, s);
+    }
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) p.d_data[((size_t)n * C + c) * hw + pix] = dD[c];
+    }
+}
+
+static inline size_t fwd_tile_lds_bytes(int c, int k) {
     return (size_t)c * (FWD_TY + k - 1) * (TX + k - 1) * sizeof(float);
 }
-static inline size_t bwd_lds_bytes(int c, int k) {
+static inline size_t bwd_tile_lds_bytes(int c, int k) {
     return (size_t)(c + 2) * (BWD_TY + k - 1) * (TX + k - 1) * sizeof(float);
+}
+// strip kernels: k = 21, <= 4 channels, and all per-row buffer offsets (up to 20 planes)
+// must stay below the 2 GiB voffset range of the descriptors
+static inline bool strip_ok(int c, int k, int h, int w) {
+    return k == 21 && c <= 4 && (size_t)h * w * 4 * 21 < 0x7ff00000ull;
+}
+
+// Development knob (not part of the ABI): SBMC_HIP_SPLAT_VARIANT=0 forces the generic tile
+// kernels even where the strip kernels apply (used by the tests to cover both at k = 21).
+static int splat_variant() {
+    const char* e = getenv("SBMC_HIP_SPLAT_VARIANT");
+    return e ? atoi(e) : 1;
 }
 
 }  // namespace sbmc
 
 using namespace sbmc;
 
+static bool bad_splat_dims(int bs, int c, int h, int w, int k) {
+    return bs < 0 || h < 0 || w < 0 || c < 1 || c > SBMC_HIP_MAX_CHANNELS || k < 1 || (k % 2) == 0;
+}
+
+extern "C" int sbmc_splat_update_supported(int c, int k) {
+    if (c < 1 || c > SBMC_HIP_MAX_CHANNELS || k < 1 || (k % 2) == 0) return 0;
+    if (strip_ok(c, k, 1, 1)) return 1;
+    return fwd_tile_lds_bytes(c, k) <= 64 * 1024 && bwd_tile_lds_bytes(c, k) <= 64 * 1024;
+}
+
+extern "C" size_t sbmc_splat_update_bwd_scratch_bytes(int bs, int c, int h, int w, int k) {
+    if (bs < 0 || h < 0 || w < 0) return 0;
+    (void)c; (void)k;
+    // sized for the widest layout (destination records) so that the variant can be
+    // chosen per call without reallocating
+    return (size_t)bs * h * w * REC * sizeof(float);
+}
+
 extern "C" int sbmc_splat_update_fwd_f32(const float* data, const float* kernels,
                                          const float* sum_r_in, const float* sum_w_in,
                                          const float* max_w_in,
                                          float* sum_r_out, float* sum_w_out,
                                          float* max_w_out, float* kmax_out,
-                                         int32_t* arow_out,
+                                         int32_t* atap_out,
                                          int bs, int c, int h, int w, int k,
                                          void* stream) {
-    if (bs < 0 || h < 0 || w < 0 || c < 1 || c > SBMC_HIP_MAX_CHANNELS || k < 1 || (k % 2) == 0)
-        return SBMC_HIP_EINVAL;
+    if (bad_splat_dims(bs, c, h, w, k)) return SBMC_HIP_EINVAL;
     const int nin = (sum_r_in != nullptr) + (sum_w_in != nullptr) + (max_w_in != nullptr);
     if (nin != 0 && nin != 3) return SBMC_HIP_EINVAL;  // modules.py:431-435
     if (bs == 0 || h == 0 || w == 0) return 0;
-    if (!data || !kernels || !sum_r_out || !sum_w_out || !max_w_out || !kmax_out || !arow_out)
+    if (!data || !kernels || !sum_r_out || !sum_w_out || !max_w_out || !kmax_out || !atap_out)
         return SBMC_HIP_EINVAL;
-    const size_t lds = fwd_lds_bytes(c, k);
+    hipStream_t s = (hipStream_t)stream;
+    const int variant = splat_variant();
+    if (variant > 0 && strip_ok(c, k, h, w)) {
+        SplatFwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out,
+                         max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), h};
+        const long items = (long)bs * h * p.ntx;
+        const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
+        SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_fwd_strip_kernel<21, C>), dim3(grid),
+                                               dim3(V2_WAVES * TX), 0, s, p));
+        return (int)hipGetLastError();
+    }
+    const size_t lds = fwd_tile_lds_bytes(c, k);
     if (lds > 64 * 1024) return SBMC_HIP_EINVAL;
     SplatFwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out,
-                     max_w_out, kmax_out, arow_out, bs, h, w, k, tiles_x(w), tiles_y(h, FWD_TY)};
+                     max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), tiles_y(h, FWD_TY)};
     const unsigned grid = (unsigned)bs * p.ntx * p.nty;
-    hipStream_t s = (hipStream_t)stream;
-    if (k == 21) {
-        SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_fwd_kernel<21, C>), dim3(grid),
-                                              dim3(FWD_TY * TX), lds, s, p));
-    } else {
-        SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_fwd_kernel<0, C>), dim3(grid),
-                                              dim3(FWD_TY * TX), lds, s, p));
-    }
+    SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_fwd_tile_kernel<C>), dim3(grid),
+                                          dim3(FWD_TY * TX), lds, s, p));
     return (int)hipGetLastError();
 }
 
@@ -400,56 +636,58 @@ extern "C" int sbmc_splat_update_bwd_f32(const float* data, const float* kernels
                                          const float* max_w_in,
                                          const float* sum_r_out, const float* sum_w_out,
                                          const float* max_w_out, const float* kmax,
-                                         const int32_t* arow,
+                                         const int32_t* atap,
                                          const float* d_sum_r_out, const float* d_sum_w_out,
                                          const float* d_max_w_out,
                                          float* d_data, float* d_kernels,
                                          float* d_sum_r_in, float* d_sum_w_in,
-                                         float* d_max_w_in, float* d_kmax_scratch,
+                                         float* d_max_w_in, float* scratch,
                                          int bs, int c, int h, int w, int k,
                                          void* stream) {
-    if (bs < 0 || h < 0 || w < 0 || c < 1 || c > SBMC_HIP_MAX_CHANNELS || k < 1 || (k % 2) == 0)
-        return SBMC_HIP_EINVAL;
+    if (bad_splat_dims(bs, c, h, w, k)) return SBMC_HIP_EINVAL;
     const int nin = (sum_r_in != nullptr) + (sum_w_in != nullptr) + (max_w_in != nullptr);
     const int ndin = (d_sum_r_in != nullptr) + (d_sum_w_in != nullptr) + (d_max_w_in != nullptr);
     if ((nin != 0 && nin != 3) || ndin != nin) return SBMC_HIP_EINVAL;
     if (bs == 0 || h == 0 || w == 0) return 0;
-    if (!data || !kernels || !sum_r_out || !sum_w_out || !max_w_out || !kmax || !arow ||
-        !d_sum_r_out || !d_sum_w_out || !d_max_w_out || !d_data || !d_kernels || !d_kmax_scratch)
+    if (!data || !kernels || !sum_r_out || !sum_w_out || !max_w_out || !kmax || !atap ||
+        !d_sum_r_out || !d_sum_w_out || !d_max_w_out || !d_data || !d_kernels || !scratch)
         return SBMC_HIP_EINVAL;
-    const size_t lds = bwd_lds_bytes(c, k);
-    if (lds > 64 * 1024) return SBMC_HIP_EINVAL;
-    SplatBwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out,
-                     kmax, arow, d_sum_r_out, d_sum_w_out, d_max_w_out, d_data, d_kernels,
-                     d_sum_r_in, d_sum_w_in, d_max_w_in, d_kmax_scratch,
-                     bs, c, h, w, k, tiles_x(w), tiles_y(h, BWD_TY)};
     hipStream_t s = (hipStream_t)stream;
     const size_t total = (size_t)bs * h * w;
     unsigned egrid = (unsigned)((total + 255) / 256);
-    if (egrid > 4096) egrid = 4096;
+    if (egrid > 8192) egrid = 8192;
+    const int variant = splat_variant();
 
-    SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_bwd_state_kernel<C>), dim3(egrid), dim3(256), 0, s, p));
+    if (variant > 0 && strip_ok(c, k, h, w)) {
+        SplatBwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out,
+                         kmax, atap, d_sum_r_out, d_sum_w_out, d_max_w_out, d_data, d_kernels,
+                         d_sum_r_in, d_sum_w_in, d_max_w_in, scratch, bs, c, h, w, k, tiles_x(w), h};
+        SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_state_kernel<C, true>), dim3(egrid), dim3(256), 0, s, p));
+        int err = (int)hipGetLastError();
+        if (err) return err;
+        const long items = (long)bs * h * p.ntx;
+        const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
+        SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_strip_kernel<21, C>), dim3(grid),
+                                               dim3(V2_WAVES * TX), 0, s, p));
+        return (int)hipGetLastError();
+    }
+
+    const size_t lds = bwd_tile_lds_bytes(c, k);
+    if (lds > 64 * 1024) return SBMC_HIP_EINVAL;
+    SplatBwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out,
+                     kmax, atap, d_sum_r_out, d_sum_w_out, d_max_w_out, d_data, d_kernels,
+                     d_sum_r_in, d_sum_w_in, d_max_w_in, scratch,
+                     bs, c, h, w, k, tiles_x(w), tiles_y(h, BWD_TY)};
+    SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_bwd_state_kernel<C, false>), dim3(egrid), dim3(256), 0, s, p));
     int err = (int)hipGetLastError();
     if (err) return err;
-
     const unsigned grid = (unsigned)bs * p.ntx * p.nty;
-    if (k == 21) {
-        SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_bwd_main_kernel<21, C>), dim3(grid),
-                                              dim3(BWD_TY * TX), lds, s, p));
-    } else {
-        SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_bwd_main_kernel<0, C>), dim3(grid),
-                                              dim3(BWD_TY * TX), lds, s, p));
-    }
+    SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_bwd_tile_kernel<C>), dim3(grid),
+                                          dim3(BWD_TY * TX), lds, s, p));
     err = (int)hipGetLastError();
     if (err) return err;
-
     hipLaunchKernelGGL(splat_bwd_route_kernel, dim3(egrid), dim3(256), 0, s, p);
     return (int)hipGetLastError();
-}
-
-extern "C" int sbmc_splat_update_supported(int c, int k) {
-    if (c < 1 || c > SBMC_HIP_MAX_CHANNELS || k < 1 || (k % 2) == 0) return 0;
-    return fwd_lds_bytes(c, k) <= 64 * 1024 && bwd_lds_bytes(c, k) <= 64 * 1024;
 }
 
 extern "C" int sbmc_hip_abi_version(void) { return SBMC_HIP_ABI_VERSION; }

@@ -186,26 +186,26 @@ class SplatUpdate(th.autograd.Function):
         new_w = data.new_empty(bs, 1, h, w)
         new_m = data.new_empty(bs, 1, h, w)
         kmax = data.new_empty(bs, h, w)
-        arow = th.empty(bs, h, w, dtype=th.int32, device=data.device)
+        atap = th.empty(bs, h, w, dtype=th.int32, device=data.device)
         dev = data.device
         with th.cuda.device(dev), _timed("splat_update_fwd", dev):
             rc = _lib.lib().sbmc_splat_update_fwd_f32(
                 _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
-                _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(arow),
+                _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(atap),
                 bs, c, h, w, k, _lib.current_stream(dev))
         _lib.check(rc, "splat_update_fwd")
         ctx.first = first
         ctx.k = k
         if first:
-            ctx.save_for_backward(data, kernels, new_r, new_w, new_m, kmax, arow)
+            ctx.save_for_backward(data, kernels, new_r, new_w, new_m, kmax, atap)
         else:
-            ctx.save_for_backward(data, kernels, new_r, new_w, new_m, kmax, arow, sum_r, sum_w, max_w)
+            ctx.save_for_backward(data, kernels, new_r, new_w, new_m, kmax, atap, sum_r, sum_w, max_w)
         return new_r, new_w, new_m
 
     @staticmethod
     def backward(ctx, d_r, d_w, d_m):
         saved = ctx.saved_tensors
-        data, kernels, new_r, new_w, new_m, kmax, arow = saved[:7]
+        data, kernels, new_r, new_w, new_m, kmax, atap = saved[:7]
         sum_r = sum_w = max_w = None
         if not ctx.first:
             sum_r, sum_w, max_w = saved[7:]
@@ -215,7 +215,8 @@ class SplatUpdate(th.autograd.Function):
         d_m = th.zeros_like(new_m) if d_m is None else d_m.contiguous()
         d_data = th.empty_like(data)
         d_kernels = th.empty_like(kernels)
-        scratch = data.new_empty(bs, h, w)
+        nbytes = _lib.lib().sbmc_splat_update_bwd_scratch_bytes(bs, c, h, w, ctx.k)
+        scratch = data.new_empty((nbytes + 3) // 4)
         d_sum_r = d_sum_w = d_max_w = None
         if not ctx.first:
             d_sum_r = th.empty_like(sum_r)
@@ -225,7 +226,7 @@ class SplatUpdate(th.autograd.Function):
         with th.cuda.device(dev), _timed("splat_update_bwd", dev):
             rc = _lib.lib().sbmc_splat_update_bwd_f32(
                 _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
-                _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(arow),
+                _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(atap),
                 _lib.ptr(d_r), _lib.ptr(d_w), _lib.ptr(d_m),
                 _lib.ptr(d_data), _lib.ptr(d_kernels),
                 _lib.ptr(d_sum_r), _lib.ptr(d_sum_w), _lib.ptr(d_max_w), _lib.ptr(scratch),

@@ -1,0 +1,198 @@
+"""Generates the committed golden fixtures (tests/golden/*.npz).
+
+AUTHORING CONTAINER ONLY: imports the *reference* Python package from
+/root/reference (via oracle/refload.py -- the hot-path files are executed from
+where they lie, with `sbmc.halide_ops` := the C oracle because Halide cannot be
+built here) and records inputs + outputs (+ gradients) of
+
+  * sbmc.functions.KernelWeighting / Scatter2Gather           -> ops.npz
+  * sbmc.modules.KernelApply / ProgressiveKernelApply          -> modules.npz
+  * sbmc.modules.ConvChain / Autoencoder (seeded state dicts)  -> backbone.npz
+  * sbmc.models.Multisteps eval + train + loss + gradients     -> multisteps.npz
+  * sbmc.losses.*                                              -> losses.npz
+
+The fixtures are data only (tensors); no reference source travels.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch as th
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import refload  # noqa: E402
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **d)
+    print("%-18s %7.1f KB  %d arrays" % (name, os.path.getsize(path) / 1024.0, len(d)))
+
+
+def gen_ops(ref):
+    out = {}
+    g = th.Generator().manual_seed(11)
+    cases = {"a": (2, 3, 9, 21, 5, 5), "b": (1, 4, 7, 66, 3, 7), "c": (1, 3, 6, 9, 21, 21)}
+    for tag, (bs, c, h, w, kh, kw) in cases.items():
+        data = th.randn(bs, c, h, w, generator=g).requires_grad_()
+        wts = th.randn(bs, kh, kw, h, w, generator=g).requires_grad_()
+        go = th.randn(bs, c, h, w, generator=g)
+        gs = th.randn(bs, h, w, generator=g)
+        o, s = ref.functions.KernelWeighting.apply(data, wts)
+        th.autograd.backward([o, s], [go, gs])
+        x = th.randn(bs, kh, kw, h, w, generator=g).requires_grad_()
+        gx = th.randn(bs, kh, kw, h, w, generator=g)
+        y = ref.functions.Scatter2Gather.apply(x)
+        y.backward(gx)
+        for k, v in dict(data=data, weights=wts, d_output=go, d_sum_w=gs, output=o, sum_w=s,
+                         d_data=data.grad, d_weights=wts.grad, s2g_in=x, s2g_out=y,
+                         s2g_gout=gx, s2g_gin=x.grad).items():
+            out["%s.%s" % (tag, k)] = npy(v)
+    save("ops.npz", out)
+
+
+def gen_modules(ref):
+    out = {}
+    g = th.Generator().manual_seed(12)
+    # KernelApply, all four (softmax, splat) combinations
+    bs, c, h, w, k = 2, 3, 8, 12, 5
+    data = th.rand(bs, c, h, w, generator=g)
+    kern = th.randn(bs, k * k, h, w, generator=g)
+    out["ka.data"], out["ka.kernels"] = npy(data), npy(kern)
+    for softmax in (False, True):
+        for splat in (False, True):
+            d = data.clone().requires_grad_()
+            kk = kern.clone().requires_grad_()
+            o, s = ref.modules.KernelApply(softmax=softmax, splat=splat)(d, kk)
+            go = th.randn(o.shape, generator=g)
+            gs = th.randn(s.shape, generator=g)
+            th.autograd.backward([o, s], [go, gs])
+            tag = "ka.sm%d.sp%d." % (softmax, splat)
+            for kname, v in dict(output=o, sum_w=s, g_output=go, g_sum_w=gs, d_data=d.grad,
+                                 d_kernels=kk.grad).items():
+                out[tag + kname] = npy(v)
+    # ProgressiveKernelApply: 3 samples, splat True / False, grads on all three outputs
+    for splat in (True, False):
+        for kname, (bs, c, h, w, k, spp) in {"p5": (1, 3, 10, 34, 5, 3), "p21": (1, 3, 7, 10, 21, 2)}.items():
+            tag = "%s.sp%d." % (kname, splat)
+            datas = [th.rand(bs, c, h, w, generator=g).requires_grad_() for _ in range(spp)]
+            kerns = [(2 * th.randn(bs, k * k, h, w, generator=g)).requires_grad_() for _ in range(spp)]
+            mod = ref.modules.ProgressiveKernelApply(splat=splat)
+            sr = sw = mw = None
+            for d, kk in zip(datas, kerns):
+                # the reference mutates (a view of) its kernel argument when splat=False
+                sr, sw, mw = mod(d, kk.clone(), sr, sw, mw)
+            grads = [th.randn(t.shape, generator=g) for t in (sr, sw, mw)]
+            th.autograd.backward([sr, sw, mw], grads)
+            out[tag + "sum_r"], out[tag + "sum_w"], out[tag + "max_w"] = npy(sr), npy(sw), npy(mw)
+            for i, gg in enumerate(grads):
+                out[tag + "g%d" % i] = npy(gg)
+            for i in range(spp):
+                out[tag + "data%d" % i] = npy(datas[i])
+                out[tag + "kernels%d" % i] = npy(kerns[i])
+                out[tag + "d_data%d" % i] = npy(datas[i].grad)
+                out[tag + "d_kernels%d" % i] = npy(kerns[i].grad)
+    save("modules.npz", out)
+
+
+def gen_backbone(ref):
+    out = {}
+    th.manual_seed(13)
+    cc = ref.modules.ConvChain(5, 7, ksize=3, width=6, depth=3, activation="leaky_relu",
+                               output_type="leaky_relu")
+    x = th.randn(2, 5, 11, 13)
+    y = cc(x)
+    for k, v in cc.state_dict().items():
+        out["cc.sd." + k] = npy(v)
+    out["cc.x"], out["cc.y"] = npy(x), npy(y)
+
+    th.manual_seed(14)
+    ae = ref.modules.Autoencoder(6, 5, num_levels=3, increase_factor=2.0, num_convs=3, width=6,
+                                 ksize=3, output_type="leaky_relu", pooling="max")
+    x = th.randn(1, 6, 20, 28)
+    y = ae(x)
+    for k, v in ae.state_dict().items():
+        out["ae.sd." + k] = npy(v)
+    out["ae.x"], out["ae.y"] = npy(x), npy(y)
+    # seeded construction must also reproduce the reference's initial parameters
+    th.manual_seed(15)
+    cc2 = ref.modules.ConvChain(4, 3, ksize=1, width=8, depth=3, pad=False)
+    for k, v in cc2.state_dict().items():
+        out["cc_init.sd." + k] = npy(v)
+    save("backbone.npz", out)
+
+
+def gen_multisteps(ref):
+    out = {}
+    nf, ngf, width, ew, ks, nsteps = 10, 3, 8, 8, 5, 2
+    bs, spp, h, w = 1, 3, 20, 24
+    th.manual_seed(16)
+    model = ref.models.Multisteps(nf, ngf, width=width, embedding_width=ew, ksize=ks, nsteps=nsteps)
+    for k, v in model.state_dict().items():
+        out["sd." + k] = npy(v)
+    g = th.Generator().manual_seed(17)
+    batch = {
+        "radiance": th.empty(bs, spp, 3, h, w).exponential_(1.0, generator=g),
+        "features": th.rand(bs, spp, nf, h, w, generator=g),
+        "global_features": th.rand(bs, ngf, 1, 1, generator=g),
+    }
+    target = th.empty(bs, 3, h, w).exponential_(1.0, generator=g)
+    for k, v in batch.items():
+        out["in." + k] = npy(v)
+    out["in.target_image"] = npy(target)
+
+    model.train(False)
+    with th.no_grad():
+        out["eval.radiance"] = npy(model({k: v.clone() for k, v in batch.items()})["radiance"])
+    model.train(True)
+    res = model({k: v.clone() for k, v in batch.items()})["radiance"]
+    out["train.radiance"] = npy(res)
+    crop = (target.shape[-1] - res.shape[-1]) // 2
+    tgt = target[..., crop:-crop, crop:-crop]
+    loss = ref.losses.TonemappedRelativeMSE()(res, tgt)
+    loss.backward()
+    out["train.loss"] = npy(loss)
+    for k, p in model.named_parameters():
+        out["grad." + k] = npy(p.grad)
+    out["meta"] = np.array([nf, ngf, width, ew, ks, nsteps])
+    save("multisteps.npz", out)
+
+
+def gen_losses(ref):
+    out = {}
+    g = th.Generator().manual_seed(18)
+    im = (th.randn(2, 3, 9, 11, generator=g) * 2).requires_grad_()
+    refim = th.empty(2, 3, 9, 11).exponential_(1.0, generator=g)
+    out["im"], out["ref"] = npy(im), npy(refim)
+    for name in ("RelativeMSE", "SMAPE", "TonemappedMSE", "TonemappedRelativeMSE"):
+        im.grad = None
+        v = getattr(ref.losses, name)()(im, refim)
+        v.backward()
+        out[name + ".value"] = npy(v)
+        out[name + ".grad"] = npy(im.grad)
+    save("losses.npz", out)
+
+
+def main():
+    if not refload.available():
+        raise SystemExit("reference tree not available: fixtures can only be regenerated in the "
+                         "authoring container")
+    ref = refload.load_reference()
+    gen_ops(ref)
+    gen_modules(ref)
+    gen_backbone(ref)
+    gen_multisteps(ref)
+    gen_losses(ref)
+
+
+if __name__ == "__main__":
+    main()

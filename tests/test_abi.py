@@ -1,0 +1,71 @@
+"""The C-ABI library: loads, and exports every symbol include/sbmc_hip.h declares (no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sbmc_hip.h")).read()
+    return sorted(set(re.findall(r"SBMC_API\s+[\w\s\*]+?\b(sbmc_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = declared_symbols()
+    for name in ("sbmc_scatter2gather_f32", "sbmc_kernel_weighting_fwd_f32",
+                 "sbmc_kernel_weighting_bwd_f32", "sbmc_splat_update_fwd_f32",
+                 "sbmc_splat_update_bwd_f32", "sbmc_hip_abi_version"):
+        assert name in syms
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from sbmc_amd import build, _lib
+    path = build.build()  # hipcc cross-compiles gfx950 without a GPU
+    assert os.path.exists(path)
+    handle = ctypes.CDLL(path)
+    for name in declared_symbols():
+        assert hasattr(handle, name), "%s missing from %s" % (name, path)
+    assert set(_lib.SYMBOLS) == set(declared_symbols())
+    handle.sbmc_hip_abi_version.restype = ctypes.c_int
+    assert handle.sbmc_hip_abi_version() == _lib.ABI_VERSION
+
+
+def test_loader_fails_loudly_when_the_library_is_missing(monkeypatch, tmp_path):
+    from sbmc_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HipExtensionMissing):
+        _lib.lib()
+
+
+def test_argument_validation_needs_no_gpu():
+    """Bad dimensions are rejected before any launch (returns SBMC_HIP_EINVAL = -1)."""
+    from sbmc_amd import _lib
+    lib = _lib.lib()
+    assert lib.sbmc_scatter2gather_f32(None, None, 1, 4, 4, 0, 3, None) == -1
+    assert lib.sbmc_kernel_weighting_fwd_f32(None, None, None, None, 1, 3, 4, 4, 3, 3, None) == -1
+    assert lib.sbmc_splat_update_fwd_f32(*([None] * 10), 1, 3, 8, 8, 4, None) == -1   # even k
+    assert lib.sbmc_splat_update_fwd_f32(*([None] * 10), 1, 9, 8, 8, 3, None) == -1   # too many channels
+    assert lib.sbmc_splat_update_supported(3, 21) == 1
+    assert lib.sbmc_splat_update_supported(3, 4) == 0
+    assert lib.sbmc_splat_update_supported(8, 21) == 0    # tile LDS budget exceeded at k=21, c=8
+    assert lib.sbmc_splat_update_supported(8, 5) == 1
+    assert lib.sbmc_splat_update_bwd_scratch_bytes(1, 3, 10, 10, 21) >= 10 * 10 * 4
+    assert b"invalid" in lib.sbmc_hip_strerror(-1)
+    # empty problems are a no-op, also without a device
+    assert lib.sbmc_scatter2gather_f32(None, None, 0, 4, 4, 3, 3, None) == 0
+
+
+def test_cpu_entry_points_refuse_without_a_registered_backend():
+    import torch as th
+    from sbmc_amd import halide_ops
+    halide_ops.register_cpu_ops_for_testing(None)
+    with pytest.raises(RuntimeError):
+        halide_ops.kernel_weighting_cpu_float32(th.zeros(1, 1, 2, 2), th.zeros(1, 1, 1, 2, 2),
+                                                th.zeros(1, 1, 2, 2), th.zeros(1, 2, 2))
+    with pytest.raises(RuntimeError):
+        halide_ops.kernel_weighting_cuda_float32(th.zeros(1, 1, 2, 2), th.zeros(1, 1, 1, 2, 2),
+                                                 th.zeros(1, 1, 2, 2), th.zeros(1, 2, 2))

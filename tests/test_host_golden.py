@@ -1,0 +1,175 @@
+"""Host logic of sbmc_amd (functions / modules / models / losses) against fixtures captured
+from the reference package (tests/golden/make_golden.py).  No GPU: the `cpu_ops` fixture
+installs the oracle behind the `*_cpu_float32` operator names, so these tests check the
+Python composition, module structure, state-dict compatibility and autograd wiring.
+"""
+import pytest
+import torch as th
+
+from helpers import close, golden, multisteps_from_golden, run_progressive, t
+
+
+def test_losses_match_reference():
+    from sbmc_amd import losses
+    g = golden("losses.npz")
+    for name in ("RelativeMSE", "SMAPE", "TonemappedMSE", "TonemappedRelativeMSE"):
+        im = t(g["im"]).requires_grad_()
+        v = getattr(losses, name)()(im, t(g["ref"]))
+        v.backward()
+        close(v, g[name + ".value"], rtol=1e-6, what=name)
+        close(im.grad, g[name + ".grad"], rtol=1e-6, what=name + " grad")
+
+
+def test_losses_closed_form():
+    """reference tests/test_losses.py:101-128 style single-pixel closed forms"""
+    from sbmc_amd import losses
+    im, ref = th.full((1, 3, 1, 1), 3.0), th.full((1, 3, 1, 1), 1.0)
+    tm = lambda x: x / (1 + x)  # noqa: E731
+    expect = 0.5 * (tm(3.0) - tm(1.0)) ** 2 / (tm(1.0) ** 2 + 1e-2)
+    assert losses.TonemappedRelativeMSE()(im, ref).item() == pytest.approx(expect, rel=1e-6)
+    assert losses.RelativeMSE()(im, ref).item() == pytest.approx(0.5 * 4.0 / (1 + 1e-2), rel=1e-6)
+    assert losses.TonemappedMSE()(im, ref).item() == pytest.approx(0.5 * (0.75 - 0.5) ** 2, rel=1e-6)
+    assert losses.SMAPE()(im, ref).item() == pytest.approx(2.0 / (1e-2 + 4.0), rel=1e-6)
+    # negative radiance is clamped before tonemapping
+    assert losses.TonemappedMSE()(-im, th.zeros_like(ref)).item() == 0.0
+
+
+def test_convchain_structure():
+    """reference tests/test_modules.py:17-60"""
+    from sbmc_amd import modules
+    with pytest.raises(ValueError):
+        modules.ConvChain(3, 3, depth=0)
+    with pytest.raises(ValueError):
+        modules.ConvChain(3, 3, depth=-1)
+    with pytest.raises(ValueError):
+        modules.ConvChain(3, 3, output_type="randomstring")
+    with pytest.raises(ValueError):
+        modules.ConvChain(3, 3, activation="randomstring")
+    with pytest.raises(ValueError):
+        modules.ConvChain(3, 3, normalize=True, normalization_type="randomstring")
+    for nrm in (False, True):
+        net = modules.ConvChain(3, 3, depth=3, width=32, normalize=nrm)
+        idx = 1 if nrm else 0
+        assert isinstance(net.layer_0, modules.ConvChain._ConvBNRelu)
+        assert isinstance(net.layer_1, modules.ConvChain._ConvBNRelu)
+        assert isinstance(net.prediction, th.nn.Conv2d)
+        for layer, cin in ((net.layer_0, 3), (net.layer_1, 32)):
+            ch = list(layer.layer.children())
+            assert isinstance(ch[0], th.nn.Conv2d) and isinstance(ch[1 + idx], th.nn.ReLU)
+            assert ch[0].kernel_size == (3, 3) and ch[0].stride == (1, 1)
+            assert ch[0].in_channels == cin and ch[0].out_channels == 32
+            if nrm:
+                assert isinstance(ch[1], th.nn.BatchNorm2d)
+        assert (net.prediction.in_channels, net.prediction.out_channels) == (32, 3)
+        assert net.prediction.kernel_size == (3, 3) and net.prediction.stride == (1, 1)
+
+
+def test_backbone_state_dict_and_numerics():
+    from sbmc_amd import modules
+    g = golden("backbone.npz")
+    cc = modules.ConvChain(5, 7, ksize=3, width=6, depth=3, activation="leaky_relu",
+                           output_type="leaky_relu")
+    cc.load_state_dict({k[6:]: t(g[k]) for k in g.files if k.startswith("cc.sd.")}, strict=True)
+    close(cc(t(g["cc.x"])), g["cc.y"], rtol=1e-6, what="ConvChain")
+    ae = modules.Autoencoder(6, 5, num_levels=3, increase_factor=2.0, num_convs=3, width=6,
+                             ksize=3, output_type="leaky_relu", pooling="max")
+    ae.load_state_dict({k[6:]: t(g[k]) for k in g.files if k.startswith("ae.sd.")}, strict=True)
+    close(ae(t(g["ae.x"])), g["ae.y"], rtol=1e-6, what="Autoencoder")
+
+
+def test_seeded_init_reproduces_reference_parameters():
+    from sbmc_amd import modules
+    g = golden("backbone.npz")
+    th.manual_seed(15)
+    cc = modules.ConvChain(4, 3, ksize=1, width=8, depth=3, pad=False)
+    sd = cc.state_dict()
+    keys = [k for k in g.files if k.startswith("cc_init.sd.")]
+    assert sorted(sd.keys()) == sorted(k[11:] for k in keys)
+    for k in keys:
+        assert th.equal(sd[k[11:]], t(g[k])), k
+
+
+def test_multisteps_parameter_count_and_keys():
+    from sbmc_amd import Multisteps
+    m = Multisteps(93, 3, ksize=21)
+    assert sum(p.numel() for p in m.parameters()) == 34813170
+    assert tuple(m.state_dict()["embedding_00.layer_0.layer.0.weight_v"].shape) == (128, 96, 1, 1)
+    with pytest.raises(ValueError):
+        Multisteps(93, 3, ksize=4)
+    with pytest.raises(ValueError):
+        Multisteps(93, 3, nsteps=0)
+
+
+def test_kernel_apply_matches_reference(cpu_ops):
+    from sbmc_amd import modules
+    g = golden("modules.npz")
+    for softmax in (False, True):
+        for splat in (False, True):
+            tag = "ka.sm%d.sp%d." % (softmax, splat)
+            d = t(g["ka.data"]).requires_grad_()
+            kk = t(g["ka.kernels"]).requires_grad_()
+            o, s = modules.KernelApply(softmax=softmax, splat=splat)(d, kk)
+            th.autograd.backward([o, s], [t(g[tag + "g_output"]), t(g[tag + "g_sum_w"])])
+            close(o, g[tag + "output"], rtol=1e-6)
+            close(s, g[tag + "sum_w"], rtol=1e-6)
+            close(d.grad, g[tag + "d_data"], rtol=1e-6)
+            close(kk.grad, g[tag + "d_kernels"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("case,spp", [("p5", 3), ("p21", 2)])
+@pytest.mark.parametrize("splat", [True, False])
+def test_progressive_kernel_apply_matches_reference(cpu_ops, case, spp, splat):
+    from sbmc_amd import modules
+    g = golden("modules.npz")
+    tag = "%s.sp%d." % (case, splat)
+    datas = [t(g[tag + "data%d" % i]) for i in range(spp)]
+    kerns = [t(g[tag + "kernels%d" % i]) for i in range(spp)]
+    grads = [t(g[tag + "g%d" % i]) for i in range(3)]
+    out, dd, dk = run_progressive(modules.ProgressiveKernelApply(splat=splat), datas, kerns, grads, "cpu")
+    for a, n in zip(out, ("sum_r", "sum_w", "max_w")):
+        close(a, g[tag + n], rtol=1e-6, what=n)
+    for i in range(spp):
+        close(dd[i], g[tag + "d_data%d" % i], rtol=1e-6)
+        close(dk[i], g[tag + "d_kernels%d" % i], rtol=1e-6)
+    # the inputs are not modified (the reference mutates its kernel argument for splat=False)
+    for i in range(spp):
+        assert th.equal(kerns[i], t(g[tag + "kernels%d" % i]))
+
+
+def test_progressive_kernel_apply_rejects_partial_state(cpu_ops):
+    from sbmc_amd import modules
+    d, k = th.zeros(1, 3, 8, 8), th.zeros(1, 9, 8, 8)
+    with pytest.raises(RuntimeError):
+        modules.ProgressiveKernelApply(splat=True)(d, k, None, th.zeros(1, 1, 8, 8), None)
+
+
+def test_multisteps_matches_reference(cpu_ops):
+    from sbmc_amd import losses
+    from sbmc_amd.utils import crop_like
+    g, model, batch = multisteps_from_golden("cpu")
+    target = batch.pop("target_image")
+    model.train(False)
+    with th.no_grad():
+        out = model(batch)["radiance"]
+    close(out, g["eval.radiance"], what="eval output")
+    ks = int(g["meta"][4])
+    assert out.shape[-2:] == (batch["radiance"].shape[-2] - (ks - 1), batch["radiance"].shape[-1] - (ks - 1))
+    model.train(True)
+    res = model(batch)["radiance"]
+    close(res, g["train.radiance"], what="train output")
+    loss = losses.TonemappedRelativeMSE()(res, crop_like(target, res))
+    close(loss, g["train.loss"], what="loss")
+    loss.backward()
+    for k, p in model.named_parameters():
+        close(p.grad, g["grad." + k], rtol=2e-5, what="grad " + k)
+
+
+def test_multisteps_sample_chunking_is_exact(cpu_ops):
+    g, model, batch = multisteps_from_golden("cpu")
+    batch.pop("target_image")
+    model.train(False)
+    with th.no_grad():
+        ref = model(batch)["radiance"]
+        model.sample_chunk = 2
+        out = model(batch)["radiance"]
+    close(out, ref, rtol=1e-6)
