@@ -1,23 +1,26 @@
 #!/usr/bin/env python
-"""Benchmark of the SBMC splat hot path on MI355X.
+"""Benchmark of the SBMC hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload splat|model]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload model|splat]
 
-Prints ONE JSON line (rank 0).  Metric (BASELINE.json): Msamples/s = S*H*W / time,
-1280x720, 8 spp, 21x21 kernels, forward + backward, fp32, inputs resident in HBM.
+Prints ONE JSON line (rank 0).  Metric (BASELINE.json): Msamples/s = S*H*W / time for the
+denoiser's forward+backward at 1280x720, 8 spp, 21x21 kernels, fp32, inputs resident in HBM.
 
 Workloads
-  splat  one step = S progressive splat updates (ProgressiveKernelApply(splat=True),
-         one per sample) + normalisation sum_r/(sum_w+eps) + backward to the logits
-         and the radiance -- SURVEY.md section 8d metric (i).  This is the part of the
-         reference step that the hand-written kernels replace.
-  model  one step = the reference training step (sbmc/interfaces.py:78-105): Multisteps
-         forward, TonemappedRelativeMSE, backward, grad-norm clip 1000, Adam(1e-4) --
-         SURVEY.md section 8d metric (ii).  The conv backbone rides MIOpen.
+  model  (default; BASELINE.json configs[2], the configuration the metric is quoted on)
+         one step = the reference training step (sbmc/interfaces.py:78-105): Multisteps
+         forward, TonemappedRelativeMSE, backward, non-finite guard, grad-norm clip 1000,
+         Adam(1e-4).  The conv backbone rides MIOpen; the splat path is the hand-written
+         HIP kernels.
+  splat  one step = S progressive splat updates (ProgressiveKernelApply(splat=True), one per
+         sample) + normalisation sum_r/(sum_w+eps) + backward to logits and radiance
+         (SURVEY.md section 8d metric (i)): the part of the step the HIP kernels replace.
+         With the default workload this is also measured, after the timed region, and
+         reported under "stages" together with the roofline figure of its dominant kernel.
 
-Multi-GPU (--gpus N under torch.distributed.run): the frame is split along H into N
-slabs; every rank splats the samples of its slab extended by the kernel radius
-(strong scaling of one frame, see DESIGN.md section "Multi-GPU").
+Multi-GPU (--gpus N under torch.distributed.run): ONE frame, split along H into N slabs
+(strong scaling).  model: per-layer halo exchange over RCCL (sbmc_amd/dist.py) + gradient
+all-reduce; splat: every rank splats the samples of its slab extended by the kernel radius.
 """
 import argparse
 import json
@@ -25,7 +28,11 @@ import os
 import sys
 import time
 
-import torch as th
+# MIOpen's default exhaustive "find" costs ~5 minutes on the first step of this model; the
+# FAST mode picks solvers from its heuristics in seconds (and was not slower here).
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+import torch as th  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -48,36 +55,25 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["splat", "model"], default="splat")
+    ap.add_argument("--workload", choices=["model", "splat"], default="model")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--ksize", type=int, default=21)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=180,
-                    help="rows of the frame used for the bounded CPU-oracle sample")
-    ap.add_argument("--cpu-spp", type=int, default=2)
+    ap.add_argument("--no-stages", action="store_true")
     return ap.parse_args()
-
-
-def slab_rows(h, world, rank, pad):
-    """Rows [y0, y1) owned by `rank` and the haloed source range it must hold."""
-    base, rem = divmod(h, world)
-    y0 = rank * base + min(rank, rem)
-    y1 = y0 + base + (1 if rank < rem else 0)
-    return y0, y1, max(0, y0 - pad), min(h, y1 + pad)
 
 
 def make_splat_inputs(h, w, spp, k, device, seed):
     g = th.Generator(device="cpu").manual_seed(seed)
-    rad = [th.empty(1, 3, h, w).exponential_(1.0, generator=g).to(device) for _ in range(spp)]
+    rad = [th.empty(1, 3, h, w).exponential_(1.0, generator=g).to(device).requires_grad_()
+           for _ in range(spp)]
     logits = []
     for _ in range(spp):
         t = th.empty(1, k * k, h, w, device=device)
         t.normal_(0, 1)
         logits.append(t.requires_grad_())
-    for r in rad:
-        r.requires_grad_()
     d_out = th.randn(1, 3, h, w, generator=g).to(device)
     return rad, logits, d_out
 
@@ -95,7 +91,8 @@ def splat_step(update, rad, logits, d_out, eps=1e-8):
     return out
 
 
-def make_model_inputs(h, w, spp, device, seed):
+def make_model_inputs(h, w, spp, device, seed, rows=None):
+    """Synthetic batch.  rows=(r0, r1): only those rows are materialised."""
     g = th.Generator(device="cpu").manual_seed(seed)
     rad = th.empty(1, spp, 3, h, w).exponential_(1.0, generator=g)
     feat = th.rand(1, spp, 93, h, w, generator=g)
@@ -104,31 +101,68 @@ def make_model_inputs(h, w, spp, device, seed):
     feat[:, :, 8:11] = lr
     gf = th.rand(1, 3, 1, 1, generator=g)
     tgt = th.empty(1, 3, h, w).exponential_(1.0, generator=g)
-    return {"radiance": rad.to(device), "features": feat.to(device),
-            "global_features": gf.to(device), "target_image": tgt.to(device)}
+    if rows is not None:
+        r0, r1 = rows
+        rad, feat, tgt = rad[..., r0:r1, :], feat[..., r0:r1, :], tgt[..., r0:r1, :]
+    return {"radiance": rad.contiguous().to(device), "features": feat.contiguous().to(device),
+            "global_features": gf.to(device), "target_image": tgt.contiguous().to(device)}
+
+
+def train_step(model, opt, loss_fn, batch):
+    """The reference training step, sbmc/interfaces.py:78-105."""
+    from sbmc_amd.utils import crop_like
+    opt.zero_grad()
+    out = model(batch)["radiance"]
+    tgt = crop_like(batch["target_image"], out)
+    loss = loss_fn(out, tgt)
+    loss.backward()
+    if not th.isfinite(loss).item():
+        raise RuntimeError("non-finite loss")
+    th.nn.utils.clip_grad_norm_(model.parameters(), 1000)
+    opt.step()
+    return loss
 
 
 def cpu_baseline(args):
-    """Times the CPU oracle ("port") on a bounded sample of the same workload."""
+    """Times the CPU port (torch-CPU convolutions + the oracle's splat operators behind the
+    same Python model code) on a bounded sample of the same workload."""
     from oracle import sbmc_oracle as orc
+    from sbmc_amd import halide_ops
     orc.lib()
-    h, w, k, spp = min(args.cpu_rows, args.height), args.width, args.ksize, args.cpu_spp
+    k, spp = args.ksize, args.spp
     threads = th.get_num_threads()
     th.manual_seed(0)
-    rad = [th.empty(1, 3, h, w).exponential_(1.0).requires_grad_() for _ in range(spp)]
-    logits = [th.randn(1, k * k, h, w).requires_grad_() for _ in range(spp)]
-    d_out = th.randn(1, 3, h, w)
-
-    def update(d, kk, a, b, m):
-        return orc.progressive_kernel_apply(d, kk, a, b, m, splat=True)
     t0 = time.time()
-    splat_step(update, rad, logits, d_out)
-    dt = time.time() - t0
+    if args.workload == "model":
+        from sbmc_amd import Multisteps, losses
+        h = w = 128
+        halide_ops.register_cpu_ops_for_testing(orc)
+        try:
+            model = Multisteps(93, 3, ksize=k)
+            model.train()
+            opt = th.optim.Adam(model.parameters(), lr=1e-4)
+            batch = make_model_inputs(h, w, spp, "cpu", seed=1)
+            t0 = time.time()
+            train_step(model, opt, losses.TonemappedRelativeMSE(), batch)
+            dt = time.time() - t0
+        finally:
+            halide_ops.register_cpu_ops_for_testing(None)
+        what = "Multisteps training step (torch-CPU convs + oracle splat ops)"
+    else:
+        h, w, spp = min(360, args.height), args.width, min(spp, 4)
+        rad = [th.empty(1, 3, h, w).exponential_(1.0).requires_grad_() for _ in range(spp)]
+        logits = [th.randn(1, k * k, h, w).requires_grad_() for _ in range(spp)]
+        d_out = th.randn(1, 3, h, w)
+        t0 = time.time()
+        splat_step(lambda d, kk, a, b, m: orc.progressive_kernel_apply(d, kk, a, b, m, splat=True),
+                   rad, logits, d_out)
+        dt = time.time() - t0
+        what = "oracle splat fwd+bwd (C ops + torch-CPU composition)"
     return {
         "value": round(spp * h * w / dt / 1e6, 4), "unit": "Msamples/s",
         "cores": threads, "kind": "port",
-        "sample": "oracle (C ops + torch-CPU composition) splat fwd+bwd on %dx%d, %d spp, k=%d, "
-                  "%.1f s, host has %d logical cpus" % (w, h, spp, k, dt, os.cpu_count()),
+        "sample": "%s on %dx%d, %d spp, k=%d: %.1f s on %d threads (host has %d logical cpus)" % (
+            what, w, h, spp, k, dt, threads, os.cpu_count()),
     }
 
 
@@ -137,9 +171,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py "
+                         "--gpus %d ..." % (args.gpus, args.gpus))
     if not th.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X)")
     th.cuda.set_device(local_rank)
@@ -150,45 +184,14 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from sbmc_amd import _lib, functions, modules
+    from sbmc_amd import dist as sdist
     _lib.lib()  # fail loudly if the HIP extension is missing
 
     H, W, S, K = args.height, args.width, args.spp, args.ksize
     pad = (K - 1) // 2
-    steps = args.steps if args.steps is not None else (10 if args.workload == "splat" else 3)
-    warmup = args.warmup if args.warmup is not None else (3 if args.workload == "splat" else 1)
-
-    y0, y1, s0, s1 = slab_rows(H, world, rank, pad)
-    local_h = s1 - s0
-    timings = []
-
-    if args.workload == "splat":
-        update = modules.ProgressiveKernelApply(splat=True)
-        rad, logits, d_out = make_splat_inputs(local_h, W, S, K, device, seed=1234 + rank)
-
-        def step():
-            splat_step(update, rad, logits, d_out)
-    else:
-        if world > 1:
-            raise SystemExit("model workload: multi-GPU H-slab path not wired into bench yet")
-        from sbmc_amd import Multisteps, losses
-        from sbmc_amd.utils import crop_like
-        th.manual_seed(0)
-        model = Multisteps(93, 3, ksize=K).to(device)
-        model.train()
-        opt = th.optim.Adam(model.parameters(), lr=1e-4)
-        loss_fn = losses.TonemappedRelativeMSE()
-        batch = make_model_inputs(H, W, S, device, seed=1234)
-
-        def step():
-            opt.zero_grad()
-            out = model(batch)["radiance"]
-            tgt = crop_like(batch["target_image"], out)
-            loss = loss_fn(out, tgt)
-            loss.backward()
-            if not th.isfinite(loss).item():
-                raise RuntimeError("non-finite loss")
-            th.nn.utils.clip_grad_norm_(model.parameters(), 1000)
-            opt.step()
+    is_model = args.workload == "model"
+    steps = args.steps if args.steps is not None else (3 if is_model else 10)
+    warmup = args.warmup if args.warmup is not None else (1 if is_model else 3)
 
     def sync():
         th.cuda.synchronize(device)
@@ -196,34 +199,82 @@ def main():
             dist.barrier()
             th.cuda.synchronize(device)
 
-    for _ in range(warmup):
-        step()
-    sync()
-    functions.enable_kernel_timing(timings)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    functions.enable_kernel_timing(None)
-    if world > 1:
-        t = th.tensor([dt], device=device, dtype=th.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    def timed(step_fn, nwarm, nsteps, store=None):
+        for _ in range(nwarm):
+            step_fn()
+        sync()
+        functions.enable_kernel_timing(store)
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step_fn()
+        sync()
+        dt = time.perf_counter() - t0
+        functions.enable_kernel_timing(None)
+        if world > 1:
+            t = th.tensor([dt], device=device, dtype=th.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
 
-    # per-call device time of the fused operators inside the timed region
+    part = sdist.SlabPartition(H, world, rank)
+    timings = []
+
+    # ---------------------------------------------------------------- main timed region
+    if is_model:
+        from sbmc_amd import Multisteps, losses
+        th.manual_seed(0)
+        model = Multisteps(93, 3, ksize=K).to(device)
+        model.train()
+        opt = th.optim.Adam(model.parameters(), lr=1e-4)
+        loss_fn = losses.TonemappedRelativeMSE()
+        if world == 1:
+            batch = make_model_inputs(H, W, S, device, seed=1234)
+
+            def step():
+                train_step(model, opt, loss_fn, batch)
+        else:
+            batch = make_model_inputs(H, W, S, device, seed=1234, rows=(part.y0, part.y1))
+            runner = sdist.ShardedDenoiser(model, part)
+
+            def step():
+                runner.train_step(opt, loss_fn, batch)
+        dt = timed(step, warmup, steps, timings)
+        del batch
+    else:
+        update = modules.ProgressiveKernelApply(splat=True)
+        s0, s1 = max(0, part.y0 - pad), min(H, part.y1 + pad)
+        rad, logits, d_out = make_splat_inputs(s1 - s0, W, S, K, device, seed=1234 + rank)
+        dt = timed(lambda: splat_step(update, rad, logits, d_out), warmup, steps, timings)
+        local_px = (s1 - s0) * W
+
+    # ---------------------------------------------------------------- splat stage (N=1, model)
+    stage = None
+    if is_model and world == 1 and not args.no_stages:
+        del model, opt
+        th.cuda.empty_cache()
+        timings = []
+        update = modules.ProgressiveKernelApply(splat=True)
+        rad, logits, d_out = make_splat_inputs(H, W, S, K, device, seed=1234)
+        sdt = timed(lambda: splat_step(update, rad, logits, d_out), 3, 10, timings)
+        local_px = H * W
+        stage = {"workload": "splat fwd+bwd only: %d x ProgressiveKernelApply(splat=True) + normalise "
+                             "+ backward" % S,
+                 "value": round(S * H * W / (sdt / 10) / 1e6, 2), "unit": "Msamples/s",
+                 "ms_per_step": round(sdt / 10 * 1e3, 3), "steps": 10, "warmup": 3}
+
+    # per-call device time of the fused operators (events on the launch stream)
     per = {}
     for name, a, b in timings:
         per.setdefault(name, []).append(a.elapsed_time(b))  # ms
     kern = {}
-    px = local_h * W
-    for name, bpp in (("splat_update_fwd", fwd_bytes_per_pixel(K)),
-                      ("splat_update_bwd", bwd_bytes_per_pixel(K))):
-        if name in per:
-            avg_ms = sum(per[name]) / len(per[name])
-            kern[name] = {"calls": len(per[name]), "avg_ms": round(avg_ms, 4),
-                          "alg_bytes": px * bpp,
-                          "GBps": round(px * bpp / (avg_ms * 1e-3) / 1e9, 1)}
+    if not is_model or stage is not None:
+        for name, bpp in (("splat_update_fwd", fwd_bytes_per_pixel(K)),
+                          ("splat_update_bwd", bwd_bytes_per_pixel(K))):
+            if name in per:
+                avg_ms = sum(per[name]) / len(per[name])
+                kern[name] = {"calls": len(per[name]), "avg_ms": round(avg_ms, 4),
+                              "alg_bytes": local_px * bpp,
+                              "GBps": round(local_px * bpp / (avg_ms * 1e-3) / 1e9, 1)}
 
     if rank == 0:
         ms = dt / steps * 1e3
@@ -235,18 +286,25 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": ("splat fwd+bwd: %d x ProgressiveKernelApply(splat=True) + normalise + "
-                             "backward" % S) if args.workload == "splat" else
-                            "Multisteps(93,3) training step: fwd + TonemappedRelativeMSE + bwd + clip + Adam",
+                "workload": "Multisteps(93,3,ksize=%d) training step: fwd + TonemappedRelativeMSE + bwd "
+                            "+ clip + Adam (BASELINE.json configs[2])" % K if is_model else
+                            "splat fwd+bwd only: %d x ProgressiveKernelApply(splat=True) + normalise + "
+                            "backward" % S,
                 "height": H, "width": W, "spp": S, "ksize": K, "batch": 1,
-                "parallelism": "single GPU" if world == 1 else "H-slabs x%d (+%d halo rows/side)" % (world, pad),
+                "parallelism": "single GPU" if world == 1 else
+                               ("H-slabs x%d, halo exchange + grad all-reduce" % world if is_model else
+                                "H-slabs x%d (+%d halo rows/side)" % (world, pad)),
             },
-            "kernels": kern,
         }
+        if stage is not None:
+            res["stages"] = {"splat": stage}
+        if kern:
+            res["kernels"] = kern
         if "splat_update_bwd" in kern:
             kb = kern["splat_update_bwd"]
             res["roofline"] = {
-                "kernel": "splat_update_bwd (state + main + route launches of one call)",
+                "kernel": "splat_update_bwd: sbmc::splat_bwd_strip_kernel (+ its per-pixel state "
+                          "pre-pass, ~2% of the call)",
                 "bound": "hbm", "achieved": kb["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(kb["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None,
             }

@@ -1,0 +1,232 @@
+"""One frame on several MI355X: H-slab sharding with halo exchange over RCCL / xGMI.
+
+New functionality (the reference is single-process; its closest analogue is the overlapped
+tiling of scripts/denoise.py:54-93, which recomputes a 256-px halo per tile).  Design
+(SURVEY.md section 8e), one process per GPU, rank r owns the contiguous row slab r:
+
+* per-sample 1x1 ConvChains (embedding, kernel regressor) and the mean over samples are
+  pointwise in space: no communication;
+* the U-net: every ConvChain of vertical reach R (three 3x3 convs -> R = 3) first receives
+  R rows from each neighbouring rank (`halo_pad`), runs unchanged on the padded slab, and
+  drops the R rows that saw the artificial zero padding; at the true image border nothing
+  is padded or dropped, so the convolutions' own zero padding acts exactly as in the
+  single-GPU model.  2x2 max-pools are local because slab boundaries are multiples of 4
+  rows; the bilinear x2 upsample takes 1 halo row of the coarse map;
+* the splat: the regressor's inputs (per-sample embeddings, pixel context, radiance) are
+  halo-padded by the kernel radius p, logits are predicted for slab + 2p source rows and the
+  fused kernels run on that extended slab; destination rows of the halo are dropped
+  (running-softmax state never crosses ranks);
+* training: the loss is the global mean (each rank contributes its rows); parameter
+  gradients are summed with one flattened all-reduce.
+
+`halo_pad` is a `torch.autograd.Function`: its backward sends the gradient of the halo
+rows back to the rank that owns them, so autograd over the sharded graph equals autograd
+over the full frame.  Neighbour traffic is batched `isend/irecv` pairs (the direct xGMI
+link between adjacent GPUs); works unchanged on gloo (CPU tests) and nccl (= RCCL).
+"""
+import torch as th
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from .utils import crop_like
+
+__all__ = ["SlabPartition", "halo_pad", "sharded_autoencoder", "ShardedDenoiser"]
+
+
+class SlabPartition(object):
+    """Rows [y0, y1) of an H-row frame owned by `rank` out of `world` ranks.
+
+    Slab boundaries are multiples of `align` rows (4: two 2x2 poolings in the U-net)."""
+
+    def __init__(self, height, world, rank, align=4, group=None):
+        self.height, self.world, self.rank, self.group = height, world, rank, group
+        if world > 1 and height % align != 0:
+            raise ValueError("sharded path needs the frame height to be a multiple of %d" % align)
+        units = height // align if world > 1 else height
+        unit = align if world > 1 else 1
+        base, rem = divmod(units, world)
+        u0 = rank * base + min(rank, rem)
+        u1 = u0 + base + (1 if rank < rem else 0)
+        self.y0, self.y1 = u0 * unit, u1 * unit
+        self.has_up = rank > 0
+        self.has_down = rank < world - 1
+
+    @property
+    def rows(self):
+        return self.y1 - self.y0
+
+    def peer(self, delta):
+        r = self.rank + delta
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+
+def _exchange(part, to_up, to_down):
+    """Sends `to_up` to rank-1 and `to_down` to rank+1; returns (from_up, from_down)."""
+    ops, from_up, from_down = [], None, None
+    if part.has_up:
+        to_up = to_up.contiguous()
+        from_up = th.empty_like(to_up)
+        ops += [dist.P2POp(dist.isend, to_up, part.peer(-1), group=part.group),
+                dist.P2POp(dist.irecv, from_up, part.peer(-1), group=part.group)]
+    if part.has_down:
+        to_down = to_down.contiguous()
+        from_down = th.empty_like(to_down)
+        ops += [dist.P2POp(dist.isend, to_down, part.peer(+1), group=part.group),
+                dist.P2POp(dist.irecv, from_down, part.peer(+1), group=part.group)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return from_up, from_down
+
+
+class _HaloPad(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, part):
+        ctx.r, ctx.part, ctx.rows = r, part, x.shape[-2]
+        if x.shape[-2] < r:
+            raise RuntimeError("slab of %d rows is thinner than the halo (%d)" % (x.shape[-2], r))
+        from_up, from_down = _exchange(part, x[..., :r, :], x[..., -r:, :])
+        pieces = [t for t in (from_up, x, from_down) if t is not None]
+        return th.cat(pieces, -2) if len(pieces) > 1 else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        r, part, h = ctx.r, ctx.part, ctx.rows
+        top = r if part.has_up else 0
+        # gradient of my halo rows goes back to their owners; theirs for my edge rows comes here
+        from_up, from_down = _exchange(part, g[..., :r, :], g[..., g.shape[-2] - r:, :])
+        gx = g[..., top:top + h, :].clone()
+        if from_up is not None:
+            gx[..., :r, :] += from_up
+        if from_down is not None:
+            gx[..., h - r:, :] += from_down
+        return gx, None, None
+
+
+def halo_pad(x, r, part):
+    """[..., h, w] -> [..., (r if up) + h + (r if down), w] with the neighbours' edge rows."""
+    if r == 0 or part.world == 1:
+        return x
+    return _HaloPad.apply(x, r, part)
+
+
+def _crop_halo(y, r, part):
+    top = r if part.has_up else 0
+    bot = r if part.has_down else 0
+    return y[..., top:y.shape[-2] - bot, :]
+
+
+def _reach(chain):
+    """Vertical receptive reach (rows per side) of a stride-1 ConvChain."""
+    r = 0
+    for m in chain.modules():
+        if isinstance(m, th.nn.Conv2d):
+            if m.stride[0] != 1:
+                raise ValueError("sharded path expects stride-1 convolutions")
+            r += m.kernel_size[0] // 2
+    return r
+
+
+def _chain(chain, x, part):
+    r = _reach(chain)
+    return _crop_halo(chain(halo_pad(x, r, part)), r, part)
+
+
+def _level(level, x, part):
+    left = _chain(level.left, x, part)
+    if level.is_last:
+        return left
+    if left.shape[-2] % 2:
+        raise RuntimeError("sharded path needs an even number of rows at every U-net level")
+    coarse = _level(level.next_level, level.downsample(left), part)
+    padded = halo_pad(coarse, 1, part)
+    up = F.interpolate(padded, size=(2 * padded.shape[-2], left.shape[-1]), mode="bilinear",
+                       align_corners=False)
+    up = _crop_halo(up, 2, part)
+    return _chain(level.right, th.cat([up, left], 1), part)
+
+
+def sharded_autoencoder(autoencoder, x, part):
+    """`modules.Autoencoder.forward` on a row slab (exact, see the module docstring)."""
+    if part.world == 1:
+        return autoencoder(x)
+    return _level(autoencoder.net, x, part)
+
+
+class ShardedDenoiser(object):
+    """Runs a `Multisteps` model on this rank's slab of one frame.
+
+    The batch holds the slab rows only: radiance [bs, spp, 3, rows, w], features
+    [bs, spp, nf, rows, w], global_features [bs, ngf, 1, 1] (replicated) and, for training,
+    target_image [bs, 3, rows, w].
+    """
+
+    def __init__(self, model, part):
+        self.model, self.part = model, part
+
+    def forward(self, batch):
+        m, part = self.model, self.part
+        radiance = batch["radiance"]
+        features = batch["features"].to(radiance.device)
+        gfeatures = batch["global_features"].to(radiance.device)
+        if m.pixel:
+            radiance = radiance.mean(1, keepdim=True)
+            features = features.mean(1, keepdim=True)
+        bs, spp, nf, h, w = features.shape
+        context = gfeatures.expand(bs, gfeatures.shape[1], h, w)
+        for step in range(m.nsteps):
+            features = m._embed(getattr(m, "embedding_{:02d}".format(step)), features, context)
+            reduced = features.mean(1)
+            context = sharded_autoencoder(getattr(m, "propagation_{:02d}".format(step)), reduced, part)
+
+        p = (m.ksize - 1) // 2
+        features = halo_pad(features, p, part)
+        context = halo_pad(context, p, part)
+        radiance = halo_pad(radiance, p, part)
+        sum_r, sum_w, max_w = None, None, None
+        for sp in range(spp):
+            kernels = m.kernel_regressor(th.cat([features[:, sp], context], 1))
+            r = crop_like(radiance[:, sp], kernels)
+            sum_r, sum_w, max_w = m.kernel_update(r.contiguous(), kernels, sum_r, sum_w, max_w)
+        output = sum_r / (sum_w + m.eps)
+        # p rows per side go in every case: the halo at an inner boundary, the invalid border
+        # (reference models.py:215-216) at the true image border
+        return {"radiance": output[..., p:-p, p:-p]}
+
+    __call__ = forward
+
+    def target_rows(self, target):
+        """The rows (and columns) of this rank's target slab matching `forward`'s output."""
+        p = (self.model.ksize - 1) // 2
+        top = 0 if self.part.has_up else p
+        bot = 0 if self.part.has_down else p
+        return target[..., top:target.shape[-2] - bot, p:-p]
+
+    def train_step(self, optimizer, loss_fn, batch, clip=1000):
+        """The reference training step (sbmc/interfaces.py:78-105) on the sharded frame.
+        `loss_fn` must be a mean over pixels (all of sbmc_amd.losses are)."""
+        part = self.part
+        optimizer.zero_grad()
+        out = self.forward(batch)["radiance"]
+        tgt = self.target_rows(batch["target_image"])
+        count = th.tensor([float(out.numel())], device=out.device)
+        if part.world > 1:
+            dist.all_reduce(count, group=part.group)
+        loss = loss_fn(out, tgt) * (out.numel() / count.item())   # this rank's share of the global mean
+        loss.backward()
+        params = [q for q in self.model.parameters() if q.grad is not None]
+        total = loss.detach().clone()
+        if part.world > 1:
+            flat = th.cat([q.grad.reshape(-1) for q in params] + [total.reshape(1)])
+            dist.all_reduce(flat, group=part.group)
+            off = 0
+            for q in params:
+                n = q.grad.numel()
+                q.grad.copy_(flat[off:off + n].view_as(q.grad))
+                off += n
+            total = flat[off]
+        if not th.isfinite(total).item():
+            raise RuntimeError("non-finite loss")
+        th.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
+        optimizer.step()
+        return total
