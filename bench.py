@@ -50,6 +50,25 @@ def bwd_bytes_per_pixel(k, c=3):
     return 8 * k * k + 8 * c + 40
 
 
+def measured_traffic(kernel_substr):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/r*_pmc.json,
+    produced by tools_prof.sh: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None, None
+    tot = 0
+    for k, v in d.items():
+        if any(sub in k for sub in kernel_substr):
+            tot += int(v["hbm_bytes_per_launch"])
+    return (tot or None), os.path.basename(files[-1])
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,11 +321,16 @@ def main():
             res["kernels"] = kern
         if "splat_update_bwd" in kern:
             kb = kern["splat_update_bwd"]
+            traffic, src = (None, None)
+            if (H, W, K) == (720, 1280, 21) and world == 1:   # the PMC summary was taken at this size
+                traffic, src = measured_traffic(("splat_bwd_strip_kernel", "splat_bwd_state_kernel"))
             res["roofline"] = {
                 "kernel": "splat_update_bwd: sbmc::splat_bwd_strip_kernel (+ its per-pixel state "
-                          "pre-pass, ~2% of the call)",
+                          "pre-pass, ~3% of the call)",
                 "bound": "hbm", "achieved": kb["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(kb["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(kb["GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": src, "alg_bytes_per_launch": kb["alg_bytes"],
+                "avg_launch_ms": kb["avg_ms"],
             }
         if world == 1 and not args.no_cpu_baseline:
             try:
