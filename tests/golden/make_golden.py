@@ -182,6 +182,62 @@ def gen_losses(ref):
     save("losses.npz", out)
 
 
+def synthetic_scene(folder, width, height, ts, spp, seed):
+    """Writes a synthetic scene with sbmc_amd.binio (low-entropy values so that the fixture stays
+    small) and returns nothing; tiles are named like the reference expects (sorted *.bin)."""
+    from sbmc_amd import binio
+    rng = np.random.RandomState(seed)
+    os.makedirs(folder, exist_ok=True)
+
+    def q(*shape, scale=1.0, lo=0.0):
+        return (np.round(rng.rand(*shape) * 16) / 16 * scale + lo).astype(np.float32)
+    idx = 0
+    for by in range(0, height, ts):
+        for bx in range(0, width, ts):
+            base = q(spp, 27, ts, ts, scale=2.0, lo=-0.25)      # some negative radiance too
+            binio.write_tile(
+                os.path.join(folder, "tile_%03d.bin" % idx), bx, by, width, height,
+                pixel_data=q(30, ts, ts), base=base, probabilities=q(spp, 24, ts, ts),
+                light_dirs=q(spp, 12, ts, ts, scale=3.0, lo=-1.5),
+                bounce_flags=rng.randint(0, 32, size=(spp, 6, ts, ts)).astype(np.int16),
+                focus_distance=2.5, aperture_radius=0.125, fov=40.0, scene_radius=7.0,
+                gt_sample_count=64)
+            idx += 1
+
+
+def gen_bin(ref_root):
+    """A scene written by sbmc_amd.binio, read back by the REFERENCE's sbmc/datasets.py
+    (FullImagesDataset, "sbmc" mode).  Commits the .bin tiles and what the reference read."""
+    import importlib.util
+    import types
+    from sbmc_amd import binio
+    scene_root = os.path.join(HERE, "bin_scene")
+    import shutil
+    shutil.rmtree(scene_root, ignore_errors=True)
+    synthetic_scene(os.path.join(scene_root, "scene0"), 32, 32, 16, 3, seed=19)
+    # stubs for what datasets.py imports: lz4.frame (absent python package -> system liblz4),
+    # ttools logger, torch Dataset; np.bool was removed from numpy 2.x
+    lz4 = types.ModuleType("lz4")
+    frame = types.ModuleType("lz4.frame")
+    frame.decompress = lambda buf: binio.lz4f_decompress(buf, None)
+    lz4.frame = frame
+    sys.modules["lz4"], sys.modules["lz4.frame"] = lz4, frame
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    spec = importlib.util.spec_from_file_location("ref_datasets", os.path.join(ref_root, "sbmc", "datasets.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for spp in (3, 2):
+        ds = mod.FullImagesDataset(scene_root, spp=spp)
+        item = ds[0]
+        assert ds.num_features == 93 and ds.num_global_features == 3
+        for k in ("features", "radiance", "low_spp", "target_image", "global_features",
+                  "image_data", "image_data_var"):
+            out["spp%d.%s" % (spp, k)] = np.asarray(item[k])
+    save("bin_scene_expected.npz", out)
+
+
 def main():
     if not refload.available():
         raise SystemExit("reference tree not available: fixtures can only be regenerated in the "
@@ -192,6 +248,7 @@ def main():
     gen_backbone(ref)
     gen_multisteps(ref)
     gen_losses(ref)
+    gen_bin(refload.REFERENCE_ROOT)
 
 
 if __name__ == "__main__":
