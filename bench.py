@@ -210,7 +210,11 @@ def main():
     pad = (K - 1) // 2
     is_model = args.workload == "model"
     steps = args.steps if args.steps is not None else (3 if is_model else 10)
-    warmup = args.warmup if args.warmup is not None else (1 if is_model else 3)
+    warmup = args.warmup if args.warmup is not None else (2 if is_model else 3)
+    if is_model:
+        # the first TWO steps carry one-time work (MIOpen solver selection forward and backward,
+        # Adam state allocation, caching-allocator growth): never time them
+        warmup = max(warmup, 2)
 
     def sync():
         th.cuda.synchronize(device)
@@ -224,8 +228,12 @@ def main():
         sync()
         functions.enable_kernel_timing(store)
         t0 = time.perf_counter()
-        for _ in range(nsteps):
+        for i in range(nsteps):
             step_fn()
+            if os.environ.get("SBMC_BENCH_VERBOSE"):   # debugging aid: adds a sync per step
+                th.cuda.synchronize(device)
+                print("step %d: %.1f ms since start" % (i, (time.perf_counter() - t0) * 1e3),
+                      file=sys.stderr, flush=True)
         sync()
         dt = time.perf_counter() - t0
         functions.enable_kernel_timing(None)

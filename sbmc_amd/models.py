@@ -38,11 +38,16 @@ class Multisteps(nn.Module):
         pixel(bool): average the samples first and treat the result as 1 spp (ablation).
         sample_chunk(int or None): embed at most this many samples per conv call
             (None: all at once).  Not a reference argument; does not change results.
+        pointwise_gemm(bool): on GPU tensors run the per-sample 1x1 ConvChains as batched GEMMs
+            (rocBLAS / hipBLASLt) instead of MIOpen convolutions: same arithmetic, no layout
+            change, ~7% faster training step at 720p.  Not a reference argument.
+            (NHWC activations for the U-nets were measured too: MIOpen's heuristic solver
+            choice for NHWC fp32 made the step 5x slower, so the backbone stays NCHW.)
     """
 
     def __init__(self, n_features, n_global_features, width=128,
                  embedding_width=128, ksize=21, splat=True, nsteps=3,
-                 pixel=False, sample_chunk=None):
+                 pixel=False, sample_chunk=None, pointwise_gemm=True):
         super(Multisteps, self).__init__()
         if ksize < 3 or (ksize % 2 == 0):
             LOG.error("Kernel size should be odd and > 3.")
@@ -75,6 +80,10 @@ class Multisteps(nn.Module):
             width + embedding_width, ksize * ksize, depth=3, width=width, ksize=1,
             activation="leaky_relu", pad=False, output_type="linear")
         self.kernel_update = ops.ProgressiveKernelApply(splat=splat)
+        if pointwise_gemm:
+            self.kernel_regressor.pointwise_as_gemm = True
+            for step in range(nsteps):
+                getattr(self, "embedding_{:02d}".format(step)).pointwise_as_gemm = True
 
     def _embed(self, module, per_sample, per_pixel):
         """Runs a 1x1 ConvChain on cat(per_sample[:, s], per_pixel) for every sample s.
@@ -89,7 +98,8 @@ class Multisteps(nn.Module):
             n = part.shape[1]
             ctx = per_pixel.unsqueeze(1).expand(bs, n, per_pixel.shape[1], h, w)
             flat = th.cat([part, ctx], 2).reshape(bs * n, c + per_pixel.shape[1], h, w)
-            outs.append(module(flat).view(bs, n, -1, h, w))
+            out = module(flat)
+            outs.append(out.view(bs, n, out.shape[1], h, w))
         return outs[0] if len(outs) == 1 else th.cat(outs, 1)
 
     def forward(self, samples):

@@ -53,6 +53,23 @@ def _init_conv(conv, nonlinearity):
     nn.init.xavier_uniform_(conv.weight.data, nn.init.calculate_gain(gain_of))
 
 
+def _is_pointwise(conv):
+    return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is not None)
+
+
+def _pointwise_gemm(conv, x):
+    """conv(x) for a 1x1 convolution as y[b] = W @ x[b] + bias on [B, Cin, H*W] (no layout change)."""
+    if hasattr(conv, "weight_g"):   # old-style weight norm: w = g * v / ||v||, norm over dims 1..3
+        w = th._weight_norm(conv.weight_v, conv.weight_g, 0)
+    else:
+        w = conv.weight
+    b, c, h, wd = x.shape
+    y = th.baddbmm(conv.bias.view(1, -1, 1), w.view(1, w.shape[0], c).expand(b, -1, -1),
+                   x.reshape(b, c, h * wd))
+    return y.view(b, w.shape[0], h, wd)
+
+
 class ConvChain(nn.Module):
     """A stack of ``depth`` convolutions: (depth-1) x [conv, (norm), activation] + conv.
 
@@ -106,9 +123,22 @@ class ConvChain(nn.Module):
         if out_act is not None:
             self.add_module("output_activation", out_act())
 
+    #: 1x1 / stride-1 convolutions as plain batched GEMMs (rocBLAS / hipBLASLt) on the planar
+    #: NCHW activations: y[b] = W @ x[b].  Same arithmetic as the convolution; set per instance
+    #: by Multisteps for its per-sample chains.
+    pointwise_as_gemm = False
+
     def forward(self, x):
+        gemm = self.pointwise_as_gemm and x.is_cuda
         for m in self.children():
-            x = m(x)
+            if gemm and isinstance(m, ConvChain._ConvBNRelu) and _is_pointwise(m.layer[0]):
+                x = _pointwise_gemm(m.layer[0], x)
+                for sub in list(m.layer.children())[1:]:
+                    x = sub(x)
+            elif gemm and isinstance(m, nn.Conv2d) and _is_pointwise(m):
+                x = _pointwise_gemm(m, x)
+            else:
+                x = m(x)
         return x
 
     class _ConvBNRelu(nn.Module):
