@@ -142,16 +142,19 @@ def train_step(model, opt, loss_fn, batch):
     return loss
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, device=None):
     """Times the CPU port (torch-CPU convolutions + the oracle's splat operators behind the
-    same Python model code) on a bounded sample of the same workload."""
+    same Python model code) on a bounded sample of the same workload.  For the model workload
+    the same seeded model and inputs are also run on the GPU, which gives the parity figures
+    of BASELINE.json's metric ("PSNR vs ref", SURVEY.md section 8d: 10*log10(1/MSE) after the
+    display curve x/(1+x), and the max relative error)."""
     from oracle import sbmc_oracle as orc
     from sbmc_amd import halide_ops
     orc.lib()
     k, spp = args.ksize, args.spp
     threads = th.get_num_threads()
     th.manual_seed(0)
-    t0 = time.time()
+    parity = None
     if args.workload == "model":
         from sbmc_amd import Multisteps, losses
         h = w = 128
@@ -159,13 +162,30 @@ def cpu_baseline(args):
         try:
             model = Multisteps(93, 3, ksize=k)
             model.train()
+            state = {n: v.clone() for n, v in model.state_dict().items()}
             opt = th.optim.Adam(model.parameters(), lr=1e-4)
             batch = make_model_inputs(h, w, spp, "cpu", seed=1)
+            with th.no_grad():
+                ref_out = model(batch)["radiance"]
             t0 = time.time()
             train_step(model, opt, losses.TonemappedRelativeMSE(), batch)
             dt = time.time() - t0
         finally:
             halide_ops.register_cpu_ops_for_testing(None)
+        if device is not None:
+            gmodel = Multisteps(93, 3, ksize=k)
+            gmodel.load_state_dict(state)
+            gmodel.to(device).train()
+            with th.no_grad():
+                out = gmodel({n: v.to(device) for n, v in batch.items()})["radiance"].cpu()
+            tm = lambda x: x.clamp(min=0) / (1 + x.clamp(min=0))  # noqa: E731
+            mse = ((tm(out) - tm(ref_out)) ** 2).mean().item()
+            parity = {
+                "psnr_db_vs_cpu_oracle": round(10 * __import__("math").log10(1.0 / max(mse, 1e-30)), 1),
+                "max_rel_err": float("%.3g" % ((out - ref_out).abs() / (ref_out.abs() + 1e-6)).max().item()),
+                "max_abs_err_over_max": float("%.3g" % ((out - ref_out).abs().max() / ref_out.abs().max()).item()),
+                "sample": "Multisteps forward, %dx%d, %d spp, k=%d, GPU (HIP splat + MIOpen/rocBLAS) "
+                          "vs CPU (oracle splat + torch-CPU convs)" % (w, h, spp, k)}
         what = "Multisteps training step (torch-CPU convs + oracle splat ops)"
     else:
         h, w, spp = min(360, args.height), args.width, min(spp, 4)
@@ -177,12 +197,13 @@ def cpu_baseline(args):
                    rad, logits, d_out)
         dt = time.time() - t0
         what = "oracle splat fwd+bwd (C ops + torch-CPU composition)"
-    return {
+    base = {
         "value": round(spp * h * w / dt / 1e6, 4), "unit": "Msamples/s",
         "cores": threads, "kind": "port",
         "sample": "%s on %dx%d, %d spp, k=%d: %.1f s on %d threads (host has %d logical cpus)" % (
             what, w, h, spp, k, dt, threads, os.cpu_count()),
     }
+    return base, parity
 
 
 def main():
@@ -342,7 +363,9 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(args)
+                res["cpu_baseline"], parity = cpu_baseline(args, device)
+                if parity is not None:
+                    res["parity"] = parity
             except Exception as e:  # the baseline must never sink the GPU measurement
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))

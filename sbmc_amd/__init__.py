@@ -5,6 +5,6 @@ per-sample kernel-splatting operators, exposed through the reference's own
 ``sbmc.functions`` / ``sbmc.modules`` / ``sbmc.models`` API.
 """
 from .models import Multisteps, KPCN  # noqa: F401
-from . import functions, modules, models, losses  # noqa: F401
+from . import functions, modules, models, losses, binio, denoise, interfaces  # noqa: F401
 
 __version__ = "0.1.0"

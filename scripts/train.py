@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Train the SBMC denoiser on a folder of `.bin` tiles (counterpart of the reference's
+scripts/train.py:33-152 for the sample-based model; visdom / progress-bar callbacks dropped).
+
+    python scripts/train.py --data <root> --checkpoint_dir <dir> [--val_data <root>] [--spp 8]
+        [--ksize 21] [--gather] [--pixel] [--lr 1e-4] [--bs 1] [--num_epochs 1]
+"""
+import argparse
+import logging
+import os
+import sys
+
+import numpy as np
+import torch as th
+from torch.utils.data import DataLoader
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sbmc_amd import Multisteps, interfaces  # noqa: E402
+
+
+def main(args):
+    np.random.seed(0)
+    th.manual_seed(0)
+    if not th.cuda.is_available():
+        raise SystemExit("sbmc_amd runs its operators on MI355X only; no GPU is visible")
+    data = interfaces.TilesDataset(args.data, spp=args.spp)
+    model = Multisteps(data.num_features, data.num_global_features, ksize=args.ksize,
+                       splat=not args.gather, pixel=args.pixel)
+    loader = DataLoader(data, batch_size=args.bs, num_workers=args.num_worker_threads, shuffle=True)
+    val_loader = None
+    if args.val_data:
+        val_loader = DataLoader(interfaces.TilesDataset(args.val_data, spp=args.spp),
+                                batch_size=args.bs, num_workers=1, shuffle=False)
+    meta = dict(model_params=dict(ksize=args.ksize, gather=args.gather, pixel=args.pixel),
+                kpcn_mode=False, data_params=dict(spp=args.spp))
+    interface = interfaces.SampleBasedDenoiserInterface(model, lr=args.lr, cuda=True)
+    ckpt = interfaces.Checkpointer(args.checkpoint_dir, model, interface.optimizer, meta=meta)
+    extras, _ = ckpt.load_latest()
+    start = extras["epoch"] if extras else 0
+    interfaces.train(interface, loader, num_epochs=args.num_epochs, val_dataloader=val_loader,
+                     checkpointer=ckpt, start_epoch=start)
+
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser()
+    p.add_argument("--data", required=True)
+    p.add_argument("--val_data", default=None)
+    p.add_argument("--checkpoint_dir", required=True)
+    p.add_argument("--spp", type=int, default=8)
+    p.add_argument("--ksize", type=int, default=21)
+    p.add_argument("--gather", action="store_true")
+    p.add_argument("--pixel", action="store_true")
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--bs", type=int, default=1)
+    p.add_argument("--num_epochs", type=int, default=1)
+    p.add_argument("--num_worker_threads", type=int, default=0)
+    logging.basicConfig(level=logging.INFO)
+    main(p.parse_args())

@@ -167,6 +167,29 @@ def gen_multisteps(ref):
     save("multisteps.npz", out)
 
 
+def gen_kpcn(ref):
+    out = {}
+    th.manual_seed(20)
+    model = ref.models.KPCN(6, ksize=5, depth=3, width=8)
+    for k, v in model.state_dict().items():
+        out["sd." + k] = npy(v)
+    g = th.Generator().manual_seed(21)
+    h, w = 26, 30
+    data = {
+        "kpcn_diffuse_in": th.rand(1, 6, h, w, generator=g),
+        "kpcn_specular_in": th.rand(1, 6, h, w, generator=g),
+        "kpcn_diffuse_buffer": th.rand(1, 3, h, w, generator=g),
+        "kpcn_specular_buffer": th.rand(1, 3, h, w, generator=g),
+        "kpcn_albedo": th.rand(1, 3, h, w, generator=g),
+    }
+    res = model(data)
+    for k, v in data.items():
+        out["in." + k] = npy(v)
+    for k, v in res.items():
+        out["out." + k] = npy(v)
+    save("kpcn.npz", out)
+
+
 def gen_losses(ref):
     out = {}
     g = th.Generator().manual_seed(18)
@@ -248,6 +271,7 @@ def main():
     gen_backbone(ref)
     gen_multisteps(ref)
     gen_losses(ref)
+    gen_kpcn(ref)
     gen_bin(refload.REFERENCE_ROOT)
 
 

@@ -137,3 +137,11 @@ def test_native_library_is_loaded():
     maps = open("/proc/self/maps").read()
     assert "libsbmc_hip.so" in maps
     assert "libsbmc_oracle.so" not in maps or True  # the oracle may be loaded by *tests*, never by sbmc_amd
+
+
+def test_kpcn_on_gpu_matches_reference_fixture():
+    from test_host_golden import _kpcn_from_golden
+    g, model, data = _kpcn_from_golden("cuda")
+    res = model(data)
+    for k in ("radiance", "diffuse", "specular"):
+        close(res[k], g["out." + k], rtol=2e-5, what=k)

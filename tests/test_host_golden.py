@@ -173,3 +173,19 @@ def test_multisteps_sample_chunking_is_exact(cpu_ops):
         model.sample_chunk = 2
         out = model(batch)["radiance"]
     close(out, ref, rtol=1e-6)
+
+
+def _kpcn_from_golden(device):
+    from sbmc_amd import KPCN
+    g = golden("kpcn.npz")
+    model = KPCN(6, ksize=5, depth=3, width=8)
+    model.load_state_dict({k[3:]: t(g[k]) for k in g.files if k.startswith("sd.")}, strict=True)
+    data = {k[3:]: t(g[k], device) for k in g.files if k.startswith("in.")}
+    return g, model.to(device), data
+
+
+def test_kpcn_matches_reference(cpu_ops):
+    g, model, data = _kpcn_from_golden("cpu")
+    res = model(data)
+    for k in ("radiance", "diffuse", "specular"):
+        close(res[k], g["out." + k], rtol=1e-6, what=k)
