@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be loaded first: brings in the HIP runtime the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsbmc_hip.so")
+# SBMC_HIP_LIB: alternative build of the same ABI (kernel A/B experiments)
+LIB_PATH = os.environ.get("SBMC_HIP_LIB") or os.path.join(_HERE, "libsbmc_hip.so")
 
 #: every extern "C" symbol include/sbmc_hip.h declares
 SYMBOLS = (

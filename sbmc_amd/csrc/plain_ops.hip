@@ -32,31 +32,51 @@ struct PlainParams {
 };
 
 // ---------------------------------------------------------------- scatter2gather
-// One lane per output pixel; taps looped.  Writes are aligned 256-B segments,
-// reads are the same segments shifted by (dx - pw) floats in the mirrored plane.
+// One wave per 64-pixel row strip (4 x-adjacent strips per workgroup), taps looped.  Writes
+// are aligned 256-B segments of plane (dy,dx); reads are the same segment shifted by (dx-pw)
+// floats in the mirrored plane (kh-1-dy, kw-1-dx) of row y+dy-ph.  Raw buffer addressing:
+// per-tap offsets are scalar, lanes whose source column is outside the image carry an
+// out-of-range voffset and read 0 (no branches).
 template <int K>
 __global__ __launch_bounds__(PLAIN_TY * TX) void s2g_kernel(PlainParams p) {
     const int kh = K > 0 ? K : p.kh, kw = K > 0 ? K : p.kw;
     const int ph = (kh - 1) / 2, pw = (kw - 1) / 2;
-    const TileCoord t = decode_tile(p.ntx, p.nty, PLAIN_TY);
+    const int wv = wave_id();
     const int lane = threadIdx.x & 63;
-    const int y = t.y0 + wave_id();
-    const int x = t.x0 + lane;
-    if (y >= p.h) return;
+    const long item = (long)logical_block_id() * PLAIN_TY + wv;
+    const long per_img = (long)p.h * p.ntx;
+    if (item >= per_img * p.bs) return;
+    const int n = __builtin_amdgcn_readfirstlane((int)(item / per_img));
+    const int rem = __builtin_amdgcn_readfirstlane((int)(item % per_img));
+    const int y = __builtin_amdgcn_readfirstlane(rem / p.ntx);
+    const int x0 = __builtin_amdgcn_readfirstlane((rem % p.ntx) * TX);
+    const int x = x0 + lane;
     const size_t hw = (size_t)p.h * p.w;
-    const float* src = p.weights + (size_t)t.n * kh * kw * hw;
-    float* dst = p.out0 + (size_t)t.n * kh * kw * hw;
-    const bool xact = x < p.w;
+    const float* src = p.weights + (size_t)n * kh * kw * hw;
+    float* dst = p.out0 + (size_t)n * kh * kw * hw + (size_t)y * p.w + x0;
+    const unsigned voff = (unsigned)lane * 4u;
+    const unsigned wvoff = x < p.w ? voff : BUF_OOB;          // stores of lanes past the edge are dropped
+    const unsigned plane_stride = (unsigned)hw * 4u;
+    const unsigned tap_stride = (unsigned)(hw - 1) * 4u;      // source: one plane back, one column on
+    const int dx_lo = pw - x, dx_hi = p.w + pw - x;           // source column inside the image
     for (int dy = 0; dy < kh; ++dy) {
         const int ys = y + dy - ph;
-        const bool yin = (ys >= 0) && (ys < p.h);
+        const bool yin = (ys >= 0) && (ys < p.h);             // wave-uniform
+        const rsrc_t ws = make_rsrc(dst + (size_t)(dy * kw) * hw);
+        if (!yin) {
+#pragma unroll 7
+            for (int dx = 0; dx < kw; ++dx) buf_store(0.f, ws, wvoff, (unsigned)dx * plane_stride);
+            continue;
+        }
+        // source of tap dx: plane (kh-1-dy)*kw + (kw-1-dx), row ys, column x0-pw+dx+lane
+        //   = rowmin + (kw-1-dx)*(hw-1) + lane with rowmin the address of tap kw-1, lane 0
+        const rsrc_t rs = make_rsrc(src + ((long)((kh - 1 - dy) * kw) * (long)hw + (long)ys * p.w +
+                                           (long)(x0 - pw + kw - 1)));
 #pragma unroll 7
         for (int dx = 0; dx < kw; ++dx) {
-            const int xs = x + dx - pw;
-            float v = 0.f;
-            if (yin && xs >= 0 && xs < p.w)
-                v = src[(size_t)((kh - 1 - dy) * kw + (kw - 1 - dx)) * hw + (size_t)ys * p.w + xs];
-            if (xact) dst[(size_t)(dy * kw + dx) * hw + (size_t)y * p.w + x] = v;
+            const unsigned vo = (dx >= dx_lo && dx < dx_hi) ? voff : BUF_OOB;
+            const float v = buf_load(rs, vo, (unsigned)(kw - 1 - dx) * tap_stride);
+            buf_store(v, ws, wvoff, (unsigned)dx * plane_stride);
         }
     }
 }
@@ -220,11 +240,14 @@ extern "C" int sbmc_scatter2gather_f32(const float* weights, float* output,
     if (bad_dims(bs, 0, h, w, kh, kw)) return SBMC_HIP_EINVAL;
     if (bs == 0 || h == 0 || w == 0) return 0;
     if (!weights || !output) return SBMC_HIP_EINVAL;
+    // per-row buffer offsets span up to kw planes and must stay in the 2 GiB voffset range
+    if ((size_t)h * w * 4 * (size_t)(kw + 1) >= 0x7ff00000ull) return SBMC_HIP_EINVAL;
     PlainParams p{};
     p.weights = weights; p.out0 = output;
     p.bs = bs; p.h = h; p.w = w; p.kh = kh; p.kw = kw;
-    p.ntx = tiles_x(w); p.nty = tiles_y(h, PLAIN_TY);
-    const unsigned grid = (unsigned)bs * p.ntx * p.nty;
+    p.ntx = tiles_x(w); p.nty = h;
+    const long items = (long)bs * h * p.ntx;
+    const unsigned grid = (unsigned)((items + PLAIN_TY - 1) / PLAIN_TY);
     hipStream_t s = (hipStream_t)stream;
     if (kh == 21 && kw == 21)
         hipLaunchKernelGGL(s2g_kernel<21>, dim3(grid), dim3(PLAIN_TY * TX), 0, s, p);

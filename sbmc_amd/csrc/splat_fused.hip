@@ -52,6 +52,9 @@ constexpr int BWD_TY = 8;   // v1 backward: 8 waves, LDS tile [C+2][TY+k-1][64+k
 constexpr int V2_WAVES = 4; // v2: 4 x-adjacent strips per workgroup
 constexpr int V2_ROW = 96;  // v2: staged positions per strip (>= 64 + k - 1)
 constexpr int REC = 8;      // v2 backward: floats per destination record
+#ifndef FWD_MIN_WAVES
+#define FWD_MIN_WAVES 7
+#endif
 
 struct SplatFwdParams {
     const float* data;       // [bs, c, h, w]
@@ -184,7 +187,7 @@ __device__ __forceinline__ void fwd_row_update(const float (&v)[K], const float*
 }
 
 template <int K, int C>
-__global__ __launch_bounds__(V2_WAVES * TX, 7) void splat_fwd_strip_kernel(SplatFwdParams p) {
+__global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_kernel(SplatFwdParams p) {
     static_assert(TX + K - 1 <= V2_ROW, "staged row too short");
     constexpr int P = (K - 1) / 2;
     __shared__ float lds[V2_WAVES * C * V2_ROW];  // per wave: [C][V2_ROW] radiance of one source row
