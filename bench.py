@@ -295,8 +295,8 @@ def main():
         dt = timed(lambda: splat_step(update, rad, logits, d_out), warmup, steps, timings)
         local_px = (s1 - s0) * W
 
-    # ---------------------------------------------------------------- splat stage (N=1, model)
-    stage = None
+    # ---------------------------------------------------------------- splat stages (N=1, model)
+    stage = stage_all = None
     if is_model and world == 1 and not args.no_stages:
         del model, opt
         th.cuda.empty_cache()
@@ -305,10 +305,26 @@ def main():
         rad, logits, d_out = make_splat_inputs(H, W, S, K, device, seed=1234)
         sdt = timed(lambda: splat_step(update, rad, logits, d_out), 3, 10, timings)
         local_px = H * W
-        stage = {"workload": "splat fwd+bwd only: %d x ProgressiveKernelApply(splat=True) + normalise "
-                             "+ backward" % S,
+        stage = {"workload": "splat fwd+bwd only, reference module API: %d x ProgressiveKernelApply("
+                             "splat=True) + normalise + backward" % S,
                  "value": round(S * H * W / (sdt / 10) / 1e6, 2), "unit": "Msamples/s",
                  "ms_per_step": round(sdt / 10 * 1e3, 3), "steps": 10, "warmup": 3}
+        # the same work the way Multisteps issues it: all samples in one launch per kernel
+        all_rad = th.stack([r.detach() for r in rad], 1).requires_grad_()
+        all_log = th.stack([t.detach() for t in logits], 1).requires_grad_()
+        del rad, logits
+        th.cuda.empty_cache()
+        if functions.splat_all_supported(all_rad, all_log):
+            def all_step():
+                all_rad.grad = None
+                all_log.grad = None
+                sr, sw, _ = functions.SplatAll.apply(all_rad, all_log)
+                (sr / (sw + 1e-8)).backward(d_out)
+            adt = timed(all_step, 3, 10, timings)
+            stage_all = {"workload": "splat fwd+bwd only, as Multisteps issues it: functions.SplatAll "
+                                     "(all %d samples per launch) + normalise + backward" % S,
+                         "value": round(S * H * W / (adt / 10) / 1e6, 2), "unit": "Msamples/s",
+                         "ms_per_step": round(adt / 10 * 1e3, 3), "steps": 10, "warmup": 3}
 
     # per-call device time of the fused operators (events on the launch stream)
     per = {}
@@ -316,13 +332,15 @@ def main():
         per.setdefault(name, []).append(a.elapsed_time(b))  # ms
     kern = {}
     if not is_model or stage is not None:
-        for name, bpp in (("splat_update_fwd", fwd_bytes_per_pixel(K)),
-                          ("splat_update_bwd", bwd_bytes_per_pixel(K))):
+        for name, bpp, nsamp in (("splat_update_fwd", fwd_bytes_per_pixel(K), 1),
+                                 ("splat_update_bwd", bwd_bytes_per_pixel(K), 1),
+                                 ("splat_update_fwd_all", fwd_bytes_per_pixel(K), S),
+                                 ("splat_update_bwd_all", bwd_bytes_per_pixel(K), S)):
             if name in per:
                 avg_ms = sum(per[name]) / len(per[name])
-                kern[name] = {"calls": len(per[name]), "avg_ms": round(avg_ms, 4),
-                              "alg_bytes": local_px * bpp,
-                              "GBps": round(local_px * bpp / (avg_ms * 1e-3) / 1e9, 1)}
+                kern[name] = {"calls": len(per[name]), "samples_per_launch": nsamp,
+                              "avg_ms": round(avg_ms, 4), "alg_bytes": local_px * bpp * nsamp,
+                              "GBps": round(local_px * bpp * nsamp / (avg_ms * 1e-3) / 1e9, 1)}
 
     if rank == 0:
         ms = dt / steps * 1e3
@@ -346,16 +364,21 @@ def main():
         }
         if stage is not None:
             res["stages"] = {"splat": stage}
+            if stage_all is not None:
+                res["stages"]["splat_all_samples"] = stage_all
         if kern:
             res["kernels"] = kern
-        if "splat_update_bwd" in kern:
-            kb = kern["splat_update_bwd"]
+        rk = "splat_update_bwd_all" if "splat_update_bwd_all" in kern else "splat_update_bwd"
+        if rk in kern:
+            kb = kern[rk]
             traffic, src = (None, None)
             if (H, W, K) == (720, 1280, 21) and world == 1:   # the PMC summary was taken at this size
-                traffic, src = measured_traffic(("splat_bwd_strip_kernel", "splat_bwd_state_kernel"))
+                traffic, src = measured_traffic(("splat_bwd_strip_kernel",))
+                if traffic is not None:
+                    traffic *= kb["samples_per_launch"]        # PMC figure is per 1-sample launch
             res["roofline"] = {
-                "kernel": "splat_update_bwd: sbmc::splat_bwd_strip_kernel (+ its per-pixel state "
-                          "pre-pass, ~3% of the call)",
+                "kernel": "sbmc::splat_bwd_strip_kernel<21,3> (%d sample(s) per launch; the timed call "
+                          "also holds its per-pixel state pre-pass, ~1-3%%)" % kb["samples_per_launch"],
                 "bound": "hbm", "achieved": kb["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(kb["GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "traffic_source": src, "alg_bytes_per_launch": kb["alg_bytes"],

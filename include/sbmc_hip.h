@@ -164,6 +164,36 @@ SBMC_API int sbmc_splat_update_bwd_f32(const float *data, const float *kernels,
                               int bs, int c, int h, int w, int k,
                               void *stream);
 
+/*
+ * All samples of a frame at once.  The running state (sum_r, sum_w, max_w) is an
+ * associative log-sum-exp monoid, so S progressive updates (the sample loop of
+ * Multisteps.forward, reference sbmc/models.py:195-209) need not be S dependent launches:
+ *   1. sbmc_splat_update_fwd_f32 with batch = bs*S and NULL incoming state reduces every
+ *      sample on its own (part_r, part_w, part_m = its sum_r_out, sum_w_out, max_w_out);
+ *   2. sbmc_splat_merge_fwd_f32 folds the S partial states per pixel, in sample order, and
+ *      keeps the running state after each sample (run_*) for the backward;
+ *   3. sbmc_splat_all_bwd_f32 = per-pixel reverse chain (the per-step state adjoint of the
+ *      progressive update, applied S times) + ONE launch producing every d_kernels/d_data.
+ * Values equal S chained sbmc_splat_update_* calls up to fp32 rounding.
+ * Layouts: part_r/run_r/data/d_data [bs,S,c,h,w]; part_w/part_m/run_w/run_m/atap [bs,S,h,w];
+ * kernels/d_kernels [bs,S,k*k,h,w]; final state and its gradients as in the per-sample calls;
+ * scratch: sbmc_splat_update_bwd_scratch_bytes(bs*S, c, h, w, k) bytes.
+ * Only where sbmc_splat_all_supported(c, k, h, w) == 1 (k = 21, c <= 4).
+ */
+SBMC_API int sbmc_splat_all_supported(int c, int k, int h, int w);
+
+SBMC_API int sbmc_splat_merge_fwd_f32(const float *part_r, const float *part_w, const float *part_m,
+                             float *sum_r, float *sum_w, float *max_w,
+                             float *run_r, float *run_w, float *run_m,
+                             int bs, int s, int c, int h, int w, void *stream);
+
+SBMC_API int sbmc_splat_all_bwd_f32(const float *data, const float *kernels,
+                           const float *part_m, const int32_t *atap,
+                           const float *run_r, const float *run_w, const float *run_m,
+                           const float *d_sum_r, const float *d_sum_w, const float *d_max_w,
+                           float *d_data, float *d_kernels, float *scratch,
+                           int bs, int s, int c, int h, int w, int k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -558,6 +558,120 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
     }
 }
 
+// ------------------------------------------------------------------ all samples at once
+// The running-softmax state is an associative (log-sum-exp) monoid, so the S per-sample
+// splats of one frame need not be chained through S launches: every sample is reduced on its
+// own (the forward strip kernel with batch = bs*S and no incoming state), and a per-pixel
+// kernel folds the S partial states in sample order -- same values as S progressive updates
+// up to rounding.  The backward mirrors it: a per-pixel chain kernel walks the samples in
+// reverse, applying exactly the per-step state adjoint of splat_bwd_state_kernel, and emits
+// the destination records of every sample; ONE launch of splat_bwd_strip_kernel (batch =
+// bs*S) then produces all d_kernels / d_data.
+struct SplatMergeParams {
+    const float* part_r;   // [bs, S, c, h, w]  per-sample sum_r with the sample's own max
+    const float* part_w;   // [bs, S, h, w]
+    const float* part_m;   // [bs, S, h, w]     per-sample max (kmax)
+    float* sum_r;          // [bs, c, h, w]     final state
+    float* sum_w;          // [bs, h, w]
+    float* max_w;          // [bs, h, w]
+    float* run_r;          // [bs, S, c, h, w]  running state after each sample (saved for backward)
+    float* run_w;          // [bs, S, h, w]
+    float* run_m;          // [bs, S, h, w]
+    int bs, s, h, w;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void splat_merge_fwd_kernel(SplatMergeParams p) {
+    const size_t hw = (size_t)p.h * p.w;
+    const size_t total = (size_t)p.bs * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / hw, pix = i % hw;
+        float M = -INFINITY, W = 0.f, R[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) R[c] = 0.f;
+        for (int s = 0; s < p.s; ++s) {
+            const size_t o = (n * p.s + s) * hw + pix;
+            const float km = p.part_m[o];
+            const float Mn = fmaxf(M, km);
+            const float sigma = expf(M - Mn);   // 0 for the first sample (M = -inf)
+            const float tau = expf(km - Mn);
+            W = W * sigma + p.part_w[o] * tau;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const size_t oc = ((n * p.s + s) * C + c) * hw + pix;
+                R[c] = R[c] * sigma + p.part_r[oc] * tau;
+                p.run_r[oc] = R[c];
+            }
+            M = Mn;
+            p.run_w[o] = W;
+            p.run_m[o] = M;
+        }
+        p.sum_w[i] = W;
+        p.max_w[i] = M;
+#pragma unroll
+        for (int c = 0; c < C; ++c) p.sum_r[(n * C + c) * hw + pix] = R[c];
+    }
+}
+
+struct SplatChainParams {
+    const float* part_m;       // [bs, S, h, w] per-sample max
+    const int32_t* atap;       // [bs, S, h, w]
+    const float* run_r;        // [bs, S, c, h, w]
+    const float* run_w;        // [bs, S, h, w]
+    const float* run_m;        // [bs, S, h, w]
+    const float* d_sum_r;      // [bs, c, h, w] upstream gradients of the final state
+    const float* d_sum_w;      // [bs, h, w]
+    const float* d_max_w;      // [bs, h, w]
+    float* records;            // [bs, S, h, w, 8]
+    int bs, s, h, w;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void splat_chain_bwd_kernel(SplatChainParams p) {
+    static_assert(C <= 4, "records hold up to 4 channels");
+    const size_t hw = (size_t)p.h * p.w;
+    const size_t total = (size_t)p.bs * hw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = i / hw, pix = i % hw;
+        float dW = p.d_sum_w[i], dM = p.d_max_w[i], dR[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) dR[c] = p.d_sum_r[(n * C + c) * hw + pix];
+        for (int s = p.s - 1; s >= 0; --s) {
+            const size_t o = (n * p.s + s) * hw + pix;
+            const float M = p.run_m[o];
+            float dot_out = dW * p.run_w[o];
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                dot_out = fmaf(dR[c], p.run_r[((n * p.s + s) * C + c) * hw + pix], dot_out);
+            const float dMtot = dM - dot_out;
+            float sel_prev = 0.f, sigma = 0.f, dot_in = 0.f;
+            if (s > 0) {
+                const size_t op = o - hw;
+                const float Mp = p.run_m[op], km = p.part_m[o];
+                sel_prev = Mp > km ? 1.f : (Mp == km ? 0.5f : 0.f);
+                sigma = expf(Mp - M);
+                dot_in = dW * p.run_w[op];
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    dot_in = fmaf(dR[c], p.run_r[((n * p.s + s - 1) * C + c) * hw + pix], dot_in);
+            }
+            float4 r0, r1;
+            r0.x = M; r0.y = dW; r0.z = dMtot * (1.f - sel_prev); r0.w = __int_as_float(p.atap[o]);
+            r1.x = dR[0]; r1.y = dR[1]; r1.z = dR[2]; r1.w = dR[3];
+            float4* rec = reinterpret_cast<float4*>(p.records) + o * 2;
+            rec[0] = r0;
+            rec[1] = r1;
+            // adjoint of the incoming state of this step = outgoing state of the previous one
+            dM = sigma * dot_in + dMtot * sel_prev;
+            dW *= sigma;
+#pragma unroll
+            for (int c = 0; c < C; ++c) dR[c] *= sigma;
+        }
+    }
+}
+
 static inline size_t fwd_tile_lds_bytes(int c, int k) {
     return (size_t)c * (FWD_TY + k - 1) * (TX + k - 1) * sizeof(float);
 }
@@ -690,6 +804,55 @@ extern "C" int sbmc_splat_update_bwd_f32(const float* data, const float* kernels
     err = (int)hipGetLastError();
     if (err) return err;
     hipLaunchKernelGGL(splat_bwd_route_kernel, dim3(egrid), dim3(256), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_splat_all_supported(int c, int k, int h, int w) { return strip_ok(c, k, h, w) ? 1 : 0; }
+
+extern "C" int sbmc_splat_merge_fwd_f32(const float* part_r, const float* part_w, const float* part_m,
+                                        float* sum_r, float* sum_w, float* max_w,
+                                        float* run_r, float* run_w, float* run_m,
+                                        int bs, int s, int c, int h, int w, void* stream) {
+    if (bs < 0 || s < 1 || h < 0 || w < 0 || c < 1 || c > 4) return SBMC_HIP_EINVAL;
+    if (bs == 0 || h == 0 || w == 0) return 0;
+    if (!part_r || !part_w || !part_m || !sum_r || !sum_w || !max_w || !run_r || !run_w || !run_m)
+        return SBMC_HIP_EINVAL;
+    SplatMergeParams p{part_r, part_w, part_m, sum_r, sum_w, max_w, run_r, run_w, run_m, bs, s, h, w};
+    const size_t total = (size_t)bs * h * w;
+    unsigned egrid = (unsigned)((total + 255) / 256);
+    if (egrid > 8192) egrid = 8192;
+    SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_merge_fwd_kernel<C>), dim3(egrid), dim3(256), 0,
+                                           (hipStream_t)stream, p));
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_splat_all_bwd_f32(const float* data, const float* kernels,
+                                      const float* part_m, const int32_t* atap,
+                                      const float* run_r, const float* run_w, const float* run_m,
+                                      const float* d_sum_r, const float* d_sum_w, const float* d_max_w,
+                                      float* d_data, float* d_kernels, float* scratch,
+                                      int bs, int s, int c, int h, int w, int k, void* stream) {
+    if (bs < 0 || s < 1 || h < 0 || w < 0 || !strip_ok(c, k, h, w) || c < 1) return SBMC_HIP_EINVAL;
+    if (bs == 0 || h == 0 || w == 0) return 0;
+    if (!data || !kernels || !part_m || !atap || !run_r || !run_w || !run_m || !d_sum_r || !d_sum_w ||
+        !d_max_w || !d_data || !d_kernels || !scratch)
+        return SBMC_HIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    SplatChainParams cp{part_m, atap, run_r, run_w, run_m, d_sum_r, d_sum_w, d_max_w, scratch, bs, s, h, w};
+    const size_t total = (size_t)bs * h * w;
+    unsigned egrid = (unsigned)((total + 255) / 256);
+    if (egrid > 8192) egrid = 8192;
+    SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_chain_bwd_kernel<C>), dim3(egrid), dim3(256), 0, st, cp));
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    // one strip launch over all bs*S samples; it only reads data, kernels and the records
+    SplatBwdParams p{};
+    p.data = data; p.kernels = kernels; p.d_data = d_data; p.d_kernels = d_kernels; p.scratch = scratch;
+    p.bs = bs * s; p.c = c; p.h = h; p.w = w; p.k = k; p.ntx = tiles_x(w); p.nty = h;
+    const long items = (long)p.bs * h * p.ntx;
+    const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
+    SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_strip_kernel<21, C>), dim3(grid),
+                                           dim3(V2_WAVES * TX), 0, st, p));
     return (int)hipGetLastError();
 }
 

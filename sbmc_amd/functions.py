@@ -12,7 +12,8 @@ import torch as th
 from . import _lib
 from . import halide_ops as ops
 
-__all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported"]
+__all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported",
+           "SplatAll", "splat_all_supported"]
 
 
 # Optional per-call device timing (used by bench.py for the roofline figure): when a list
@@ -233,3 +234,97 @@ class SplatUpdate(th.autograd.Function):
                 bs, c, h, w, ctx.k, _lib.current_stream(dev))
         _lib.check(rc, "splat_update_bwd")
         return d_data, d_kernels, d_sum_r, d_sum_w, d_max_w
+
+
+def splat_all_supported(data, kernels):
+    """True when `SplatAll` can take data [bs, S, c, h, w] / kernels [bs, S, k*k, h, w]."""
+    if not (data.is_cuda and kernels.is_cuda) or data.dim() != 5 or kernels.dim() != 5:
+        return False
+    if data.dtype != th.float32 or kernels.dtype != th.float32:
+        return False
+    k2 = kernels.shape[2]
+    k = int(round(k2 ** 0.5))
+    if k * k != k2:
+        return False
+    h, w = kernels.shape[-2:]
+    return bool(_lib.lib().sbmc_splat_all_supported(int(data.shape[2]), k, int(h), int(w)))
+
+
+class SplatAll(th.autograd.Function):
+    """All S progressive splat updates of a frame in three launches per direction.
+
+    Equivalent (up to fp32 rounding) to
+        state = None, None, None
+        for s in range(S): state = ProgressiveKernelApply(splat=True)(data[:, s], kernels[:, s], *state)
+    i.e. to the sample loop of the reference's Multisteps.forward (sbmc/models.py:195-209): the
+    running state is a log-sum-exp monoid, so every sample is reduced independently by ONE
+    launch of the fused forward kernel over bs*S images and a per-pixel kernel folds the
+    partial states in sample order; backward likewise (include/sbmc_hip.h).
+
+    Args:
+      data(th.Tensor)[bs, S, c, h, w]: sample radiance.
+      kernels(th.Tensor)[bs, S, k*k, h, w]: per-sample splat kernel logits.
+    Returns:
+      sum_r[bs, c, h, w], sum_w[bs, 1, h, w], max_w[bs, 1, h, w].
+    """
+
+    @staticmethod
+    def forward(ctx, data, kernels):
+        bs, S, k2, h, w = kernels.shape
+        k = int(round(k2 ** 0.5))
+        c = data.shape[2]
+        if tuple(data.shape) != (bs, S, c, h, w):
+            raise RuntimeError("data should be [bs, S, c, h, w] matching kernels [bs, S, k*k, h, w]")
+        data = data.contiguous()
+        kernels = kernels.contiguous()
+        dev = data.device
+        part_r = th.empty_like(data)
+        part_w = data.new_empty(bs, S, h, w)
+        part_m = data.new_empty(bs, S, h, w)
+        kmax = data.new_empty(bs, S, h, w)
+        atap = th.empty(bs, S, h, w, dtype=th.int32, device=dev)
+        lib = _lib.lib()
+        with th.cuda.device(dev):
+            with _timed("splat_update_fwd_all", dev):
+                rc = lib.sbmc_splat_update_fwd_f32(
+                    _lib.ptr(data), _lib.ptr(kernels), None, None, None,
+                    _lib.ptr(part_r), _lib.ptr(part_w), _lib.ptr(part_m), _lib.ptr(kmax), _lib.ptr(atap),
+                    bs * S, c, h, w, k, _lib.current_stream(dev))
+            _lib.check(rc, "splat_update_fwd (all samples)")
+            sum_r = data.new_empty(bs, c, h, w)
+            sum_w = data.new_empty(bs, 1, h, w)
+            max_w = data.new_empty(bs, 1, h, w)
+            run_r = th.empty_like(data)
+            run_w = data.new_empty(bs, S, h, w)
+            run_m = data.new_empty(bs, S, h, w)
+            rc = lib.sbmc_splat_merge_fwd_f32(
+                _lib.ptr(part_r), _lib.ptr(part_w), _lib.ptr(part_m),
+                _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
+                _lib.ptr(run_r), _lib.ptr(run_w), _lib.ptr(run_m),
+                bs, S, c, h, w, _lib.current_stream(dev))
+            _lib.check(rc, "splat_merge_fwd")
+        ctx.k = k
+        ctx.save_for_backward(data, kernels, part_m, atap, run_r, run_w, run_m)
+        return sum_r, sum_w, max_w
+
+    @staticmethod
+    def backward(ctx, d_r, d_w, d_m):
+        data, kernels, part_m, atap, run_r, run_w, run_m = ctx.saved_tensors
+        bs, S, c, h, w = data.shape
+        dev = data.device
+        d_r = data.new_zeros(bs, c, h, w) if d_r is None else d_r.contiguous()
+        d_w = data.new_zeros(bs, 1, h, w) if d_w is None else d_w.contiguous()
+        d_m = data.new_zeros(bs, 1, h, w) if d_m is None else d_m.contiguous()
+        d_data = th.empty_like(data)
+        d_kernels = th.empty_like(kernels)
+        nbytes = _lib.lib().sbmc_splat_update_bwd_scratch_bytes(bs * S, c, h, w, ctx.k)
+        scratch = data.new_empty((nbytes + 3) // 4)
+        with th.cuda.device(dev), _timed("splat_update_bwd_all", dev):
+            rc = _lib.lib().sbmc_splat_all_bwd_f32(
+                _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(part_m), _lib.ptr(atap),
+                _lib.ptr(run_r), _lib.ptr(run_w), _lib.ptr(run_m),
+                _lib.ptr(d_r), _lib.ptr(d_w), _lib.ptr(d_m),
+                _lib.ptr(d_data), _lib.ptr(d_kernels), _lib.ptr(scratch),
+                bs, S, c, h, w, ctx.k, _lib.current_stream(dev))
+        _lib.check(rc, "splat_all_bwd")
+        return d_data, d_kernels

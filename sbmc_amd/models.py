@@ -16,6 +16,7 @@ import logging
 import torch as th
 import torch.nn as nn
 
+from . import functions as funcs
 from . import modules as ops
 from .utils import crop_like
 
@@ -38,6 +39,10 @@ class Multisteps(nn.Module):
         pixel(bool): average the samples first and treat the result as 1 spp (ablation).
         sample_chunk(int or None): embed at most this many samples per conv call
             (None: all at once).  Not a reference argument; does not change results.
+        batch_samples(bool): on GPU, predict the kernels of all samples in one regressor pass
+            and splat them with `functions.SplatAll` (3 launches per direction instead of 2-3
+            per sample; same values up to fp32 rounding).  Needs the logits of all samples
+            resident (1.63 GB per sample at 720p).  Not a reference argument.
         pointwise_gemm(bool): on GPU tensors run the per-sample 1x1 ConvChains as batched GEMMs
             (rocBLAS / hipBLASLt) instead of MIOpen convolutions: same arithmetic, no layout
             change, ~7% faster training step at 720p.  Not a reference argument.
@@ -47,7 +52,7 @@ class Multisteps(nn.Module):
 
     def __init__(self, n_features, n_global_features, width=128,
                  embedding_width=128, ksize=21, splat=True, nsteps=3,
-                 pixel=False, sample_chunk=None, pointwise_gemm=True):
+                 pixel=False, sample_chunk=None, pointwise_gemm=True, batch_samples=True):
         super(Multisteps, self).__init__()
         if ksize < 3 or (ksize % 2 == 0):
             LOG.error("Kernel size should be odd and > 3.")
@@ -64,6 +69,7 @@ class Multisteps(nn.Module):
         self.eps = 1e-8  # kernel normalisation (reference models.py:75)
         self.nsteps = nsteps
         self.sample_chunk = sample_chunk
+        self.batch_samples = batch_samples
 
         for step in range(nsteps):
             n_in = n_features + n_global_features if step == 0 else embedding_width + width
@@ -102,6 +108,31 @@ class Multisteps(nn.Module):
             outs.append(out.view(bs, n, out.shape[1], h, w))
         return outs[0] if len(outs) == 1 else th.cat(outs, 1)
 
+    def _predict_and_splat(self, features, context, radiance):
+        """Kernel regression + splat of every sample (reference models.py:193-209).
+
+        features [bs, spp, e, h, w], context [bs, c, h, w], radiance [bs, spp, 3, h, w] ->
+        running state (sum_r, sum_w, max_w) after the last sample.
+        """
+        bs, spp, _, h, w = features.shape
+        if self.batch_samples and self.splat and self.kernel_update.fused:
+            # all samples at once: one regressor pass over bs*spp images, three splat launches
+            # per direction instead of 2-3 per sample (functions.SplatAll)
+            if (radiance.is_cuda and radiance.dtype == th.float32 and funcs._lib.lib().sbmc_splat_all_supported(
+                    radiance.shape[2], self.ksize, h, w)):
+                ctx = context.unsqueeze(1).expand(bs, spp, context.shape[1], h, w)
+                flat = th.cat([features, ctx], 2).reshape(bs * spp, -1, h, w)
+                kernels = self.kernel_regressor(flat)
+                kernels = kernels.view(bs, spp, kernels.shape[1], h, w)
+                return funcs.SplatAll.apply(radiance, kernels)
+        sum_r, sum_w, max_w = None, None, None
+        for sp in range(spp):
+            f = th.cat([features[:, sp], context], 1)
+            kernels = self.kernel_regressor(f)
+            r = crop_like(radiance[:, sp], kernels)
+            sum_r, sum_w, max_w = self.kernel_update(r, kernels, sum_r, sum_w, max_w)
+        return sum_r, sum_w, max_w
+
     def forward(self, samples):
         """
         Args:
@@ -132,12 +163,7 @@ class Multisteps(nn.Module):
             context = getattr(self, "propagation_{:02d}".format(step))(reduced)
 
         # -- per-sample kernel prediction + progressive splat ----------------------
-        sum_r, sum_w, max_w = None, None, None
-        for sp in range(spp):
-            f = th.cat([features[:, sp], context], 1)
-            kernels = self.kernel_regressor(f)
-            r = crop_like(radiance[:, sp], kernels)
-            sum_r, sum_w, max_w = self.kernel_update(r, kernels, sum_r, sum_w, max_w)
+        sum_r, sum_w, max_w = self._predict_and_splat(features, context, radiance)
 
         output = sum_r / (sum_w + self.eps)
         crop = (self.ksize - 1) // 2

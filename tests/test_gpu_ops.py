@@ -178,3 +178,75 @@ def test_cpu_tensors_are_refused():
     from sbmc_amd import functions as F
     with pytest.raises(RuntimeError):
         F.KernelWeighting.apply(th.zeros(1, 3, 8, 8), th.zeros(1, 3, 3, 8, 8))
+
+
+@pytest.mark.parametrize("bs,c,h,w,spp", [(1, 3, 30, 150, 3), (2, 3, 9, 70, 2), (1, 4, 5, 7, 4)])
+def test_splat_all_vs_oracle(oracle, bs, c, h, w, spp):
+    """All samples in one launch (functions.SplatAll) == S chained progressive updates of the
+    reference composition, forward and backward, with upstream gradients on all three outputs."""
+    from sbmc_amd import functions as F
+    th.manual_seed(8)
+    k = 21
+    data = th.rand(bs, spp, c, h, w) * 2
+    kern = th.randn(bs, spp, k * k, h, w) * 2
+    grads = [th.randn(bs, c, h, w), th.randn(bs, 1, h, w), th.randn(bs, 1, h, w)]
+    ref_out, ref_dd, ref_dk = _progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=True),
+        [data[:, s] for s in range(spp)], [kern[:, s] for s in range(spp)], grads, "cpu")
+    dg = data.cuda().requires_grad_()
+    kg = kern.cuda().requires_grad_()
+    assert F.splat_all_supported(dg, kg)
+    out = F.SplatAll.apply(dg, kg)
+    th.autograd.backward(out, [g.cuda() for g in grads])
+    for a, b, n in zip(out, ref_out, ("sum_r", "sum_w", "max_w")):
+        close(a, b, what=n)
+    for s in range(spp):
+        close(dg.grad[:, s], ref_dd[s], what="d_data[%d]" % s)
+        close(kg.grad[:, s], ref_dk[s], what="d_kernels[%d]" % s)
+
+
+def test_splat_all_running_max_branches(oracle):
+    """spike / never-raises / exact tie between a sample's max and the running max"""
+    from sbmc_amd import functions as F
+    th.manual_seed(9)
+    bs, c, h, w, k = 1, 3, 8, 70, 21
+    base = th.randn(bs, k * k, h, w)
+    spike = base.clone()
+    spike[:, 200] += 30.0
+    kern = th.stack([base, spike, base - 50.0, spike.clone()], 1)
+    data = th.rand(bs, 4, c, h, w)
+    grads = [th.randn(bs, c, h, w), th.randn(bs, 1, h, w), th.randn(bs, 1, h, w)]
+    ref_out, ref_dd, ref_dk = _progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=True),
+        [data[:, s] for s in range(4)], [kern[:, s] for s in range(4)], grads, "cpu")
+    dg, kg = data.cuda().requires_grad_(), kern.cuda().requires_grad_()
+    out = F.SplatAll.apply(dg, kg)
+    th.autograd.backward(out, [g.cuda() for g in grads])
+    for a, b in zip(out, ref_out):
+        close(a, b)
+    for s in range(4):
+        close(dg.grad[:, s], ref_dd[s], what="d_data[%d]" % s)
+        close(kg.grad[:, s], ref_dk[s], what="d_kernels[%d]" % s)
+
+
+def test_multisteps_batched_samples_equals_sequential():
+    """Multisteps(k=21): the all-samples path (one regressor pass + SplatAll) vs the per-sample
+    loop of the reference, outputs and parameter gradients."""
+    from sbmc_amd import Multisteps
+    th.manual_seed(10)
+    kw = dict(width=8, embedding_width=8, ksize=21, nsteps=1)
+    a = Multisteps(6, 3, batch_samples=True, **kw).cuda()
+    b = Multisteps(6, 3, batch_samples=False, **kw).cuda()
+    b.load_state_dict(a.state_dict())
+    g = th.Generator().manual_seed(11)
+    batch = {"radiance": th.empty(1, 3, 3, 40, 72).exponential_(1.0, generator=g).cuda(),
+             "features": th.rand(1, 3, 6, 40, 72, generator=g).cuda(),
+             "global_features": th.rand(1, 3, 1, 1, generator=g).cuda()}
+    oa = a(batch)["radiance"]
+    ob = b(batch)["radiance"]
+    close(oa, ob, what="output")
+    go = th.randn(oa.shape, generator=g).cuda()
+    oa.backward(go)
+    ob.backward(go)
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        close(pa.grad, pb.grad, rtol=5e-5, what=n)
