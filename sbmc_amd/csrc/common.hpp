@@ -87,11 +87,15 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* uniform_base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_base), /*stride*/ 0,
                                              BUF_RANGE, 0x00020000);
 }
+// AUX: cache-policy bits of the buffer instruction (0 = default, 2 = nt: streaming data that
+// is touched once, so that it does not evict the small re-used operands from L2).
+template <int AUX = 0>
 __device__ __forceinline__ float buf_load(rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, AUX);
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

@@ -55,6 +55,18 @@ constexpr int REC = 8;      // v2 backward: floats per destination record
 #ifndef FWD_MIN_WAVES
 #define FWD_MIN_WAVES 7
 #endif
+// cache policy of the big streams (A/B knobs; see common.hpp buf_load)
+#ifndef AUX_FWD_LD
+#define AUX_FWD_LD 0
+#endif
+// backward: nt on both the logit loads and the d_logit stores measured -1.2% (three interleaved
+// A/B rounds); forward: nt loads measured +12% (they defeat the L1/L2 sharing of straddled lines)
+#ifndef AUX_BWD_LD
+#define AUX_BWD_LD 2
+#endif
+#ifndef AUX_BWD_ST
+#define AUX_BWD_ST 2
+#endif
 
 struct SplatFwdParams {
     const float* data;       // [bs, c, h, w]
@@ -249,12 +261,12 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
         const rsrc_t rs = make_rsrc(S + ((long)((2 * P - dy) * K) * (long)hw + (long)ys * p.w + (long)(X0 + P)));
         if (interior_x) {
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) v[dx] = buf_load(rs, voff, (unsigned)(K - 1 - dx) * tap_stride);
+            for (int dx = 0; dx < K; ++dx) v[dx] = buf_load<AUX_FWD_LD>(rs, voff, (unsigned)(K - 1 - dx) * tap_stride);
         } else {
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
                 const unsigned vo = (dx >= dx_lo && dx < dx_hi) ? voff : BUF_OOB;  // OOB lanes read 0
-                v[dx] = buf_load(rs, vo, (unsigned)(K - 1 - dx) * tap_stride);
+                v[dx] = buf_load<AUX_FWD_LD>(rs, vo, (unsigned)(K - 1 - dx) * tap_stride);
             }
         }
 #pragma unroll
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
     auto load_logits = [&](int ky, float (&s)[K]) {
         const rsrc_t rs = make_rsrc(S + (size_t)(ky * K) * hw);  // tap (ky, 0); tap kx is kx planes further
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) s[kx] = buf_load(rs, voff, (unsigned)kx * plane_stride);
+        for (int kx = 0; kx < K; ++kx) s[kx] = buf_load<AUX_BWD_LD>(rs, voff, (unsigned)kx * plane_stride);
     };
     auto step = [&](int ky, const float (&s)[K]) {
         const int yd = ys + ky - P;
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
             if constexpr (C > 3) { g = fmaf(q1.w, D[C > 3 ? 3 : 0], g); dD[C > 3 ? 3 : 0] = fmaf(e, q1.w, dD[C > 3 ? 3 : 0]); }
             float ds = e * g;
             ds += (__float_as_int(q0.w) == tg0 - kx) ? q0.z : 0.f;
-            buf_store(ds, ws, voff, (unsigned)kx * plane_stride);
+            buf_store<AUX_BWD_ST>(ds, ws, voff, (unsigned)kx * plane_stride);
         }
         __builtin_amdgcn_sched_barrier(0);
         }

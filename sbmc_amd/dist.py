@@ -183,11 +183,7 @@ class ShardedDenoiser(object):
         features = halo_pad(features, p, part)
         context = halo_pad(context, p, part)
         radiance = halo_pad(radiance, p, part)
-        sum_r, sum_w, max_w = None, None, None
-        for sp in range(spp):
-            kernels = m.kernel_regressor(th.cat([features[:, sp], context], 1))
-            r = crop_like(radiance[:, sp], kernels)
-            sum_r, sum_w, max_w = m.kernel_update(r.contiguous(), kernels, sum_r, sum_w, max_w)
+        sum_r, sum_w, max_w = m._predict_and_splat(features, context, radiance.contiguous())
         output = sum_r / (sum_w + m.eps)
         # p rows per side go in every case: the halo at an inner boundary, the invalid border
         # (reference models.py:215-216) at the true image border
