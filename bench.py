@@ -52,7 +52,7 @@ def bwd_bytes_per_pixel(k, c=3):
 
 def measured_traffic(kernel_substr):
     """HBM bytes per launch from the newest committed PMC summary (profiles/r*_pmc.json,
-    produced by tools_prof.sh: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE,
+    produced by tools/prof.sh: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))

@@ -107,15 +107,13 @@ __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_tile_kernel(SplatFwdPar
     const size_t pix = (size_t)Y * p.w + (xact ? X : p.w - 1);
     const bool first = (p.sum_r_in == nullptr);
 
+    // This sample is reduced on its own (m starts at -inf, sums at 0) and merged with the
+    // incoming state at the very end, like the reference (modules.py:450-471): folding 441 small
+    // terms one by one into an already large running sum would cost ~1e-4 of relative accuracy
+    // over 32 samples.
     float m = -INFINITY, accw = 0.f, acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    if (!first) {
-        m = p.max_w_in[(size_t)t.n * hw + pix];
-        accw = p.sum_w_in[(size_t)t.n * hw + pix];
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = p.sum_r_in[((size_t)t.n * C + c) * hw + pix];
-    }
     float kmax = -INFINITY;
     int atap = 0;
 
@@ -150,8 +148,18 @@ __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_tile_kernel(SplatFwdPar
 
     if (xact) {
         const size_t o = (size_t)t.n * hw + pix;
+        float M = m;  // == kmax here
+        if (!first) {
+            const float Mp = p.max_w_in[o];
+            M = fmaxf(Mp, m);
+            const float sigma = expf(Mp - M), tau = expf(m - M);
+            accw = p.sum_w_in[o] * sigma + accw * tau;
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                acc[c] = p.sum_r_in[((size_t)t.n * C + c) * hw + pix] * sigma + acc[c] * tau;
+        }
         p.sum_w_out[o] = accw;
-        p.max_w_out[o] = m;
+        p.max_w_out[o] = M;
         p.kmax_out[o] = kmax;
         p.atap_out[o] = atap;
 #pragma unroll
@@ -222,15 +230,11 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     const bool first = (p.sum_r_in == nullptr);
     float* buf = lds + wv * (C * V2_ROW);
 
+    // the sample is reduced on its own and merged with the incoming state at the end (see the
+    // tile kernel above for why)
     float m = -INFINITY, accw = 0.f, acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    if (!first) {
-        m = p.max_w_in[(size_t)n * hw + pix];
-        accw = p.sum_w_in[(size_t)n * hw + pix];
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = p.sum_r_in[((size_t)n * C + c) * hw + pix];
-    }
     float kmax = -INFINITY;
     int atap = 0;
 
@@ -298,8 +302,18 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
 
     if (xact) {
         const size_t o = (size_t)n * hw + pix;
+        float M = m;  // == kmax here
+        if (!first) {
+            const float Mp = p.max_w_in[o];
+            M = fmaxf(Mp, m);
+            const float sigma = expf(Mp - M), tau = expf(m - M);
+            accw = p.sum_w_in[o] * sigma + accw * tau;
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                acc[c] = p.sum_r_in[((size_t)n * C + c) * hw + pix] * sigma + acc[c] * tau;
+        }
         p.sum_w_out[o] = accw;
-        p.max_w_out[o] = m;
+        p.max_w_out[o] = M;
         p.kmax_out[o] = kmax;
         p.atap_out[o] = atap;
 #pragma unroll

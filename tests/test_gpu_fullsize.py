@@ -96,3 +96,43 @@ def test_fullsize_scatter2gather_involution_and_kw_linearity():
     close(o12, o1 + 2 * o2, rtol=2e-5)
     assert th.equal(s1, s12)
     close(s1, y.sum((1, 2)), rtol=2e-5)
+
+
+def test_4k_frame_indexing():
+    """BASELINE configs[3] size (3840x2160, k=21): 441 * H * W = 3.66e9 elements per sample, past
+    2^31 -- every offset in the kernels must be 64-bit (or a per-row rebased 32-bit buffer
+    offset).  Fused forward+backward vs the composed boundary-level operators on the full
+    frame, plus a full-width band vs the oracle at the bottom of the frame (largest offsets)."""
+    from sbmc_amd import modules
+    h, w = 2160, 3840
+    g = th.Generator(device="cuda").manual_seed(31)
+    rad = th.rand(1, 3, h, w, device="cuda", generator=g)
+    ker = th.randn(1, K * K, h, w, device="cuda", generator=g)
+    grads = [th.randn(1, 3, h, w, device="cuda", generator=g), th.randn(1, 1, h, w, device="cuda", generator=g),
+             th.zeros(1, 1, h, w, device="cuda")]
+    a_out, a_dd, a_dk = run_progressive(modules.ProgressiveKernelApply(splat=True, fused=True), [rad], [ker], grads, "cuda")
+    b_out, b_dd, b_dk = run_progressive(modules.ProgressiveKernelApply(splat=True, fused=False), [rad], [ker], grads, "cuda")
+    for a, b, n in zip(a_out, b_out, ("sum_r", "sum_w", "max_w")):
+        err = (a - b).abs().max().item()
+        assert err <= 1e-5 * b.abs().max().item(), (n, err)
+    for a, b, n in ((a_dd[0], b_dd[0], "d_data"), (a_dk[0], b_dk[0], "d_kernels")):
+        err = (a - b).abs().max().item()
+        assert err <= 1e-5 * b.abs().max().item() + 1e-12, (n, err)
+
+
+def test_4k_bottom_band_against_oracle(oracle):
+    """The last 32 rows of a 4K frame computed inside the full frame == the oracle on the band
+    extended by the kernel radius (interior rows of the band only)."""
+    from sbmc_amd import modules
+    h, w, band, p = 2160, 3840, 32, (K - 1) // 2
+    g = th.Generator(device="cuda").manual_seed(32)
+    rad = th.rand(1, 3, h, w, device="cuda", generator=g)
+    ker = th.randn(1, K * K, h, w, device="cuda", generator=g)
+    sr, sw, mw = modules.ProgressiveKernelApply(splat=True)(rad, ker, None, None, None)
+    y0 = h - band - p
+    o_sr, o_sw, o_mw = oracle.progressive_kernel_apply(
+        rad[..., y0:, :].cpu().contiguous(), ker[..., y0:, :].cpu().contiguous(), None, None, None, splat=True)
+    # rows >= p of the band see the same neighbourhood as in the full frame (bottom border included)
+    close(sr[..., y0 + p:, :], o_sr[..., p:, :])
+    close(sw[..., y0 + p:, :], o_sw[..., p:, :])
+    close(mw[..., y0 + p:, :], o_mw[..., p:, :])

@@ -250,3 +250,26 @@ def test_multisteps_batched_samples_equals_sequential():
     ob.backward(go)
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         close(pa.grad, pb.grad, rtol=5e-5, what=n)
+
+
+def test_32spp_fused_vs_scatter2gather_dual_path():
+    """BASELINE configs[4] shape of the sample loop: 32 spp, 21x21 kernels, the fused path
+    (per-sample updates and the all-samples launch) vs the Scatter2Gather + KernelWeighting dual
+    path on the GPU."""
+    from sbmc_amd import functions as F, modules
+    th.manual_seed(12)
+    bs, c, h, w, k, spp = 1, 3, 24, 130, 21, 32
+    data = th.rand(bs, spp, c, h, w, device="cuda")
+    kern = th.randn(bs, spp, k * k, h, w, device="cuda")
+    dual = modules.ProgressiveKernelApply(splat=True, fused=False)
+    fused = modules.ProgressiveKernelApply(splat=True, fused=True)
+    sa = sb = (None, None, None)
+    for s in range(spp):
+        sa = dual(data[:, s], kern[:, s], *sa)
+        sb = fused(data[:, s], kern[:, s], *sb)
+    sc = F.SplatAll.apply(data, kern)
+    for a, b, c_ in zip(sa, sb, sc):
+        close(b, a)
+        close(c_, a)
+    out = sa[0] / (sa[1] + 1e-8)
+    close(sc[0] / (sc[1] + 1e-8), out)

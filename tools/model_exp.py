@@ -1,7 +1,7 @@
 """Backbone experiments (not part of the product): timing of the Multisteps training step under
 different conv configurations.  usage: tools_model_exp.py [--cl] [--bench] [--gemm1x1] [--prof]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch as th
 import bench
 from sbmc_amd import Multisteps, losses

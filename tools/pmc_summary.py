@@ -1,4 +1,4 @@
-"""Condenses rocprofv3 output (tools_prof.sh) into small committed summaries.
+"""Condenses rocprofv3 output (tools/prof.sh) into small committed summaries.
 
   <tag>_splat_kernel_stats.csv / <tag>_model_kernel_stats.csv : rocprofv3 --stats tables with
         kernel names shortened (the dominant kernels keep their full name)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Profiling recipe (run on the GPU box through gpurun):  ./tools_prof.sh <tag>
+# Profiling recipe (run on the GPU box through gpurun):  ./tools/prof.sh <tag>
 #   1. rocprofv3 --kernel-trace --stats of the splat workload and of the model workload
 #   2. PMC passes (one counter group per run; never combined with trace domains other than
 #      --kernel-trace) for the splat kernels: FETCH_SIZE / WRITE_SIZE / TCC / SQ
@@ -19,6 +19,6 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_
   i=$((i+1))
   rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $out/p$i -o p -- python $root/bench.py --workload splat --steps 1 --warmup 1 --no-cpu-baseline > $out/p$i.log 2>&1
 done
-python $root/tools_pmc_summary.py $out $sum $tag
+python $root/tools/pmc_summary.py $out $sum $tag
 grep -h '^{' $out/splat.log $out/model.log > $sum/${tag}_bench_lines_under_rocprof.jsonl
 ls $sum
