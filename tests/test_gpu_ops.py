@@ -273,3 +273,57 @@ def test_32spp_fused_vs_scatter2gather_dual_path():
         close(c_, a)
     out = sa[0] / (sa[1] + 1e-8)
     close(sc[0] / (sc[1] + 1e-8), out)
+
+
+@pytest.mark.parametrize("bs,c,h,w,k", [(1, 3, 1, 1, 3), (1, 3, 2, 3, 1), (3, 2, 4, 64, 1), (1, 3, 1, 200, 21),
+                                         (1, 3, 100, 1, 21), (1, 3, 7, 63, 5), (1, 3, 8, 65, 21)])
+def test_degenerate_shapes(oracle, bs, c, h, w, k):
+    """1x1 images, 1x1 kernels (the reference's scatter2gather profile script uses ksize=1),
+    single rows / columns, widths around the 64-lane strip."""
+    from sbmc_amd import functions as F, modules
+    th.manual_seed(13)
+    data = th.rand(bs, c, h, w)
+    kern = th.randn(bs, k * k, h, w)
+    x5 = kern.view(bs, k, k, h, w)
+    assert th.equal(F.Scatter2Gather.apply(x5.cuda()).cpu(), oracle.Scatter2Gather.apply(x5))
+    o_ref, s_ref = oracle.KernelWeighting.apply(data, x5)
+    o, s = F.KernelWeighting.apply(data.cuda(), x5.cuda())
+    close(o, o_ref); close(s, s_ref)
+    grads = [th.randn(bs, c, h, w), th.randn(bs, 1, h, w), th.randn(bs, 1, h, w)]
+    ref_out, ref_dd, ref_dk = _progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=True),
+        [data, data * 0.5], [kern, kern.flip(1)], grads, "cpu")
+    out, dd, dk = _progressive(modules.ProgressiveKernelApply(splat=True), [data, data * 0.5],
+                               [kern, kern.flip(1)], grads, "cuda")
+    for a, b in zip(out, ref_out):
+        close(a, b)
+    for i in range(2):
+        close(dd[i], ref_dd[i]); close(dk[i], ref_dk[i])
+
+
+def test_empty_batch_is_a_no_op():
+    from sbmc_amd import functions as F, modules
+    d = th.zeros(0, 3, 8, 8, device="cuda")
+    k = th.zeros(0, 9, 8, 8, device="cuda")
+    o, s = F.KernelWeighting.apply(d, k.view(0, 3, 3, 8, 8))
+    assert o.shape == (0, 3, 8, 8) and s.shape == (0, 8, 8)
+    assert F.Scatter2Gather.apply(k.view(0, 3, 3, 8, 8)).shape == (0, 3, 3, 8, 8)
+    r = modules.ProgressiveKernelApply(splat=True)(d, k, None, None, None)
+    assert r[0].shape == (0, 3, 8, 8) and r[1].shape == (0, 1, 8, 8)
+
+
+def test_bad_arguments_raise():
+    from sbmc_amd import functions as F, halide_ops
+    d = th.zeros(1, 3, 8, 8, device="cuda")
+    w = th.zeros(1, 3, 3, 8, 8, device="cuda")
+    with pytest.raises(RuntimeError):   # shape mismatch between data and weights
+        halide_ops.kernel_weighting_cuda_float32(d, th.zeros(1, 3, 3, 8, 9, device="cuda"), th.empty_like(d),
+                                                 th.empty(1, 8, 8, device="cuda"))
+    with pytest.raises(RuntimeError):   # non-contiguous
+        halide_ops.scatter2gather_cuda_float32(w.transpose(3, 4), th.empty_like(w))
+    with pytest.raises(RuntimeError):   # wrong dtype
+        halide_ops.scatter2gather_cuda_float32(w.double(), th.empty_like(w).double())
+    with pytest.raises(RuntimeError):   # output aliasing the input
+        halide_ops.scatter2gather_cuda_float32(w, w)
+    with pytest.raises(RuntimeError):   # partial running state
+        F.SplatUpdate.apply(d, th.zeros(1, 9, 8, 8, device="cuda"), None, th.zeros(1, 1, 8, 8, device="cuda"), None)
