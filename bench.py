@@ -296,7 +296,7 @@ def main():
         local_px = (s1 - s0) * W
 
     # ---------------------------------------------------------------- splat stages (N=1, model)
-    stage = stage_all = None
+    stage = stage_all = stage_f16 = None
     if is_model and world == 1 and not args.no_stages:
         del model, opt
         th.cuda.empty_cache()
@@ -325,6 +325,22 @@ def main():
                                      "(all %d samples per launch) + normalise + backward" % S,
                          "value": round(S * H * W / (adt / 10) / 1e6, 2), "unit": "Msamples/s",
                          "ms_per_step": round(adt / 10 * 1e3, 3), "steps": 10, "warmup": 3}
+            # informational: the same with fp16 logit storage (BASELINE configs[4] "fp16 activations";
+            # NOT the fp32 metric -- reported separately, never mixed into `value`)
+            all_log16 = all_log.detach().half().requires_grad_()
+            del all_log
+            th.cuda.empty_cache()
+
+            def all_step16():
+                all_rad.grad = None
+                all_log16.grad = None
+                sr, sw, _ = functions.SplatAll.apply(all_rad, all_log16)
+                (sr / (sw + 1e-8)).backward(d_out)
+            hdt = timed(all_step16, 3, 10, timings)
+            stage_f16 = {"workload": "as splat_all_samples but with fp16 logit / logit-gradient storage "
+                                     "(fp32 arithmetic)", "dtype": "f16 storage, f32 math",
+                         "value": round(S * H * W / (hdt / 10) / 1e6, 2), "unit": "Msamples/s",
+                         "ms_per_step": round(hdt / 10 * 1e3, 3), "steps": 10, "warmup": 3}
 
     # per-call device time of the fused operators (events on the launch stream)
     per = {}
@@ -366,6 +382,8 @@ def main():
             res["stages"] = {"splat": stage}
             if stage_all is not None:
                 res["stages"]["splat_all_samples"] = stage_all
+            if stage_f16 is not None:
+                res["stages"]["splat_all_samples_fp16_storage"] = stage_f16
         if kern:
             res["kernels"] = kern
         rk = "splat_update_bwd_all" if "splat_update_bwd_all" in kern else "splat_update_bwd"

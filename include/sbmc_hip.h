@@ -194,6 +194,35 @@ SBMC_API int sbmc_splat_all_bwd_f32(const float *data, const float *kernels,
                            float *d_data, float *d_kernels, float *scratch,
                            int bs, int s, int c, int h, int w, int k, void *stream);
 
+/*
+ * fp16 logits ("fp16 activations", BASELINE.json configs[4]).  Same calls as
+ * the _f32 ones except that `kernels` and `d_kernels` are IEEE half tensors (torch.float16);
+ * radiance, running state, every accumulation and every other gradient stay fp32.  Halves the
+ * bytes of the two big streams.  Only for the strip kernels (sbmc_splat_all_supported(c,k,h,w)),
+ * SBMC_HIP_EINVAL otherwise (the caller up-casts and uses the _f32 entry points).
+ */
+SBMC_API int sbmc_splat_update_fwd_f16(const float *data, const void *kernels,
+                              const float *sum_r_in, const float *sum_w_in, const float *max_w_in,
+                              float *sum_r_out, float *sum_w_out, float *max_w_out,
+                              float *kmax_out, int32_t *atap_out,
+                              int bs, int c, int h, int w, int k, void *stream);
+
+SBMC_API int sbmc_splat_update_bwd_f16(const float *data, const void *kernels,
+                              const float *sum_r_in, const float *sum_w_in, const float *max_w_in,
+                              const float *sum_r_out, const float *sum_w_out, const float *max_w_out,
+                              const float *kmax, const int32_t *atap,
+                              const float *d_sum_r_out, const float *d_sum_w_out, const float *d_max_w_out,
+                              float *d_data, void *d_kernels,
+                              float *d_sum_r_in, float *d_sum_w_in, float *d_max_w_in, float *scratch,
+                              int bs, int c, int h, int w, int k, void *stream);
+
+SBMC_API int sbmc_splat_all_bwd_f16(const float *data, const void *kernels,
+                           const float *part_m, const int32_t *atap,
+                           const float *run_r, const float *run_w, const float *run_m,
+                           const float *d_sum_r, const float *d_sum_w, const float *d_max_w,
+                           float *d_data, void *d_kernels, float *scratch,
+                           int bs, int s, int c, int h, int w, int k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

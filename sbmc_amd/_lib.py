@@ -27,6 +27,9 @@ SYMBOLS = (
     "sbmc_splat_all_supported",
     "sbmc_splat_merge_fwd_f32",
     "sbmc_splat_all_bwd_f32",
+    "sbmc_splat_update_fwd_f16",
+    "sbmc_splat_update_bwd_f16",
+    "sbmc_splat_all_bwd_f16",
 )
 ABI_VERSION = 1
 MAX_CHANNELS = 8
@@ -65,6 +68,9 @@ def lib():
     handle.sbmc_splat_all_supported.argtypes = [i] * 4
     handle.sbmc_splat_merge_fwd_f32.argtypes = [p] * 9 + [i] * 5 + [p]
     handle.sbmc_splat_all_bwd_f32.argtypes = [p] * 13 + [i] * 6 + [p]
+    handle.sbmc_splat_update_fwd_f16.argtypes = handle.sbmc_splat_update_fwd_f32.argtypes
+    handle.sbmc_splat_update_bwd_f16.argtypes = handle.sbmc_splat_update_bwd_f32.argtypes
+    handle.sbmc_splat_all_bwd_f16.argtypes = handle.sbmc_splat_all_bwd_f32.argtypes
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t

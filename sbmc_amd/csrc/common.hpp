@@ -98,6 +98,25 @@ __device__ __forceinline__ void buf_store(float v, rsrc_t r, unsigned voff, unsi
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, AUX);
 }
 
+// Logits / logit gradients come in two storage types: float (the reference's dtype) and
+// _Float16 ("fp16 activations", BASELINE configs[4]); all arithmetic is fp32 either way.
+template <typename T, int AUX = 0>
+__device__ __forceinline__ float logit_load(rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+    } else {
+        return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX));
+    }
+}
+template <typename T, int AUX = 0>
+__device__ __forceinline__ void logit_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(T) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, AUX);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), r, voff, soff, AUX);
+    }
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // Orders this wave's LDS traffic: LDS operations of one wavefront execute in issue

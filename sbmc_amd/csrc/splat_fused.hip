@@ -70,7 +70,7 @@ constexpr int REC = 8;      // v2 backward: floats per destination record
 
 struct SplatFwdParams {
     const float* data;       // [bs, c, h, w]
-    const float* kernels;    // [bs, k*k, h, w]
+    const void* kernels;     // [bs, k*k, h, w] float (or _Float16 for the strip kernels)
     const float* sum_r_in;   // [bs, c, h, w] or null
     const float* sum_w_in;   // [bs, h, w]    or null
     const float* max_w_in;   // [bs, h, w]    or null
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_tile_kernel(SplatFwdPar
     float kmax = -INFINITY;
     int atap = 0;
 
-    const float* S = p.kernels + (size_t)t.n * k * k * hw;
+    const float* S = static_cast<const float*>(p.kernels) + (size_t)t.n * k * k * hw;
     const int cstride = th * tw;
 
     for (int dy = 0; dy < k; ++dy) {
@@ -206,7 +206,7 @@ __device__ __forceinline__ void fwd_row_update(const float (&v)[K], const float*
     }
 }
 
-template <int K, int C>
+template <int K, int C, typename LT>
 __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_kernel(SplatFwdParams p) {
     static_assert(TX + K - 1 <= V2_ROW, "staged row too short");
     constexpr int P = (K - 1) / 2;
@@ -238,15 +238,15 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     float kmax = -INFINITY;
     int atap = 0;
 
-    const float* S = p.kernels + (size_t)n * K * K * hw;
+    const LT* S = static_cast<const LT*>(p.kernels) + (size_t)n * K * K * hw;
     const float* data = p.data + (size_t)n * C * hw;
     const bool interior_x = (X0 - P >= 0) && (X0 + TX - 1 + P < p.w);  // wave-uniform
     // staged source columns: positions 0..63 by every lane, 64..64+K-2 by the first K-1 lanes
     const int colA = X0 - P + lane, colB = colA + TX;
     const bool inA = (colA >= 0) && (colA < p.w);
     const bool inB = (lane < K - 1) && (colB < p.w);
-    const unsigned voff = (unsigned)lane * 4u;
-    const unsigned tap_stride = (unsigned)(hw - 1) * 4u;  // bytes between taps dx+1 -> dx
+    const unsigned voff = (unsigned)lane * (unsigned)sizeof(LT);
+    const unsigned tap_stride = (unsigned)(hw - 1) * (unsigned)sizeof(LT);  // bytes between taps dx+1 -> dx
     // border strips: lane's source column X+dx-P is inside the image for dx in [dx_lo, dx_hi)
     const int dx_lo = P - X, dx_hi = p.w + P - X;
 
@@ -265,12 +265,12 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
         const rsrc_t rs = make_rsrc(S + ((long)((2 * P - dy) * K) * (long)hw + (long)ys * p.w + (long)(X0 + P)));
         if (interior_x) {
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) v[dx] = buf_load<AUX_FWD_LD>(rs, voff, (unsigned)(K - 1 - dx) * tap_stride);
+            for (int dx = 0; dx < K; ++dx) v[dx] = logit_load<LT, AUX_FWD_LD>(rs, voff, (unsigned)(K - 1 - dx) * tap_stride);
         } else {
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
                 const unsigned vo = (dx >= dx_lo && dx < dx_hi) ? voff : BUF_OOB;  // OOB lanes read 0
-                v[dx] = buf_load<AUX_FWD_LD>(rs, vo, (unsigned)(K - 1 - dx) * tap_stride);
+                v[dx] = logit_load<LT, AUX_FWD_LD>(rs, vo, (unsigned)(K - 1 - dx) * tap_stride);
             }
         }
 #pragma unroll
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
 // ------------------------------------------------------------------ backward
 struct SplatBwdParams {
     const float* data;         // [bs, c, h, w]
-    const float* kernels;      // [bs, k*k, h, w]
+    const void* kernels;       // [bs, k*k, h, w] float (or _Float16 for the strip kernels)
     const float* sum_r_in;     // or null (initialisation call)
     const float* sum_w_in;
     const float* max_w_in;
@@ -337,7 +337,7 @@ struct SplatBwdParams {
     const float* d_sum_w_out;
     const float* d_max_w_out;
     float* d_data;
-    float* d_kernels;
+    void* d_kernels;           // same storage type as kernels
     float* d_sum_r_in;         // or null
     float* d_sum_w_in;
     float* d_max_w_in;
@@ -438,8 +438,8 @@ __global__ __launch_bounds__(BWD_TY * TX) void splat_bwd_tile_kernel(SplatBwdPar
         D[c] = p.data[((size_t)t.n * C + c) * hw + pix];
         dD[c] = 0.f;
     }
-    const float* S = p.kernels + (size_t)t.n * k * k * hw + (size_t)ys * p.w + t.x0;
-    float* dS = p.d_kernels + (size_t)t.n * k * k * hw + (size_t)ys * p.w + t.x0;
+    const float* S = static_cast<const float*>(p.kernels) + (size_t)t.n * k * k * hw + (size_t)ys * p.w + t.x0;
+    float* dS = static_cast<float*>(p.d_kernels) + (size_t)t.n * k * k * hw + (size_t)ys * p.w + t.x0;
 
     for (int ky = 0; ky < k; ++ky) {
         const float* trow = lds + (wv + ky) * tw + lane;
@@ -480,14 +480,14 @@ __global__ __launch_bounds__(256) void splat_bwd_route_kernel(SplatBwdParams p) 
         if (ys < 0 || ys >= p.h || xs < 0 || xs >= p.w) continue;  // arg-max is a zero-filled tap
         const size_t idx = n * (size_t)k * k * hw + ((size_t)((2 * pad - dy) * k + (2 * pad - dx))) * hw +
                            (size_t)ys * p.w + xs;
-        p.d_kernels[idx] += dk;
+        static_cast<float*>(p.d_kernels)[idx] += dk;
     }
 }
 
 // v2 main: strip kernel (one wave = one 64-sample row strip).  Destination records
 // {M, dW, d_kmax, atap | dR0..3} of one destination row at a time are staged per wave
 // in LDS as two float4 arrays, so each tap costs two conflict-free ds_read_b128.
-template <int K, int C>
+template <int K, int C, typename LT>
 __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(SplatBwdParams p) {
     static_assert(TX + K - 1 <= V2_ROW, "staged row too short");
     static_assert(C <= 4, "records hold up to 4 channels");
@@ -516,11 +516,11 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
         D[c] = p.data[((size_t)n * C + c) * hw + pix];
         dD[c] = 0.f;
     }
-    const float* S = p.kernels + (size_t)n * K * K * hw + (size_t)ys * p.w + X0;
-    float* dS = p.d_kernels + (size_t)n * K * K * hw + (size_t)ys * p.w + X0;
+    const LT* S = static_cast<const LT*>(p.kernels) + (size_t)n * K * K * hw + (size_t)ys * p.w + X0;
+    LT* dS = static_cast<LT*>(p.d_kernels) + (size_t)n * K * K * hw + (size_t)ys * p.w + X0;
     const float4* rec = reinterpret_cast<const float4*>(p.scratch) + (size_t)n * hw * 2;
-    const unsigned voff = active ? (unsigned)lane * 4u : BUF_OOB;  // sample-less lanes: loads 0, stores dropped
-    const unsigned plane_stride = (unsigned)hw * 4u;
+    const unsigned voff = active ? (unsigned)lane * (unsigned)sizeof(LT) : BUF_OOB;  // sample-less lanes: loads 0, stores dropped
+    const unsigned plane_stride = (unsigned)hw * (unsigned)sizeof(LT);
 
     // staged destination columns: positions 0..63 by every lane, 64..64+K-2 by the first K-1 lanes
     const int colA = X0 - P + lane, colB = colA + TX;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
     auto load_logits = [&](int ky, float (&s)[K]) {
         const rsrc_t rs = make_rsrc(S + (size_t)(ky * K) * hw);  // tap (ky, 0); tap kx is kx planes further
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) s[kx] = buf_load<AUX_BWD_LD>(rs, voff, (unsigned)kx * plane_stride);
+        for (int kx = 0; kx < K; ++kx) s[kx] = logit_load<LT, AUX_BWD_LD>(rs, voff, (unsigned)kx * plane_stride);
     };
     auto step = [&](int ky, const float (&s)[K]) {
         const int yd = ys + ky - P;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
             if constexpr (C > 3) { g = fmaf(q1.w, D[C > 3 ? 3 : 0], g); dD[C > 3 ? 3 : 0] = fmaf(e, q1.w, dD[C > 3 ? 3 : 0]); }
             float ds = e * g;
             ds += (__float_as_int(q0.w) == tg0 - kx) ? q0.z : 0.f;
-            buf_store<AUX_BWD_ST>(ds, ws, voff, (unsigned)kx * plane_stride);
+            logit_store<LT, AUX_BWD_ST>(ds, ws, voff, (unsigned)kx * plane_stride);
         }
         __builtin_amdgcn_sched_barrier(0);
         }
@@ -739,14 +739,15 @@ extern "C" size_t sbmc_splat_update_bwd_scratch_bytes(int bs, int c, int h, int 
     return (size_t)bs * h * w * REC * sizeof(float);
 }
 
-extern "C" int sbmc_splat_update_fwd_f32(const float* data, const float* kernels,
-                                         const float* sum_r_in, const float* sum_w_in,
-                                         const float* max_w_in,
-                                         float* sum_r_out, float* sum_w_out,
-                                         float* max_w_out, float* kmax_out,
-                                         int32_t* atap_out,
-                                         int bs, int c, int h, int w, int k,
-                                         void* stream) {
+template <typename LT>
+static int splat_update_fwd_impl(const float* data, const void* kernels,
+                                 const float* sum_r_in, const float* sum_w_in,
+                                 const float* max_w_in,
+                                 float* sum_r_out, float* sum_w_out,
+                                 float* max_w_out, float* kmax_out,
+                                 int32_t* atap_out,
+                                 int bs, int c, int h, int w, int k,
+                                 void* stream) {
     if (bad_splat_dims(bs, c, h, w, k)) return SBMC_HIP_EINVAL;
     const int nin = (sum_r_in != nullptr) + (sum_w_in != nullptr) + (max_w_in != nullptr);
     if (nin != 0 && nin != 3) return SBMC_HIP_EINVAL;  // modules.py:431-435
@@ -760,10 +761,11 @@ extern "C" int sbmc_splat_update_fwd_f32(const float* data, const float* kernels
                          max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), h};
         const long items = (long)bs * h * p.ntx;
         const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
-        SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_fwd_strip_kernel<21, C>), dim3(grid),
+        SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_fwd_strip_kernel<21, C, LT>), dim3(grid),
                                                dim3(V2_WAVES * TX), 0, s, p));
         return (int)hipGetLastError();
     }
+    if (sizeof(LT) != 4) return SBMC_HIP_EINVAL;  // the generic tile kernels are fp32 only
     const size_t lds = fwd_tile_lds_bytes(c, k);
     if (lds > 64 * 1024) return SBMC_HIP_EINVAL;
     SplatFwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out,
@@ -774,19 +776,20 @@ extern "C" int sbmc_splat_update_fwd_f32(const float* data, const float* kernels
     return (int)hipGetLastError();
 }
 
-extern "C" int sbmc_splat_update_bwd_f32(const float* data, const float* kernels,
-                                         const float* sum_r_in, const float* sum_w_in,
-                                         const float* max_w_in,
-                                         const float* sum_r_out, const float* sum_w_out,
-                                         const float* max_w_out, const float* kmax,
-                                         const int32_t* atap,
-                                         const float* d_sum_r_out, const float* d_sum_w_out,
-                                         const float* d_max_w_out,
-                                         float* d_data, float* d_kernels,
-                                         float* d_sum_r_in, float* d_sum_w_in,
-                                         float* d_max_w_in, float* scratch,
-                                         int bs, int c, int h, int w, int k,
-                                         void* stream) {
+template <typename LT>
+static int splat_update_bwd_impl(const float* data, const void* kernels,
+                                 const float* sum_r_in, const float* sum_w_in,
+                                 const float* max_w_in,
+                                 const float* sum_r_out, const float* sum_w_out,
+                                 const float* max_w_out, const float* kmax,
+                                 const int32_t* atap,
+                                 const float* d_sum_r_out, const float* d_sum_w_out,
+                                 const float* d_max_w_out,
+                                 float* d_data, void* d_kernels,
+                                 float* d_sum_r_in, float* d_sum_w_in,
+                                 float* d_max_w_in, float* scratch,
+                                 int bs, int c, int h, int w, int k,
+                                 void* stream) {
     if (bad_splat_dims(bs, c, h, w, k)) return SBMC_HIP_EINVAL;
     const int nin = (sum_r_in != nullptr) + (sum_w_in != nullptr) + (max_w_in != nullptr);
     const int ndin = (d_sum_r_in != nullptr) + (d_sum_w_in != nullptr) + (d_max_w_in != nullptr);
@@ -810,11 +813,12 @@ extern "C" int sbmc_splat_update_bwd_f32(const float* data, const float* kernels
         if (err) return err;
         const long items = (long)bs * h * p.ntx;
         const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
-        SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_strip_kernel<21, C>), dim3(grid),
+        SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_strip_kernel<21, C, LT>), dim3(grid),
                                                dim3(V2_WAVES * TX), 0, s, p));
         return (int)hipGetLastError();
     }
 
+    if (sizeof(LT) != 4) return SBMC_HIP_EINVAL;  // the generic tile kernels are fp32 only
     const size_t lds = bwd_tile_lds_bytes(c, k);
     if (lds > 64 * 1024) return SBMC_HIP_EINVAL;
     SplatBwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out,
@@ -852,12 +856,13 @@ extern "C" int sbmc_splat_merge_fwd_f32(const float* part_r, const float* part_w
     return (int)hipGetLastError();
 }
 
-extern "C" int sbmc_splat_all_bwd_f32(const float* data, const float* kernels,
-                                      const float* part_m, const int32_t* atap,
-                                      const float* run_r, const float* run_w, const float* run_m,
-                                      const float* d_sum_r, const float* d_sum_w, const float* d_max_w,
-                                      float* d_data, float* d_kernels, float* scratch,
-                                      int bs, int s, int c, int h, int w, int k, void* stream) {
+template <typename LT>
+static int splat_all_bwd_impl(const float* data, const void* kernels,
+                              const float* part_m, const int32_t* atap,
+                              const float* run_r, const float* run_w, const float* run_m,
+                              const float* d_sum_r, const float* d_sum_w, const float* d_max_w,
+                              float* d_data, void* d_kernels, float* scratch,
+                              int bs, int s, int c, int h, int w, int k, void* stream) {
     if (bs < 0 || s < 1 || h < 0 || w < 0 || !strip_ok(c, k, h, w) || c < 1) return SBMC_HIP_EINVAL;
     if (bs == 0 || h == 0 || w == 0) return 0;
     if (!data || !kernels || !part_m || !atap || !run_r || !run_w || !run_m || !d_sum_r || !d_sum_w ||
@@ -877,9 +882,51 @@ extern "C" int sbmc_splat_all_bwd_f32(const float* data, const float* kernels,
     p.bs = bs * s; p.c = c; p.h = h; p.w = w; p.k = k; p.ntx = tiles_x(w); p.nty = h;
     const long items = (long)p.bs * h * p.ntx;
     const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
-    SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_strip_kernel<21, C>), dim3(grid),
+    SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_strip_kernel<21, C, LT>), dim3(grid),
                                            dim3(V2_WAVES * TX), 0, st, p));
     return (int)hipGetLastError();
+}
+
+#define SPLAT_FWD_ARGS const float *sum_r_in, const float *sum_w_in, const float *max_w_in, float *sum_r_out,  \
+                       float *sum_w_out, float *max_w_out, float *kmax_out, int32_t *atap_out, int bs, int c,  \
+                       int h, int w, int k, void *stream
+#define SPLAT_FWD_PASS sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out, kmax_out, atap_out, bs, c, h, w, k, stream
+extern "C" int sbmc_splat_update_fwd_f32(const float* data, const float* kernels, SPLAT_FWD_ARGS) {
+    return splat_update_fwd_impl<float>(data, kernels, SPLAT_FWD_PASS);
+}
+extern "C" int sbmc_splat_update_fwd_f16(const float* data, const void* kernels, SPLAT_FWD_ARGS) {
+    return splat_update_fwd_impl<_Float16>(data, kernels, SPLAT_FWD_PASS);
+}
+
+#define SPLAT_BWD_ARGS const float *sum_r_in, const float *sum_w_in, const float *max_w_in,                    \
+                       const float *sum_r_out, const float *sum_w_out, const float *max_w_out,                 \
+                       const float *kmax, const int32_t *atap, const float *d_sum_r_out,                       \
+                       const float *d_sum_w_out, const float *d_max_w_out
+#define SPLAT_BWD_TAIL float *d_sum_r_in, float *d_sum_w_in, float *d_max_w_in, float *scratch, int bs, int c, \
+                       int h, int w, int k, void *stream
+#define SPLAT_BWD_PASS1 sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out, kmax, atap, d_sum_r_out, d_sum_w_out, d_max_w_out
+#define SPLAT_BWD_PASS2 d_sum_r_in, d_sum_w_in, d_max_w_in, scratch, bs, c, h, w, k, stream
+extern "C" int sbmc_splat_update_bwd_f32(const float* data, const float* kernels, SPLAT_BWD_ARGS,
+                                         float* d_data, float* d_kernels, SPLAT_BWD_TAIL) {
+    return splat_update_bwd_impl<float>(data, kernels, SPLAT_BWD_PASS1, d_data, d_kernels, SPLAT_BWD_PASS2);
+}
+extern "C" int sbmc_splat_update_bwd_f16(const float* data, const void* kernels, SPLAT_BWD_ARGS,
+                                         float* d_data, void* d_kernels, SPLAT_BWD_TAIL) {
+    return splat_update_bwd_impl<_Float16>(data, kernels, SPLAT_BWD_PASS1, d_data, d_kernels, SPLAT_BWD_PASS2);
+}
+
+#define SPLAT_ALL_ARGS const float *part_m, const int32_t *atap, const float *run_r, const float *run_w,       \
+                       const float *run_m, const float *d_sum_r, const float *d_sum_w, const float *d_max_w
+#define SPLAT_ALL_PASS part_m, atap, run_r, run_w, run_m, d_sum_r, d_sum_w, d_max_w
+extern "C" int sbmc_splat_all_bwd_f32(const float* data, const float* kernels, SPLAT_ALL_ARGS, float* d_data,
+                                      float* d_kernels, float* scratch, int bs, int s, int c, int h, int w,
+                                      int k, void* stream) {
+    return splat_all_bwd_impl<float>(data, kernels, SPLAT_ALL_PASS, d_data, d_kernels, scratch, bs, s, c, h, w, k, stream);
+}
+extern "C" int sbmc_splat_all_bwd_f16(const float* data, const void* kernels, SPLAT_ALL_ARGS, float* d_data,
+                                      void* d_kernels, float* scratch, int bs, int s, int c, int h, int w,
+                                      int k, void* stream) {
+    return splat_all_bwd_impl<_Float16>(data, kernels, SPLAT_ALL_PASS, d_data, d_kernels, scratch, bs, s, c, h, w, k, stream);
 }
 
 extern "C" int sbmc_hip_abi_version(void) { return SBMC_HIP_ABI_VERSION; }

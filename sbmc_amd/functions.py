@@ -132,16 +132,23 @@ class KernelWeighting(th.autograd.Function):
         return d_data, d_weights
 
 
+def _half_ok(c, k, h, w):
+    return bool(_lib.lib().sbmc_splat_all_supported(int(c), int(k), int(h), int(w)))
+
+
 def splat_update_supported(data, kernels):
-    """True when the fused kernels can take these operands (GPU, fp32, odd k, <= 8 channels)."""
+    """True when the fused kernels can take these operands: GPU tensors, odd k, <= 8 channels,
+    fp32 radiance, fp32 logits -- or fp16 logits where the strip kernels apply (k = 21)."""
     if not (data.is_cuda and kernels.is_cuda):
         return False
-    if data.dtype != th.float32 or kernels.dtype != th.float32:
+    if data.dtype != th.float32 or kernels.dtype not in (th.float32, th.float16):
         return False
     k2 = kernels.shape[1]
     k = int(round(k2 ** 0.5))
     if k * k != k2:
         return False
+    if kernels.dtype == th.float16:
+        return _half_ok(data.shape[1], k, kernels.shape[-2], kernels.shape[-1])
     return bool(_lib.lib().sbmc_splat_update_supported(int(data.shape[1]), k))
 
 
@@ -189,8 +196,10 @@ class SplatUpdate(th.autograd.Function):
         kmax = data.new_empty(bs, h, w)
         atap = th.empty(bs, h, w, dtype=th.int32, device=data.device)
         dev = data.device
+        half = kernels.dtype == th.float16
+        fwd = _lib.lib().sbmc_splat_update_fwd_f16 if half else _lib.lib().sbmc_splat_update_fwd_f32
         with th.cuda.device(dev), _timed("splat_update_fwd", dev):
-            rc = _lib.lib().sbmc_splat_update_fwd_f32(
+            rc = fwd(
                 _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
                 _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(atap),
                 bs, c, h, w, k, _lib.current_stream(dev))
@@ -224,8 +233,10 @@ class SplatUpdate(th.autograd.Function):
             d_sum_w = th.empty_like(sum_w)
             d_max_w = th.empty_like(max_w)
         dev = data.device
+        half = kernels.dtype == th.float16
+        bwd = _lib.lib().sbmc_splat_update_bwd_f16 if half else _lib.lib().sbmc_splat_update_bwd_f32
         with th.cuda.device(dev), _timed("splat_update_bwd", dev):
-            rc = _lib.lib().sbmc_splat_update_bwd_f32(
+            rc = bwd(
                 _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
                 _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(atap),
                 _lib.ptr(d_r), _lib.ptr(d_w), _lib.ptr(d_m),
@@ -240,7 +251,7 @@ def splat_all_supported(data, kernels):
     """True when `SplatAll` can take data [bs, S, c, h, w] / kernels [bs, S, k*k, h, w]."""
     if not (data.is_cuda and kernels.is_cuda) or data.dim() != 5 or kernels.dim() != 5:
         return False
-    if data.dtype != th.float32 or kernels.dtype != th.float32:
+    if data.dtype != th.float32 or kernels.dtype not in (th.float32, th.float16):
         return False
     k2 = kernels.shape[2]
     k = int(round(k2 ** 0.5))
@@ -285,8 +296,9 @@ class SplatAll(th.autograd.Function):
         atap = th.empty(bs, S, h, w, dtype=th.int32, device=dev)
         lib = _lib.lib()
         with th.cuda.device(dev):
-            with _timed("splat_update_fwd_all", dev):
-                rc = lib.sbmc_splat_update_fwd_f32(
+            half = kernels.dtype == th.float16
+            with _timed("splat_update_fwd_all_f16" if half else "splat_update_fwd_all", dev):
+                rc = (lib.sbmc_splat_update_fwd_f16 if half else lib.sbmc_splat_update_fwd_f32)(
                     _lib.ptr(data), _lib.ptr(kernels), None, None, None,
                     _lib.ptr(part_r), _lib.ptr(part_w), _lib.ptr(part_m), _lib.ptr(kmax), _lib.ptr(atap),
                     bs * S, c, h, w, k, _lib.current_stream(dev))
@@ -319,8 +331,10 @@ class SplatAll(th.autograd.Function):
         d_kernels = th.empty_like(kernels)
         nbytes = _lib.lib().sbmc_splat_update_bwd_scratch_bytes(bs * S, c, h, w, ctx.k)
         scratch = data.new_empty((nbytes + 3) // 4)
-        with th.cuda.device(dev), _timed("splat_update_bwd_all", dev):
-            rc = _lib.lib().sbmc_splat_all_bwd_f32(
+        half = kernels.dtype == th.float16
+        bwd = _lib.lib().sbmc_splat_all_bwd_f16 if half else _lib.lib().sbmc_splat_all_bwd_f32
+        with th.cuda.device(dev), _timed("splat_update_bwd_all_f16" if half else "splat_update_bwd_all", dev):
+            rc = bwd(
                 _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(part_m), _lib.ptr(atap),
                 _lib.ptr(run_r), _lib.ptr(run_w), _lib.ptr(run_m),
                 _lib.ptr(d_r), _lib.ptr(d_w), _lib.ptr(d_m),

@@ -327,3 +327,59 @@ def test_bad_arguments_raise():
         halide_ops.scatter2gather_cuda_float32(w, w)
     with pytest.raises(RuntimeError):   # partial running state
         F.SplatUpdate.apply(d, th.zeros(1, 9, 8, 8, device="cuda"), None, th.zeros(1, 1, 8, 8, device="cuda"), None)
+
+
+@pytest.mark.parametrize("bs,c,h,w,spp", [(1, 3, 30, 150, 3), (1, 3, 6, 9, 2)])
+def test_fp16_logits_vs_oracle(oracle, bs, c, h, w, spp):
+    """fp16 logit storage (SURVEY row N4 / BASELINE configs[4]): the kernels read half logits and
+    write half logit-gradients, all arithmetic in fp32.  The oracle gets the same (exactly
+    representable) logits in fp32: forward within 1e-5; d_kernels within half rounding (2^-11)."""
+    from sbmc_amd import functions as F, modules
+    th.manual_seed(14)
+    k = 21
+    data = th.rand(bs, spp, c, h, w) * 2
+    kern_h = (th.randn(bs, spp, k * k, h, w) * 2).half()
+    grads = [th.randn(bs, c, h, w), th.randn(bs, 1, h, w), th.randn(bs, 1, h, w)]
+    ref_out, ref_dd, ref_dk = _progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=True),
+        [data[:, s] for s in range(spp)], [kern_h[:, s].float() for s in range(spp)], grads, "cpu")
+    # all samples per launch
+    dg = data.cuda().requires_grad_()
+    kg = kern_h.cuda().requires_grad_()
+    assert F.splat_all_supported(dg, kg)
+    out = F.SplatAll.apply(dg, kg)
+    th.autograd.backward(out, [g.cuda() for g in grads])
+    assert kg.grad.dtype == th.float16
+    for a, b, n in zip(out, ref_out, ("sum_r", "sum_w", "max_w")):
+        close(a, b, what=n)
+    for s in range(spp):
+        close(dg.grad[:, s], ref_dd[s], what="d_data")
+        close(kg.grad[:, s].float(), ref_dk[s], rtol=1e-3, what="d_kernels (half)")
+    # per-sample module interface
+    upd = modules.ProgressiveKernelApply(splat=True)
+    out2, dd2, dk2 = _progressive(upd, [data[:, s] for s in range(spp)],
+                                  [kern_h[:, s] for s in range(spp)], grads, "cuda")
+    for a, b in zip(out2, ref_out):
+        close(a, b)
+    for s in range(spp):
+        close(dd2[s], ref_dd[s])
+        close(dk2[s].float(), ref_dk[s], rtol=1e-3)
+
+
+def test_multisteps_under_fp16_autocast():
+    """fp16 activations end to end: backbone under torch.autocast(float16), half logits into the
+    fused splat, fp32 accumulation.  Sanity against the fp32 model (not a parity claim)."""
+    from sbmc_amd import Multisteps
+    th.manual_seed(15)
+    model = Multisteps(6, 3, width=16, embedding_width=16, ksize=21, nsteps=1).cuda()
+    g = th.Generator().manual_seed(16)
+    batch = {"radiance": th.empty(1, 2, 3, 40, 72).exponential_(1.0, generator=g).cuda(),
+             "features": th.rand(1, 2, 6, 40, 72, generator=g).cuda(),
+             "global_features": th.rand(1, 3, 1, 1, generator=g).cuda()}
+    ref = model(batch)["radiance"]
+    with th.autocast("cuda", dtype=th.float16):
+        out = model(batch)["radiance"]
+    assert out.dtype == th.float32 and th.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    out.sum().backward()
+    assert all(th.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
