@@ -101,8 +101,11 @@ __global__ __launch_bounds__(PLAIN_TY * TX) void kw_fwd_kernel(PlainParams p) {
     const int y = t.y0 + wv, x = t.x0 + lane;
     if (y >= p.h) return;
     const bool xact = x < p.w;
-    const int xc = xact ? x : p.w - 1;  // clamped column for loads of inactive lanes
-    const float* wgt = p.weights + (size_t)t.n * kh * kw * hw + (size_t)y * p.w + xc;
+    // weights of this row strip: plane (ry, rx) sits (ry*kw + rx) * hw floats further; raw buffer
+    // access with one descriptor per kernel row keeps every per-tap offset scalar and < 4 GiB
+    const float* wgt = p.weights + (size_t)t.n * kh * kw * hw + (size_t)y * p.w + t.x0;
+    const unsigned voff = xact ? (unsigned)lane * 4u : BUF_OOB;   // lanes past the edge read 0
+    const unsigned plane_stride = (unsigned)hw * 4u;
 
     float acc[C];
     float accw = 0.f;
@@ -111,9 +114,10 @@ __global__ __launch_bounds__(PLAIN_TY * TX) void kw_fwd_kernel(PlainParams p) {
 
     for (int ry = 0; ry < kh; ++ry) {
         const float* trow = lds + (wv + ry) * tw + lane;
+        const rsrc_t rs = make_rsrc(wgt + (size_t)(ry * kw) * hw);
 #pragma unroll 7
         for (int rx = 0; rx < kw; ++rx) {
-            const float wt = wgt[(size_t)(ry * kw + rx) * hw];
+            const float wt = buf_load(rs, voff, (unsigned)rx * plane_stride);
             accw += wt;
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] = fmaf(wt, trow[c * th * tw + rx], acc[c]);
@@ -152,18 +156,20 @@ __global__ __launch_bounds__(PLAIN_TY * TX) void kw_bwd_dweights_kernel(PlainPar
 #pragma unroll
     for (int c = 0; c < C; ++c) go[c] = p.d_output[((size_t)t.n * p.ctot + c) * hw + pix];
     const float dsw = p.accumulate ? 0.f : p.d_sum_w[(size_t)t.n * hw + pix];
-    float* dw = p.out0 + (size_t)t.n * kh * kw * hw + pix;
+    float* dw = p.out0 + (size_t)t.n * kh * kw * hw + (size_t)y * p.w + t.x0;
+    const unsigned voff = (unsigned)lane * 4u;
+    const unsigned plane_stride = (unsigned)hw * 4u;
 
     for (int dy = 0; dy < kh; ++dy) {
         const float* trow = lds + (wv + dy) * tw + lane;
+        const rsrc_t ws = make_rsrc(dw + (size_t)(dy * kw) * hw);
 #pragma unroll 7
         for (int dx = 0; dx < kw; ++dx) {
             float v = dsw;
 #pragma unroll
             for (int c = 0; c < C; ++c) v = fmaf(trow[c * th * tw + dx], go[c], v);
-            float* o = dw + (size_t)(dy * kw + dx) * hw;
-            if (p.accumulate) v += *o;
-            *o = v;
+            if (p.accumulate) v += buf_load(ws, voff, (unsigned)dx * plane_stride);
+            buf_store(v, ws, voff, (unsigned)dx * plane_stride);
         }
     }
 }
@@ -189,6 +195,9 @@ __global__ __launch_bounds__(PLAIN_TY * TX) void kw_bwd_ddata_kernel(PlainParams
     const int y = t.y0 + wv, x = t.x0 + lane;
     if (y >= p.h) return;
     const float* wgt = p.weights + (size_t)t.n * kh * kw * hw;
+    const unsigned voff = (unsigned)lane * 4u;
+    const unsigned tap_stride = (unsigned)(hw - 1) * 4u;   // one plane back, one column on
+    const int rx_lo = pw - x, rx_hi = p.w + pw - x;        // source column inside the image
 
     float acc[C];
 #pragma unroll
@@ -198,14 +207,18 @@ __global__ __launch_bounds__(PLAIN_TY * TX) void kw_bwd_ddata_kernel(PlainParams
         const int ys = y + ry - ph;
         if (ys < 0 || ys >= p.h) continue;  // wave-uniform
         const float* trow = lds + (wv + ry) * tw + lane;
+        // tap rx: plane (kh-1-ry)*kw + (kw-1-rx), row ys, column x0-pw+rx+lane
+        //   = rowmin + (kw-1-rx)*(hw-1) + lane, rowmin = address of tap kw-1, lane 0
+        const rsrc_t rs = make_rsrc(wgt + ((long)((kh - 1 - ry) * kw) * (long)hw + (long)ys * p.w +
+                                           (long)(t.x0 - pw + kw - 1)));
 #pragma unroll 7
         for (int rx = 0; rx < kw; ++rx) {
-            const int xs = x + rx - pw;
-            float wt = 0.f;
-            if (xs >= 0 && xs < p.w)
-                wt = wgt[(size_t)((kh - 1 - ry) * kw + (kw - 1 - rx)) * hw + (size_t)ys * p.w + xs];
+            const unsigned vo = (rx >= rx_lo && rx < rx_hi) ? voff : BUF_OOB;   // outside: weight 0
+            const float wt = buf_load(rs, vo, (unsigned)(kw - 1 - rx) * tap_stride);
+            {
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = fmaf(wt, trow[c * th * tw + rx], acc[c]);
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(wt, trow[c * th * tw + rx], acc[c]);
+            }
         }
     }
     if (x < p.w) {
@@ -264,6 +277,7 @@ extern "C" int sbmc_kernel_weighting_fwd_f32(const float* data, const float* wei
     if (bs == 0 || h == 0 || w == 0) return 0;
     if (!weights || !sum_w || !data || !output) return SBMC_HIP_EINVAL;
     if (plain_lds_bytes(1, kh, kw) > 64 * 1024) return SBMC_HIP_EINVAL;
+    if ((size_t)h * w * 4 * (size_t)(kw + 1) >= 0x7ff00000ull) return SBMC_HIP_EINVAL;  // buffer offset range
     hipStream_t s = (hipStream_t)stream;
     const size_t hw = (size_t)h * w;
     PlainParams p{};
@@ -303,6 +317,7 @@ extern "C" int sbmc_kernel_weighting_bwd_f32(const float* data, const float* wei
     if (bs == 0 || h == 0 || w == 0) return 0;
     if (!data || !weights || !d_output || !d_sum_w || !d_data || !d_weights) return SBMC_HIP_EINVAL;
     if (plain_lds_bytes(1, kh, kw) > 64 * 1024) return SBMC_HIP_EINVAL;
+    if ((size_t)h * w * 4 * (size_t)(kw + 1) >= 0x7ff00000ull) return SBMC_HIP_EINVAL;  // buffer offset range
     hipStream_t s = (hipStream_t)stream;
     const size_t hw = (size_t)h * w;
     PlainParams p{};
