@@ -10,8 +10,9 @@ import os
 import torch  # noqa: F401  (must be loaded first: brings in the HIP runtime the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT_LIB_PATH = os.path.join(_HERE, "libsbmc_hip.so")
 # SBMC_HIP_LIB: alternative build of the same ABI (kernel A/B experiments)
-LIB_PATH = os.environ.get("SBMC_HIP_LIB") or os.path.join(_HERE, "libsbmc_hip.so")
+LIB_PATH = os.environ.get("SBMC_HIP_LIB") or _DEFAULT_LIB_PATH
 
 #: every extern "C" symbol include/sbmc_hip.h declares
 SYMBOLS = (
@@ -46,6 +47,14 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    if not os.path.exists(LIB_PATH) and LIB_PATH == _DEFAULT_LIB_PATH:
+        # not built yet (fresh checkout: *.so is git-ignored): build the real thing with hipcc.
+        # This is a build step, not a fallback -- if hipcc is unavailable the error below stands.
+        try:
+            from . import build as _build
+            _build.build()
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise HipExtensionMissing(
             "%s not found: build it with `python -m sbmc_amd.build` (hipcc, gfx950). "
