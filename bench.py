@@ -12,6 +12,8 @@ Workloads
          forward, TonemappedRelativeMSE, backward, non-finite guard, grad-norm clip 1000,
          Adam(1e-4).  The conv backbone rides MIOpen; the splat path is the hand-written
          HIP kernels.
+  infer  (BASELINE.json configs[1] with --spp 4) one step = Multisteps forward only, eval mode,
+         no_grad -- what scripts/denoise.py runs per frame.  Not the headline metric.
   splat  one step = S progressive splat updates (ProgressiveKernelApply(splat=True), one per
          sample) + normalisation sum_r/(sum_w+eps) + backward to logits and radiance
          (SURVEY.md section 8d metric (i)): the part of the step the HIP kernels replace.
@@ -74,7 +76,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["model", "splat"], default="model")
+    ap.add_argument("--workload", choices=["model", "splat", "infer"], default="model")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--spp", type=int, default=8)
@@ -229,7 +231,8 @@ def main():
 
     H, W, S, K = args.height, args.width, args.spp, args.ksize
     pad = (K - 1) // 2
-    is_model = args.workload == "model"
+    is_model = args.workload in ("model", "infer")
+    infer = args.workload == "infer"
     steps = args.steps if args.steps is not None else (3 if is_model else 10)
     warmup = args.warmup if args.warmup is not None else (2 if is_model else 3)
     if is_model:
@@ -272,10 +275,21 @@ def main():
         from sbmc_amd import Multisteps, losses
         th.manual_seed(0)
         model = Multisteps(93, 3, ksize=K).to(device)
-        model.train()
+        model.train(not infer)
         opt = th.optim.Adam(model.parameters(), lr=1e-4)
         loss_fn = losses.TonemappedRelativeMSE()
-        if world == 1:
+        if infer:
+            if world > 1:
+                batch = make_model_inputs(H, W, S, device, seed=1234, rows=(part.y0, part.y1))
+                runner = sdist.ShardedDenoiser(model, part)
+            else:
+                batch = make_model_inputs(H, W, S, device, seed=1234)
+                runner = model
+
+            def step():
+                with th.no_grad():
+                    runner(batch)
+        elif world == 1:
             batch = make_model_inputs(H, W, S, device, seed=1234)
 
             def step():
@@ -297,7 +311,7 @@ def main():
 
     # ---------------------------------------------------------------- splat stages (N=1, model)
     stage = stage_all = stage_f16 = None
-    if is_model and world == 1 and not args.no_stages:
+    if is_model and not infer and world == 1 and not args.no_stages:
         del model, opt
         th.cuda.empty_cache()
         timings = []
@@ -362,13 +376,15 @@ def main():
         ms = dt / steps * 1e3
         value = S * H * W / (dt / steps) / 1e6
         res = {
-            "metric": "Msamples/s (SxHxW) denoise fwd+bwd, %dx%d %dspp %dx%d kernel" % (W, H, S, K, K),
+            "metric": "Msamples/s (SxHxW) denoise %s, %dx%d %dspp %dx%d kernel" % (
+                "fwd only" if infer else "fwd+bwd", W, H, S, K, K),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "Multisteps(93,3,ksize=%d) training step: fwd + TonemappedRelativeMSE + bwd "
+                "workload": "Multisteps(93,3,ksize=%d) forward only (eval, no_grad)" % K if infer else
+                            "Multisteps(93,3,ksize=%d) training step: fwd + TonemappedRelativeMSE + bwd "
                             "+ clip + Adam (BASELINE.json configs[2])" % K if is_model else
                             "splat fwd+bwd only: %d x ProgressiveKernelApply(splat=True) + normalise + "
                             "backward" % S,
@@ -402,7 +418,7 @@ def main():
                 "traffic_source": src, "alg_bytes_per_launch": kb["alg_bytes"],
                 "avg_launch_ms": kb["avg_ms"],
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not infer:
             try:
                 res["cpu_baseline"], parity = cpu_baseline(args, device)
                 if parity is not None:
