@@ -13,7 +13,7 @@ from . import _lib
 from . import halide_ops as ops
 
 __all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported",
-           "SplatAll", "splat_all_supported"]
+           "SplatAll", "splat_all_supported", "splat_all_supported_dims"]
 
 
 # Optional per-call device timing (used by bench.py for the roofline figure): when a list
@@ -245,6 +245,11 @@ class SplatUpdate(th.autograd.Function):
                 bs, c, h, w, ctx.k, _lib.current_stream(dev))
         _lib.check(rc, "splat_update_bwd")
         return d_data, d_kernels, d_sum_r, d_sum_w, d_max_w
+
+
+def splat_all_supported_dims(c, k, h, w):
+    """`SplatAll` applies to fp32 radiance with c channels, kernel size k, on an h x w frame."""
+    return bool(_lib.lib().sbmc_splat_all_supported(int(c), int(k), int(h), int(w)))
 
 
 def splat_all_supported(data, kernels):

@@ -118,8 +118,8 @@ class Multisteps(nn.Module):
         if self.batch_samples and self.splat and self.kernel_update.fused:
             # all samples at once: one regressor pass over bs*spp images, three splat launches
             # per direction instead of 2-3 per sample (functions.SplatAll)
-            if (radiance.is_cuda and radiance.dtype == th.float32 and funcs._lib.lib().sbmc_splat_all_supported(
-                    radiance.shape[2], self.ksize, h, w)):
+            if (radiance.is_cuda and radiance.dtype == th.float32
+                    and funcs.splat_all_supported_dims(radiance.shape[2], self.ksize, h, w)):
                 ctx = context.unsqueeze(1).expand(bs, spp, context.shape[1], h, w)
                 flat = th.cat([features, ctx], 2).reshape(bs * spp, -1, h, w)
                 kernels = self.kernel_regressor(flat)

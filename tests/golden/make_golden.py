@@ -190,6 +190,28 @@ def gen_kpcn(ref):
     save("kpcn.npz", out)
 
 
+def gen_multisteps_odd(ref):
+    """Odd frame sizes (the U-net pools with floor and upsamples to the skip's size), 3 steps,
+    gather-kernel ablation too."""
+    out = {}
+    g = th.Generator().manual_seed(23)
+    for tag, splat in (("splat", True), ("gather", False)):
+        th.manual_seed(22)
+        model = ref.models.Multisteps(5, 3, width=4, embedding_width=4, ksize=3, nsteps=3, splat=splat)
+        model.train(False)
+        batch = {"radiance": th.empty(2, 2, 3, 21, 27).exponential_(1.0, generator=g),
+                 "features": th.rand(2, 2, 5, 21, 27, generator=g),
+                 "global_features": th.rand(2, 3, 1, 1, generator=g)}
+        with th.no_grad():
+            res = model({k: v.clone() for k, v in batch.items()})["radiance"]
+        for k, v in model.state_dict().items():
+            out["%s.sd.%s" % (tag, k)] = npy(v)
+        for k, v in batch.items():
+            out["%s.in.%s" % (tag, k)] = npy(v)
+        out[tag + ".eval.radiance"] = npy(res)
+    save("multisteps_odd.npz", out)
+
+
 def gen_losses(ref):
     out = {}
     g = th.Generator().manual_seed(18)
@@ -272,6 +294,7 @@ def main():
     gen_multisteps(ref)
     gen_losses(ref)
     gen_kpcn(ref)
+    gen_multisteps_odd(ref)
     gen_bin(refload.REFERENCE_ROOT)
 
 

@@ -145,3 +145,12 @@ def test_kpcn_on_gpu_matches_reference_fixture():
     res = model(data)
     for k in ("radiance", "diffuse", "specular"):
         close(res[k], g["out." + k], rtol=2e-5, what=k)
+
+
+@pytest.mark.parametrize("tag", ["splat", "gather"])
+def test_multisteps_odd_sizes_on_gpu(tag):
+    from test_host_golden import _multisteps_odd
+    g, model, batch = _multisteps_odd(tag, "cuda")
+    with th.no_grad():
+        out = model(batch)["radiance"]
+    close(out, g[tag + ".eval.radiance"], rtol=2e-5, what=tag)

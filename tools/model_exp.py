@@ -24,6 +24,36 @@ for i in range(3):
     step()
 th.cuda.synchronize()
 print("ms/step", (time.time() - t0) / 3 * 1e3, "cfg", sys.argv[1:], "mem GB", th.cuda.max_memory_allocated() / 1e9, flush=True)
+if "--graph" in sys.argv:
+    from sbmc_amd.utils import crop_like
+    opt = th.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+    def gstep():
+        opt.zero_grad(set_to_none=False)
+        out = model(batch)["radiance"]
+        loss = loss_fn(out, crop_like(batch["target_image"], out))
+        loss.backward()
+        th.nn.utils.clip_grad_norm_(model.parameters(), 1000)
+        opt.step()
+        return loss
+    s_ = th.cuda.Stream()
+    s_.wait_stream(th.cuda.current_stream())
+    with th.cuda.stream(s_):
+        for i in range(2):
+            gstep()
+    th.cuda.current_stream().wait_stream(s_)
+    th.cuda.synchronize(); th.cuda.empty_cache()
+    g = th.cuda.CUDAGraph()
+    with th.cuda.graph(g):
+        static_loss = gstep()
+    th.cuda.synchronize()
+    for i in range(2):
+        g.replay()
+    th.cuda.synchronize()
+    t0 = time.time()
+    for i in range(3):
+        g.replay()
+    th.cuda.synchronize()
+    print("graph ms/step", (time.time() - t0) / 3 * 1e3, "loss", static_loss.item(), "mem GB", th.cuda.max_memory_allocated() / 1e9, flush=True)
 if "--prof" in sys.argv:
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
