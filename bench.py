@@ -302,6 +302,8 @@ def main():
                 runner.train_step(opt, loss_fn, batch)
         dt = timed(step, warmup, steps, timings)
         del batch
+        # rows the splat kernels see on this rank (the slab plus the kernel radius at inner edges)
+        local_px = (min(H, part.y1 + pad) - max(0, part.y0 - pad)) * W if world > 1 else H * W
     else:
         update = modules.ProgressiveKernelApply(splat=True)
         s0, s1 = max(0, part.y0 - pad), min(H, part.y1 + pad)
@@ -361,7 +363,7 @@ def main():
     for name, a, b in timings:
         per.setdefault(name, []).append(a.elapsed_time(b))  # ms
     kern = {}
-    if not is_model or stage is not None:
+    for _once in (0,):
         for name, bpp, nsamp in (("splat_update_fwd", fwd_bytes_per_pixel(K), 1),
                                  ("splat_update_bwd", bwd_bytes_per_pixel(K), 1),
                                  ("splat_update_fwd_all", fwd_bytes_per_pixel(K), S),
