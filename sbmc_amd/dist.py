@@ -61,22 +61,45 @@ class SlabPartition(object):
 
 
 def _exchange(part, to_up, to_down):
-    """Sends `to_up` to rank-1 and `to_down` to rank+1; returns (from_up, from_down)."""
+    """Sends `to_up` to rank-1 and `to_down` to rank+1; returns (from_up, from_down).
+
+    RCCL ("nccl") moves device tensors directly over xGMI.  A backend without device support
+    (gloo: the CPU tests, and the single-GPU two-process test of the device kernels) gets the
+    halo rows staged through host memory.
+    """
+    staged = to_up.is_cuda and dist.get_backend(part.group) != "nccl"
+    dev = to_up.device
     ops, from_up, from_down = [], None, None
     if part.has_up:
-        to_up = to_up.contiguous()
+        to_up = to_up.contiguous().cpu() if staged else to_up.contiguous()
         from_up = th.empty_like(to_up)
         ops += [dist.P2POp(dist.isend, to_up, part.peer(-1), group=part.group),
                 dist.P2POp(dist.irecv, from_up, part.peer(-1), group=part.group)]
     if part.has_down:
-        to_down = to_down.contiguous()
+        to_down = to_down.contiguous().cpu() if staged else to_down.contiguous()
         from_down = th.empty_like(to_down)
         ops += [dist.P2POp(dist.isend, to_down, part.peer(+1), group=part.group),
                 dist.P2POp(dist.irecv, from_down, part.peer(+1), group=part.group)]
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    if staged:
+        from_up = None if from_up is None else from_up.to(dev)
+        from_down = None if from_down is None else from_down.to(dev)
     return from_up, from_down
+
+
+def _all_reduce_sum(t, part):
+    """Sum over ranks; device tensors go through host memory when the backend is not RCCL."""
+    if dist.get_backend(part.group) == "nccl":
+        if not t.is_cuda:
+            t = t.cuda()
+        dist.all_reduce(t, group=part.group)
+        return t
+    dev = t.device
+    h = t.cpu()
+    dist.all_reduce(h, group=part.group)
+    return h.to(dev)
 
 
 class _HaloPad(th.autograd.Function):
@@ -205,16 +228,16 @@ class ShardedDenoiser(object):
         optimizer.zero_grad()
         out = self.forward(batch)["radiance"]
         tgt = self.target_rows(batch["target_image"])
-        count = th.tensor([float(out.numel())], device=out.device)
+        count = th.tensor([float(out.numel())])
         if part.world > 1:
-            dist.all_reduce(count, group=part.group)
+            count = _all_reduce_sum(count, part)
         loss = loss_fn(out, tgt) * (out.numel() / count.item())   # this rank's share of the global mean
         loss.backward()
         params = [q for q in self.model.parameters() if q.grad is not None]
         total = loss.detach().clone()
         if part.world > 1:
             flat = th.cat([q.grad.reshape(-1) for q in params] + [total.reshape(1)])
-            dist.all_reduce(flat, group=part.group)
+            flat = _all_reduce_sum(flat, part)
             off = 0
             for q in params:
                 n = q.grad.numel()

@@ -1,0 +1,79 @@
+"""The sharded denoiser with the DEVICE kernels: two processes on one MI355X (gloo transport,
+halos staged through host memory), k = 21 so that the strip kernels and the all-samples splat run
+on halo-padded slabs.  Everything but the RCCL transport itself is exercised."""
+import os
+import socket
+import sys
+
+import pytest
+import torch as th
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _close(a, b, rtol, what):
+    scale = b.abs().max().item()
+    err = (a - b).abs().max().item()
+    assert err <= rtol * max(scale, 1e-30) + 1e-12, "%s: err %.3e scale %.3e" % (what, err, scale)
+
+
+def _worker(rank, world, port, height):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sbmc_amd import Multisteps, losses
+        from sbmc_amd import dist as sdist
+        from sbmc_amd.utils import crop_like
+        dev = th.device("cuda", 0)
+        nf, ks, spp, w = 6, 21, 2, 72
+        th.manual_seed(3)
+        model = Multisteps(nf, 3, width=8, embedding_width=8, ksize=ks, nsteps=2).to(dev)
+        g = th.Generator().manual_seed(4)
+        full = {
+            "radiance": th.empty(1, spp, 3, height, w).exponential_(1.0, generator=g).to(dev),
+            "features": th.rand(1, spp, nf, height, w, generator=g).to(dev),
+            "global_features": th.rand(1, 3, 1, 1, generator=g).to(dev),
+            "target_image": th.empty(1, 3, height, w).exponential_(1.0, generator=g).to(dev),
+        }
+        loss_fn = losses.TonemappedRelativeMSE()
+        model.train(True)
+        ref_out = model(full)["radiance"]
+        ref_loss = loss_fn(ref_out, crop_like(full["target_image"], ref_out))
+        ref_loss.backward()
+        ref_grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+        model.zero_grad()
+
+        part = sdist.SlabPartition(height, world, rank)
+        slab = {k: (v if k == "global_features" else v[..., part.y0:part.y1, :].contiguous())
+                for k, v in full.items()}
+        runner = sdist.ShardedDenoiser(model, part)
+        p = (ks - 1) // 2
+        lo, hi = max(part.y0, p) - p, min(part.y1, height - p) - p
+        with th.no_grad():
+            out = runner(slab)["radiance"]
+        assert out.shape[-2] == hi - lo
+        _close(out, ref_out[..., lo:hi, :].detach(), 2e-5, "output rows")
+        opt = th.optim.SGD(model.parameters(), lr=0.0)
+        loss = runner.train_step(opt, loss_fn, slab)
+        _close(loss, ref_loss.detach(), 2e-5, "loss")
+        for k, q in model.named_parameters():
+            _close(q.grad, ref_grads[k], 5e-4, "grad " + k)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_denoiser_on_device_kernels():
+    mp.spawn(_worker, args=(2, _free_port(), 64), nprocs=2, join=True)
