@@ -223,6 +223,21 @@ SBMC_API int sbmc_splat_all_bwd_f16(const float *data, const void *kernels,
                            float *d_data, void *d_kernels, float *scratch,
                            int bs, int s, int c, int h, int w, int k, void *stream);
 
+/*
+ * Fused bias + activation around the 1x1 convolutions of the per-sample ConvChains (reference:
+ * nn.Conv2d(1x1) + ReLU / LeakyReLU, sbmc/modules.py:154-175 as used at sbmc/models.py:79-102),
+ * whose matrix product runs as a batched GEMM on the planar [b, c, hw] activations.
+ *   act: 0 linear, 1 relu, 2 leaky_relu(slope)
+ *   fwd (in place):  y = act(y + bias[c])
+ *   bwd:             gx = gy * act'(y)   (y = the forward OUTPUT; gx may alias gy),
+ *                    gbias[c] = sum_{b, pixels} gx      (gbias is zeroed by the call)
+ * hw must be a multiple of 4 and the tensors 16-byte aligned (SBMC_HIP_EINVAL otherwise).
+ */
+SBMC_API int sbmc_bias_act_fwd_f32(float *y, const float *bias, int b, int c, long hw, int act,
+                          float slope, void *stream);
+SBMC_API int sbmc_bias_act_bwd_f32(const float *gy, const float *y, float *gx, float *gbias,
+                          int b, int c, long hw, int act, float slope, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ from . import _lib
 from . import halide_ops as ops
 
 __all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported",
-           "SplatAll", "splat_all_supported", "splat_all_supported_dims"]
+           "SplatAll", "splat_all_supported", "splat_all_supported_dims", "BiasAct"]
 
 
 # Optional per-call device timing (used by bench.py for the roofline figure): when a list
@@ -245,6 +245,52 @@ class SplatUpdate(th.autograd.Function):
                 bs, c, h, w, ctx.k, _lib.current_stream(dev))
         _lib.check(rc, "splat_update_bwd")
         return d_data, d_kernels, d_sum_r, d_sum_w, d_max_w
+
+
+class BiasAct(th.autograd.Function):
+    """y <- act(y + bias[c]) in place on a planar [b, c, ...] tensor, one HBM pass; backward
+    produces the input gradient and the bias gradient in one pass (csrc/bias_act.hip).
+
+    act: 0 linear, 1 relu, 2 leaky_relu(slope).  Used around the batched-GEMM form of the
+    per-sample 1x1 convolutions (modules._pointwise_gemm).
+    """
+
+    @staticmethod
+    def supported(y):
+        hw = y[0, 0].numel() if y.dim() >= 2 and y.numel() else 0
+        return (y.is_cuda and y.dtype == th.float32 and y.is_contiguous() and hw % 4 == 0
+                and y.data_ptr() % 16 == 0 and y.shape[0] <= 65535 and y.shape[1] <= 65535)
+
+    @staticmethod
+    def forward(ctx, y, bias, act, slope):
+        b, c = y.shape[0], y.shape[1]
+        hw = y[0, 0].numel()
+        bias = bias.contiguous()
+        dev = y.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_bias_act_fwd_f32(_lib.ptr(y), _lib.ptr(bias), b, c, hw, act, slope,
+                                                  _lib.current_stream(dev))
+        _lib.check(rc, "bias_act_fwd")
+        ctx.mark_dirty(y)
+        ctx.act, ctx.slope = act, slope
+        if act != 0:
+            ctx.save_for_backward(y)   # the linear case needs no activation mask
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        y = ctx.saved_tensors[0] if ctx.act != 0 else gy   # placeholder pointer, never read when linear
+        b, c = gy.shape[0], gy.shape[1]
+        hw = gy[0, 0].numel()
+        gx = th.empty_like(gy)
+        gbias = gy.new_empty(c)
+        dev = gy.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_bias_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gx), _lib.ptr(gbias),
+                                                  b, c, hw, ctx.act, ctx.slope, _lib.current_stream(dev))
+        _lib.check(rc, "bias_act_bwd")
+        return gx, gbias, None, None
 
 
 def splat_all_supported_dims(c, k, h, w):

@@ -58,16 +58,28 @@ def _is_pointwise(conv):
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is not None)
 
 
-def _pointwise_gemm(conv, x):
-    """conv(x) for a 1x1 convolution as y[b] = W @ x[b] + bias on [B, Cin, H*W] (no layout change)."""
+def _pointwise_gemm(conv, x, activation=None):
+    """conv(x) [+ activation] for a 1x1 convolution as y[b] = W @ x[b] on [B, Cin, H*W] (no
+    layout change), with bias and ReLU / LeakyReLU applied by one fused in-place HIP pass.
+    Returns (y, activation_was_applied)."""
     if hasattr(conv, "weight_g"):   # old-style weight norm: w = g * v / ||v||, norm over dims 1..3
         w = th._weight_norm(conv.weight_v, conv.weight_g, 0)
     else:
         w = conv.weight
     b, c, h, wd = x.shape
-    y = th.baddbmm(conv.bias.view(1, -1, 1), w.view(1, w.shape[0], c).expand(b, -1, -1),
-                   x.reshape(b, c, h * wd))
-    return y.view(b, w.shape[0], h, wd)
+    wmat = w.view(1, w.shape[0], c).expand(b, -1, -1)
+    x3 = x.reshape(b, c, h * wd)
+    act, slope = 0, 0.0
+    if isinstance(activation, nn.ReLU):
+        act = 1
+    elif isinstance(activation, nn.LeakyReLU):
+        act, slope = 2, float(activation.negative_slope)
+    y = th.bmm(wmat, x3)
+    if funcs.BiasAct.supported(y):
+        y = funcs.BiasAct.apply(y, conv.bias, act, slope)
+        return y.view(b, w.shape[0], h, wd), act != 0
+    y = y + conv.bias.view(1, -1, 1)
+    return y.view(b, w.shape[0], h, wd), False
 
 
 class ConvChain(nn.Module):
@@ -130,13 +142,21 @@ class ConvChain(nn.Module):
 
     def forward(self, x):
         gemm = self.pointwise_as_gemm and x.is_cuda
-        for m in self.children():
+        mods = list(self.children())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            i += 1
             if gemm and isinstance(m, ConvChain._ConvBNRelu) and _is_pointwise(m.layer[0]):
-                x = _pointwise_gemm(m.layer[0], x)
-                for sub in list(m.layer.children())[1:]:
+                rest = list(m.layer.children())[1:]
+                x, fused = _pointwise_gemm(m.layer[0], x, rest[0] if len(rest) == 1 else None)
+                for sub in (rest[1:] if fused else rest):
                     x = sub(x)
             elif gemm and isinstance(m, nn.Conv2d) and _is_pointwise(m):
-                x = _pointwise_gemm(m, x)
+                nxt = mods[i] if i < len(mods) else None          # the chain's output activation
+                x, fused = _pointwise_gemm(m, x, nxt)
+                if fused:
+                    i += 1
             else:
                 x = m(x)
         return x

@@ -383,3 +383,48 @@ def test_multisteps_under_fp16_autocast():
     assert (out - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
     out.sum().backward()
     assert all(th.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("act,slope", [(0, 0.0), (1, 0.0), (2, 0.01), (2, 0.2)])
+def test_bias_act_kernels(act, slope):
+    """Fused bias + activation (csrc/bias_act.hip) vs torch, forward and backward."""
+    from sbmc_amd import functions as F
+    th.manual_seed(17)
+    for shape in ((2, 5, 12, 20), (1, 128, 8, 64), (3, 1, 4, 4)):
+        y0 = th.randn(*shape, device="cuda")
+        bias = th.randn(shape[1], device="cuda", requires_grad=True)
+        x = y0.clone().requires_grad_()
+        pre = x + bias.view(1, -1, 1, 1)
+        ref = pre if act == 0 else th.nn.functional.leaky_relu(pre, slope if act == 2 else 0.0)
+        g = th.randn_like(ref)
+        ref.backward(g)
+        gx_ref, gb_ref = x.grad.clone(), bias.grad.clone()
+        x2 = y0.clone().requires_grad_()
+        b2 = bias.detach().clone().requires_grad_()
+        out = F.BiasAct.apply(x2 * 1.0, b2, act, slope)   # *1.0: BiasAct works in place on its input
+        assert F.BiasAct.supported(out)
+        out.backward(g)
+        assert th.equal(out.detach(), ref.detach())
+        assert th.equal(x2.grad, gx_ref)
+        close(b2.grad, gb_ref, rtol=1e-5)
+
+
+def test_pointwise_chain_as_gemm_matches_convolution():
+    """ConvChain(ksize=1) through the batched-GEMM + fused bias/activation path == the nn.Conv2d path."""
+    from sbmc_amd import modules
+    th.manual_seed(18)
+    for out_type, actv in (("linear", "relu"), ("leaky_relu", "leaky_relu")):
+        chain = modules.ConvChain(12, 7, ksize=1, width=16, depth=3, pad=False, activation=actv,
+                                  output_type=out_type).cuda()
+        x = th.randn(3, 12, 10, 24, device="cuda")
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        ya = chain(xa)
+        chain.pointwise_as_gemm = True
+        yb = chain(xb)
+        chain.pointwise_as_gemm = False
+        close(yb, ya, rtol=1e-5)
+        g = th.randn_like(ya)
+        ga = th.autograd.grad(ya, [xa] + list(chain.parameters()), g)
+        gb = th.autograd.grad(yb, [xb] + list(chain.parameters()), g)
+        for a, b in zip(ga, gb):
+            close(b, a, rtol=2e-5)
