@@ -218,12 +218,19 @@ def main():
                          "--gpus %d ..." % (args.gpus, args.gpus))
     if not th.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X)")
+    # test hooks (single-GPU dry run of the multi-rank code path): all ranks on device 0 over gloo
+    backend = os.environ.get("SBMC_BENCH_BACKEND", "nccl")
+    if os.environ.get("SBMC_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     th.cuda.set_device(local_rank)
     device = th.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from sbmc_amd import _lib, functions, modules
     from sbmc_amd import dist as sdist
@@ -262,7 +269,7 @@ def main():
         dt = time.perf_counter() - t0
         functions.enable_kernel_timing(None)
         if world > 1:
-            t = th.tensor([dt], device=device, dtype=th.float64)
+            t = th.tensor([dt], dtype=th.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         return dt
