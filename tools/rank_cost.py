@@ -1,0 +1,41 @@
+"""Per-rank cost of the sharded training step on ONE GPU (no communication: neighbour halos are
+replaced by zeros): an upper bound on the strong-scaling speed-up, T(1 GPU) / T(one rank of N)."""
+import os, sys, time
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch as th
+import bench
+from sbmc_amd import Multisteps, losses
+from sbmc_amd import dist as sdist
+
+def fake_exchange(part, to_up, to_down):
+    return (th.zeros_like(to_up) if part.has_up else None, th.zeros_like(to_down) if part.has_down else None)
+sdist._exchange = fake_exchange
+sdist._all_reduce_sum = lambda t, part: t.cuda() if not t.is_cuda else t
+
+dev = th.device("cuda")
+H, W, S, K = 720, 1280, 8, 21
+full = bench.make_model_inputs(H, W, S, dev, seed=1234)
+for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    th.manual_seed(0)
+    model = Multisteps(93, 3, ksize=K).to(dev).train()
+    opt = th.optim.Adam(model.parameters(), lr=1e-4)
+    loss_fn = losses.TonemappedRelativeMSE()
+    rank = world // 2 if world > 1 else 0          # an interior rank (halos on both sides)
+    part = sdist.SlabPartition(H, world, rank)
+    batch = {k: (v if k == "global_features" else v[..., part.y0:part.y1, :].contiguous()) for k, v in full.items()}
+    runner = sdist.ShardedDenoiser(model, part)
+    if world == 1:
+        step = lambda: bench.train_step(model, opt, loss_fn, batch)
+    else:
+        step = lambda: runner.train_step(opt, loss_fn, batch)
+    for _ in range(2):
+        step()
+    th.cuda.synchronize(); t0 = time.time()
+    for _ in range(3):
+        step()
+    th.cuda.synchronize()
+    ms = (time.time() - t0) / 3 * 1e3
+    print("world %d rank %d rows %d: %.1f ms/step" % (world, rank, part.rows, ms), flush=True)
+    del model, opt, runner, batch
+    th.cuda.empty_cache()
