@@ -238,6 +238,22 @@ SBMC_API int sbmc_bias_act_fwd_f32(float *y, const float *bias, int b, int c, lo
 SBMC_API int sbmc_bias_act_bwd_f32(const float *gy, const float *y, float *gx, float *gbias,
                           int b, int c, long hw, int act, float slope, void *stream);
 
+/*
+ * The same for a chain whose first 1x1 layer sees [per-sample features ; per-pixel context]
+ * (reference: th.cat([f, propagated], 1) for every sample, sbmc/models.py:147-153,171-177,
+ * 196-199).  The layer is linear, so the context term t = W_c ctx is the same for all s samples
+ * of a pixel; it is computed once per pixel by the caller and added here with bias + activation:
+ *   fwd (in place):  y[b,s,c,p] = act(y[b,s,c,p] + t[b,c,p] + bias[c])
+ *   bwd:             gx = gy * act'(y);  gt[b,c,p] = sum_s gx;  gbias[c] = sum_{b,s,p} gx
+ * y, gy, gx: [b*s, c, hw];  t, gt: [b, c, hw] (t_per_pixel = 1) or [b, c] (t_per_pixel = 0: the
+ * context is constant over the image, e.g. the global features of the first step).
+ */
+SBMC_API int sbmc_ctx_act_fwd_f32(float *y, const float *t, const float *bias, int b, int s, int c, long hw,
+                         int t_per_pixel, int act, float slope, void *stream);
+SBMC_API int sbmc_ctx_act_bwd_f32(const float *gy, const float *y, float *gx, float *gt, float *gbias,
+                         int b, int s, int c, long hw, int t_per_pixel, int act, float slope,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

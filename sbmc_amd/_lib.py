@@ -33,6 +33,8 @@ SYMBOLS = (
     "sbmc_splat_all_bwd_f16",
     "sbmc_bias_act_fwd_f32",
     "sbmc_bias_act_bwd_f32",
+    "sbmc_ctx_act_fwd_f32",
+    "sbmc_ctx_act_bwd_f32",
 )
 ABI_VERSION = 1
 MAX_CHANNELS = 8
@@ -84,6 +86,8 @@ def lib():
     handle.sbmc_splat_all_bwd_f16.argtypes = handle.sbmc_splat_all_bwd_f32.argtypes
     handle.sbmc_bias_act_fwd_f32.argtypes = [p, p, i, i, ctypes.c_long, i, ctypes.c_float, p]
     handle.sbmc_bias_act_bwd_f32.argtypes = [p, p, p, p, i, i, ctypes.c_long, i, ctypes.c_float, p]
+    handle.sbmc_ctx_act_fwd_f32.argtypes = [p, p, p, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_ctx_act_bwd_f32.argtypes = [p, p, p, p, p, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t

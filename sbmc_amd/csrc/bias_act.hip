@@ -79,6 +79,73 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
     if (threadIdx.x == 0) atomicAdd(gbias + c, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// Per-sample chains whose first layer sees [sample features ; pixel context] (reference
+// sbmc/models.py:147-153,171-177,196-199: th.cat([f, propagated], 1) for every sample): the
+// layer is linear, so W [f ; ctx] = W_f f + W_c ctx, and the context term W_c ctx + bias is the
+// same for all S samples of a pixel.  It is computed ONCE per pixel (t[b, c, p]) and added here,
+// together with the activation, in one in-place pass over the per-sample product:
+//   forward : y[b,s,c,p] = act(y[b,s,c,p] + t[b,c,p*tp] + bias[c])        (tp = 0: t is per image)
+//   backward: gx = gy * act'(y);  gt[b,c,p] = sum_s gx;  gbias[c] = sum_{b,s,p} gx
+__global__ __launch_bounds__(256) void ctx_act_fwd_kernel(float* __restrict__ y, const float* __restrict__ t,
+                                                         const float* __restrict__ bias, size_t hw, int C,
+                                                         int S, int t_per_pixel, float slope, int linear) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const float bv = bias[c];
+    const size_t n4 = hw / 4;
+    const float* tplane = t + ((size_t)b * C + c) * (t_per_pixel ? hw : 1);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 tv;
+        if (t_per_pixel) tv = reinterpret_cast<const float4*>(tplane)[i];
+        else tv = make_float4(tplane[0], tplane[0], tplane[0], tplane[0]);
+        tv.x += bv; tv.y += bv; tv.z += bv; tv.w += bv;
+        for (int s = 0; s < S; ++s) {
+            float4* p4 = reinterpret_cast<float4*>(y + (((size_t)b * S + s) * C + c) * hw) + i;
+            float4 v = *p4;
+            v.x += tv.x; v.y += tv.y; v.z += tv.z; v.w += tv.w;
+            if (!linear) {
+                v.x = act_fwd(v.x, slope); v.y = act_fwd(v.y, slope);
+                v.z = act_fwd(v.z, slope); v.w = act_fwd(v.w, slope);
+            }
+            *p4 = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ctx_act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                         float* __restrict__ gx, float* __restrict__ gt,
+                                                         float* __restrict__ gbias, size_t hw, int C, int S,
+                                                         int t_per_pixel, float slope, int linear) {
+    __shared__ float red[4];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const size_t n4 = hw / 4;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < S; ++s) {
+            const size_t off = (((size_t)b * S + s) * C + c) * hw;
+            float4 g = reinterpret_cast<const float4*>(gy + off)[i];
+            if (!linear) {
+                const float4 v = reinterpret_cast<const float4*>(y + off)[i];
+                g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
+                g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
+            }
+            reinterpret_cast<float4*>(gx + off)[i] = g;
+            sum.x += g.x; sum.y += g.y; sum.z += g.z; sum.w += g.w;
+        }
+        if (t_per_pixel) reinterpret_cast<float4*>(gt + ((size_t)b * C + c) * hw)[i] = sum;
+        acc += (sum.x + sum.y) + (sum.z + sum.w);
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_down(acc, s, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+        atomicAdd(gbias + c, tot);
+        if (!t_per_pixel) atomicAdd(gt + (size_t)b * C + c, tot);
+    }
+}
+
 }  // namespace sbmc
 
 using namespace sbmc;
@@ -120,5 +187,41 @@ extern "C" int sbmc_bias_act_bwd_f32(const float* gy, const float* y, float* gx,
     const float s = act == 1 ? 0.f : slope;
     hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(chunks_for((size_t)hw, b * c), c, b), dim3(256), 0, st,
                        gy, y, gx, gbias, (size_t)hw, c, s, act == 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_ctx_act_fwd_f32(float* y, const float* t, const float* bias, int b, int s, int c, long hw,
+                                    int t_per_pixel, int act, float slope, void* stream) {
+    if (b < 0 || s < 1 || c < 0 || hw < 0 || act < 0 || act > 2) return SBMC_HIP_EINVAL;
+    if (b == 0 || c == 0 || hw == 0) return 0;
+    if (!y || !t || !bias || c > 65535 || b > 65535 || hw % 4 || (uintptr_t)y % 16 || (uintptr_t)t % 16)
+        return SBMC_HIP_EINVAL;
+    const float sl = act == 1 ? 0.f : slope;
+    hipLaunchKernelGGL(ctx_act_fwd_kernel, dim3(chunks_for((size_t)hw, b * c), c, b), dim3(256), 0,
+                       (hipStream_t)stream, y, t, bias, (size_t)hw, c, s, t_per_pixel != 0, sl, act == 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_ctx_act_bwd_f32(const float* gy, const float* y, float* gx, float* gt, float* gbias,
+                                    int b, int s, int c, long hw, int t_per_pixel, int act, float slope,
+                                    void* stream) {
+    if (b < 0 || s < 1 || c < 0 || hw < 0 || act < 0 || act > 2) return SBMC_HIP_EINVAL;
+    if ((c > 0 && !gbias) || (b > 0 && c > 0 && !gt)) return SBMC_HIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (c > 0) {
+        hipError_t e = hipMemsetAsync(gbias, 0, sizeof(float) * c, st);
+        if (e != hipSuccess) return (int)e;
+        if (!t_per_pixel && b > 0) {
+            e = hipMemsetAsync(gt, 0, sizeof(float) * (size_t)b * c, st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    if (b == 0 || c == 0 || hw == 0) return 0;
+    if (!gy || !y || !gx || c > 65535 || b > 65535 || hw % 4) return SBMC_HIP_EINVAL;
+    if ((uintptr_t)gy % 16 || (uintptr_t)y % 16 || (uintptr_t)gx % 16 || (t_per_pixel && (uintptr_t)gt % 16))
+        return SBMC_HIP_EINVAL;
+    const float sl = act == 1 ? 0.f : slope;
+    hipLaunchKernelGGL(ctx_act_bwd_kernel, dim3(chunks_for((size_t)hw, b * c), c, b), dim3(256), 0, st,
+                       gy, y, gx, gt, gbias, (size_t)hw, c, s, t_per_pixel != 0, sl, act == 0);
     return (int)hipGetLastError();
 }

@@ -196,7 +196,7 @@ class ShardedDenoiser(object):
             radiance = radiance.mean(1, keepdim=True)
             features = features.mean(1, keepdim=True)
         bs, spp, nf, h, w = features.shape
-        context = gfeatures.expand(bs, gfeatures.shape[1], h, w)
+        context = gfeatures
         for step in range(m.nsteps):
             features = m._embed(getattr(m, "embedding_{:02d}".format(step)), features, context)
             reduced = features.mean(1)

@@ -13,7 +13,7 @@ from . import _lib
 from . import halide_ops as ops
 
 __all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported",
-           "SplatAll", "splat_all_supported", "splat_all_supported_dims", "BiasAct"]
+           "SplatAll", "splat_all_supported", "splat_all_supported_dims", "BiasAct", "CtxAct"]
 
 
 # Optional per-call device timing (used by bench.py for the roofline figure): when a list
@@ -291,6 +291,61 @@ class BiasAct(th.autograd.Function):
                                                   b, c, hw, ctx.act, ctx.slope, _lib.current_stream(dev))
         _lib.check(rc, "bias_act_bwd")
         return gx, gbias, None, None
+
+
+class CtxAct(th.autograd.Function):
+    """y[b,s] <- act(y[b,s] + t[b] + bias) in place: the per-pixel context term of a chain's
+    first layer added to the per-sample product (csrc/bias_act.hip, include/sbmc_hip.h).
+
+    y [b*s, c, ...pixels] (modified in place), t [b, c, ...pixels] or [b, c, 1...] (constant over
+    the image), bias [c]; act: 0 linear, 1 relu, 2 leaky_relu(slope).
+    """
+
+    @staticmethod
+    def supported(y, t, s):
+        if not BiasAct.supported(y) or y.shape[0] % s or not t.is_contiguous() or t.dtype != th.float32:
+            return False
+        b = y.shape[0] // s
+        hw = y[0, 0].numel()
+        return (t.shape[0] == b and t.shape[1] == y.shape[1] and t[0, 0].numel() in (1, hw)
+                and t.data_ptr() % 16 == 0)
+
+    @staticmethod
+    def forward(ctx, y, t, bias, s, act, slope):
+        c = y.shape[1]
+        b = y.shape[0] // s
+        hw = y[0, 0].numel()
+        per_pixel = int(t[0, 0].numel() == hw and hw > 1)
+        bias = bias.contiguous()
+        dev = y.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_ctx_act_fwd_f32(_lib.ptr(y), _lib.ptr(t), _lib.ptr(bias), b, s, c, hw,
+                                                 per_pixel, act, slope, _lib.current_stream(dev))
+        _lib.check(rc, "ctx_act_fwd")
+        ctx.mark_dirty(y)
+        ctx.cfg = (s, act, slope, per_pixel, tuple(t.shape))
+        if act != 0:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        s, act, slope, per_pixel, tshape = ctx.cfg
+        gy = gy.contiguous()
+        y = ctx.saved_tensors[0] if act != 0 else gy
+        c = gy.shape[1]
+        b = gy.shape[0] // s
+        hw = gy[0, 0].numel()
+        gx = th.empty_like(gy)
+        gt = gy.new_empty(tshape)
+        gbias = gy.new_empty(c)
+        dev = gy.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_ctx_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gx), _lib.ptr(gt),
+                                                 _lib.ptr(gbias), b, s, c, hw, per_pixel, act, slope,
+                                                 _lib.current_stream(dev))
+        _lib.check(rc, "ctx_act_bwd")
+        return gx, gt, gbias, None, None, None
 
 
 def splat_all_supported_dims(c, k, h, w):

@@ -102,9 +102,15 @@ class Multisteps(nn.Module):
         for s0 in range(0, spp, chunk):
             part = per_sample[:, s0:s0 + chunk]
             n = part.shape[1]
-            ctx = per_pixel.unsqueeze(1).expand(bs, n, per_pixel.shape[1], h, w)
-            flat = th.cat([part, ctx], 2).reshape(bs * n, c + per_pixel.shape[1], h, w)
-            out = module(flat)
+            out = None
+            if module.pointwise_as_gemm:
+                # context half of the first layer once per pixel, no concatenation
+                out = ops.pointwise_chain_with_context(module, part, per_pixel)
+            if out is None:
+                ctx = per_pixel.expand(bs, per_pixel.shape[1], h, w).unsqueeze(1).expand(
+                    bs, n, per_pixel.shape[1], h, w)
+                flat = th.cat([part, ctx], 2).reshape(bs * n, c + per_pixel.shape[1], h, w)
+                out = module(flat)
             outs.append(out.view(bs, n, out.shape[1], h, w))
         return outs[0] if len(outs) == 1 else th.cat(outs, 1)
 
@@ -120,9 +126,12 @@ class Multisteps(nn.Module):
             # per direction instead of 2-3 per sample (functions.SplatAll)
             if (radiance.is_cuda and radiance.dtype == th.float32
                     and funcs.splat_all_supported_dims(radiance.shape[2], self.ksize, h, w)):
-                ctx = context.unsqueeze(1).expand(bs, spp, context.shape[1], h, w)
-                flat = th.cat([features, ctx], 2).reshape(bs * spp, -1, h, w)
-                kernels = self.kernel_regressor(flat)
+                kernels = ops.pointwise_chain_with_context(self.kernel_regressor, features, context) \
+                    if self.kernel_regressor.pointwise_as_gemm else None
+                if kernels is None:
+                    ctx = context.unsqueeze(1).expand(bs, spp, context.shape[1], h, w)
+                    flat = th.cat([features, ctx], 2).reshape(bs * spp, -1, h, w)
+                    kernels = self.kernel_regressor(flat)
                 kernels = kernels.view(bs, spp, kernels.shape[1], h, w)
                 return funcs.SplatAll.apply(radiance, kernels)
         sum_r, sum_w, max_w = None, None, None
@@ -155,7 +164,7 @@ class Multisteps(nn.Module):
         # step 0 sees the global features, later steps the propagated pixel context
         # (reference models.py:142-189; batch elements are paired correctly for
         # bs > 1, where the reference's train path mis-tiles them).
-        context = gfeatures.expand(bs, gfeatures.shape[1], h, w)
+        context = gfeatures          # [bs, ngf, 1, 1]: constant over the image at the first step
         for step in range(self.nsteps):
             features = self._embed(getattr(self, "embedding_{:02d}".format(step)),
                                    features, context)

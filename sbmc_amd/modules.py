@@ -82,6 +82,56 @@ def _pointwise_gemm(conv, x, activation=None):
     return y.view(b, w.shape[0], h, wd), False
 
 
+def pointwise_chain_with_context(chain, per_sample, context):
+    """`chain(cat([per_sample[:, s], context], 1))` for every sample s of a 1x1 ConvChain, without
+    building the concatenation: the first layer is linear, so its context half W_c @ context is
+    computed once per pixel and added (with bias and activation) to the per-sample half
+    W_f @ per_sample[:, s] by one fused pass (functions.CtxAct).  Same arithmetic as the
+    reference's th.cat([f, propagated], 1) -> conv (sbmc/models.py:147-153,171-177,196-199) up to
+    fp32 summation order; the context product is done once instead of once per sample.
+
+    per_sample [bs, S, cs, h, w], context [bs, cp, h, w] or [bs, cp, 1, 1] -> [bs*S, cout, h, w];
+    returns None when the fused path does not apply (the caller then concatenates).
+    """
+    mods = list(chain.children())
+    first = mods[0]
+    if isinstance(first, ConvChain._ConvBNRelu):
+        if len(first.layer) != 2:
+            return None
+        conv, act_mod = first.layer[0], first.layer[1]
+    elif isinstance(first, nn.Conv2d):
+        conv, act_mod = first, (mods[1] if len(mods) > 1 else None)
+    else:
+        return None
+    if not (_is_pointwise(conv) and per_sample.is_cuda and per_sample.dtype == th.float32):
+        return None
+    act = 0, 0.0
+    if isinstance(act_mod, nn.ReLU):
+        act = 1, 0.0
+    elif isinstance(act_mod, nn.LeakyReLU):
+        act = 2, float(act_mod.negative_slope)
+    elif act_mod is not None and isinstance(first, ConvChain._ConvBNRelu):
+        return None                      # tanh / elu chains keep the generic path
+    bs, S, cs, h, w = per_sample.shape
+    cp = context.shape[1]
+    if conv.in_channels != cs + cp:
+        return None
+    wt = th._weight_norm(conv.weight_v, conv.weight_g, 0) if hasattr(conv, "weight_g") else conv.weight
+    wt = wt.view(wt.shape[0], cs + cp)
+    cout = wt.shape[0]
+    xs = per_sample.reshape(bs * S, cs, h * w)
+    y = th.bmm(wt[:, :cs].unsqueeze(0).expand(bs * S, -1, -1), xs)
+    ctx3 = context.reshape(bs, cp, -1)
+    t = th.bmm(wt[:, cs:].unsqueeze(0).expand(bs, -1, -1), ctx3).contiguous()
+    if not funcs.CtxAct.supported(y, t, S):
+        return None
+    y = funcs.CtxAct.apply(y, t, conv.bias, S, act[0], act[1]).view(bs * S, cout, h, w)
+    # the rest of the chain, minus what has been consumed
+    consumed = 1 if isinstance(first, ConvChain._ConvBNRelu) else (2 if act[0] != 0 else 1)
+    rest = mods[consumed:]
+    return chain._run(rest, y) if rest else y
+
+
 class ConvChain(nn.Module):
     """A stack of ``depth`` convolutions: (depth-1) x [conv, (norm), activation] + conv.
 
@@ -143,8 +193,10 @@ class ConvChain(nn.Module):
     pointwise_as_gemm = False
 
     def forward(self, x):
+        return self._run(list(self.children()), x)
+
+    def _run(self, mods, x):
         gemm = self.pointwise_as_gemm and x.is_cuda
-        mods = list(self.children())
         i = 0
         while i < len(mods):
             m = mods[i]

@@ -428,3 +428,53 @@ def test_pointwise_chain_as_gemm_matches_convolution():
         gb = th.autograd.grad(yb, [xb] + list(chain.parameters()), g)
         for a, b in zip(ga, gb):
             close(b, a, rtol=2e-5)
+
+
+@pytest.mark.parametrize("per_pixel", [True, False])
+@pytest.mark.parametrize("act,slope", [(0, 0.0), (1, 0.0), (2, 0.01)])
+def test_ctx_act_kernels(per_pixel, act, slope):
+    """y[b,s] = act(y[b,s] + t[b] + bias): fused context-term pass vs torch, forward and backward."""
+    from sbmc_amd import functions as F
+    th.manual_seed(19)
+    b, s, c, h, w = 2, 3, 6, 5, 16
+    y0 = th.randn(b * s, c, h, w, device="cuda")
+    t0 = th.randn(b, c, h, w, device="cuda") if per_pixel else th.randn(b, c, 1, 1, device="cuda")
+    bias0 = th.randn(c, device="cuda")
+    x, t, bias = (v.clone().requires_grad_() for v in (y0, t0, bias0))
+    pre = (x.view(b, s, c, h, w) + t.unsqueeze(1) + bias.view(1, 1, -1, 1, 1)).view(b * s, c, h, w)
+    ref = pre if act == 0 else th.nn.functional.leaky_relu(pre, slope if act == 2 else 0.0)
+    g = th.randn_like(ref)
+    ref.backward(g)
+    x2, t2, b2 = (v.clone().requires_grad_() for v in (y0, t0, bias0))
+    inp = x2 * 1.0
+    assert F.CtxAct.supported(inp, t2, s)
+    out = F.CtxAct.apply(inp, t2, b2, s, act, slope)
+    out.backward(g)
+    close(out, ref, rtol=1e-6)
+    close(x2.grad, x.grad, rtol=1e-6)
+    close(t2.grad, t.grad, rtol=1e-5)
+    close(b2.grad, bias.grad, rtol=1e-5)
+
+
+def test_pointwise_chain_with_context_matches_concatenation():
+    from sbmc_amd import modules
+    th.manual_seed(20)
+    for ctx_shape in ((2, 5, 12, 20), (2, 3, 1, 1)):
+        cp = ctx_shape[1]
+        chain = modules.ConvChain(7 + cp, 9, ksize=1, width=16, depth=3, pad=False,
+                                  activation="leaky_relu").cuda()
+        per_sample = th.randn(2, 4, 7, 12, 20, device="cuda")
+        ctx = th.randn(*ctx_shape, device="cuda")
+        pa, ca = per_sample.clone().requires_grad_(), ctx.clone().requires_grad_()
+        pb, cb = per_sample.clone().requires_grad_(), ctx.clone().requires_grad_()
+        cat = th.cat([pa, ca.expand(2, cp, 12, 20).unsqueeze(1).expand(2, 4, cp, 12, 20)], 2)
+        ya = chain(cat.reshape(8, 7 + cp, 12, 20))
+        chain.pointwise_as_gemm = True
+        yb = modules.pointwise_chain_with_context(chain, pb, cb)
+        assert yb is not None
+        close(yb, ya, rtol=1e-5)
+        g = th.randn_like(ya)
+        ga = th.autograd.grad(ya, [pa, ca] + list(chain.parameters()), g)
+        gb = th.autograd.grad(yb, [pb, cb] + list(chain.parameters()), g)
+        for a, b_ in zip(ga, gb):
+            close(b_, a, rtol=3e-5)
