@@ -185,8 +185,9 @@ class ConvChain(nn.Module):
         if out_act is not None:
             self.add_module("output_activation", out_act())
 
-    # (The same fusion around MIOpen's 3x3 convolutions -- bias-free conv + BiasAct -- measured
-    # 2-5 % SLOWER than torch's conv-with-bias + activation, so only the 1x1 chains use it.)
+    # (The same fusion around MIOpen's 3x3 convolutions -- F.conv2d without bias + BiasAct -- was
+    # measured twice, three interleaved rounds: 624-639 ms/step vs 606 ms/step for torch's
+    # conv-with-bias + activation, so only the 1x1 chains use it.)
     #: 1x1 / stride-1 convolutions as plain batched GEMMs (rocBLAS / hipBLASLt) on the planar
     #: NCHW activations: y[b] = W @ x[b].  Same arithmetic as the convolution; set per instance
     #: by Multisteps for its per-sample chains.
