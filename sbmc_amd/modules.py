@@ -346,7 +346,9 @@ class KernelApply(nn.Module):
         """data [bs, c, h, w], kernels [bs, k*k, h, w] -> (output [bs, c, h, w], sum_w [bs, 1, h, w])."""
         bs, k2, h, w = kernels.shape
         k = _ksize_of(kernels)
-        kernels = kernels.view(bs, k, k, h, w)
+        # the boundary-level operators are fp32 (as the reference's): half logits are up-cast
+        kernels = kernels.float().view(bs, k, k, h, w)
+        data = data.float()
         if self.splat:
             kernels = funcs.Scatter2Gather.apply(kernels)
         if self.softmax:
@@ -400,7 +402,9 @@ class ProgressiveKernelApply(nn.Module):
         # with sub_/exp_; values and gradients are identical).
         bs, k2, h, w = kernels.shape
         k = _ksize_of(kernels)
-        kernels = kernels.view(bs, k, k, h, w)
+        # the boundary-level operators are fp32 (as the reference's): half logits are up-cast
+        kernels = kernels.float().view(bs, k, k, h, w)
+        data = data.float()
         if self.splat:
             kernels = funcs.Scatter2Gather.apply(kernels)
         kmax = kernels.reshape(bs, k * k, h, w).max(1, keepdim=True)[0]

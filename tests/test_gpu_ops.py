@@ -478,3 +478,23 @@ def test_pointwise_chain_with_context_matches_concatenation():
         gb = th.autograd.grad(yb, [pb, cb] + list(chain.parameters()), g)
         for a, b_ in zip(ga, gb):
             close(b_, a, rtol=3e-5)
+
+
+def test_half_logits_fall_back_to_fp32_operators_where_the_strip_kernels_do_not_apply():
+    """k = 5 with half logits: no fp16 kernel exists, the module up-casts and composes the fp32 ops."""
+    from sbmc_amd import modules
+    th.manual_seed(21)
+    d = th.rand(1, 3, 12, 70, device="cuda")
+    kh = th.randn(1, 25, 12, 70, device="cuda").half().requires_grad_()
+    kf = kh.detach().float().requires_grad_()
+    a = modules.ProgressiveKernelApply(splat=True)(d, kh, None, None, None)
+    b = modules.ProgressiveKernelApply(splat=True)(d, kf, None, None, None)
+    for x, y in zip(a, b):
+        close(x, y)
+    a[0].sum().backward()
+    b[0].sum().backward()
+    assert kh.grad.dtype == th.float16
+    close(kh.grad.float(), kf.grad, rtol=1e-3)
+    o1, s1 = modules.KernelApply(softmax=True, splat=True)(d, kh.detach())
+    o2, s2 = modules.KernelApply(softmax=True, splat=True)(d, kf.detach())
+    close(o1, o2); close(s1, s2)
