@@ -69,3 +69,14 @@ def test_cpu_entry_points_refuse_without_a_registered_backend():
     with pytest.raises(RuntimeError):
         halide_ops.kernel_weighting_cuda_float32(th.zeros(1, 1, 2, 2), th.zeros(1, 1, 1, 2, 2),
                                                  th.zeros(1, 1, 2, 2), th.zeros(1, 2, 2))
+
+
+def test_product_never_imports_the_oracle():
+    """Nothing under sbmc_amd/ may import or reference oracle/ (it is test infrastructure)."""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "sbmc_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), path
+        assert "sbmc_oracle" not in src, path
+    for path in glob.glob(os.path.join(ROOT, "sbmc_amd", "csrc", "*")):
+        assert "oracle" not in open(path).read(), path

@@ -134,9 +134,18 @@ def test_native_library_is_loaded():
     """The GPU tests must run on the hand-written kernels, not on a fallback."""
     from sbmc_amd import _lib
     _lib.lib()
-    maps = open("/proc/self/maps").read()
-    assert "libsbmc_hip.so" in maps
-    assert "libsbmc_oracle.so" not in maps or True  # the oracle may be loaded by *tests*, never by sbmc_amd
+    assert "libsbmc_hip.so" in open("/proc/self/maps").read()
+
+
+def test_product_never_imports_the_oracle():
+    """Nothing under sbmc_amd/ may import or reference oracle/ (it is test infrastructure)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "sbmc_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), path
+        assert "sbmc_oracle" not in src, path
 
 
 def test_kpcn_on_gpu_matches_reference_fixture():
