@@ -55,6 +55,12 @@ constexpr int REC = 8;      // v2 backward: floats per destination record
 #ifndef FWD_MIN_WAVES
 #define FWD_MIN_WAVES 7
 #endif
+#ifndef FWD_TAP_GROUP
+#define FWD_TAP_GROUP 7
+#endif
+#ifndef BWD_TAP_GROUP
+#define BWD_TAP_GROUP 3
+#endif
 // cache policy of the big streams (A/B knobs; see common.hpp buf_load)
 #ifndef AUX_FWD_LD
 #define AUX_FWD_LD 0
@@ -192,7 +198,7 @@ __device__ __forceinline__ void fwd_row_update(const float (&v)[K], const float*
     for (int c = 0; c < C; ++c) acc[c] *= sc;
     // taps in groups of G: the scheduling barrier keeps the compiler from hoisting all
     // K*C LDS reads of the row to the top (which costs >100 VGPRs and the occupancy)
-    constexpr int G = 7;
+    constexpr int G = FWD_TAP_GROUP;
 #pragma unroll
     for (int g = 0; g < K; g += G) {
 #pragma unroll
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
         wave_lds_sync();
         const rsrc_t ws = make_rsrc(dS + (size_t)(ky * K) * hw);
         const int tg0 = K * K - 1 - ky * K;  // gather tap index of (ky, kx) is tg0 - kx
-        constexpr int G = 3;  // taps per scheduling group (bounds the live LDS values)
+        constexpr int G = BWD_TAP_GROUP;  // taps per scheduling group (bounds the live LDS values)
 #pragma unroll
         for (int g = 0; g < K; g += G) {
 #pragma unroll
