@@ -178,7 +178,8 @@ SBMC_API int sbmc_splat_update_bwd_f32(const float *data, const float *kernels,
  * Layouts: part_r/run_r/data/d_data [bs,S,c,h,w]; part_w/part_m/run_w/run_m/atap [bs,S,h,w];
  * kernels/d_kernels [bs,S,k*k,h,w]; final state and its gradients as in the per-sample calls;
  * scratch: sbmc_splat_update_bwd_scratch_bytes(bs*S, c, h, w, k) bytes.
- * Only where sbmc_splat_all_supported(c, k, h, w) == 1 (k = 21, c <= 4).
+ * Only where sbmc_splat_all_supported(c, k, h, w) == 1 (the strip kernels: k = 21 with
+ * c <= 4, or odd k in 3..19 with c = 3).
  */
 SBMC_API int sbmc_splat_all_supported(int c, int k, int h, int w);
 
@@ -198,9 +199,12 @@ SBMC_API int sbmc_splat_all_bwd_f32(const float *data, const float *kernels,
  * fp16 logits ("fp16 activations", BASELINE.json configs[4]).  Same calls as
  * the _f32 ones except that `kernels` and `d_kernels` are IEEE half tensors (torch.float16);
  * radiance, running state, every accumulation and every other gradient stay fp32.  Halves the
- * bytes of the two big streams.  Only for the strip kernels (sbmc_splat_all_supported(c,k,h,w)),
+ * bytes of the two big streams.  Only where sbmc_splat_f16_supported(c,k,h,w) == 1,
  * SBMC_HIP_EINVAL otherwise (the caller up-casts and uses the _f32 entry points).
  */
+/* 1 if the *_f16 entry points accept this (channels, kernel size, frame): k = 21, c <= 4. */
+SBMC_API int sbmc_splat_f16_supported(int c, int k, int h, int w);
+
 SBMC_API int sbmc_splat_update_fwd_f16(const float *data, const void *kernels,
                               const float *sum_r_in, const float *sum_w_in, const float *max_w_in,
                               float *sum_r_out, float *sum_w_out, float *max_w_out,

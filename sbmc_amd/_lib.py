@@ -28,6 +28,7 @@ SYMBOLS = (
     "sbmc_splat_all_supported",
     "sbmc_splat_merge_fwd_f32",
     "sbmc_splat_all_bwd_f32",
+    "sbmc_splat_f16_supported",
     "sbmc_splat_update_fwd_f16",
     "sbmc_splat_update_bwd_f16",
     "sbmc_splat_all_bwd_f16",
@@ -79,6 +80,7 @@ def lib():
     handle.sbmc_splat_update_bwd_f32.argtypes = [p] * 19 + [i] * 5 + [p]
     handle.sbmc_splat_update_bwd_scratch_bytes.argtypes = [i] * 5
     handle.sbmc_splat_all_supported.argtypes = [i] * 4
+    handle.sbmc_splat_f16_supported.argtypes = [i] * 4
     handle.sbmc_splat_merge_fwd_f32.argtypes = [p] * 9 + [i] * 5 + [p]
     handle.sbmc_splat_all_bwd_f32.argtypes = [p] * 13 + [i] * 6 + [p]
     handle.sbmc_splat_update_fwd_f16.argtypes = handle.sbmc_splat_update_fwd_f32.argtypes

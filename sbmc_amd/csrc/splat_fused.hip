@@ -710,11 +710,39 @@ static inline size_t fwd_tile_lds_bytes(int c, int k) {
 static inline size_t bwd_tile_lds_bytes(int c, int k) {
     return (size_t)(c + 2) * (BWD_TY + k - 1) * (TX + k - 1) * sizeof(float);
 }
-// strip kernels: k = 21, <= 4 channels, and all per-row buffer offsets (up to 20 planes)
-// must stay below the 2 GiB voffset range of the descriptors
-static inline bool strip_ok(int c, int k, int h, int w) {
-    return k == 21 && c <= 4 && (size_t)h * w * 4 * 21 < 0x7ff00000ull;
+// Strip kernels exist for k = 21 with 1..4 channels in fp32 and fp16 (the SBMC configuration),
+// and for the other odd kernel sizes up to 19 with the 3 radiance channels in fp32 (--ksize of
+// the reference's train.py); everything else runs on the generic tile kernels.  All per-row
+// buffer offsets (up to k planes) must stay below the 2 GiB voffset range of the descriptors.
+static inline bool strip_ok(int c, int k, int h, int w, bool half = false) {
+    if ((size_t)h * w * 4 * (size_t)(k + 1) >= 0x7ff00000ull) return false;
+    if (k == 21) return c >= 1 && c <= 4;
+    return !half && c == 3 && k >= 3 && k <= 19 && (k % 2) == 1;
 }
+
+// launches KERNEL<K, C, LT> for the (k, c) combinations strip_ok admits
+#define SBMC_LAUNCH_STRIP(KERNEL, grid, stream, params)                                                   \
+    do {                                                                                                  \
+        if (k == 21) {                                                                                    \
+            SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((KERNEL<21, C, LT>), dim3(grid), dim3(V2_WAVES * TX),  \
+                                                   0, stream, params));                                   \
+        } else if constexpr (sizeof(LT) == 4) {                                                           \
+            switch (k) {                                                                                  \
+                case 3: hipLaunchKernelGGL((KERNEL<3, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
+                case 5: hipLaunchKernelGGL((KERNEL<5, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
+                case 7: hipLaunchKernelGGL((KERNEL<7, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
+                case 9: hipLaunchKernelGGL((KERNEL<9, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
+                case 11: hipLaunchKernelGGL((KERNEL<11, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                case 13: hipLaunchKernelGGL((KERNEL<13, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                case 15: hipLaunchKernelGGL((KERNEL<15, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                case 17: hipLaunchKernelGGL((KERNEL<17, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                case 19: hipLaunchKernelGGL((KERNEL<19, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                default: return SBMC_HIP_EINVAL;                                                          \
+            }                                                                                             \
+        } else {                                                                                          \
+            return SBMC_HIP_EINVAL;                                                                       \
+        }                                                                                                 \
+    } while (0)
 
 // Development knob (not part of the ABI): SBMC_HIP_SPLAT_VARIANT=0 forces the generic tile
 // kernels even where the strip kernels apply (used by the tests to cover both at k = 21).
@@ -762,13 +790,12 @@ static int splat_update_fwd_impl(const float* data, const void* kernels,
         return SBMC_HIP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int variant = splat_variant();
-    if (variant > 0 && strip_ok(c, k, h, w)) {
+    if (variant > 0 && strip_ok(c, k, h, w, sizeof(LT) != 4)) {
         SplatFwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out,
                          max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), h};
         const long items = (long)bs * h * p.ntx;
         const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
-        SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_fwd_strip_kernel<21, C, LT>), dim3(grid),
-                                               dim3(V2_WAVES * TX), 0, s, p));
+        SBMC_LAUNCH_STRIP(splat_fwd_strip_kernel, grid, s, p);
         return (int)hipGetLastError();
     }
     if (sizeof(LT) != 4) return SBMC_HIP_EINVAL;  // the generic tile kernels are fp32 only
@@ -810,7 +837,7 @@ static int splat_update_bwd_impl(const float* data, const void* kernels,
     if (egrid > 8192) egrid = 8192;
     const int variant = splat_variant();
 
-    if (variant > 0 && strip_ok(c, k, h, w)) {
+    if (variant > 0 && strip_ok(c, k, h, w, sizeof(LT) != 4)) {
         SplatBwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out,
                          kmax, atap, d_sum_r_out, d_sum_w_out, d_max_w_out, d_data, d_kernels,
                          d_sum_r_in, d_sum_w_in, d_max_w_in, scratch, bs, c, h, w, k, tiles_x(w), h};
@@ -819,8 +846,7 @@ static int splat_update_bwd_impl(const float* data, const void* kernels,
         if (err) return err;
         const long items = (long)bs * h * p.ntx;
         const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
-        SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_strip_kernel<21, C, LT>), dim3(grid),
-                                               dim3(V2_WAVES * TX), 0, s, p));
+        SBMC_LAUNCH_STRIP(splat_bwd_strip_kernel, grid, s, p);
         return (int)hipGetLastError();
     }
 
@@ -844,6 +870,9 @@ static int splat_update_bwd_impl(const float* data, const void* kernels,
 }
 
 extern "C" int sbmc_splat_all_supported(int c, int k, int h, int w) { return strip_ok(c, k, h, w) ? 1 : 0; }
+extern "C" int sbmc_splat_f16_supported(int c, int k, int h, int w) {
+    return splat_variant() > 0 && strip_ok(c, k, h, w, true) ? 1 : 0;
+}
 
 extern "C" int sbmc_splat_merge_fwd_f32(const float* part_r, const float* part_w, const float* part_m,
                                         float* sum_r, float* sum_w, float* max_w,
@@ -869,7 +898,7 @@ static int splat_all_bwd_impl(const float* data, const void* kernels,
                               const float* d_sum_r, const float* d_sum_w, const float* d_max_w,
                               float* d_data, void* d_kernels, float* scratch,
                               int bs, int s, int c, int h, int w, int k, void* stream) {
-    if (bs < 0 || s < 1 || h < 0 || w < 0 || !strip_ok(c, k, h, w) || c < 1) return SBMC_HIP_EINVAL;
+    if (bs < 0 || s < 1 || h < 0 || w < 0 || c < 1 || !strip_ok(c, k, h, w, sizeof(LT) != 4)) return SBMC_HIP_EINVAL;
     if (bs == 0 || h == 0 || w == 0) return 0;
     if (!data || !kernels || !part_m || !atap || !run_r || !run_w || !run_m || !d_sum_r || !d_sum_w ||
         !d_max_w || !d_data || !d_kernels || !scratch)
@@ -888,8 +917,7 @@ static int splat_all_bwd_impl(const float* data, const void* kernels,
     p.bs = bs * s; p.c = c; p.h = h; p.w = w; p.k = k; p.ntx = tiles_x(w); p.nty = h;
     const long items = (long)p.bs * h * p.ntx;
     const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
-    SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_strip_kernel<21, C, LT>), dim3(grid),
-                                           dim3(V2_WAVES * TX), 0, st, p));
+    SBMC_LAUNCH_STRIP(splat_bwd_strip_kernel, grid, st, p);
     return (int)hipGetLastError();
 }
 

@@ -133,7 +133,7 @@ class KernelWeighting(th.autograd.Function):
 
 
 def _half_ok(c, k, h, w):
-    return bool(_lib.lib().sbmc_splat_all_supported(int(c), int(k), int(h), int(w)))
+    return bool(_lib.lib().sbmc_splat_f16_supported(int(c), int(k), int(h), int(w)))
 
 
 def splat_update_supported(data, kernels):
@@ -364,6 +364,8 @@ def splat_all_supported(data, kernels):
     if k * k != k2:
         return False
     h, w = kernels.shape[-2:]
+    if kernels.dtype == th.float16:
+        return _half_ok(data.shape[2], k, h, w)
     return bool(_lib.lib().sbmc_splat_all_supported(int(data.shape[2]), k, int(h), int(w)))
 
 

@@ -53,6 +53,8 @@ def test_argument_validation_needs_no_gpu():
     assert lib.sbmc_splat_update_supported(3, 4) == 0
     assert lib.sbmc_splat_update_supported(8, 21) == 0    # tile LDS budget exceeded at k=21, c=8
     assert lib.sbmc_splat_update_supported(8, 5) == 1
+    assert lib.sbmc_splat_all_supported(3, 5, 64, 64) == 1 and lib.sbmc_splat_all_supported(4, 5, 64, 64) == 0
+    assert lib.sbmc_splat_f16_supported(3, 21, 64, 64) == 1 and lib.sbmc_splat_f16_supported(3, 5, 64, 64) == 0
     assert lib.sbmc_splat_update_bwd_scratch_bytes(1, 3, 10, 10, 21) >= 10 * 10 * 4
     assert b"invalid" in lib.sbmc_hip_strerror(-1)
     # empty problems are a no-op, also without a device
