@@ -165,6 +165,32 @@ SBMC_API int sbmc_splat_update_bwd_f32(const float *data, const float *kernels,
                               void *stream);
 
 /*
+ * Gather-kernel variant (ProgressiveKernelApply(splat=False), the reference's `--gather`
+ * ablation, sbmc/modules.py:422-471 without the Scatter2Gather step): `kernels` are
+ * pixel-centred, tap (dy,dx) of pixel (y,x) weighs data[y+dy-p, x+dx-p]; every tap counts in the
+ * running softmax (only the data outside the image is zero).  Same arguments, outputs and
+ * saved tensors as sbmc_splat_update_{fwd,bwd}_f32.  fp32; only where
+ * sbmc_gather_update_supported(c, k, h, w) == 1 (otherwise the caller composes
+ * kernel_weighting with torch ops, as the reference does).
+ */
+SBMC_API int sbmc_gather_update_supported(int c, int k, int h, int w);
+
+SBMC_API int sbmc_gather_update_fwd_f32(const float *data, const float *kernels,
+                               const float *sum_r_in, const float *sum_w_in, const float *max_w_in,
+                               float *sum_r_out, float *sum_w_out, float *max_w_out,
+                               float *kmax_out, int32_t *atap_out,
+                               int bs, int c, int h, int w, int k, void *stream);
+
+SBMC_API int sbmc_gather_update_bwd_f32(const float *data, const float *kernels,
+                               const float *sum_r_in, const float *sum_w_in, const float *max_w_in,
+                               const float *sum_r_out, const float *sum_w_out, const float *max_w_out,
+                               const float *kmax, const int32_t *atap,
+                               const float *d_sum_r_out, const float *d_sum_w_out, const float *d_max_w_out,
+                               float *d_data, float *d_kernels,
+                               float *d_sum_r_in, float *d_sum_w_in, float *d_max_w_in, float *scratch,
+                               int bs, int c, int h, int w, int k, void *stream);
+
+/*
  * All samples of a frame at once.  The running state (sum_r, sum_w, max_w) is an
  * associative log-sum-exp monoid, so S progressive updates (the sample loop of
  * Multisteps.forward, reference sbmc/models.py:195-209) need not be S dependent launches:

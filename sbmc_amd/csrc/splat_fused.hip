@@ -212,7 +212,11 @@ __device__ __forceinline__ void fwd_row_update(const float (&v)[K], const float*
     }
 }
 
-template <int K, int C, typename LT>
+// GATHER = true: the kernels are pixel-centred (ProgressiveKernelApply(splat=False), the
+// reference's `--gather` ablation): tap (dy,dx) of destination (Y,X) is plane dy*K+dx at (Y,X)
+// itself -- aligned loads, no Scatter2Gather index algebra, and every tap counts in the softmax
+// (only the *radiance* outside the image is zero).
+template <int K, int C, typename LT, bool GATHER = false>
 __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_kernel(SplatFwdParams p) {
     static_assert(TX + K - 1 <= V2_ROW, "staged row too short");
     constexpr int P = (K - 1) / 2;
@@ -259,6 +263,20 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     auto load_row = [&](int dy, float (&v)[K], float (&s)[2 * C]) {
         const int ys = Y + dy - P;
         const bool yin = (ys >= 0) && (ys < p.h);  // wave-uniform
+        if constexpr (GATHER) {
+            const rsrc_t rs = make_rsrc(S + ((size_t)(dy * K) * hw + (size_t)Y * p.w + (size_t)X0));
+            const unsigned vo = xact ? voff : BUF_OOB;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx)
+                v[dx] = logit_load<LT, AUX_FWD_LD>(rs, vo, (unsigned)dx * (unsigned)(hw * sizeof(LT)));
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float* dr = data + c * hw + (size_t)(yin ? ys : 0) * p.w;
+                s[2 * c] = (yin && inA) ? dr[colA] : 0.f;
+                s[2 * c + 1] = (yin && inB) ? dr[colB] : 0.f;
+            }
+            return;
+        }
         if (!yin) {
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) v[dx] = 0.f;
@@ -590,6 +608,165 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
     }
 }
 
+// ------------------------------------------------------------------ gather-mode backward
+// Adjoint of the GATHER forward.  The per-pixel state pre-pass (records) is the same as for the
+// splat.  d_kernels is destination-centred (aligned read + aligned write of the logits, the
+// destination's record in registers, radiance of the tap's source from the LDS row buffer);
+// d_data is source-centred (second, read-only sweep of the logits, destination records staged
+// per row exactly as in splat_bwd_strip_kernel).
+template <int K, int C, typename LT>
+__global__ __launch_bounds__(V2_WAVES * TX, 7) void gather_bwd_dg_kernel(SplatBwdParams p) {
+    static_assert(TX + K - 1 <= V2_ROW, "staged row too short");
+    static_assert(C <= 4, "records hold up to 4 channels");
+    constexpr int P = (K - 1) / 2;
+    __shared__ float lds[V2_WAVES * C * V2_ROW];
+    const int wv = wave_id();
+    const int lane = threadIdx.x & 63;
+    const long item = (long)logical_block_id() * V2_WAVES + wv;
+    const int nseg = p.ntx;
+    const long per_img = (long)p.h * nseg;
+    if (item >= per_img * p.bs) return;
+    const int n = __builtin_amdgcn_readfirstlane((int)(item / per_img));
+    const int rem = __builtin_amdgcn_readfirstlane((int)(item % per_img));
+    const int Y = __builtin_amdgcn_readfirstlane(rem / nseg);
+    const int X0 = __builtin_amdgcn_readfirstlane((rem % nseg) * TX);
+    const int X = X0 + lane;
+    const bool xact = X < p.w;
+    const size_t hw = (size_t)p.h * p.w;
+    float* buf = lds + wv * (C * V2_ROW);
+    const float4* rec = reinterpret_cast<const float4*>(p.scratch) + ((size_t)n * hw + (size_t)Y * p.w) * 2;
+    float4 q0 = make_float4(OUTSIDE_MAX, 0.f, 0.f, __int_as_float(-1)), q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xact) { q0 = rec[(size_t)X * 2]; q1 = rec[(size_t)X * 2 + 1]; }
+    const float dRv[4] = {q1.x, q1.y, q1.z, q1.w};
+    const int atap = __float_as_int(q0.w);
+    const LT* S = static_cast<const LT*>(p.kernels) + (size_t)n * K * K * hw + (size_t)Y * p.w + X0;
+    LT* dS = static_cast<LT*>(p.d_kernels) + (size_t)n * K * K * hw + (size_t)Y * p.w + X0;
+    const float* data = p.data + (size_t)n * C * hw;
+    const unsigned voff = xact ? (unsigned)lane * (unsigned)sizeof(LT) : BUF_OOB;
+    const unsigned plane_stride = (unsigned)hw * (unsigned)sizeof(LT);
+    const int colA = X0 - P + lane, colB = colA + TX;
+    const bool inA = (colA >= 0) && (colA < p.w);
+    const bool inB = (lane < K - 1) && (colB < p.w);
+#pragma unroll 1
+    for (int dy = 0; dy < K; ++dy) {
+        const int ys = Y + dy - P;
+        const bool yin = (ys >= 0) && (ys < p.h);
+        const rsrc_t rs = make_rsrc(S + (size_t)(dy * K) * hw);
+        const rsrc_t ws = make_rsrc(dS + (size_t)(dy * K) * hw);
+        float g[K];
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) g[dx] = logit_load<LT, AUX_BWD_LD>(rs, voff, (unsigned)dx * plane_stride);
+        float sa[C], sb[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float* dr = data + c * hw + (size_t)(yin ? ys : 0) * p.w;
+            sa[c] = (yin && inA) ? dr[colA] : 0.f;
+            sb[c] = (yin && inB) ? dr[colB] : 0.f;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            buf[c * V2_ROW + lane] = sa[c];
+            if (lane < K - 1) buf[c * V2_ROW + TX + lane] = sb[c];
+        }
+        wave_lds_sync();
+        constexpr int G = 7;
+#pragma unroll
+        for (int g0 = 0; g0 < K; g0 += G) {
+#pragma unroll
+            for (int dx = g0; dx < (g0 + G < K ? g0 + G : K); ++dx) {
+                const float e = fast_exp2((g[dx] - q0.x) * LOG2E);
+                float val = q0.y;
+#pragma unroll
+                for (int c = 0; c < C; ++c) val = fmaf(dRv[c], buf[c * V2_ROW + lane + dx], val);
+                float dg = e * val;
+                dg += (atap == dy * K + dx) ? q0.z : 0.f;
+                logit_store<LT, AUX_BWD_ST>(dg, ws, voff, (unsigned)dx * plane_stride);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int K, int C, typename LT>
+__global__ __launch_bounds__(V2_WAVES * TX, 8) void gather_bwd_ddata_kernel(SplatBwdParams p) {
+    static_assert(TX + K - 1 <= V2_ROW, "staged row too short");
+    static_assert(C <= 4, "records hold up to 4 channels");
+    constexpr int P = (K - 1) / 2;
+    __shared__ float4 lds[V2_WAVES * 2 * V2_ROW];
+    const int wv = wave_id();
+    const int lane = threadIdx.x & 63;
+    const long item = (long)logical_block_id() * V2_WAVES + wv;
+    const int nseg = p.ntx;
+    const long per_img = (long)p.h * nseg;
+    if (item >= per_img * p.bs) return;
+    const int n = __builtin_amdgcn_readfirstlane((int)(item / per_img));
+    const int rem = __builtin_amdgcn_readfirstlane((int)(item % per_img));
+    const int ys = __builtin_amdgcn_readfirstlane(rem / nseg);
+    const int X0 = __builtin_amdgcn_readfirstlane((rem % nseg) * TX);
+    const int xs = X0 + lane;
+    const bool active = xs < p.w;
+    const size_t hw = (size_t)p.h * p.w;
+    float4* h0 = lds + wv * (2 * V2_ROW);
+    float4* h1 = h0 + V2_ROW;
+    float dD[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) dD[c] = 0.f;
+    const LT* S = static_cast<const LT*>(p.kernels) + (size_t)n * K * K * hw;
+    const float4* rec = reinterpret_cast<const float4*>(p.scratch) + (size_t)n * hw * 2;
+    const unsigned voff = (unsigned)lane * (unsigned)sizeof(LT);
+    const unsigned tap_stride = (unsigned)(hw - 1) * (unsigned)sizeof(LT);   // one plane on, one column back
+    const int colA = X0 - P + lane, colB = colA + TX;   // staged destination columns
+    const bool inA = (colA >= 0) && (colA < p.w);
+    const bool inB = (lane < K - 1) && (colB < p.w);
+    const float4 fill0 = make_float4(OUTSIDE_MAX, 0.f, 0.f, __int_as_float(-1));
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // destination column xs - dx + P is inside the image for dx in (xs + P - w, xs + P]
+    const int dx_lo = xs + P - p.w + 1, dx_hi = xs + P + 1;
+#pragma unroll 1
+    for (int dy = 0; dy < K; ++dy) {
+        const int yd = ys - dy + P;
+        if (yd < 0 || yd >= p.h) continue;   // wave-uniform: no such destination
+        // tap dx: plane dy*K + dx, row yd, column X0 + P - dx + lane = base + dx*(hw-1) + lane
+        const rsrc_t rs = make_rsrc(S + ((long)(dy * K) * (long)hw + (long)yd * p.w + (long)(X0 + P)));
+        float g[K];
+#pragma unroll
+        for (int dx = 0; dx < K; ++dx) {
+            const unsigned vo = (active && dx >= dx_lo && dx < dx_hi) ? voff : BUF_OOB;
+            g[dx] = logit_load<LT, AUX_FWD_LD>(rs, vo, (unsigned)dx * tap_stride);
+        }
+        float4 a0 = fill0, a1 = zero4, b0 = fill0, b1 = zero4;
+        const float4* rrow = rec + (size_t)yd * p.w * 2;
+        if (inA) { a0 = rrow[(size_t)colA * 2]; a1 = rrow[(size_t)colA * 2 + 1]; }
+        if (inB) { b0 = rrow[(size_t)colB * 2]; b1 = rrow[(size_t)colB * 2 + 1]; }
+        wave_lds_sync();
+        h0[lane] = a0;
+        h1[lane] = a1;
+        if (lane < K - 1) { h0[TX + lane] = b0; h1[TX + lane] = b1; }
+        wave_lds_sync();
+        constexpr int G = 3;
+#pragma unroll
+        for (int g0 = 0; g0 < K; g0 += G) {
+#pragma unroll
+            for (int dx = g0; dx < (g0 + G < K ? g0 + G : K); ++dx) {
+                const float4 q0 = h0[lane + (K - 1 - dx)];
+                const float4 q1 = h1[lane + (K - 1 - dx)];
+                const float e = fast_exp2((g[dx] - q0.x) * LOG2E);
+                dD[0] = fmaf(e, q1.x, dD[0]);
+                if constexpr (C > 1) dD[C > 1 ? 1 : 0] = fmaf(e, q1.y, dD[C > 1 ? 1 : 0]);
+                if constexpr (C > 2) dD[C > 2 ? 2 : 0] = fmaf(e, q1.z, dD[C > 2 ? 2 : 0]);
+                if constexpr (C > 3) dD[C > 3 ? 3 : 0] = fmaf(e, q1.w, dD[C > 3 ? 3 : 0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (active) {
+        const size_t pix = (size_t)ys * p.w + xs;
+#pragma unroll
+        for (int c = 0; c < C; ++c) p.d_data[((size_t)n * C + c) * hw + pix] = dD[c];
+    }
+}
+
 // ------------------------------------------------------------------ all samples at once
 // The running-softmax state is an associative (log-sum-exp) monoid, so the S per-sample
 // splats of one frame need not be chained through S launches: every sample is reduced on its
@@ -721,22 +898,22 @@ static inline bool strip_ok(int c, int k, int h, int w, bool half = false) {
 }
 
 // launches KERNEL<K, C, LT> for the (k, c) combinations strip_ok admits
-#define SBMC_LAUNCH_STRIP(KERNEL, grid, stream, params)                                                   \
+#define SBMC_LAUNCH_STRIP(KERNEL, grid, stream, params, ...)                                                 \
     do {                                                                                                  \
         if (k == 21) {                                                                                    \
-            SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((KERNEL<21, C, LT>), dim3(grid), dim3(V2_WAVES * TX),  \
+            SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((KERNEL<21, C, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX),  \
                                                    0, stream, params));                                   \
         } else if constexpr (sizeof(LT) == 4) {                                                           \
             switch (k) {                                                                                  \
-                case 3: hipLaunchKernelGGL((KERNEL<3, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
-                case 5: hipLaunchKernelGGL((KERNEL<5, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
-                case 7: hipLaunchKernelGGL((KERNEL<7, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
-                case 9: hipLaunchKernelGGL((KERNEL<9, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
-                case 11: hipLaunchKernelGGL((KERNEL<11, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
-                case 13: hipLaunchKernelGGL((KERNEL<13, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
-                case 15: hipLaunchKernelGGL((KERNEL<15, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
-                case 17: hipLaunchKernelGGL((KERNEL<17, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
-                case 19: hipLaunchKernelGGL((KERNEL<19, 3, LT>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                case 3: hipLaunchKernelGGL((KERNEL<3, 3, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
+                case 5: hipLaunchKernelGGL((KERNEL<5, 3, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
+                case 7: hipLaunchKernelGGL((KERNEL<7, 3, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
+                case 9: hipLaunchKernelGGL((KERNEL<9, 3, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break;   \
+                case 11: hipLaunchKernelGGL((KERNEL<11, 3, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                case 13: hipLaunchKernelGGL((KERNEL<13, 3, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                case 15: hipLaunchKernelGGL((KERNEL<15, 3, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                case 17: hipLaunchKernelGGL((KERNEL<17, 3, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
+                case 19: hipLaunchKernelGGL((KERNEL<19, 3, LT, ##__VA_ARGS__>), dim3(grid), dim3(V2_WAVES * TX), 0, stream, params); break; \
                 default: return SBMC_HIP_EINVAL;                                                          \
             }                                                                                             \
         } else {                                                                                          \
@@ -918,6 +1095,69 @@ static int splat_all_bwd_impl(const float* data, const void* kernels,
     const long items = (long)p.bs * h * p.ntx;
     const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
     SBMC_LAUNCH_STRIP(splat_bwd_strip_kernel, grid, st, p);
+    return (int)hipGetLastError();
+}
+
+// ---- gather-kernel (splat=False) progressive update: strip kernels only, fp32
+extern "C" int sbmc_gather_update_supported(int c, int k, int h, int w) {
+    return splat_variant() > 0 && strip_ok(c, k, h, w) ? 1 : 0;
+}
+
+extern "C" int sbmc_gather_update_fwd_f32(const float* data, const float* kernels,
+                                          const float* sum_r_in, const float* sum_w_in, const float* max_w_in,
+                                          float* sum_r_out, float* sum_w_out, float* max_w_out,
+                                          float* kmax_out, int32_t* atap_out,
+                                          int bs, int c, int h, int w, int k, void* stream) {
+    using LT = float;
+    if (bad_splat_dims(bs, c, h, w, k) || !strip_ok(c, k, h, w)) return SBMC_HIP_EINVAL;
+    const int nin = (sum_r_in != nullptr) + (sum_w_in != nullptr) + (max_w_in != nullptr);
+    if (nin != 0 && nin != 3) return SBMC_HIP_EINVAL;
+    if (bs == 0 || h == 0 || w == 0) return 0;
+    if (!data || !kernels || !sum_r_out || !sum_w_out || !max_w_out || !kmax_out || !atap_out)
+        return SBMC_HIP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    SplatFwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out,
+                     max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), h};
+    const long items = (long)bs * h * p.ntx;
+    const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
+    SBMC_LAUNCH_STRIP(splat_fwd_strip_kernel, grid, s, p, true);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_gather_update_bwd_f32(const float* data, const float* kernels,
+                                          const float* sum_r_in, const float* sum_w_in, const float* max_w_in,
+                                          const float* sum_r_out, const float* sum_w_out, const float* max_w_out,
+                                          const float* kmax, const int32_t* atap,
+                                          const float* d_sum_r_out, const float* d_sum_w_out,
+                                          const float* d_max_w_out,
+                                          float* d_data, float* d_kernels,
+                                          float* d_sum_r_in, float* d_sum_w_in, float* d_max_w_in,
+                                          float* scratch, int bs, int c, int h, int w, int k, void* stream) {
+    using LT = float;
+    if (bad_splat_dims(bs, c, h, w, k) || !strip_ok(c, k, h, w)) return SBMC_HIP_EINVAL;
+    const int nin = (sum_r_in != nullptr) + (sum_w_in != nullptr) + (max_w_in != nullptr);
+    const int ndin = (d_sum_r_in != nullptr) + (d_sum_w_in != nullptr) + (d_max_w_in != nullptr);
+    if ((nin != 0 && nin != 3) || ndin != nin) return SBMC_HIP_EINVAL;
+    if (bs == 0 || h == 0 || w == 0) return 0;
+    if (!data || !kernels || !sum_r_out || !sum_w_out || !max_w_out || !kmax || !atap ||
+        !d_sum_r_out || !d_sum_w_out || !d_max_w_out || !d_data || !d_kernels || !scratch)
+        return SBMC_HIP_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    SplatBwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out,
+                     kmax, atap, d_sum_r_out, d_sum_w_out, d_max_w_out, d_data, d_kernels,
+                     d_sum_r_in, d_sum_w_in, d_max_w_in, scratch, bs, c, h, w, k, tiles_x(w), h};
+    const size_t total = (size_t)bs * h * w;
+    unsigned egrid = (unsigned)((total + 255) / 256);
+    if (egrid > 8192) egrid = 8192;
+    SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_state_kernel<C, true>), dim3(egrid), dim3(256), 0, s, p));
+    int err = (int)hipGetLastError();
+    if (err) return err;
+    const long items = (long)bs * h * p.ntx;
+    const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
+    SBMC_LAUNCH_STRIP(gather_bwd_dg_kernel, grid, s, p);
+    err = (int)hipGetLastError();
+    if (err) return err;
+    SBMC_LAUNCH_STRIP(gather_bwd_ddata_kernel, grid, s, p);
     return (int)hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ from . import _lib
 from . import halide_ops as ops
 
 __all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported",
-           "SplatAll", "splat_all_supported", "splat_all_supported_dims", "BiasAct", "CtxAct"]
+           "SplatAll", "splat_all_supported", "splat_all_supported_dims", "gather_update_supported", "BiasAct", "CtxAct"]
 
 
 # Optional per-call device timing (used by bench.py for the roofline figure): when a list
@@ -171,7 +171,7 @@ class SplatUpdate(th.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, data, kernels, sum_r, sum_w, max_w):
+    def forward(ctx, data, kernels, sum_r, sum_w, max_w, gather=False):
         if sum_r is None:
             if sum_w is not None or max_w is not None:
                 raise RuntimeError("all of sum_r, sum_w, max_w should be none")
@@ -198,7 +198,10 @@ class SplatUpdate(th.autograd.Function):
         dev = data.device
         half = kernels.dtype == th.float16
         fwd = _lib.lib().sbmc_splat_update_fwd_f16 if half else _lib.lib().sbmc_splat_update_fwd_f32
-        with th.cuda.device(dev), _timed("splat_update_fwd", dev):
+        if gather:
+            fwd = _lib.lib().sbmc_gather_update_fwd_f32
+        ctx.gather = gather
+        with th.cuda.device(dev), _timed("gather_update_fwd" if gather else "splat_update_fwd", dev):
             rc = fwd(
                 _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
                 _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(atap),
@@ -235,7 +238,9 @@ class SplatUpdate(th.autograd.Function):
         dev = data.device
         half = kernels.dtype == th.float16
         bwd = _lib.lib().sbmc_splat_update_bwd_f16 if half else _lib.lib().sbmc_splat_update_bwd_f32
-        with th.cuda.device(dev), _timed("splat_update_bwd", dev):
+        if ctx.gather:
+            bwd = _lib.lib().sbmc_gather_update_bwd_f32
+        with th.cuda.device(dev), _timed("gather_update_bwd" if ctx.gather else "splat_update_bwd", dev):
             rc = bwd(
                 _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
                 _lib.ptr(new_r), _lib.ptr(new_w), _lib.ptr(new_m), _lib.ptr(kmax), _lib.ptr(atap),
@@ -244,7 +249,7 @@ class SplatUpdate(th.autograd.Function):
                 _lib.ptr(d_sum_r), _lib.ptr(d_sum_w), _lib.ptr(d_max_w), _lib.ptr(scratch),
                 bs, c, h, w, ctx.k, _lib.current_stream(dev))
         _lib.check(rc, "splat_update_bwd")
-        return d_data, d_kernels, d_sum_r, d_sum_w, d_max_w
+        return d_data, d_kernels, d_sum_r, d_sum_w, d_max_w, None
 
 
 class BiasAct(th.autograd.Function):
@@ -346,6 +351,18 @@ class CtxAct(th.autograd.Function):
                                                  _lib.current_stream(dev))
         _lib.check(rc, "ctx_act_bwd")
         return gx, gt, gbias, None, None, None
+
+
+def gather_update_supported(data, kernels):
+    """True when the fused gather-kernel update (`SplatUpdate(..., gather=True)`) applies."""
+    if not (data.is_cuda and kernels.is_cuda) or data.dtype != th.float32 or kernels.dtype != th.float32:
+        return False
+    k2 = kernels.shape[1]
+    k = int(round(k2 ** 0.5))
+    if k * k != k2:
+        return False
+    return bool(_lib.lib().sbmc_gather_update_supported(int(data.shape[1]), k, int(kernels.shape[-2]),
+                                                        int(kernels.shape[-1])))
 
 
 def splat_all_supported_dims(c, k, h, w):

@@ -369,7 +369,7 @@ class ProgressiveKernelApply(nn.Module):
     Args:
         splat(bool): kernels are sample-centred (splat) rather than gather kernels.
         fused(bool): allow the single-kernel HIP path when the operands qualify
-            (ROCm tensors, fp32, splat=True).  ``False`` forces the reference
+            (ROCm tensors, fp32; splat kernels, or gather kernels where the strip kernels apply).  ``False`` forces the reference
             composition of the boundary-level operators (used by the tests to check
             one against the other on the GPU).
     """
@@ -395,6 +395,8 @@ class ProgressiveKernelApply(nn.Module):
 
         if self.splat and self.fused and funcs.splat_update_supported(data, kernels):
             return funcs.SplatUpdate.apply(data, kernels, sum_r, sum_w, max_w)
+        if not self.splat and self.fused and funcs.gather_update_supported(data, kernels):
+            return funcs.SplatUpdate.apply(data, kernels, sum_r, sum_w, max_w, True)
         return self._composed(data, kernels, sum_r, sum_w, max_w)
 
     def _composed(self, data, kernels, sum_r, sum_w, max_w):

@@ -70,6 +70,15 @@ def main():
             r = upd(dg, kg, *st)
             th.autograd.backward(r, [go, gs.unsqueeze(1), gs.unsqueeze(1)])
         rows.append(("fused splat update fwd+bwd", fused_fb, 12 * k * k + 116))
+        gupd = modules.ProgressiveKernelApply(splat=False)
+        gst = tuple(t.detach() for t in gupd(data, kern, None, None, None))
+
+        def gather_fb():
+            kg.grad = None
+            dg.grad = None
+            r = gupd(dg, kg, *gst)
+            th.autograd.backward(r, [go, gs.unsqueeze(1), gs.unsqueeze(1)])
+        rows.append(("fused gather update fwd+bwd (splat=False)", gather_fb, 16 * k * k + 116))
         for name, fn, bpp in rows:
             ms = timeit(fn, args.reps)
             gbps = px * bpp / (ms * 1e-3) / 1e9

@@ -498,3 +498,47 @@ def test_half_logits_fall_back_to_fp32_operators_where_the_strip_kernels_do_not_
     o1, s1 = modules.KernelApply(softmax=True, splat=True)(d, kh.detach())
     o2, s2 = modules.KernelApply(softmax=True, splat=True)(d, kf.detach())
     close(o1, o2); close(s1, s2)
+
+
+@pytest.mark.parametrize("bs,c,h,w,k,spp", [
+    (1, 3, 16, 16, 3, 3), (2, 3, 19, 70, 5, 2), (1, 3, 40, 150, 21, 3), (1, 3, 5, 7, 21, 2),
+    (1, 4, 9, 130, 21, 2), (1, 3, 33, 65, 9, 2)])
+def test_fused_gather_update_vs_oracle(oracle, bs, c, h, w, k, spp):
+    """ProgressiveKernelApply(splat=False) -- pixel-centred (gather) kernels, the reference's
+    `--gather` ablation -- on the fused gather kernels vs the oracle composition, forward and
+    backward with upstream gradients on all three outputs."""
+    from sbmc_amd import functions as F, modules
+    th.manual_seed(22)
+    datas = [th.rand(bs, c, h, w) * 2 for _ in range(spp)]
+    kerns = [th.randn(bs, k * k, h, w) * 2 for _ in range(spp)]
+    grads = [th.randn(bs, c, h, w), th.randn(bs, 1, h, w), th.randn(bs, 1, h, w)]
+    assert F.gather_update_supported(datas[0].cuda(), kerns[0].cuda())
+    ref_out, ref_dd, ref_dk = _progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=False),
+        datas, kerns, grads, "cpu")
+    out, dd, dk = _progressive(modules.ProgressiveKernelApply(splat=False), datas, kerns, grads, "cuda")
+    for a, b, n in zip(out, ref_out, ("sum_r", "sum_w", "max_w")):
+        close(a, b, what=n)
+    for s in range(spp):
+        close(dd[s], ref_dd[s], what="d_data[%d]" % s)
+        close(dk[s], ref_dk[s], rtol=5e-5, what="d_kernels[%d]" % s)
+
+
+def test_fused_gather_running_max_branches(oracle):
+    from sbmc_amd import modules
+    th.manual_seed(23)
+    bs, c, h, w, k = 1, 3, 12, 70, 5
+    base = th.randn(bs, k * k, h, w)
+    spike = base.clone()
+    spike[:, 7] += 30.0
+    datas = [th.rand(bs, c, h, w) for _ in range(4)]
+    kerns = [base, spike, base - 50.0, spike.clone()]
+    grads = [th.randn(bs, c, h, w), th.randn(bs, 1, h, w), th.randn(bs, 1, h, w)]
+    ref_out, ref_dd, ref_dk = _progressive(
+        lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=False),
+        datas, kerns, grads, "cpu")
+    out, dd, dk = _progressive(modules.ProgressiveKernelApply(splat=False), datas, kerns, grads, "cuda")
+    for a, b in zip(out, ref_out):
+        close(a, b)
+    for s in range(4):
+        close(dd[s], ref_dd[s]); close(dk[s], ref_dk[s], rtol=5e-5)

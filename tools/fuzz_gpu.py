@@ -56,6 +56,15 @@ def main():
                 close(a, b)
             for s in range(spp):
                 close(dd[s], ref_dd[s]); close(dk[s], ref_dk[s], rtol=DK_RTOL)
+            # gather-kernel (splat=False) update, fused where the strip kernels apply
+            g_ref, g_dd, g_dk = run_progressive(
+                lambda d, kk, a, b, m: orc.progressive_kernel_apply(d, kk, a, b, m, splat=False),
+                datas, kerns, grads, "cpu")
+            g_out, gdd, gdk = run_progressive(modules.ProgressiveKernelApply(splat=False), datas, kerns, grads, "cuda")
+            for a, b in zip(g_out, g_ref):
+                close(a, b)
+            for s in range(spp):
+                close(gdd[s], g_dd[s]); close(gdk[s], g_dk[s], rtol=DK_RTOL)
             dg = th.stack(datas, 1).cuda().requires_grad_()
             kg = th.stack(kerns, 1).cuda().requires_grad_()
             if F.splat_all_supported(dg, kg):
