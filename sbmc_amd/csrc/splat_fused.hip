@@ -29,17 +29,21 @@
 //   Destinations outside the image carry M = +1e30 => e = 0 (Scatter2Gather's
 //   zero fill and its adjoint).
 //
-// Two generations of kernels live here:
-//   v1  "tile" kernels: a workgroup owns a 64 x TY pixel tile and stages a haloed
-//       tile of the small operand in LDS.  Any odd k, up to 8 channels.  This is
-//       the generic path.
-//   v2  "strip" kernels (k = 21, <= 4 channels -- the SBMC configuration): a
-//       wavefront owns one 64-pixel row strip; the 4 waves of a workgroup are
-//       x-adjacent so that the cache lines their misaligned segments share are
-//       requested from one CU at nearly the same time; the small operand is staged
-//       per wave, one kernel row at a time, in a 1-2 KB LDS ring (no s_barrier
-//       anywhere); the big streams go through raw buffer loads/stores whose per-tap
+// Kernels in this file:
+//   "tile" kernels (splat_{fwd,bwd}_tile_kernel, splat_bwd_route_kernel): a workgroup owns a
+//       64 x TY pixel tile and stages a haloed tile of the small operand in LDS.  Any odd k,
+//       up to 8 channels, fp32.  The generic path.
+//   "strip" kernels (splat_{fwd,bwd}_strip_kernel; k = 21 with <= 4 channels in fp32 / fp16
+//       logits, and every odd k in 3..19 with 3 channels): a wavefront owns one 64-pixel row
+//       strip; the 4 waves of a workgroup are x-adjacent so that the cache lines their
+//       misaligned segments share are requested from one CU at nearly the same time; the small
+//       operand is staged per wave, one kernel row at a time, in a 1-2 KB LDS row buffer (no
+//       s_barrier anywhere); the big streams go through raw buffer loads/stores whose per-tap
 //       offsets are scalar, so a strip needs one VGPR of addressing in total.
+//   gather-kernel variant (GATHER flag of the forward strip kernel, gather_bwd_{dg,ddata}_kernel):
+//       ProgressiveKernelApply(splat=False).
+//   per-pixel state kernels: splat_bwd_state_kernel (state adjoint + destination records),
+//       splat_merge_fwd_kernel / splat_chain_bwd_kernel (all samples of a frame per launch).
 #include "common.hpp"
 #include "../../include/sbmc_hip.h"
 #include <math.h>
@@ -47,11 +51,11 @@
 
 namespace sbmc {
 
-constexpr int FWD_TY = 4;   // v1 forward : 4 waves, LDS tile [C][TY+k-1][64+k-1]
-constexpr int BWD_TY = 8;   // v1 backward: 8 waves, LDS tile [C+2][TY+k-1][64+k-1]
-constexpr int V2_WAVES = 4; // v2: 4 x-adjacent strips per workgroup
-constexpr int V2_ROW = 96;  // v2: staged positions per strip (>= 64 + k - 1)
-constexpr int REC = 8;      // v2 backward: floats per destination record
+constexpr int FWD_TY = 4;   // tile forward : 4 waves, LDS tile [C][TY+k-1][64+k-1]
+constexpr int BWD_TY = 8;   // tile backward: 8 waves, LDS tile [C+2][TY+k-1][64+k-1]
+constexpr int V2_WAVES = 4; // strip kernels: 4 x-adjacent strips per workgroup
+constexpr int V2_ROW = 96;  // strip kernels: staged positions per strip (>= 64 + k - 1)
+constexpr int REC = 8;      // strip backward: floats per destination record
 #ifndef FWD_MIN_WAVES
 #define FWD_MIN_WAVES 7
 #endif
@@ -89,7 +93,7 @@ struct SplatFwdParams {
     int ntx, nty;
 };
 
-// ------------------------------------------------------------------ v1 forward
+// ------------------------------------------------------------------ tile forward
 template <int C>
 __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_tile_kernel(SplatFwdParams p) {
     extern __shared__ float lds[];  // [C][th][tw] radiance halo tile, zero outside the image
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_tile_kernel(SplatFwdPar
     }
 }
 
-// ------------------------------------------------------------------ v2 forward
+// ------------------------------------------------------------------ strip forward
 // One kernel row (K taps) of the online softmax for one destination pixel.
 //   v[dx] : the K gather logits of this row;  srow : LDS, staged radiance positions
 template <int K, int C>
@@ -365,7 +369,7 @@ struct SplatBwdParams {
     float* d_sum_r_in;         // or null
     float* d_sum_w_in;
     float* d_max_w_in;
-    float* scratch;            // v1: d_kmax [bs, h, w];  v2: destination records [bs, h, w, REC]
+    float* scratch;            // tile: d_kmax [bs, h, w];  strip: destination records [bs, h, w, REC]
     int bs, c, h, w, k;
     int ntx, nty;
 };
@@ -377,8 +381,8 @@ struct SplatBwdParams {
 //   d_max_in   = sigma * (dR . sum_r_in + dW * sum_w_in) + dM_total * [max_in >  kmax] (1/2 on ties)
 //   d_kmax     =                                           dM_total * [kmax   >  max_in] (1/2 on ties)
 // (torch.max(a, b) splits the gradient evenly on ties.)
-// RECORDS = false: writes d_kmax to scratch[bs,h,w]                          (v1)
-// RECORDS = true : writes {M, dW, d_kmax, atap | dR0..dR3} to scratch[bs,h,w,8] (v2)
+// RECORDS = false: writes d_kmax to scratch[bs,h,w]                          (tile kernels)
+// RECORDS = true : writes {M, dW, d_kmax, atap | dR0..dR3} to scratch[bs,h,w,8] (strip kernels)
 template <int C, bool RECORDS>
 __global__ __launch_bounds__(256) void splat_bwd_state_kernel(SplatBwdParams p) {
     const size_t hw = (size_t)p.h * p.w;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(256) void splat_bwd_state_kernel(SplatBwdParams p) 
     }
 }
 
-// v1 main: tile kernel, any odd k, up to 8 channels.
+// tile backward main kernel, any odd k, up to 8 channels.
 template <int C>
 __global__ __launch_bounds__(BWD_TY * TX) void splat_bwd_tile_kernel(SplatBwdParams p) {
     extern __shared__ float lds[];  // [C+2][th][tw]: M (1e30 outside), dR[0..C) (0 outside), dW (0 outside)
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(BWD_TY * TX) void splat_bwd_tile_kernel(SplatBwdPar
     for (int c = 0; c < C; ++c) p.d_data[((size_t)t.n * C + c) * hw + pix] = dD[c];
 }
 
-// v1 routing: adds d_kmax to the arg-max tap recorded by the forward (torch:
+// tile backward routing: adds d_kmax to the arg-max tap recorded by the forward (torch:
 // kernels_view.max(1) backward scatters to one index, modules.py:429).  Distinct
 // destinations map to distinct (tap, sample) elements of d_kernels, so plain
 // read-modify-write is race free.  Must run after splat_bwd_tile_kernel.
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(256) void splat_bwd_route_kernel(SplatBwdParams p) 
     }
 }
 
-// v2 main: strip kernel (one wave = one 64-sample row strip).  Destination records
+// strip backward main kernel (one wave = one 64-sample row strip).  Destination records
 // {M, dW, d_kmax, atap | dR0..3} of one destination row at a time are staged per wave
 // in LDS as two float4 arrays, so each tap costs two conflict-free ds_read_b128.
 template <int K, int C, typename LT>
