@@ -17,7 +17,8 @@ import torch as th
 from . import binio, losses
 from .utils import crop_like
 
-__all__ = ["SampleBasedDenoiserInterface", "TilesDataset", "Checkpointer", "train"]
+__all__ = ["SampleBasedDenoiserInterface", "TilesDataset", "MultiSampleCountDataset", "Checkpointer",
+           "train"]
 
 LOG = logging.getLogger(__name__)
 
@@ -99,6 +100,23 @@ class TilesDataset(th.utils.data.Dataset):
         tile = binio.read_tile(self.files[idx], self.spp)
         return {k: th.from_numpy(np.ascontiguousarray(tile[k]))
                 for k in ("radiance", "features", "global_features", "target_image", "low_spp")}
+
+
+class MultiSampleCountDataset(th.utils.data.ConcatDataset):
+    """Every tile at every sample count 2..spp (reference sbmc/datasets.py:1015-1043); the
+    sample dimension varies between items, so use batch_size = 1."""
+
+    def __init__(self, path, spp=None):
+        if spp is None:
+            LOG.error("MultiSampleCountDataset requires a number of spps")
+            raise RuntimeError("spp not provided.")
+        if spp < 2:
+            LOG.error("MultiSampleCountDataset needs at least 2spp")
+            raise RuntimeError("spp too low to randomize sample count, should be at least 2.")
+        parts = [TilesDataset(path, spp=s) for s in range(2, spp + 1)]
+        super(MultiSampleCountDataset, self).__init__(parts)
+        self.num_features = parts[0].num_features
+        self.num_global_features = parts[0].num_global_features
 
 
 class Checkpointer(object):

@@ -23,7 +23,12 @@ def main(args):
     th.manual_seed(0)
     if not th.cuda.is_available():
         raise SystemExit("sbmc_amd runs its operators on MI355X only; no GPU is visible")
-    data = interfaces.TilesDataset(args.data, spp=args.spp)
+    if args.randomize_spp:
+        if args.bs != 1:
+            raise RuntimeError("Training with randomized spp is only valid for batch_size=1")
+        data = interfaces.MultiSampleCountDataset(args.data, spp=args.spp)
+    else:
+        data = interfaces.TilesDataset(args.data, spp=args.spp)
     model = Multisteps(data.num_features, data.num_global_features, ksize=args.ksize,
                        splat=not args.gather, pixel=args.pixel)
     loader = DataLoader(data, batch_size=args.bs, num_workers=args.num_worker_threads, shuffle=True)
@@ -50,6 +55,7 @@ if __name__ == "__main__":
     p.add_argument("--ksize", type=int, default=21)
     p.add_argument("--gather", action="store_true")
     p.add_argument("--pixel", action="store_true")
+    p.add_argument("--constant_spp", dest="randomize_spp", action="store_false", default=True)
     p.add_argument("--lr", type=float, default=1e-4)
     p.add_argument("--bs", type=int, default=1)
     p.add_argument("--num_epochs", type=int, default=1)

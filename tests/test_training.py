@@ -48,3 +48,8 @@ def test_train_loop_dataset_checkpoint(cpu_ops, tmp_path):
     for a, b in zip(model.state_dict().values(), model2.state_dict().values()):
         assert th.equal(a, b)
     assert interfaces.Checkpointer.load_meta(str(tmp_path / "ckpt")) == {"a": 1}
+    multi = interfaces.MultiSampleCountDataset(str(root), spp=2)
+    assert len(multi) == 2 and multi[1]["features"].shape[0] == 2
+    import pytest
+    with pytest.raises(RuntimeError):
+        interfaces.MultiSampleCountDataset(str(root), spp=1)
