@@ -12,7 +12,7 @@ dev = th.device("cuda")
 th.manual_seed(0)
 model = Multisteps(93, 3, ksize=21, pointwise_gemm="--nogemm1x1" not in sys.argv).to(dev)
 model.train()
-opt = th.optim.Adam(model.parameters(), lr=1e-4)
+opt = th.optim.Adam(model.parameters(), lr=1e-4, fused="--fusedadam" in sys.argv)
 loss_fn = losses.TonemappedRelativeMSE()
 batch = bench.make_model_inputs(720, 1280, 8, dev, seed=1234)
 def step():
