@@ -346,6 +346,16 @@ class KernelApply(nn.Module):
         """data [bs, c, h, w], kernels [bs, k*k, h, w] -> (output [bs, c, h, w], sum_w [bs, 1, h, w])."""
         bs, k2, h, w = kernels.shape
         k = _ksize_of(kernels)
+        if self.softmax and kernels.is_cuda:
+            # softmax over the taps followed by the weighted sum IS one initialisation call of the
+            # fused progressive update, normalised: exp(g - max) / sum exp(g - max) -- one pass
+            # over the logits instead of softmax's three plus KernelWeighting's one
+            ok = (funcs.splat_update_supported(data, kernels) if self.splat
+                  else funcs.gather_update_supported(data, kernels))
+            if ok and kernels.dtype == th.float32:
+                sum_r, sum_w, _ = funcs.SplatUpdate.apply(data, kernels, None, None, None, not self.splat)
+                # the softmax weights sum to one: value 1, gradient exactly 0, still part of the graph
+                return sum_r / sum_w, sum_w / sum_w
         # the boundary-level operators are fp32 (as the reference's): half logits are up-cast
         kernels = kernels.float().view(bs, k, k, h, w)
         data = data.float()
