@@ -195,9 +195,10 @@ def gen_multisteps_odd(ref):
     gather-kernel ablation too."""
     out = {}
     g = th.Generator().manual_seed(23)
-    for tag, splat in (("splat", True), ("gather", False)):
+    for tag, splat in (("splat", True), ("gather", False), ("pixel", True)):
         th.manual_seed(22)
-        model = ref.models.Multisteps(5, 3, width=4, embedding_width=4, ksize=3, nsteps=3, splat=splat)
+        model = ref.models.Multisteps(5, 3, width=4, embedding_width=4, ksize=3, nsteps=3, splat=splat,
+                                      pixel=(tag == "pixel"))
         model.train(False)
         batch = {"radiance": th.empty(2, 2, 3, 21, 27).exponential_(1.0, generator=g),
                  "features": th.rand(2, 2, 5, 21, 27, generator=g),

@@ -156,7 +156,7 @@ def test_kpcn_on_gpu_matches_reference_fixture():
         close(res[k], g["out." + k], rtol=2e-5, what=k)
 
 
-@pytest.mark.parametrize("tag", ["splat", "gather"])
+@pytest.mark.parametrize("tag", ["splat", "gather", "pixel"])
 def test_multisteps_odd_sizes_on_gpu(tag):
     from test_host_golden import _multisteps_odd
     g, model, batch = _multisteps_odd(tag, "cuda")

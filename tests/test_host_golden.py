@@ -194,7 +194,8 @@ def test_kpcn_matches_reference(cpu_ops):
 def _multisteps_odd(tag, device):
     from sbmc_amd import Multisteps
     g = golden("multisteps_odd.npz")
-    model = Multisteps(5, 3, width=4, embedding_width=4, ksize=3, nsteps=3, splat=(tag == "splat"))
+    model = Multisteps(5, 3, width=4, embedding_width=4, ksize=3, nsteps=3, splat=(tag != "gather"),
+                       pixel=(tag == "pixel"))
     pre = tag + ".sd."
     model.load_state_dict({k[len(pre):]: t(g[k]) for k in g.files if k.startswith(pre)}, strict=True)
     pre = tag + ".in."
@@ -202,7 +203,7 @@ def _multisteps_odd(tag, device):
     return g, model.to(device).train(False), batch
 
 
-@pytest.mark.parametrize("tag", ["splat", "gather"])
+@pytest.mark.parametrize("tag", ["splat", "gather", "pixel"])
 def test_multisteps_odd_sizes_batch2_and_gather_ablation(cpu_ops, tag):
     """21x27 frame (odd at every U-net level), batch of 2 (the eval path of the reference pairs
     batch elements correctly), 3 steps, and the gather-kernel ablation (splat=False)."""
