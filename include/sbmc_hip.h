@@ -260,12 +260,15 @@ SBMC_API int sbmc_splat_all_bwd_f16(const float *data, const void *kernels,
  *   act: 0 linear, 1 relu, 2 leaky_relu(slope)
  *   fwd (in place):  y = act(y + bias[c])
  *   bwd:             gx = gy * act'(y)   (y = the forward OUTPUT; gx may alias gy),
- *                    gbias[c] = sum_{b, pixels} gx      (gbias is zeroed by the call)
+ *                    partial[b, c, j] = sum of gx over chunk j of plane (b, c),
+ *                    j < sbmc_bias_act_chunks(b, c, hw); the bias gradient is the sum of the
+ *                    partials over b and j (done by the caller: no atomics, deterministic)
  * hw must be a multiple of 4 and the tensors 16-byte aligned (SBMC_HIP_EINVAL otherwise).
  */
+SBMC_API int sbmc_bias_act_chunks(int b, int c, long hw);
 SBMC_API int sbmc_bias_act_fwd_f32(float *y, const float *bias, int b, int c, long hw, int act,
                           float slope, void *stream);
-SBMC_API int sbmc_bias_act_bwd_f32(const float *gy, const float *y, float *gx, float *gbias,
+SBMC_API int sbmc_bias_act_bwd_f32(const float *gy, const float *y, float *gx, float *partial,
                           int b, int c, long hw, int act, float slope, void *stream);
 
 /*
@@ -274,13 +277,15 @@ SBMC_API int sbmc_bias_act_bwd_f32(const float *gy, const float *y, float *gx, f
  * 196-199).  The layer is linear, so the context term t = W_c ctx is the same for all s samples
  * of a pixel; it is computed once per pixel by the caller and added here with bias + activation:
  *   fwd (in place):  y[b,s,c,p] = act(y[b,s,c,p] + t[b,c,p] + bias[c])
- *   bwd:             gx = gy * act'(y);  gt[b,c,p] = sum_s gx;  gbias[c] = sum_{b,s,p} gx
+ *   bwd:             gx = gy * act'(y);  gt[b,c,p] = sum_s gx  (t_per_pixel = 1 only);
+ *                    partial[b, c, j] = sum_{s, p in chunk j} gx, j < sbmc_bias_act_chunks(b, c, hw)
+ *                    (bias gradient = sum over b, j; for t_per_pixel = 0, gt[b,c] = sum over j)
  * y, gy, gx: [b*s, c, hw];  t, gt: [b, c, hw] (t_per_pixel = 1) or [b, c] (t_per_pixel = 0: the
  * context is constant over the image, e.g. the global features of the first step).
  */
 SBMC_API int sbmc_ctx_act_fwd_f32(float *y, const float *t, const float *bias, int b, int s, int c, long hw,
                          int t_per_pixel, int act, float slope, void *stream);
-SBMC_API int sbmc_ctx_act_bwd_f32(const float *gy, const float *y, float *gx, float *gt, float *gbias,
+SBMC_API int sbmc_ctx_act_bwd_f32(const float *gy, const float *y, float *gx, float *gt, float *partial,
                          int b, int s, int c, long hw, int t_per_pixel, int act, float slope,
                          void *stream);
 

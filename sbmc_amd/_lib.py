@@ -35,6 +35,7 @@ SYMBOLS = (
     "sbmc_gather_update_supported",
     "sbmc_gather_update_fwd_f32",
     "sbmc_gather_update_bwd_f32",
+    "sbmc_bias_act_chunks",
     "sbmc_bias_act_fwd_f32",
     "sbmc_bias_act_bwd_f32",
     "sbmc_ctx_act_fwd_f32",
@@ -92,6 +93,7 @@ def lib():
     handle.sbmc_gather_update_supported.argtypes = [i] * 4
     handle.sbmc_gather_update_fwd_f32.argtypes = handle.sbmc_splat_update_fwd_f32.argtypes
     handle.sbmc_gather_update_bwd_f32.argtypes = handle.sbmc_splat_update_bwd_f32.argtypes
+    handle.sbmc_bias_act_chunks.argtypes = [i, i, ctypes.c_long]
     handle.sbmc_bias_act_fwd_f32.argtypes = [p, p, i, i, ctypes.c_long, i, ctypes.c_float, p]
     handle.sbmc_bias_act_bwd_f32.argtypes = [p, p, p, p, i, i, ctypes.c_long, i, ctypes.c_float, p]
     handle.sbmc_ctx_act_fwd_f32.argtypes = [p, p, p, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]

@@ -7,8 +7,9 @@
 // broadcast, activation, activation backward, bias-gradient reduction).  These two kernels do
 // that glue in ONE pass per direction, in place:
 //   forward : y = act(y + bias[c])
-//   backward: gx = gy * act'(y);  gbias[c] = sum over b, pixels of gx        (y is the OUTPUT:
-//             for relu and leaky_relu the sign of the output equals the sign of the input)
+//   backward: gx = gy * act'(y);  partial[b, c, chunk] = sum of gx over the workgroup's pixels
+//             (the caller adds the partials up: no atomics, deterministic; y is the OUTPUT: for
+//             relu and leaky_relu the sign of the output equals the sign of the input)
 // HBM-bound: 8 bytes/element forward, 12 bytes/element backward; float4 accesses.
 #include "common.hpp"
 #include "../../include/sbmc_hip.h"
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ y
 }
 
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
-                                                          float* __restrict__ gx, float* __restrict__ gbias,
+                                                          float* __restrict__ gx, float* __restrict__ partial,
                                                           size_t hw, int C, float slope, int linear) {
     __shared__ float red[4];
     const int c = blockIdx.y, b = blockIdx.z;
@@ -71,12 +72,13 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
             acc += g;
         }
     }
-    // wave reduction, then one atomic per workgroup
+    // wave reduction, then one partial sum per workgroup (no atomics: deterministic)
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) acc += __shfl_down(acc, s, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(gbias + c, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0)
+        partial[((size_t)b * C + c) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // Per-sample chains whose first layer sees [sample features ; pixel context] (reference
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
 // same for all S samples of a pixel.  It is computed ONCE per pixel (t[b, c, p]) and added here,
 // together with the activation, in one in-place pass over the per-sample product:
 //   forward : y[b,s,c,p] = act(y[b,s,c,p] + t[b,c,p*tp] + bias[c])        (tp = 0: t is per image)
-//   backward: gx = gy * act'(y);  gt[b,c,p] = sum_s gx;  gbias[c] = sum_{b,s,p} gx
+//   backward: gx = gy * act'(y);  gt[b,c,p] = sum_s gx;  partial[b,c,chunk] = sum_{s,p in chunk} gx
 __global__ __launch_bounds__(256) void ctx_act_fwd_kernel(float* __restrict__ y, const float* __restrict__ t,
                                                          const float* __restrict__ bias, size_t hw, int C,
                                                          int S, int t_per_pixel, float slope, int linear) {
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void ctx_act_fwd_kernel(float* __restrict__ y,
 
 __global__ __launch_bounds__(256) void ctx_act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                          float* __restrict__ gx, float* __restrict__ gt,
-                                                         float* __restrict__ gbias, size_t hw, int C, int S,
+                                                         float* __restrict__ partial, size_t hw, int C, int S,
                                                          int t_per_pixel, float slope, int linear) {
     __shared__ float red[4];
     const int c = blockIdx.y, b = blockIdx.z;
@@ -139,11 +141,8 @@ __global__ __launch_bounds__(256) void ctx_act_bwd_kernel(const float* __restric
     for (int s = 32; s > 0; s >>= 1) acc += __shfl_down(acc, s, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-        atomicAdd(gbias + c, tot);
-        if (!t_per_pixel) atomicAdd(gt + (size_t)b * C + c, tot);
-    }
+    if (threadIdx.x == 0)
+        partial[((size_t)b * C + c) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 }  // namespace sbmc
@@ -172,21 +171,20 @@ extern "C" int sbmc_bias_act_fwd_f32(float* y, const float* bias, int b, int c, 
     return (int)hipGetLastError();
 }
 
-extern "C" int sbmc_bias_act_bwd_f32(const float* gy, const float* y, float* gx, float* gbias,
+extern "C" int sbmc_bias_act_chunks(int b, int c, long hw) {
+    if (b <= 0 || c <= 0 || hw <= 0) return 1;
+    return (int)chunks_for((size_t)hw, b * c);
+}
+
+extern "C" int sbmc_bias_act_bwd_f32(const float* gy, const float* y, float* gx, float* partial,
                                      int b, int c, long hw, int act, float slope, void* stream) {
     if (b < 0 || c < 0 || hw < 0 || act < 0 || act > 2) return SBMC_HIP_EINVAL;
-    if (c > 0 && !gbias) return SBMC_HIP_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    if (c > 0) {
-        const hipError_t e = hipMemsetAsync(gbias, 0, sizeof(float) * c, st);
-        if (e != hipSuccess) return (int)e;
-    }
     if (b == 0 || c == 0 || hw == 0) return 0;
-    if (!gy || !y || !gx || c > 65535 || b > 65535 || hw % 4) return SBMC_HIP_EINVAL;
+    if (!gy || !y || !gx || !partial || c > 65535 || b > 65535 || hw % 4) return SBMC_HIP_EINVAL;
     if ((uintptr_t)gy % 16 || (uintptr_t)y % 16 || (uintptr_t)gx % 16) return SBMC_HIP_EINVAL;
     const float s = act == 1 ? 0.f : slope;
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(chunks_for((size_t)hw, b * c), c, b), dim3(256), 0, st,
-                       gy, y, gx, gbias, (size_t)hw, c, s, act == 0);
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(chunks_for((size_t)hw, b * c), c, b), dim3(256), 0,
+                       (hipStream_t)stream, gy, y, gx, partial, (size_t)hw, c, s, act == 0);
     return (int)hipGetLastError();
 }
 
@@ -202,26 +200,18 @@ extern "C" int sbmc_ctx_act_fwd_f32(float* y, const float* t, const float* bias,
     return (int)hipGetLastError();
 }
 
-extern "C" int sbmc_ctx_act_bwd_f32(const float* gy, const float* y, float* gx, float* gt, float* gbias,
+extern "C" int sbmc_ctx_act_bwd_f32(const float* gy, const float* y, float* gx, float* gt, float* partial,
                                     int b, int s, int c, long hw, int t_per_pixel, int act, float slope,
                                     void* stream) {
     if (b < 0 || s < 1 || c < 0 || hw < 0 || act < 0 || act > 2) return SBMC_HIP_EINVAL;
-    if ((c > 0 && !gbias) || (b > 0 && c > 0 && !gt)) return SBMC_HIP_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    if (c > 0) {
-        hipError_t e = hipMemsetAsync(gbias, 0, sizeof(float) * c, st);
-        if (e != hipSuccess) return (int)e;
-        if (!t_per_pixel && b > 0) {
-            e = hipMemsetAsync(gt, 0, sizeof(float) * (size_t)b * c, st);
-            if (e != hipSuccess) return (int)e;
-        }
-    }
     if (b == 0 || c == 0 || hw == 0) return 0;
-    if (!gy || !y || !gx || c > 65535 || b > 65535 || hw % 4) return SBMC_HIP_EINVAL;
+    if (!gy || !y || !gx || !partial || (t_per_pixel && !gt) || c > 65535 || b > 65535 || hw % 4)
+        return SBMC_HIP_EINVAL;
     if ((uintptr_t)gy % 16 || (uintptr_t)y % 16 || (uintptr_t)gx % 16 || (t_per_pixel && (uintptr_t)gt % 16))
         return SBMC_HIP_EINVAL;
     const float sl = act == 1 ? 0.f : slope;
-    hipLaunchKernelGGL(ctx_act_bwd_kernel, dim3(chunks_for((size_t)hw, b * c), c, b), dim3(256), 0, st,
-                       gy, y, gx, gt, gbias, (size_t)hw, c, s, t_per_pixel != 0, sl, act == 0);
+    hipLaunchKernelGGL(ctx_act_bwd_kernel, dim3(chunks_for((size_t)hw, b * c), c, b), dim3(256), 0,
+                       (hipStream_t)stream, gy, y, gx, gt, partial, (size_t)hw, c, s, t_per_pixel != 0, sl,
+                       act == 0);
     return (int)hipGetLastError();
 }

@@ -289,13 +289,13 @@ class BiasAct(th.autograd.Function):
         b, c = gy.shape[0], gy.shape[1]
         hw = gy[0, 0].numel()
         gx = th.empty_like(gy)
-        gbias = gy.new_empty(c)
+        partial = gy.new_empty(b, c, _lib.lib().sbmc_bias_act_chunks(b, c, hw))
         dev = gy.device
         with th.cuda.device(dev):
-            rc = _lib.lib().sbmc_bias_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gx), _lib.ptr(gbias),
+            rc = _lib.lib().sbmc_bias_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gx), _lib.ptr(partial),
                                                   b, c, hw, ctx.act, ctx.slope, _lib.current_stream(dev))
         _lib.check(rc, "bias_act_bwd")
-        return gx, gbias, None, None
+        return gx, partial.sum((0, 2)), None, None
 
 
 class CtxAct(th.autograd.Function):
@@ -342,15 +342,18 @@ class CtxAct(th.autograd.Function):
         b = gy.shape[0] // s
         hw = gy[0, 0].numel()
         gx = th.empty_like(gy)
-        gt = gy.new_empty(tshape)
-        gbias = gy.new_empty(c)
+        gt = gy.new_empty(tshape) if per_pixel else None
+        partial = gy.new_empty(b, c, _lib.lib().sbmc_bias_act_chunks(b, c, hw))
         dev = gy.device
         with th.cuda.device(dev):
             rc = _lib.lib().sbmc_ctx_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gx), _lib.ptr(gt),
-                                                 _lib.ptr(gbias), b, s, c, hw, per_pixel, act, slope,
+                                                 _lib.ptr(partial), b, s, c, hw, per_pixel, act, slope,
                                                  _lib.current_stream(dev))
         _lib.check(rc, "ctx_act_bwd")
-        return gx, gt, gbias, None, None, None
+        per_image = partial.sum(2)                 # [b, c]
+        if not per_pixel:
+            gt = per_image.view(tshape)
+        return gx, gt, per_image.sum(0), None, None, None
 
 
 def gather_update_supported(data, kernels):
