@@ -289,6 +289,20 @@ SBMC_API int sbmc_ctx_act_bwd_f32(const float *gy, const float *y, float *gx, fl
                          int b, int s, int c, long hw, int t_per_pixel, int act, float slope,
                          void *stream);
 
+/* ---- a whole 1x1 convolution layer in one pass (fp32 MFMA) -------------------------------------
+ * The per-sample layers of the reference's ConvChains (sbmc/modules.py:154-175 with ksize = 1;
+ * sbmc/models.py:79-102) on planar activations:
+ *     y[b, co, p] = act( sum_ci w[co, ci] * x[b, ci, p] + bias[co] + t )
+ * x: [b, cin, hw], w: [cout, cin] (the convolution weight), y: [b, cout, hw]; cin <= 128.
+ * t (the context half of a chain's first layer, see ctx_act above): t_mode 0 = none,
+ * 1 = [b/s, cout] (constant over the image), 2 = [b/s, cout, hw]; batch element b uses t[b / s].
+ * act / slope as for bias_act.  y must not alias x.
+ */
+SBMC_API int sbmc_pointwise_supported(int cin, int cout, long hw);
+SBMC_API int sbmc_pointwise_fwd_f32(const float *x, const float *w, const float *bias, const float *t,
+                           float *y, int b, int s, int cin, int cout, long hw, int t_mode, int act,
+                           float slope, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,8 @@ SYMBOLS = (
     "sbmc_bias_act_bwd_f32",
     "sbmc_ctx_act_fwd_f32",
     "sbmc_ctx_act_bwd_f32",
+    "sbmc_pointwise_supported",
+    "sbmc_pointwise_fwd_f32",
 )
 ABI_VERSION = 1
 MAX_CHANNELS = 8
@@ -98,6 +100,8 @@ def lib():
     handle.sbmc_bias_act_bwd_f32.argtypes = [p, p, p, p, i, i, ctypes.c_long, i, ctypes.c_float, p]
     handle.sbmc_ctx_act_fwd_f32.argtypes = [p, p, p, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_ctx_act_bwd_f32.argtypes = [p, p, p, p, p, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_pointwise_supported.argtypes = [i, i, ctypes.c_long]
+    handle.sbmc_pointwise_fwd_f32.argtypes = [p] * 5 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t

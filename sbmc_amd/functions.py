@@ -356,6 +356,86 @@ class CtxAct(th.autograd.Function):
         return gx, gt, per_image.sum(0), None, None, None
 
 
+def pointwise_supported(x, cout):
+    """True when `PointwiseLayer` applies to the planar activations x [B, cin, ...pixels]."""
+    if not (x.is_cuda and x.dtype == th.float32 and x.dim() >= 3 and x.numel() > 0):
+        return False
+    hw = x[0, 0].numel()
+    return (x.data_ptr() % 16 == 0 and x.shape[0] <= 65535 and cout <= 65535
+            and bool(_lib.lib().sbmc_pointwise_supported(x.shape[1], cout, hw)))
+
+
+class PointwiseLayer(th.autograd.Function):
+    """A whole 1x1-convolution layer in one pass: y[b] = act(w @ x[b] + bias (+ t[b // s])).
+
+    x [B, cin, hw] (cin <= 128), w [cout, cin], bias [cout]; t = None, [B/s, cout] (context term
+    constant over the image) or [B/s, cout, hw] (per pixel) -- the context half of a chain's first
+    layer, see modules.pointwise_chain_with_context; act: 0 linear, 1 relu, 2 leaky_relu(slope).
+    fp32 MFMA kernel csrc/pointwise.hip (exact fp32 products and sums; differs from a library GEMM
+    by summation order).  Backward: one pass for gz = gy * act'(y), the bias gradient and the
+    context gradient (csrc/bias_act.hip), then dx = w^T gz and dw = sum_b gz x^T as GEMMs.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, bias, t, s, act, slope):
+        x = x.contiguous()
+        w = w.contiguous()
+        bias = bias.contiguous()
+        B, cin, hw = x.shape
+        cout = w.shape[0]
+        t_mode = 0
+        if t is not None:
+            t = t.contiguous()
+            t_mode = 2 if (t.dim() == 3 and t.shape[2] == hw and hw > 1) else 1
+        y = x.new_empty(B, cout, hw)
+        dev = x.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_pointwise_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
+                                                   _lib.ptr(t) if t is not None else None, _lib.ptr(y),
+                                                   B, s, cin, cout, hw, t_mode, act, slope,
+                                                   _lib.current_stream(dev))
+        _lib.check(rc, "pointwise_fwd")
+        ctx.cfg = (s, act, slope, t_mode, None if t is None else tuple(t.shape))
+        ctx.save_for_backward(x, w, y if act != 0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        s, act, slope, t_mode, tshape = ctx.cfg
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, cout, hw = gy.shape
+        if y is None:
+            y = gy                                   # placeholder pointer, never read when linear
+        L = _lib.lib()
+        dev = gy.device
+        gz = th.empty_like(gy)
+        gt = None
+        with th.cuda.device(dev):
+            if t_mode == 0:
+                partial = gy.new_empty(B, cout, L.sbmc_bias_act_chunks(B, cout, hw))
+                rc = L.sbmc_bias_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gz), _lib.ptr(partial),
+                                             B, cout, hw, act, slope, _lib.current_stream(dev))
+            else:
+                b = B // s
+                gt = gy.new_empty(tshape) if t_mode == 2 else None
+                partial = gy.new_empty(b, cout, L.sbmc_bias_act_chunks(b, cout, hw))
+                rc = L.sbmc_ctx_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gz), _lib.ptr(gt),
+                                            _lib.ptr(partial), b, s, cout, hw, int(t_mode == 2), act, slope,
+                                            _lib.current_stream(dev))
+        _lib.check(rc, "pointwise_bwd")
+        per_image = partial.sum(2)
+        gbias = per_image.sum(0)
+        if t_mode == 1:
+            gt = per_image.view(tshape)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = th.bmm(w.t().unsqueeze(0).expand(B, -1, -1), gz)
+        if ctx.needs_input_grad[1]:
+            gw = th.bmm(gz, x.transpose(1, 2)).sum(0)
+        return gx, gw, gbias, gt, None, None, None
+
+
 def gather_update_supported(data, kernels):
     """True when the fused gather-kernel update (`SplatUpdate(..., gather=True)`) applies."""
     if not (data.is_cuda and kernels.is_cuda) or data.dtype != th.float32 or kernels.dtype != th.float32:

@@ -74,6 +74,9 @@ def _pointwise_gemm(conv, x, activation=None):
         act = 1
     elif isinstance(activation, nn.LeakyReLU):
         act, slope = 2, float(activation.negative_slope)
+    if funcs.pointwise_supported(x3, w.shape[0]):
+        y = funcs.PointwiseLayer.apply(x3, w.view(w.shape[0], c), conv.bias, None, 1, act, slope)
+        return y.view(b, w.shape[0], h, wd), act != 0
     y = th.bmm(wmat, x3)
     if funcs.BiasAct.supported(y):
         y = funcs.BiasAct.apply(y, conv.bias, act, slope)
@@ -120,12 +123,17 @@ def pointwise_chain_with_context(chain, per_sample, context):
     wt = wt.view(wt.shape[0], cs + cp)
     cout = wt.shape[0]
     xs = per_sample.reshape(bs * S, cs, h * w)
-    y = th.bmm(wt[:, :cs].unsqueeze(0).expand(bs * S, -1, -1), xs)
     ctx3 = context.reshape(bs, cp, -1)
     t = th.bmm(wt[:, cs:].unsqueeze(0).expand(bs, -1, -1), ctx3).contiguous()
-    if not funcs.CtxAct.supported(y, t, S):
-        return None
-    y = funcs.CtxAct.apply(y, t, conv.bias, S, act[0], act[1]).view(bs * S, cout, h, w)
+    if funcs.pointwise_supported(xs, cout):
+        tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)
+        y = funcs.PointwiseLayer.apply(xs, wt[:, :cs], conv.bias, tt, S, act[0], act[1])
+        y = y.view(bs * S, cout, h, w)
+    else:
+        y = th.bmm(wt[:, :cs].unsqueeze(0).expand(bs * S, -1, -1), xs)
+        if not funcs.CtxAct.supported(y, t, S):
+            return None
+        y = funcs.CtxAct.apply(y, t, conv.bias, S, act[0], act[1]).view(bs * S, cout, h, w)
     # the rest of the chain, minus what has been consumed
     consumed = 1 if isinstance(first, ConvChain._ConvBNRelu) else (2 if act[0] != 0 else 1)
     rest = mods[consumed:]

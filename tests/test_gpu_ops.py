@@ -409,6 +409,50 @@ def test_bias_act_kernels(act, slope):
         close(b2.grad, gb_ref, rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [
+    # B, S, cin, cout, hw, context (0 none, 1 per image, 2 per pixel), act
+    (2, 1, 128, 128, 1024, 0, 1), (3, 1, 93, 128, 1000, 0, 2), (4, 2, 128, 128, 260, 2, 1),
+    (4, 2, 93, 128, 516, 1, 1), (2, 1, 128, 441, 388, 0, 0), (2, 2, 128, 441, 132, 2, 2),
+    (1, 1, 7, 5, 4, 0, 1), (2, 1, 33, 200, 36, 0, 0), (6, 3, 64, 25, 640, 2, 0), (16, 8, 128, 128, 128 * 40 + 4, 2, 1),
+])
+def test_pointwise_layer_kernel(shape):
+    """A whole 1x1-convolution layer in one MFMA pass (csrc/pointwise.hip) vs an fp64 torch
+    restatement of conv1x1 + context term + bias + activation, forward and backward."""
+    from sbmc_amd import functions as F
+    B, S, cin, cout, hw, tm, act = shape
+    slope = 0.01 if act == 2 else 0.0
+    th.manual_seed(B * 1000 + cin + cout + hw)
+    x0 = th.randn(B, cin, hw, device="cuda")
+    w0 = th.randn(cout, cin, device="cuda") / cin ** 0.5
+    b0 = th.randn(cout, device="cuda")
+    t0 = None if tm == 0 else (th.randn(B // S, cout, device="cuda") if tm == 1
+                               else th.randn(B // S, cout, hw, device="cuda"))
+    assert F.pointwise_supported(x0, cout)
+
+    def leaves(dtype):
+        return [None if v is None else v.to(dtype).requires_grad_() for v in (x0, w0, b0, t0)]
+    x, w, b, t = leaves(th.float64)
+    pre = th.matmul(w, x) + b.view(1, -1, 1)
+    if tm == 1:
+        pre = pre + t.repeat_interleave(S, 0).unsqueeze(-1)
+    elif tm == 2:
+        pre = pre + t.repeat_interleave(S, 0)
+    ref = pre if act == 0 else th.nn.functional.leaky_relu(pre, slope)
+    g = th.randn(B, cout, hw, device="cuda")
+    # no gradient through pre-activations at the kink: fp32 and fp64 may disagree on their sign
+    g = g * (pre.detach().abs() > 1e-4).float()
+    ref.backward(g.double())
+    x2, w2, b2, t2 = leaves(th.float32)
+    out = F.PointwiseLayer.apply(x2, w2, b2, t2, S, act, slope)
+    out.backward(g)
+    close(out, ref.float(), rtol=1e-5)
+    close(x2.grad, x.grad.float(), rtol=1e-5)
+    close(w2.grad, w.grad.float(), rtol=2e-5)
+    close(b2.grad, b.grad.float(), rtol=2e-5)
+    if tm:
+        close(t2.grad, t.grad.float(), rtol=1e-5)
+
+
 def test_pointwise_chain_as_gemm_matches_convolution():
     """ConvChain(ksize=1) through the batched-GEMM + fused bias/activation path == the nn.Conv2d path."""
     from sbmc_amd import modules
