@@ -302,6 +302,20 @@ SBMC_API int sbmc_pointwise_supported(int cin, int cout, long hw);
 SBMC_API int sbmc_pointwise_fwd_f32(const float *x, const float *w, const float *bias, const float *t,
                            float *y, int b, int s, int cin, int cout, long hw, int t_mode, int act,
                            float slope, void *stream);
+/* Backward of the same layer in one pass over gy, y (the forward output) and x; cout <= 128:
+ *     gz = gy * act'(y);   gx[b] = w^T gz[b]   (gx may be NULL: not computed);
+ *     gw_partial[g] = this workgroup's share of sum_b gz[b] x[b]^T     [groups, cout, cin]
+ *     gb_partial[g] = its share of the row sums of gz                  [groups, nb, cout]
+ *                     (nb = b / s for t_mode 1 -- the per-image context gradient is the sum over g --
+ *                      else 1; the bias gradient is the sum over g and nb)
+ *     gt[b / s]     = sum over the s samples of a pixel of gz          (t_mode 2 only) [b / s, cout, hw]
+ * groups = sbmc_pointwise_bwd_groups(b, s, t_mode, hw); the caller adds the partials up (no atomics).
+ */
+SBMC_API int sbmc_pointwise_bwd_supported(int cin, int cout, long hw);
+SBMC_API int sbmc_pointwise_bwd_groups(int b, int s, int t_mode, long hw);
+SBMC_API int sbmc_pointwise_bwd_f32(const float *gy, const float *y, const float *x, const float *w,
+                           float *gx, float *gw_partial, float *gb_partial, float *gt, int b, int s,
+                           int cin, int cout, long hw, int t_mode, int act, float slope, void *stream);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,9 @@ SYMBOLS = (
     "sbmc_ctx_act_bwd_f32",
     "sbmc_pointwise_supported",
     "sbmc_pointwise_fwd_f32",
+    "sbmc_pointwise_bwd_supported",
+    "sbmc_pointwise_bwd_groups",
+    "sbmc_pointwise_bwd_f32",
 )
 ABI_VERSION = 1
 MAX_CHANNELS = 8
@@ -102,6 +105,9 @@ def lib():
     handle.sbmc_ctx_act_bwd_f32.argtypes = [p, p, p, p, p, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_supported.argtypes = [i, i, ctypes.c_long]
     handle.sbmc_pointwise_fwd_f32.argtypes = [p] * 5 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_pointwise_bwd_supported.argtypes = [i, i, ctypes.c_long]
+    handle.sbmc_pointwise_bwd_groups.argtypes = [i, i, i, ctypes.c_long]
+    handle.sbmc_pointwise_bwd_f32.argtypes = [p] * 8 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t

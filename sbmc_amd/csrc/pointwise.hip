@@ -238,6 +238,279 @@ __global__ __launch_bounds__(PW_THREADS) void pw_fwd_kernel(PwFwdParams p) {
     for (int j = 0; j < 16; ++j) store_prev(j);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of the layer in ONE pass over gy, y and x (cout <= 128):
+//   gz = gy * act'(y)                      (never written to HBM)
+//   gx[b]  = w^T @ gz[b]                    (MFMA, reduction over cout)
+//   gw    += gz[b] @ x[b]^T                 (MFMA, reduction over pixels; per-workgroup partial sums)
+//   gbias += row sums of gz, gt = sum over the samples of a pixel of gz (context term)
+// Tiles of 64 pixels; gz and x tiles live in LDS with a row pitch of 66 words, which makes both the
+// row-wise operand reads (gx) and the column-wise ones (gw: lanes walk rows) conflict-free.
+// Same software pipeline as the forward: next tile's gy / y / x in flight during the MFMAs, the
+// previous tile's gx stored between them.
+constexpr int PB_NT = 64;
+constexpr int PB_PITCH = 66;
+
+struct PwBwdParams {
+    const float* gy;     // [B, Cout, hw]
+    const float* y;      // [B, Cout, hw] (forward output; unused when linear)
+    const float* x;      // [B, K, hw]
+    const float* w;      // [Cout, K]
+    float* gx;           // [B, K, hw] or nullptr
+    float* gwp;          // [G, Cout, K] per-workgroup partial sums of gw
+    float* gbp;          // [G, Bq, Cout] per-workgroup partial sums of gbias (zeroed by the host)
+    float* gt;           // [B/S, Cout, hw] (t_mode 2) or nullptr
+    int B, S, K, Cout, Bq;
+    unsigned hw, tiles_per_plane, nunits;
+    int t_mode;
+    float slope;
+};
+
+template <int KP, bool DX, bool TPIX>
+__global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
+    extern __shared__ float4 pw_lds[];
+    float* lds = reinterpret_cast<float*>(pw_lds);
+    constexpr int BUF = (128 + KP) * PB_PITCH;          // floats per pipeline stage: gz tile, then x tile
+    constexpr int NB = KP / 32;                         // 32-column blocks of gw
+    constexpr int NX = KP / 32;                         // staging passes of the x tile
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int rb = wave & 3, ph = wave >> 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const unsigned hw = p.hw;
+    const unsigned g = blockIdx.x, G = gridDim.x;
+    const bool masked = p.slope != 1.f;
+
+    // staging role: float4 column c4 of rows (threadIdx.x >> 4) + 32 i
+    const unsigned c4 = (threadIdx.x & 15) * 4, srow = threadIdx.x >> 4;
+
+    // w^T rows of this wave as MFMA A-operands for gx: a2[kk] = w[2 kk + lane / 32][32 rb + lane % 32]
+    float a2[DX ? 64 : 1];
+    if (DX) {
+        const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
+        const int k = rb * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) {
+            const int co = 2 * kk + lhi;
+            a2[kk] = buf_load(rw, (co < p.Cout && k < p.K) ? (unsigned)(co * p.K + k) * 4u : PW_OOB, 0);
+        }
+    }
+
+    struct Cursor { unsigned unit, s; };
+    auto coords = [&](Cursor c, unsigned& b, unsigned& bq, unsigned& p0) {
+        bq = c.unit / p.tiles_per_plane;
+        p0 = (c.unit % p.tiles_per_plane) * PB_NT;
+        b = bq * (unsigned)p.S + c.s;
+    };
+    auto advance = [&](Cursor c) {
+        Cursor n;
+        n.s = c.s + 1;
+        n.unit = c.unit;
+        if (n.s == (unsigned)p.S) {
+            n.s = 0;
+            n.unit = c.unit + G;
+        }
+        return n;
+    };
+
+    u32x4 pg[4], py[4], px[NX];
+    auto issue = [&](Cursor c) {
+        unsigned b, bq, p0;
+        coords(c, b, bq, p0);
+        const rsrc_t rg = make_rsrc_n(p.gy + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
+        const rsrc_t ry = make_rsrc_n(p.y + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
+        const rsrc_t rx = make_rsrc_n(p.x + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
+        const bool colok = p0 + c4 < hw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned r = srow + 32u * i;
+            const unsigned off = (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB;
+            pg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
+            if (masked) py[i] = __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const unsigned r = srow + 32u * i;
+            const unsigned off = (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * 4u : PW_OOB;
+            px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+        }
+    };
+
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // row sums of gz (rows srow + 32 i)
+    float4 gts[TPIX ? 4 : 1];                           // sum over the samples of a pixel of gz
+    if (TPIX) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gts[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto flush_bias = [&](unsigned bq) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = bsum[i];
+            v += __shfl_xor(v, 8, 16);
+            v += __shfl_xor(v, 4, 16);
+            v += __shfl_xor(v, 2, 16);
+            v += __shfl_xor(v, 1, 16);
+            const unsigned r = srow + 32u * i;
+            if ((threadIdx.x & 15) == 0 && r < (unsigned)p.Cout)
+                p.gbp[((size_t)g * p.Bq + bq) * p.Cout + r] += v;     // this workgroup's own slice
+            bsum[i] = 0.f;
+        }
+    };
+    // registers -> LDS stage `buf`: gz = gy * act'(y) and x; side sums
+    auto commit = [&](Cursor c, int buf) {
+        unsigned b, bq, p0;
+        coords(c, b, bq, p0);
+        float* gzs = lds + buf * BUF;
+        float* xst = gzs + 128 * PB_PITCH;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 gv = __builtin_bit_cast(float4, pg[i]);
+            if (masked) {
+                const float4 v = __builtin_bit_cast(float4, py[i]);
+                gv.x = v.x > 0.f ? gv.x : gv.x * p.slope;
+                gv.y = v.y > 0.f ? gv.y : gv.y * p.slope;
+                gv.z = v.z > 0.f ? gv.z : gv.z * p.slope;
+                gv.w = v.w > 0.f ? gv.w : gv.w * p.slope;
+            }
+            bsum[i] += (gv.x + gv.y) + (gv.z + gv.w);
+            if (TPIX) {
+                gts[i].x += gv.x; gts[i].y += gv.y; gts[i].z += gv.z; gts[i].w += gv.w;
+            }
+            float2* d = reinterpret_cast<float2*>(gzs + (srow + 32 * i) * PB_PITCH + c4);
+            d[0] = make_float2(gv.x, gv.y);
+            d[1] = make_float2(gv.z, gv.w);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const float4 xv = __builtin_bit_cast(float4, px[i]);
+            float2* d = reinterpret_cast<float2*>(xst + (srow + 32 * i) * PB_PITCH + c4);
+            d[0] = make_float2(xv.x, xv.y);
+            d[1] = make_float2(xv.z, xv.w);
+        }
+        if (c.s + 1 == (unsigned)p.S) {                 // last sample of this pixel tile
+            if (TPIX) {
+                const rsrc_t rt = make_rsrc_n(p.gt + (size_t)bq * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned r = srow + 32u * i;
+                    const unsigned off = (p0 + c4 < hw && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gts[i]), rt, off, 0, 0);
+                    gts[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (p.t_mode == 1) flush_bias(bq);
+        }
+    };
+
+    Cursor cur;
+    cur.unit = g;
+    cur.s = 0;
+    bool valid = cur.unit < p.nunits;
+    if (valid) {
+        issue(cur);
+        commit(cur, 0);
+    }
+    __syncthreads();
+
+    f32x16 acc_w[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc_w[0][j] = acc_w[1][j] = 0.f;
+
+    // gx of the previous step, waiting to be stored
+    f32x16 out;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out[j] = 0.f;
+    unsigned b_prev = 0, o_prev = PW_OOB;
+    const int kr0 = rb * 32;
+    const int nkrows = p.K - kr0 < 32 ? (p.K - kr0 > 0 ? p.K - kr0 : 0) : 32;
+    auto store_prev = [&](int j) {
+        const rsrc_t rgx = make_rsrc_n(p.gx + ((size_t)b_prev * p.K + kr0) * hw, (unsigned)nkrows * hw * 4u);
+        const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
+        buf_store(out[j], rgx, o_prev != PW_OOB ? o_prev + ro : PW_OOB, 0);
+    };
+
+    int buf = 0;
+    while (valid) {
+        const Cursor nxt = advance(cur);
+        const bool nvalid = nxt.unit < p.nunits;
+        if (nvalid) issue(nxt);
+
+        unsigned b, bq, p0;
+        coords(cur, b, bq, p0);
+        const float* gzs = lds + buf * BUF;
+        const float* xst = gzs + 128 * PB_PITCH;
+
+        // ---- gx tile: rows 32 rb .. of K, pixels 32 ph ..; reduction over cout
+        f32x16 acc_x;
+        if (DX) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc_x[j] = 0.f;
+            const float* gb = gzs + lhi * PB_PITCH + ph * 32 + l31;
+#pragma unroll
+            for (int grp = 0; grp < 8; ++grp) {
+#pragma unroll
+                for (int kk = grp * 8; kk < grp * 8 + 8; ++kk)
+                    acc_x = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk], gb[(2 * kk) * PB_PITCH], acc_x, 0, 0, 0);
+                store_prev(2 * grp);
+                store_prev(2 * grp + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- gw: rows 32 rb .. of cout, column blocks 2 ph, 2 ph + 1 of K; reduction over the 64 pixels
+        {
+            const float* ga = gzs + (rb * 32 + l31) * PB_PITCH + lhi;
+            const float* xb0 = xst + ((2 * ph) * 32 + l31) * PB_PITCH + lhi;
+            const float* xb1 = xst + ((2 * ph + 1) * 32 + l31) * PB_PITCH + lhi;
+            const bool two = 2 * ph + 1 < NB;
+            if (2 * ph < NB) {
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+#pragma unroll
+                    for (int kk = grp * 8; kk < grp * 8 + 8; ++kk) {
+                        const float av = ga[2 * kk];
+                        acc_w[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb0[2 * kk], acc_w[0], 0, 0, 0);
+                        if (two) acc_w[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb1[2 * kk], acc_w[1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (DX) {
+            const unsigned col = p0 + ph * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) out[j] = acc_x[j];
+            b_prev = __builtin_amdgcn_readfirstlane(b);
+            o_prev = (col < hw && nkrows > 0) ? (4u * lhi * hw + col) * 4u : PW_OOB;
+        }
+
+        if (nvalid) commit(nxt, buf ^ 1);
+        __syncthreads();
+        cur = nxt;
+        valid = nvalid;
+        buf ^= 1;
+    }
+    if (DX) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) store_prev(j);
+    }
+    if (p.t_mode != 1) flush_bias(0);
+
+    // ---- this workgroup's partial gw
+    {
+        const int r0 = rb * 32;
+        const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
+        const rsrc_t rgw = make_rsrc_n(p.gwp + ((size_t)g * p.Cout + r0) * p.K, (unsigned)(nrows * p.K) * 4u);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = (2 * ph + n) * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rl = (j & 3) + 8 * (j >> 2) + 4 * lhi;
+                buf_store(acc_w[n][j], rgw, (col < p.K && nrows > 0) ? (unsigned)(rl * p.K + col) * 4u : PW_OOB, 0);
+            }
+        }
+    }
+}
+
 static bool pw_dims_ok(int cin, int cout, long hw) {
     if (cin < 1 || cin > 128 || cout < 1 || hw < 4 || hw % 4) return false;
     const int kp = (cin + 31) / 32 * 32;
@@ -296,6 +569,74 @@ extern "C" int sbmc_pointwise_fwd_f32(const float* x, const float* w, const floa
         default: SBMC_PW_LAUNCH(128); break;
     }
 #undef SBMC_PW_LAUNCH
+    if (e != hipSuccess) return (int)e;
+    return (int)hipGetLastError();
+}
+
+static unsigned pw_bwd_grid(int b, int s, long hw, unsigned* nunits_out) {
+    const unsigned tpp = (unsigned)((hw + PB_NT - 1) / PB_NT);
+    const unsigned long long nunits = (unsigned long long)tpp * (unsigned)(b / s);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    if (nunits_out) *nunits_out = (unsigned)nunits;
+    return nunits < (unsigned long long)cus ? (unsigned)nunits : (unsigned)cus;
+}
+
+extern "C" int sbmc_pointwise_bwd_supported(int cin, int cout, long hw) {
+    return (pw_dims_ok(cin, cout, hw) && cout <= 128 && (double)cout * (double)hw * 4.0 < 4294967000.0) ? 1 : 0;
+}
+
+extern "C" int sbmc_pointwise_bwd_groups(int b, int s, int t_mode, long hw) {
+    if (b <= 0 || s < 1 || hw <= 0) return 1;
+    return (int)pw_bwd_grid(b, t_mode ? s : 1, hw, nullptr);
+}
+
+extern "C" int sbmc_pointwise_bwd_f32(const float* gy, const float* y, const float* x, const float* w, float* gx,
+                                      float* gw_partial, float* gb_partial, float* gt, int b, int s, int cin,
+                                      int cout, long hw, int t_mode, int act, float slope, void* stream) {
+    if (b < 0 || s < 1 || act < 0 || act > 2 || t_mode < 0 || t_mode > 2) return SBMC_HIP_EINVAL;
+    if (b == 0) return 0;
+    if (!sbmc_pointwise_bwd_supported(cin, cout, hw) || b % s || !gy || !x || !w || !gw_partial || !gb_partial ||
+        (act != 0 && !y) || (t_mode == 2 && !gt))
+        return SBMC_HIP_EINVAL;
+    if ((uintptr_t)gy % 16 || (uintptr_t)x % 16 || (act != 0 && (uintptr_t)y % 16) || (t_mode == 2 && (uintptr_t)gt % 16))
+        return SBMC_HIP_EINVAL;
+    PwBwdParams p;
+    p.gy = gy; p.y = act != 0 ? y : gy; p.x = x; p.w = w; p.gx = gx; p.gwp = gw_partial; p.gbp = gb_partial; p.gt = gt;
+    p.B = b; p.S = t_mode ? s : 1; p.K = cin; p.Cout = cout;
+    p.Bq = t_mode == 1 ? b / s : 1;
+    p.hw = (unsigned)hw;
+    p.tiles_per_plane = (unsigned)((hw + PB_NT - 1) / PB_NT);
+    p.t_mode = t_mode;
+    p.slope = act == 0 ? 1.f : (act == 1 ? 0.f : slope);
+    const unsigned grid = pw_bwd_grid(b, p.S, hw, &p.nunits);
+    hipError_t e = hipMemsetAsync(gb_partial, 0, (size_t)grid * p.Bq * cout * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    const int kp = (cin + 31) / 32 * 32;
+    const size_t lds = (size_t)2 * (128 + kp) * PB_PITCH * sizeof(float);
+#define SBMC_PWB_LAUNCH2(KPV, DXV, TPV)                                                                  \
+    do {                                                                                                 \
+        auto kern = pw_bwd_kernel<KPV, DXV, TPV>;                                                        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        if (e == hipSuccess)                                                                             \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(PW_THREADS), lds, (hipStream_t)stream, p);         \
+    } while (0)
+#define SBMC_PWB_LAUNCH(KPV)                                                                             \
+    do {                                                                                                 \
+        if (gx) { if (t_mode == 2) SBMC_PWB_LAUNCH2(KPV, true, true); else SBMC_PWB_LAUNCH2(KPV, true, false); } \
+        else    { if (t_mode == 2) SBMC_PWB_LAUNCH2(KPV, false, true); else SBMC_PWB_LAUNCH2(KPV, false, false); } \
+    } while (0)
+    switch (kp) {
+        case 32: SBMC_PWB_LAUNCH(32); break;
+        case 64: SBMC_PWB_LAUNCH(64); break;
+        case 96: SBMC_PWB_LAUNCH(96); break;
+        default: SBMC_PWB_LAUNCH(128); break;
+    }
+#undef SBMC_PWB_LAUNCH
+#undef SBMC_PWB_LAUNCH2
     if (e != hipSuccess) return (int)e;
     return (int)hipGetLastError();
 }

@@ -372,8 +372,9 @@ class PointwiseLayer(th.autograd.Function):
     constant over the image) or [B/s, cout, hw] (per pixel) -- the context half of a chain's first
     layer, see modules.pointwise_chain_with_context; act: 0 linear, 1 relu, 2 leaky_relu(slope).
     fp32 MFMA kernel csrc/pointwise.hip (exact fp32 products and sums; differs from a library GEMM
-    by summation order).  Backward: one pass for gz = gy * act'(y), the bias gradient and the
-    context gradient (csrc/bias_act.hip), then dx = w^T gz and dw = sum_b gz x^T as GEMMs.
+    by summation order).  Backward, cout <= 128: one fused pass as well (activation adjoint, gx = w^T gz,
+    gw = sum_b gz x^T, bias and context gradients); wider layers: one pass for gz = gy * act'(y) and
+    the bias / context gradients (csrc/bias_act.hip), then the two products as library GEMMs.
     """
 
     @staticmethod
@@ -409,6 +410,26 @@ class PointwiseLayer(th.autograd.Function):
             y = gy                                   # placeholder pointer, never read when linear
         L = _lib.lib()
         dev = gy.device
+        cin = x.shape[1]
+        if L.sbmc_pointwise_bwd_supported(cin, cout, hw):
+            # one pass: activation adjoint, both GEMMs, bias and context gradients
+            groups = L.sbmc_pointwise_bwd_groups(B, s, t_mode, hw)
+            nb = B // s if t_mode == 1 else 1
+            gx = th.empty_like(x) if ctx.needs_input_grad[0] else None
+            gwp = gy.new_empty(groups, cout, cin)
+            gbp = gy.new_empty(groups, nb, cout)
+            gt = gy.new_empty(tshape) if t_mode == 2 else None
+            with th.cuda.device(dev):
+                rc = L.sbmc_pointwise_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(w),
+                                              _lib.ptr(gx) if gx is not None else None, _lib.ptr(gwp),
+                                              _lib.ptr(gbp), _lib.ptr(gt) if gt is not None else None,
+                                              B, s, cin, cout, hw, t_mode, act, slope,
+                                              _lib.current_stream(dev))
+            _lib.check(rc, "pointwise_bwd")
+            per_image = gbp.sum(0)                   # [nb, cout]
+            if t_mode == 1:
+                gt = per_image.view(tshape)
+            return gx, gwp.sum(0), per_image.sum(0), gt, None, None, None
         gz = th.empty_like(gy)
         gt = None
         with th.cuda.device(dev):

@@ -82,3 +82,17 @@ if __name__ == "__main__":
             print("cin %d cout %d: fused %.3f ms (%.1f TFLOP/s, %.2f TB/s) | bmm+BiasAct %.3f ms" % (
                 cin, cout, tf, fl / tf / 1e9, by / tf / 1e9, tl), flush=True)
             del x
+
+if "--bwd" in sys.argv:
+    hw = 1280 * 720
+    for cin, cout, act, needx in [(128, 128, 1, True), (93, 128, 1, False)]:
+        x = th.randn(8, cin, hw, device=dev, requires_grad=needx)
+        w = (th.randn(cout, cin, device=dev) / cin ** 0.5).requires_grad_()
+        bias = th.randn(cout, device=dev, requires_grad=True)
+        y = funcs.PointwiseLayer.apply(x, w, bias, None, 1, act, 0.0)
+        g = th.randn_like(y)
+        tb = timeit(lambda: th.autograd.grad(y, [w, bias] + ([x] if needx else []), g, retain_graph=True))
+        fl = 2.0 * cin * cout * 8 * hw * (2 if needx else 1)
+        by = 4.0 * 8 * hw * (cin + 2 * cout + (cin if needx else 0))
+        print("bwd cin %d cout %d dx=%s: %.3f ms (%.1f TFLOP/s, %.2f TB/s)" % (cin, cout, needx, tb, fl / tb / 1e9, by / tb / 1e9), flush=True)
+        del x, y, g
