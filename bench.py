@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
 
 
 def fwd_bytes_per_pixel(k, c=3):
@@ -276,6 +277,7 @@ def main():
 
     part = sdist.SlabPartition(H, world, rank)
     timings = []
+    model_timings = []
 
     # ---------------------------------------------------------------- main timed region
     if is_model:
@@ -308,6 +310,7 @@ def main():
             def step():
                 runner.train_step(opt, loss_fn, batch)
         dt = timed(step, warmup, steps, timings)
+        model_timings = timings
         del batch
         # rows the splat kernels see on this rank (the slab plus the kernel radius at inner edges)
         local_px = (min(H, part.y1 + pad) - max(0, part.y0 - pad)) * W if world > 1 else H * W
@@ -381,6 +384,22 @@ def main():
                               "avg_ms": round(avg_ms, 4), "alg_bytes": local_px * bpp * nsamp,
                               "GBps": round(local_px * bpp * nsamp / (avg_ms * 1e-3) / 1e9, 1)}
 
+    # the fused 1x1-convolution layers inside the timed model steps (fp32 MFMA kernels)
+    layers = {}
+    for name, a, b in model_timings:
+        if name.startswith("pointwise"):
+            layers.setdefault(name, []).append(a.elapsed_time(b))
+    for name in list(layers):
+        v = layers[name]
+        kind, dims = name.split(" ")[0], name.split(" ")[1]
+        cout, cin = (int(t) for t in dims.split("x"))
+        nprod = 1 if kind.endswith("fwd") or "no gx" in name else 2
+        flop = 2.0 * cin * cout * S * (local_px if world > 1 else H * W) * nprod
+        avg = sum(v) / len(v)
+        layers[name] = {"calls_per_step": len(v) // max(steps, 1), "avg_ms": round(avg, 3),
+                        "TFLOPs": round(flop / (avg * 1e-3) / 1e12, 1),
+                        "frac_of_fp32_mfma_peak": round(flop / (avg * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)}
+
     if rank == 0:
         ms = dt / steps * 1e3
         value = S * H * W / (dt / steps) / 1e6
@@ -411,6 +430,8 @@ def main():
                 res["stages"]["splat_all_samples_fp16_storage"] = stage_f16
         if kern:
             res["kernels"] = kern
+        if layers:
+            res["pointwise_layers"] = layers
         rk = "splat_update_bwd_all" if "splat_update_bwd_all" in kern else "splat_update_bwd"
         if rk in kern:
             kb = kern[rk]

@@ -259,7 +259,8 @@ SBMC_API int sbmc_splat_all_bwd_f16(const float *data, const void *kernels,
  * whose matrix product runs as a batched GEMM on the planar [b, c, hw] activations.
  *   act: 0 linear, 1 relu, 2 leaky_relu(slope)
  *   fwd (in place):  y = act(y + bias[c])
- *   bwd:             gx = gy * act'(y)   (y = the forward OUTPUT; gx may alias gy),
+ *   bwd:             gx = gy * act'(y)   (y = the forward OUTPUT; gx may alias gy -- for act = 0 the
+ *                    aliased call only computes the sums),
  *                    partial[b, c, j] = sum of gx over chunk j of plane (b, c),
  *                    j < sbmc_bias_act_chunks(b, c, hw); the bias gradient is the sum of the
  *                    partials over b and j (done by the caller: no atomics, deterministic)

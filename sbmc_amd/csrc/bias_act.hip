@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
     const float4* g4 = reinterpret_cast<const float4*>(gy + off);
     const float4* y4 = reinterpret_cast<const float4*>(y + off);
     float4* o4 = reinterpret_cast<float4*>(gx + off);
+    const bool store = !(linear && gx == gy);     // linear and in place: gx IS gy, only the sums are needed
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 g = g4[i];
@@ -61,14 +62,14 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
             g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
             g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
         }
-        o4[i] = g;
+        if (store) o4[i] = g;
         acc += (g.x + g.y) + (g.z + g.w);
     }
     if (blockIdx.x == 0) {
         for (size_t i = n4 * 4 + threadIdx.x; i < hw; i += blockDim.x) {
             float g = gy[off + i];
             if (!linear) g = y[off + i] > 0.f ? g : g * slope;
-            gx[off + i] = g;
+            if (store) gx[off + i] = g;
             acc += g;
         }
     }

@@ -23,7 +23,9 @@ namespace sbmc {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int PW_NT = 128;          // pixels per tile
+#ifndef PW_FWD_PH
+#define PW_FWD_PH 2
+#endif
 constexpr int PW_THREADS = 512;     // 8 waves: 4 row blocks of 32 output channels x 2 pixel halves of 64
 constexpr unsigned PW_OOB = 0xFFFFFFF0u;
 #ifndef PW_KGROUP_V
@@ -64,10 +66,11 @@ struct PwFwdParams {
 // Work assignment: workgroup g works on row tile (g / 8) % nrt of the pixel tiles
 // ((g / 8) / nrt) * 8 + g % 8 + i * (gridDim.x / nrt): the nrt workgroups that read the same
 // input tile sit on the same XCD (g % 8) and walk in step, so the tile comes from HBM once.
-template <int KP, int TMODE>
-__global__ __launch_bounds__(PW_THREADS) void pw_fwd_kernel(PwFwdParams p) {
+template <int KP, int TMODE, int PH>
+__global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
+    constexpr int NT = 64 * PH;                        // pixels per tile
     extern __shared__ float4 pw_lds[];
-    float* xs = reinterpret_cast<float*>(pw_lds);      // [2][KP][PW_NT]
+    float* xs = reinterpret_cast<float*>(pw_lds);      // [2][KP][NT]
     constexpr int KS = KP / 2;                         // MFMA k-steps
     constexpr int NG = KS / PW_KGROUP;                 // scheduling groups per tile
     constexpr int NLD = KP / 16;                       // float4 loads per thread per tile
@@ -83,8 +86,8 @@ __global__ __launch_bounds__(PW_THREADS) void pw_fwd_kernel(PwFwdParams p) {
     const int r0 = rt * 128 + rb * 32;
     const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
 
-    // staging role of this thread: float4 column c4 of rows (threadIdx.x >> 5) + 16 i
-    const unsigned c4 = (threadIdx.x & 31) * 4, srow = threadIdx.x >> 5;
+    // staging role of this thread: float4 column c4 of rows srow + 16 i
+    const unsigned c4 = (threadIdx.x % (NT / 4)) * 4, srow = threadIdx.x / (NT / 4);
 
     auto tile_coords = [&](unsigned tile, unsigned& b, unsigned& bq, unsigned& p0) {
         // samples of one pixel tile are adjacent in the walk: their context tile stays in L2
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_fwd_kernel(PwFwdParams p) {
         const unsigned pt = rest % p.tiles_per_plane;
         bq = rest / p.tiles_per_plane;
         b = bq * (unsigned)p.S + s;
-        p0 = pt * PW_NT;
+        p0 = pt * NT;
     };
     auto issue_loads = [&](unsigned tile, u32x4 (&regs)[NLD]) {
         unsigned b, bq, p0;
@@ -107,10 +110,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_fwd_kernel(PwFwdParams p) {
         }
     };
     auto commit = [&](int buf, const u32x4 (&regs)[NLD]) {
-        float* dst = xs + buf * (KP * PW_NT);
+        float* dst = xs + buf * (KP * NT);
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            *reinterpret_cast<u32x4*>(dst + (srow + 16 * i) * PW_NT + c4) = regs[i];
+            *reinterpret_cast<u32x4*>(dst + (srow + 16 * i) * NT + c4) = regs[i];
     };
 
     // weight rows of this wave as MFMA A-operands: a[kk] = W[r0 + lane % 32][2 kk + lane / 32]
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_fwd_kernel(PwFwdParams p) {
             }
         }
 
-        const float* xb = xs + buf * (KP * PW_NT) + lhi * PW_NT + ph * 64 + l31;
+        const float* xb = xs + buf * (KP * NT) + lhi * NT + ph * 64 + l31;
 #pragma unroll
         for (int grp = 0; grp < NG; ++grp) {
 #pragma unroll
@@ -198,8 +201,8 @@ __global__ __launch_bounds__(PW_THREADS) void pw_fwd_kernel(PwFwdParams p) {
 #ifdef PW_EXP_NOLDS
                 const float b0 = a[(kk + 1) % KS], b1 = a[(kk + 2) % KS];
 #else
-                const float b0 = xb[(2 * kk) * PW_NT];
-                const float b1 = xb[(2 * kk) * PW_NT + 32];
+                const float b0 = xb[(2 * kk) * NT];
+                const float b1 = xb[(2 * kk) * NT + 32];
 #endif
 #ifndef PW_EXP_NOMFMA
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b0, acc0, 0, 0, 0);
@@ -534,7 +537,9 @@ extern "C" int sbmc_pointwise_fwd_f32(const float* x, const float* w, const floa
     p.x = x; p.w = w; p.bias = bias; p.t = t; p.y = y;
     p.B = b; p.S = t_mode ? s : 1; p.K = cin; p.Cout = cout;
     p.hw = (unsigned)hw;
-    p.tiles_per_plane = (unsigned)((hw + PW_NT - 1) / PW_NT);
+    const int ph = PW_FWD_PH;
+    const int ntile = 64 * ph;
+    p.tiles_per_plane = (unsigned)((hw + ntile - 1) / ntile);
     const unsigned long long nt = (unsigned long long)p.tiles_per_plane * (unsigned)b;
     if (nt > 0xFFFFFFFFull - 4096) return SBMC_HIP_EINVAL;
     p.ntiles = (unsigned)nt;
@@ -546,21 +551,22 @@ extern "C" int sbmc_pointwise_fwd_f32(const float* x, const float* w, const floa
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         cus = 256;
     const int kp = (cin + 31) / 32 * 32;
-    const size_t lds = (size_t)2 * kp * PW_NT * sizeof(float);
+    const size_t lds = (size_t)2 * kp * ntile * sizeof(float);
     // a multiple of 8 * nrt workgroups (see the kernel's work assignment), no more than there is work
     unsigned unit = (unsigned)(NUM_XCD * p.nrt);
-    unsigned grid = (unsigned)cus / unit * unit;
+    unsigned grid = (unsigned)(cus * (3 - ph)) / unit * unit;
     const unsigned long long need = ((unsigned long long)p.ntiles + NUM_XCD - 1) / NUM_XCD * unit;
     if (grid > need) grid = (unsigned)need;
     if (grid < unit) grid = unit;
     hipError_t e = hipSuccess;
 #define SBMC_PW_LAUNCH(KPV)                                                                              \
     do {                                                                                                 \
-        auto kern = t_mode == 2 ? pw_fwd_kernel<KPV, 2> : (t_mode == 1 ? pw_fwd_kernel<KPV, 1> : pw_fwd_kernel<KPV, 0>); \
+        auto kern = t_mode == 2 ? pw_fwd_kernel<KPV, 2, PW_FWD_PH>                                        \
+                                : (t_mode == 1 ? pw_fwd_kernel<KPV, 1, PW_FWD_PH> : pw_fwd_kernel<KPV, 0, PW_FWD_PH>); \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
         if (e == hipSuccess)                                                                             \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(PW_THREADS), lds, (hipStream_t)stream, p);         \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * PW_FWD_PH), lds, (hipStream_t)stream, p);    \
     } while (0)
     switch (kp) {
         case 32: SBMC_PW_LAUNCH(32); break;

@@ -390,7 +390,7 @@ class PointwiseLayer(th.autograd.Function):
             t_mode = 2 if (t.dim() == 3 and t.shape[2] == hw and hw > 1) else 1
         y = x.new_empty(B, cout, hw)
         dev = x.device
-        with th.cuda.device(dev):
+        with th.cuda.device(dev), _timed("pointwise_fwd %dx%d" % (cout, cin), dev):
             rc = _lib.lib().sbmc_pointwise_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
                                                    _lib.ptr(t) if t is not None else None, _lib.ptr(y),
                                                    B, s, cin, cout, hw, t_mode, act, slope,
@@ -419,7 +419,7 @@ class PointwiseLayer(th.autograd.Function):
             gwp = gy.new_empty(groups, cout, cin)
             gbp = gy.new_empty(groups, nb, cout)
             gt = gy.new_empty(tshape) if t_mode == 2 else None
-            with th.cuda.device(dev):
+            with th.cuda.device(dev), _timed("pointwise_bwd %dx%d%s" % (cout, cin, "" if gx is not None else " (no gx)"), dev):
                 rc = L.sbmc_pointwise_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(w),
                                               _lib.ptr(gx) if gx is not None else None, _lib.ptr(gwp),
                                               _lib.ptr(gbp), _lib.ptr(gt) if gt is not None else None,
@@ -430,7 +430,7 @@ class PointwiseLayer(th.autograd.Function):
             if t_mode == 1:
                 gt = per_image.view(tshape)
             return gx, gwp.sum(0), per_image.sum(0), gt, None, None, None
-        gz = th.empty_like(gy)
+        gz = gy if (act == 0 and t_mode == 0) else th.empty_like(gy)   # linear: gz is gy, only sums needed
         gt = None
         with th.cuda.device(dev):
             if t_mode == 0:
