@@ -136,3 +136,33 @@ def test_4k_bottom_band_against_oracle(oracle):
     close(sr[..., y0 + p:, :], o_sr[..., p:, :])
     close(sw[..., y0 + p:, :], o_sw[..., p:, :])
     close(mw[..., y0 + p:, :], o_mw[..., p:, :])
+
+
+def test_4k_pointwise_layer_indexing():
+    """The fused 1x1 layer at 3840x2160 (32-bit byte offsets up to 4.2 GB per batch element):
+    sampled pixels of the output and of the input gradient against fp64 matmuls, the weight /
+    bias gradients against sums over a pixel subset that carries all of the upstream gradient."""
+    from sbmc_amd import functions as F
+    hw = 3840 * 2160
+    th.manual_seed(77)
+    x = th.randn(1, 128, hw, device="cuda").requires_grad_()
+    w = (th.randn(128, 128, device="cuda") / 128 ** 0.5).requires_grad_()
+    b = th.randn(128, device="cuda").requires_grad_()
+    assert F.pointwise_supported(x, 128)
+    y = F.PointwiseLayer.apply(x, w, b, None, 1, 1, 0.0)
+    # pixels at both ends, around every 2^k boundary that could break the offset arithmetic, and random ones
+    idx = th.cat([th.arange(0, 260), th.arange(hw - 260, hw), th.arange(2 ** 22 - 130, 2 ** 22 + 130),
+                  th.randint(0, hw, (4096,))]).unique().cuda()
+    xs = x.detach()[0][:, idx].double()
+    pre = w.detach().double() @ xs + b.detach().double().view(-1, 1)
+    close(y.detach()[0][:, idx], pre.clamp(min=0).float(), rtol=1e-5)
+    # upstream gradient only on the sampled pixels (and away from the kink)
+    g = th.zeros_like(y)
+    gs = th.randn(128, idx.numel(), device="cuda") * (pre.abs() > 1e-4).float()
+    g[0][:, idx] = gs
+    y.backward(g)
+    gz = gs.double() * (pre > 0).double()
+    close(x.grad[0][:, idx], (w.detach().double().t() @ gz).float(), rtol=1e-5)
+    assert x.grad.abs().sum().item() == pytest.approx(x.grad[0][:, idx].abs().sum().item(), rel=1e-6)
+    close(w.grad, (gz @ xs.t()).float(), rtol=2e-5)
+    close(b.grad, gz.sum(1).float(), rtol=2e-5)

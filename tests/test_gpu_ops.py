@@ -464,7 +464,12 @@ def test_pointwise_chain_as_gemm_matches_convolution():
         xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
         ya = chain(xa)
         chain.pointwise_as_gemm = True
+        from sbmc_amd import functions as F
+        launches = []
+        F.enable_kernel_timing(launches)
         yb = chain(xb)
+        F.enable_kernel_timing(None)
+        assert sum(n.startswith("pointwise_fwd") for n, _, _ in launches) == 3   # the fused MFMA layers ran
         chain.pointwise_as_gemm = False
         close(yb, ya, rtol=1e-5)
         g = th.randn_like(ya)
