@@ -23,15 +23,11 @@ namespace sbmc {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-#ifndef PW_FWD_PH
-#define PW_FWD_PH 2
-#endif
+constexpr int PW_FWD_PH = 2;        // pixel halves per workgroup: 2 = one 8-wave workgroup per CU, 128-pixel tiles
+                                    // (1 = two 4-wave workgroups per CU on 64-pixel tiles: measured equal)
 constexpr int PW_THREADS = 512;     // 8 waves: 4 row blocks of 32 output channels x 2 pixel halves of 64
 constexpr unsigned PW_OOB = 0xFFFFFFF0u;
-#ifndef PW_KGROUP_V
-#define PW_KGROUP_V 8
-#endif
-constexpr int PW_KGROUP = PW_KGROUP_V;   // k-steps per scheduling group
+constexpr int PW_KGROUP = 8;        // k-steps per scheduling group (2 / 4 / 16 measured: no difference)
 
 // Descriptor over [base, base + bytes).  Both are wave-uniform by construction; saying so keeps the
 // descriptor in SGPRs (the compiler otherwise guards every access with a waterfall loop).
@@ -160,9 +156,7 @@ __global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
     int buf = 0;
     for (; tile < p.ntiles; tile += stride, buf ^= 1) {
         const unsigned next = tile + stride;
-#ifndef PW_EXP_NOLOAD
         if (next < p.ntiles) issue_loads(next, pre);
-#endif
 
         unsigned b, bq, p0;
         tile_coords(tile, b, bq, p0);
@@ -198,24 +192,13 @@ __global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
         for (int grp = 0; grp < NG; ++grp) {
 #pragma unroll
             for (int kk = grp * PW_KGROUP; kk < (grp + 1) * PW_KGROUP; ++kk) {
-#ifdef PW_EXP_NOLDS
-                const float b0 = a[(kk + 1) % KS], b1 = a[(kk + 2) % KS];
-#else
                 const float b0 = xb[(2 * kk) * NT];
                 const float b1 = xb[(2 * kk) * NT + 32];
-#endif
-#ifndef PW_EXP_NOMFMA
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b1, acc1, 0, 0, 0);
-#else
-                acc0[kk & 15] += a[kk] * b0;
-                acc1[kk & 15] += a[kk] * b1;
-#endif
             }
-#ifndef PW_EXP_NOSTORE
 #pragma unroll
             for (int j = grp * 16 / NG; j < (grp + 1) * 16 / NG; ++j) store_prev(j);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
 
