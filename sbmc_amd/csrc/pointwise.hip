@@ -254,6 +254,9 @@ struct PwBwdParams {
 
 template <int KP, bool DX, bool TPIX>
 __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
+    // gx of a tile is stored between the MFMAs of the next one; the per-pixel context variant has no
+    // registers left for that (16 more would spill) and stores it right away
+    constexpr bool PIPE = !TPIX;
     extern __shared__ float4 pw_lds[];
     float* lds = reinterpret_cast<float*>(pw_lds);
     constexpr int BUF = (128 + KP) * PB_PITCH;          // floats per pipeline stage: gz tile, then x tile
@@ -436,8 +439,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 #pragma unroll
                 for (int kk = grp * 8; kk < grp * 8 + 8; ++kk)
                     acc_x = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk], gb[(2 * kk) * PB_PITCH], acc_x, 0, 0, 0);
-                store_prev(2 * grp);
-                store_prev(2 * grp + 1);
+                if (PIPE) {
+                    store_prev(2 * grp);
+                    store_prev(2 * grp + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -466,6 +471,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             for (int j = 0; j < 16; ++j) out[j] = acc_x[j];
             b_prev = __builtin_amdgcn_readfirstlane(b);
             o_prev = (col < hw && nkrows > 0) ? (4u * lhi * hw + col) * 4u : PW_OOB;
+            if (!PIPE) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) store_prev(j);
+            }
         }
 
         if (nvalid) commit(nxt, buf ^ 1);
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         valid = nvalid;
         buf ^= 1;
     }
-    if (DX) {
+    if (DX && PIPE) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) store_prev(j);
     }

@@ -96,3 +96,12 @@ if "--bwd" in sys.argv:
         by = 4.0 * 8 * hw * (cin + 2 * cout + (cin if needx else 0))
         print("bwd cin %d cout %d dx=%s: %.3f ms (%.1f TFLOP/s, %.2f TB/s)" % (cin, cout, needx, tb, fl / tb / 1e9, by / tb / 1e9), flush=True)
         del x, y, g
+
+    x = th.randn(8, 128, hw, device=dev, requires_grad=True)
+    w = (th.randn(128, 128, device=dev) / 128 ** 0.5).requires_grad_()
+    bias = th.randn(128, device=dev, requires_grad=True)
+    t = th.randn(1, 128, hw, device=dev, requires_grad=True)
+    y = funcs.PointwiseLayer.apply(x, w, bias, t, 8, 1, 0.0)
+    g = th.randn_like(y)
+    tb = timeit(lambda: th.autograd.grad(y, [w, bias, x, t], g, retain_graph=True))
+    print("bwd 128x128 per-pixel context, 8 samples: %.3f ms" % tb, flush=True)
