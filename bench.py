@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--ksize", type=int, default=21)
+    ap.add_argument("--fp16-activations", action="store_true",
+                    help="infer only, informational (BASELINE configs[4]): run the network under "
+                         "torch.autocast(float16); splat arithmetic stays fp32. Never the fp32 metric.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true")
     return ap.parse_args()
@@ -296,7 +299,7 @@ def main():
                 runner = model
 
             def step():
-                with th.no_grad():
+                with th.no_grad(), th.autocast("cuda", dtype=th.float16, enabled=args.fp16_activations):
                     runner(batch)
         elif world == 1:
             batch = make_model_inputs(H, W, S, device, seed=1234)
@@ -409,7 +412,8 @@ def main():
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f16 activations, f32 splat math" if (infer and args.fp16_activations) else "f32",
+            "data": "synthetic",
             "config": {
                 "workload": "Multisteps(93,3,ksize=%d) forward only (eval, no_grad)" % K if infer else
                             "Multisteps(93,3,ksize=%d) training step: fwd + TonemappedRelativeMSE + bwd "
