@@ -59,6 +59,18 @@ def test_argument_validation_needs_no_gpu():
     assert b"invalid" in lib.sbmc_hip_strerror(-1)
     # empty problems are a no-op, also without a device
     assert lib.sbmc_scatter2gather_f32(None, None, 0, 4, 4, 3, 3, None) == 0
+    # fused 1x1 layers: at most 128 input channels, whole float4s, 32-bit byte offsets per batch element
+    hw = 1280 * 720
+    assert lib.sbmc_pointwise_supported(128, 441, hw) == 1 and lib.sbmc_pointwise_supported(93, 128, hw) == 1
+    assert lib.sbmc_pointwise_supported(129, 128, hw) == 0 and lib.sbmc_pointwise_supported(128, 128, hw + 2) == 0
+    assert lib.sbmc_pointwise_supported(128, 128, 3840 * 2160) == 1
+    assert lib.sbmc_pointwise_supported(128, 128, 2 * 3840 * 2160) == 0
+    assert lib.sbmc_pointwise_bwd_supported(128, 128, hw) == 1 and lib.sbmc_pointwise_bwd_supported(128, 441, hw) == 0
+    assert lib.sbmc_pointwise_fwd_f32(*([None] * 5), 2, 1, 129, 128, 64, 0, 1, 0.0, None) == -1
+    assert lib.sbmc_pointwise_fwd_f32(*([None] * 5), 3, 2, 128, 128, 64, 1, 1, 0.0, None) == -1     # b % s
+    assert lib.sbmc_pointwise_bwd_f32(*([None] * 8), 2, 1, 128, 441, 64, 0, 1, 0.0, None) == -1
+    assert lib.sbmc_pointwise_fwd_f32(*([None] * 5), 0, 1, 128, 128, 64, 0, 1, 0.0, None) == 0
+    assert lib.sbmc_bias_act_chunks(8, 128, hw) >= 1
 
 
 def test_cpu_entry_points_refuse_without_a_registered_backend():
