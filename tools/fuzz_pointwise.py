@@ -1,0 +1,79 @@
+"""Randomised parity sweep of the fused 1x1-convolution layer (csrc/pointwise.hip) against an
+fp64 torch restatement (conv1x1 + context term + bias + activation), forward and backward:
+random batch / sample count / channel counts / pixel counts / context modes / activations.
+
+    python tools/fuzz_pointwise.py [--seconds 120] [--seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from helpers import close  # noqa: E402
+from sbmc_amd import functions as F  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.RandomState(args.seed)
+    t0, n, fused_bwd = time.time(), 0, 0
+    while time.time() - t0 < args.seconds:
+        S = int(rng.choice([1, 1, 2, 3, 8]))
+        B = S * int(rng.choice([1, 1, 2, 3]))
+        cin = int(rng.choice([1, 3, 31, 32, 33, 64, 93, 96, 100, 127, 128]))
+        cout = int(rng.choice([1, 5, 32, 33, 100, 128, 128, 129, 200, 441]))
+        hw = 4 * int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 100, 1000, rng.randint(1, 3000)]))
+        tm = int(rng.choice([0, 0, 1, 2]))
+        act = int(rng.choice([0, 1, 2]))
+        needx = bool(rng.randint(2))
+        slope = float(rng.choice([0.01, 0.2])) if act == 2 else 0.0
+        tag = "B%d S%d cin%d cout%d hw%d t%d act%d dx%d" % (B, S, cin, cout, hw, tm, act, needx)
+        th.manual_seed(int(rng.randint(1 << 30)))
+        x0 = th.randn(B, cin, hw, device="cuda")
+        w0 = th.randn(cout, cin, device="cuda") / max(cin, 1) ** 0.5
+        b0 = th.randn(cout, device="cuda")
+        t0_ = None if tm == 0 else (th.randn(B // S, cout, device="cuda") if tm == 1
+                                    else th.randn(B // S, cout, hw, device="cuda"))
+        try:
+            assert F.pointwise_supported(x0, cout)
+
+            def leaves(dt):
+                return [None if v is None else v.to(dt).requires_grad_(needx or i > 0)
+                        for i, v in enumerate((x0, w0, b0, t0_))]
+            x, w, b, t = leaves(th.float64)
+            pre = th.matmul(w, x) + b.view(1, -1, 1)
+            if tm == 1:
+                pre = pre + t.repeat_interleave(S, 0).unsqueeze(-1)
+            elif tm == 2:
+                pre = pre + t.repeat_interleave(S, 0)
+            ref = pre if act == 0 else th.nn.functional.leaky_relu(pre, slope)
+            g = th.randn(B, cout, hw, device="cuda") * (pre.detach().abs() > 1e-4).float()
+            ref.backward(g.double())
+            x2, w2, b2, t2 = leaves(th.float32)
+            out = F.PointwiseLayer.apply(x2, w2, b2, t2, S, act, slope)
+            out.backward(g)
+            close(out, ref.float(), rtol=1e-5)
+            if needx:
+                close(x2.grad, x.grad.float(), rtol=1e-5)
+            close(w2.grad, w.grad.float(), rtol=3e-5)
+            close(b2.grad, b.grad.float(), rtol=3e-5)
+            if tm:
+                close(t2.grad, t.grad.float(), rtol=1e-5)
+        except Exception:
+            print("FAILED case:", tag, flush=True)
+            raise
+        n += 1
+        fused_bwd += int(cout <= 128)
+    print("fuzz ok: %d random layers (%d with the fused backward) in %.0f s" % (n, fused_bwd, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
