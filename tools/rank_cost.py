@@ -15,6 +15,9 @@ sdist._all_reduce_sum = lambda t, part: t.cuda() if not t.is_cuda else t
 
 dev = th.device("cuda")
 H, W, S, K = 720, 1280, 8, 21
+if "--4k" in sys.argv:                      # BASELINE configs[3]: 3840x2160 (one rank of 8 fits one GPU)
+    sys.argv.remove("--4k")
+    H, W = 2160, 3840
 full = bench.make_model_inputs(H, W, S, dev, seed=1234)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     th.manual_seed(0)
