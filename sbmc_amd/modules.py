@@ -193,9 +193,10 @@ class ConvChain(nn.Module):
         if out_act is not None:
             self.add_module("output_activation", out_act())
 
-    # (The same fusion around MIOpen's 3x3 convolutions -- F.conv2d without bias + BiasAct -- was
-    # measured twice, three interleaved rounds: 624-639 ms/step vs 606 ms/step for torch's
-    # conv-with-bias + activation, so only the 1x1 chains use it.)
+    # (The same fusion around MIOpen's 3x3 convolutions -- F.conv2d without bias + BiasAct -- saves
+    # 10 ms of kernel time per step but costs 17-28 ms of wall clock: the U-net is close to
+    # launch-bound on the host and a Python autograd.Function per convolution opens gaps.  So only
+    # the 1x1 chains, whose kernels are milliseconds long, use fused passes.)
     #: 1x1 / stride-1 convolutions as plain batched GEMMs (rocBLAS / hipBLASLt) on the planar
     #: NCHW activations: y[b] = W @ x[b].  Same arithmetic as the convolution; set per instance
     #: by Multisteps for its per-sample chains.
