@@ -260,8 +260,8 @@ def main():
     def timed(step_fn, nwarm, nsteps, store=None, events_inside=True):
         """Wall time of `nsteps` steps.  `store` collects (name, start, end) HIP-event triples of the
         fused operators: inside the timed steps when `events_inside`, else in two extra, untimed
-        steps -- creating and recording ~50 events per step costs the model workload 25 ms per step
-        of host time it does not have (554 vs 579 ms), which must not leak into `value`."""
+        steps -- the first timing events of a process carry a one-time cost of ~75 ms (measured: 579 vs
+        554 ms per step over 3 timed steps), which must not leak into the model workload's `value`."""
         if os.environ.get("SBMC_BENCH_EVENTS_OUTSIDE"):   # debugging aid: never any event in a timed step
             events_inside = False
         for _ in range(nwarm):
