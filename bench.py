@@ -260,8 +260,10 @@ def main():
     def timed(step_fn, nwarm, nsteps, store=None, events_inside=True):
         """Wall time of `nsteps` steps.  `store` collects (name, start, end) HIP-event triples of the
         fused operators: inside the timed steps when `events_inside`, else in two extra, untimed
-        steps -- the first timing events of a process carry a one-time cost of ~75 ms (measured: 579 vs
-        554 ms per step over 3 timed steps), which must not leak into the model workload's `value`."""
+        steps: with ~50 event pairs per step switched on at the start of the 3 timed model steps they
+        read 579 instead of 554 ms per step (not so when the events are already on during the warm-up,
+        nor in the splat workload -- a start-up effect, not isolated further), which must not leak
+        into the model workload's `value`."""
         if os.environ.get("SBMC_BENCH_EVENTS_OUTSIDE"):   # debugging aid: never any event in a timed step
             events_inside = False
         for _ in range(nwarm):
