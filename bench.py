@@ -25,6 +25,7 @@ Multi-GPU (--gpus N under torch.distributed.run): ONE frame, split along H into 
 all-reduce; splat: every rank splats the samples of its slab extended by the kernel radius.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -269,6 +270,11 @@ def main():
         for _ in range(nwarm):
             step_fn()
         sync()
+        # as interfaces.train does after its first step: what is alive now stays alive, keep the
+        # cyclic collector from walking it (a full collection costs ~50 ms of host time here and
+        # lands right after a step's loss.item() sync, where the GPU waits for the host)
+        gc.collect()
+        gc.freeze()
         functions.enable_kernel_timing(store if events_inside else None)
         t0 = time.perf_counter()
         for i in range(nsteps):

@@ -7,6 +7,7 @@ sbmc/interfaces.py:35-132 (Adam(lr), TonemappedRelativeMSE, non-finite guard, gr
 relies on are not in its tree, so minimal stand-ins live here: `TilesDataset` (over
 `sbmc_amd.binio`), `Checkpointer` (plain torch.save) and `train` (the epoch loop).
 """
+import gc
 import glob
 import logging
 import os
@@ -154,11 +155,21 @@ class Checkpointer(object):
 def train(interface, dataloader, num_epochs=1, val_dataloader=None, checkpointer=None,
           start_epoch=0, log_every=10):
     history = []
+    frozen = False
     for epoch in range(start_epoch, num_epochs):
         interface.model.train(True)
         for it, batch in enumerate(dataloader):
             stats = interface.backward(batch, interface.forward(batch))
             history.append(stats)
+            if not frozen:
+                # everything alive after the first step (modules, parameters, optimizer state, the
+                # MIOpen / HIP runtime's Python side) stays for the whole run: take it out of the
+                # cyclic collector's reach, so that a full collection -- 50 ms of host time with a
+                # model of this size, which lands right after the step's loss.item() sync where
+                # the GPU is waiting for the host -- only ever walks the objects of a few steps
+                gc.collect()
+                gc.freeze()
+                frozen = True
             if it % log_every == 0:
                 LOG.info("epoch %d it %d loss %.5f rmse %.5f", epoch, it, stats["loss"], stats["rmse"])
         if val_dataloader is not None:
@@ -172,4 +183,6 @@ def train(interface, dataloader, num_epochs=1, val_dataloader=None, checkpointer
             checkpointer.save("epoch_%04d" % epoch, epoch + 1)
     if checkpointer is not None:
         checkpointer.save("training_end", num_epochs)
+    if frozen:
+        gc.unfreeze()
     return history

@@ -46,6 +46,8 @@ class Multisteps(nn.Module):
         pointwise_gemm(bool): on GPU tensors run the per-sample 1x1 ConvChains as batched GEMMs
             (rocBLAS / hipBLASLt) instead of MIOpen convolutions: same arithmetic, no layout
             change, ~7% faster training step at 720p.  Not a reference argument.
+            The same switch makes the U-nets run their 3x3 convolutions without bias followed by
+            one fused in-place bias / activation pass per direction (functions.BiasAct).
             (NHWC activations for the U-nets were measured too: MIOpen's heuristic solver
             choice for NHWC fp32 made the step 5x slower, so the backbone stays NCHW.)
     """
@@ -90,6 +92,10 @@ class Multisteps(nn.Module):
             self.kernel_regressor.pointwise_as_gemm = True
             for step in range(nsteps):
                 getattr(self, "embedding_{:02d}".format(step)).pointwise_as_gemm = True
+                # U-nets: MIOpen convolution + one fused bias / activation pass per direction
+                for m in getattr(self, "propagation_{:02d}".format(step)).modules():
+                    if isinstance(m, ops.ConvChain):
+                        m.fuse_bias_act = True
 
     def _embed(self, module, per_sample, per_pixel):
         """Runs a 1x1 ConvChain on cat(per_sample[:, s], per_pixel) for every sample s.

@@ -193,17 +193,35 @@ class ConvChain(nn.Module):
         if out_act is not None:
             self.add_module("output_activation", out_act())
 
-    # (The same fusion around MIOpen's 3x3 convolutions -- F.conv2d without bias + BiasAct -- saves
-    # 10 ms of kernel time per step but costs 17-28 ms of wall clock: the U-net is close to
-    # launch-bound on the host and a Python autograd.Function per convolution opens gaps.  So only
-    # the 1x1 chains, whose kernels are milliseconds long, use fused passes.)
     #: 1x1 / stride-1 convolutions as plain batched GEMMs (rocBLAS / hipBLASLt) on the planar
     #: NCHW activations: y[b] = W @ x[b].  Same arithmetic as the convolution; set per instance
     #: by Multisteps for its per-sample chains.
     pointwise_as_gemm = False
+    #: spatial convolutions without bias + ONE fused in-place bias / activation pass per direction
+    #: (functions.BiasAct) instead of torch's separate bias add, activation, activation backward and
+    #: bias-gradient reduction; set per instance by Multisteps for its U-nets.
+    fuse_bias_act = False
 
     def forward(self, x):
         return self._run(list(self.children()), x)
+
+    @staticmethod
+    def _conv_bias_act(conv, x, activation):
+        """conv(x) without bias, then bias + activation by the fused pass.  Returns (y, activation
+        was applied), or (None, False) when the fused pass does not apply."""
+        if (conv.bias is None or conv.padding_mode != "zeros" or not isinstance(conv.padding, tuple)
+                or th.is_autocast_enabled()):
+            return None, False
+        w = th._weight_norm(conv.weight_v, conv.weight_g, 0) if hasattr(conv, "weight_g") else conv.weight
+        act, slope = 0, 0.0
+        if isinstance(activation, nn.ReLU):
+            act = 1
+        elif isinstance(activation, nn.LeakyReLU):
+            act, slope = 2, float(activation.negative_slope)
+        y = th.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if not funcs.BiasAct.supported(y):
+            return None, False
+        return funcs.BiasAct.apply(y, conv.bias, act, slope), act != 0
 
     def _run(self, mods, x):
         gemm = self.pointwise_as_gemm and x.is_cuda
@@ -221,6 +239,20 @@ class ConvChain(nn.Module):
                 x, fused = _pointwise_gemm(m, x, nxt)
                 if fused:
                     i += 1
+            elif (self.fuse_bias_act and x.is_cuda and x.dtype == th.float32
+                  and isinstance(m, ConvChain._ConvBNRelu) and len(m.layer) == 2
+                  and isinstance(m.layer[0], nn.Conv2d)):
+                y, fused = ConvChain._conv_bias_act(m.layer[0], x, m.layer[1])
+                x = m(x) if y is None else (y if fused else m.layer[1](y))
+            elif self.fuse_bias_act and x.is_cuda and x.dtype == th.float32 and isinstance(m, nn.Conv2d):
+                nxt = mods[i] if i < len(mods) else None
+                y, fused = ConvChain._conv_bias_act(m, x, nxt)
+                if y is None:
+                    x = m(x)
+                else:
+                    x = y
+                    if fused:
+                        i += 1
             else:
                 x = m(x)
         return x

@@ -12,6 +12,11 @@ dev = th.device("cuda")
 th.manual_seed(0)
 model = Multisteps(93, 3, ksize=21, pointwise_gemm="--nogemm1x1" not in sys.argv).to(dev)
 model.train()
+if "--nofuseconv" in sys.argv:
+    from sbmc_amd import modules
+    for m in model.modules():
+        if isinstance(m, modules.ConvChain):
+            m.fuse_bias_act = False
 opt = th.optim.Adam(model.parameters(), lr=1e-4, fused="--fusedadam" in sys.argv)
 loss_fn = losses.TonemappedRelativeMSE()
 batch = bench.make_model_inputs(720, 1280, 8, dev, seed=1234)
@@ -19,11 +24,17 @@ def step():
     bench.train_step(model, opt, loss_fn, batch)
 for i in range(2):
     t0 = time.time(); step(); th.cuda.synchronize(); print("warm", i, time.time() - t0, flush=True)
+import gc
+if "--gcfreeze" in sys.argv:
+    gc.collect(); gc.freeze()
+if "--gcoff" in sys.argv:
+    gc.collect(); gc.disable()
+_g0 = [g["collections"] for g in gc.get_stats()]
 t0 = time.time()
 for i in range(3):
     step()
 th.cuda.synchronize()
-print("ms/step", (time.time() - t0) / 3 * 1e3, "cfg", sys.argv[1:], "mem GB", th.cuda.max_memory_allocated() / 1e9, flush=True)
+print("ms/step", (time.time() - t0) / 3 * 1e3, "cfg", sys.argv[1:], "gc", [b["collections"] - a for a, b in zip(_g0, gc.get_stats())], flush=True)
 if "--graph" in sys.argv:
     from sbmc_amd.utils import crop_like
     opt = th.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
