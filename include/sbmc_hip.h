@@ -318,6 +318,20 @@ SBMC_API int sbmc_pointwise_bwd_f32(const float *gy, const float *y, const float
                            float *gx, float *gw_partial, float *gb_partial, float *gt, int b, int s,
                            int cin, int cout, long hw, int t_mode, int act, float slope, void *stream);
 
+/* ---- the U-net's up path: bilinear x2 upsampling + channel concatenation in one pass ---------
+ * Reference sbmc/modules.py:300-320: F.interpolate(coarse, scale 2, "bilinear", align_corners=False)
+ * followed by th.cat([up, left], 1).
+ *   fwd: out[b, :cu] = upsample(coarse[b]), out[b, cu:] = left[b]
+ *        coarse [b, cu, h, w], left [b, cl, 2h, 2w], out [b, cu + cl, 2h, 2w]; w even
+ *   bwd: gcoarse = adjoint of the upsampling applied to gout[:, :cu] (a gather: no atomics);
+ *        the gradient of `left` is the channel slice gout[:, cu:] itself
+ */
+SBMC_API int sbmc_upsample2x_cat_supported(int h, int w);
+SBMC_API int sbmc_upsample2x_cat_fwd_f32(const float *coarse, const float *left, float *out, int b,
+                                int cu, int cl, int h, int w, void *stream);
+SBMC_API int sbmc_upsample2x_cat_bwd_f32(const float *gout, float *gcoarse, int b, int cu, int cl,
+                                int h, int w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,9 @@ SYMBOLS = (
     "sbmc_pointwise_bwd_supported",
     "sbmc_pointwise_bwd_groups",
     "sbmc_pointwise_bwd_f32",
+    "sbmc_upsample2x_cat_supported",
+    "sbmc_upsample2x_cat_fwd_f32",
+    "sbmc_upsample2x_cat_bwd_f32",
 )
 ABI_VERSION = 1
 MAX_CHANNELS = 8
@@ -108,6 +111,9 @@ def lib():
     handle.sbmc_pointwise_bwd_supported.argtypes = [i, i, ctypes.c_long]
     handle.sbmc_pointwise_bwd_groups.argtypes = [i, i, i, ctypes.c_long]
     handle.sbmc_pointwise_bwd_f32.argtypes = [p] * 8 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_upsample2x_cat_supported.argtypes = [i, i]
+    handle.sbmc_upsample2x_cat_fwd_f32.argtypes = [p, p, p, i, i, i, i, i, p]
+    handle.sbmc_upsample2x_cat_bwd_f32.argtypes = [p, p, i, i, i, i, i, p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t

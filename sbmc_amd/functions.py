@@ -457,6 +457,50 @@ class PointwiseLayer(th.autograd.Function):
         return gx, gw, gbias, gt, None, None, None
 
 
+def upsample_cat_supported(coarse, left):
+    """True when `UpsampleCat` applies: fp32 GPU tensors, `left` exactly twice the size of `coarse`."""
+    return (coarse.is_cuda and left.is_cuda and coarse.dtype == th.float32 and left.dtype == th.float32
+            and coarse.dim() == 4 and left.dim() == 4 and coarse.shape[0] == left.shape[0]
+            and left.shape[2] == 2 * coarse.shape[2] and left.shape[3] == 2 * coarse.shape[3]
+            and coarse.numel() > 0 and not th.is_autocast_enabled()
+            and bool(_lib.lib().sbmc_upsample2x_cat_supported(coarse.shape[2], coarse.shape[3])))
+
+
+class UpsampleCat(th.autograd.Function):
+    """th.cat([F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=False), left], 1)
+    in one pass (csrc/resample.hip); backward: a gather for the upsampling adjoint (PyTorch scatters
+    with atomics), the gradient of `left` is a channel slice of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, coarse, left):
+        coarse = coarse.contiguous()
+        left = left.contiguous()
+        b, cu, h, w = coarse.shape
+        cl = left.shape[1]
+        out = coarse.new_empty(b, cu + cl, 2 * h, 2 * w)
+        dev = coarse.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_upsample2x_cat_fwd_f32(_lib.ptr(coarse), _lib.ptr(left), _lib.ptr(out),
+                                                        b, cu, cl, h, w, _lib.current_stream(dev))
+        _lib.check(rc, "upsample2x_cat_fwd")
+        ctx.dims = (b, cu, cl, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, cu, cl, h, w = ctx.dims
+        g = g.contiguous()
+        gcoarse = None
+        if ctx.needs_input_grad[0]:
+            gcoarse = g.new_empty(b, cu, h, w)
+            dev = g.device
+            with th.cuda.device(dev):
+                rc = _lib.lib().sbmc_upsample2x_cat_bwd_f32(_lib.ptr(g), _lib.ptr(gcoarse), b, cu, cl, h, w,
+                                                            _lib.current_stream(dev))
+            _lib.check(rc, "upsample2x_cat_bwd")
+        return gcoarse, (g[:, cu:] if ctx.needs_input_grad[1] else None)
+
+
 def gather_update_supported(data, kernels):
     """True when the fused gather-kernel update (`SplatUpdate(..., gather=True)`) applies."""
     if not (data.is_cuda and kernels.is_cuda) or data.dtype != th.float32 or kernels.dtype != th.float32:

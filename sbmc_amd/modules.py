@@ -359,6 +359,8 @@ class Autoencoder(nn.Module):
             if self.is_last:
                 return left
             coarse = self.next_level(self.downsample(left))
+            if funcs.upsample_cat_supported(coarse, left):
+                return self.right(funcs.UpsampleCat.apply(coarse, left))   # one pass, same values
             up = F.interpolate(coarse, size=left.shape[-2:], mode="bilinear",
                                align_corners=False)
             return self.right(th.cat([up, left], 1))

@@ -591,3 +591,27 @@ def test_fused_gather_running_max_branches(oracle):
         close(a, b)
     for s in range(4):
         close(dd[s], ref_dd[s]); close(dk[s], ref_dk[s], rtol=5e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 2, 1, 2), (2, 5, 3, 7, 10), (1, 16, 8, 45, 64), (3, 4, 0, 6, 4), (1, 2, 2, 1, 6)])
+def test_upsample_cat_kernels(shape):
+    """Bilinear x2 upsampling + concatenation in one pass (csrc/resample.hip) vs
+    F.interpolate + th.cat, forward and backward (gather adjoint vs PyTorch's atomics)."""
+    from sbmc_amd import functions as F
+    import torch.nn.functional as nnf
+    b, cu, cl, h, w = shape
+    th.manual_seed(sum(shape))
+    c0 = th.randn(b, cu, h, w, device="cuda")
+    l0 = th.randn(b, cl, 2 * h, 2 * w, device="cuda")
+    ca, la = c0.clone().requires_grad_(), l0.clone().requires_grad_()
+    ref = th.cat([nnf.interpolate(ca, scale_factor=2, mode="bilinear", align_corners=False), la], 1)
+    g = th.randn_like(ref)
+    ref.backward(g)
+    cb, lb = c0.clone().requires_grad_(), l0.clone().requires_grad_()
+    assert F.upsample_cat_supported(cb, lb)
+    out = F.UpsampleCat.apply(cb, lb)
+    out.backward(g)
+    close(out, ref, rtol=1e-6)
+    close(cb.grad, ca.grad, rtol=1e-5)
+    if cl:
+        assert th.equal(lb.grad, la.grad)
