@@ -65,41 +65,41 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
     }
 }
 
-// one thread: one coarse pixel (i, j) of one (b, c) plane
+// one thread: two adjacent coarse pixels (i, 2q), (i, 2q + 1) of one (b, c) plane: their 4 x 6 fine
+// neighbourhood is one aligned float4 plus one pixel on each side per row
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gcoarse,
-                                                       int cu, int cl, int h, int w, size_t total) {
-    const int W = 2 * w, H = 2 * h;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+                                                       int cu, int cl, int h, int w, size_t total2) {
+    const int W = 2 * w, H = 2 * h, w2 = w / 2;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total2;
          idx += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(idx % w);
-        size_t rest = idx / w;
+        const int q = (int)(idx % w2);
+        size_t rest = idx / w2;
         const int i = (int)(rest % h);
         rest /= h;
         const int c = (int)(rest % cu);
         const size_t b = rest / cu;
         const float* g = gout + ((b * (cu + cl) + c) * H) * (size_t)W;
         // fine rows 2i-1 .. 2i+2 with weights .25 .75 .75 .25; a partner that falls off the image
-        // was clamped to this row in the forward, so its weight comes back here
-        float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+        // was clamped to this row / column in the forward, so its weight comes back here
+        float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f};
         if (i == 0) { wy[0] = 0.f; wy[1] = 1.f; }
         if (i == h - 1) { wy[3] = 0.f; wy[2] = 1.f; }
-        if (j == 0) { wx[0] = 0.f; wx[1] = 1.f; }
-        if (j == w - 1) { wx[3] = 0.f; wx[2] = 1.f; }
-        float acc = 0.f;
+        const bool first = q == 0, last = q == w2 - 1;
+        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy) {
-            const int y = 2 * i - 1 + dy;
             if (wy[dy] == 0.f) continue;
-            const float* row = g + (size_t)y * W;
-            float s = 0.f;
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx) {
-                const int x = 2 * j - 1 + dx;
-                if (wx[dx] != 0.f) s += wx[dx] * row[x];
-            }
-            acc += wy[dy] * s;
+            const float* row = g + (size_t)(2 * i - 1 + dy) * W + 4 * q;
+            const float4 m = *reinterpret_cast<const float4*>(row);       // fine columns 4q .. 4q+3
+            const float lft = first ? 0.f : row[-1], rgt = last ? 0.f : row[4];
+            // coarse column 2q   <- fine 4q-1 (.25), 4q (.75, or 1 at the left edge), 4q+1 (.75), 4q+2 (.25)
+            // coarse column 2q+1 <- fine 4q+1 (.25), 4q+2 (.75), 4q+3 (.75, or 1 at the right edge), 4q+4 (.25)
+            const float s0 = 0.25f * lft + (first ? 1.f : 0.75f) * m.x + 0.75f * m.y + 0.25f * m.z;
+            const float s1 = 0.25f * m.y + 0.75f * m.z + (last ? 1.f : 0.75f) * m.w + 0.25f * rgt;
+            a0 += wy[dy] * s0;
+            a1 += wy[dy] * s1;
         }
-        gcoarse[idx] = acc;
+        *reinterpret_cast<float2*>(gcoarse + ((b * cu + c) * h + i) * (size_t)w + 2 * q) = make_float2(a0, a1);
     }
 }
 
@@ -125,10 +125,10 @@ extern "C" int sbmc_upsample2x_cat_bwd_f32(const float* gout, float* gcoarse, in
                                            void* stream) {
     if (b < 0 || cu < 1 || cl < 0 || !sbmc_upsample2x_cat_supported(h, w)) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
-    if (!gout || !gcoarse) return SBMC_HIP_EINVAL;
-    const size_t total = (size_t)b * cu * h * w;
-    const size_t blocks = (total + 255) / 256;
+    if (!gout || !gcoarse || (uintptr_t)gout % 16 || (uintptr_t)gcoarse % 8) return SBMC_HIP_EINVAL;
+    const size_t total2 = (size_t)b * cu * h * (w / 2);
+    const size_t blocks = (total2 + 255) / 256;
     hipLaunchKernelGGL(upcat_bwd_kernel, dim3((unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16)), dim3(256), 0,
-                       (hipStream_t)stream, gout, gcoarse, cu, cl, h, w, total);
+                       (hipStream_t)stream, gout, gcoarse, cu, cl, h, w, total2);
     return (int)hipGetLastError();
 }

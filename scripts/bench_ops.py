@@ -16,7 +16,8 @@ import torch as th
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sbmc_amd import functions as F, modules  # noqa: E402
 
-PEAK = 8000.0
+PEAK = 8000.0          # GB/s, HBM3E spec
+MFMA_PEAK = 157.3      # TFLOP/s, dense fp32 MFMA
 
 
 def timeit(fn, reps, warm=3):
@@ -85,6 +86,61 @@ def main():
             print(json.dumps({"op": name, "shape": label, "ms": round(ms, 4),
                               "alg_bytes": px * bpp, "GBps": round(gbps, 1),
                               "roofline_frac": round(gbps / PEAK, 4)}))
+        del data, wts, go, gs, out, sw, dd, dw, s2g, kern, kg, dg, st, gst
+        th.cuda.empty_cache()
+    cnn_glue(dev, args.reps)
+
+
+def cnn_glue(dev, reps):
+    """The kernels around the kernel-predicting CNN at 1280x720, 8 samples: fused 1x1 layers (fp32
+    MFMA; flop = 2*cin*cout per output pixel and product), bias/activation passes and the U-net's
+    upsample + concat (HBM-bound)."""
+    hw, B = 1280 * 720, 8
+    label = "720p, 8 samples"
+
+    def emit(name, fn, flop=None, nbytes=None):
+        ms = timeit(fn, reps)
+        rec = {"op": name, "shape": label, "ms": round(ms, 4)}
+        if flop is not None:
+            rec.update(TFLOPs=round(flop / (ms * 1e-3) / 1e12, 1),
+                       frac_of_fp32_mfma_peak=round(flop / (ms * 1e-3) / 1e12 / MFMA_PEAK, 4))
+        if nbytes is not None:
+            rec.update(alg_bytes=nbytes, GBps=round(nbytes / (ms * 1e-3) / 1e9, 1),
+                       roofline_frac=round(nbytes / (ms * 1e-3) / 1e9 / PEAK, 4))
+        print(json.dumps(rec))
+
+    for cin, cout, act in ((128, 128, 1), (128, 441, 0)):
+        x = th.randn(B, cin, hw, device=dev, requires_grad=True)
+        w = (th.randn(cout, cin, device=dev) / cin ** 0.5).requires_grad_()
+        bias = th.randn(cout, device=dev, requires_grad=True)
+        emit("pointwise layer %d->%d fwd (GEMM + bias + act)" % (cin, cout),
+             lambda: F.PointwiseLayer.apply(x.detach(), w.detach(), bias.detach(), None, 1, act, 0.0),
+             flop=2.0 * cin * cout * B * hw, nbytes=4.0 * B * hw * (cin + cout))
+        y = F.PointwiseLayer.apply(x, w, bias, None, 1, act, 0.0)
+        g = th.randn_like(y)
+        emit("pointwise layer %d->%d bwd (gx + gw + gbias)" % (cin, cout),
+             lambda: th.autograd.grad(y, [x, w, bias], g, retain_graph=True),
+             flop=4.0 * cin * cout * B * hw, nbytes=4.0 * B * hw * (2 * cin + (2 if act else 1) * cout))
+        del x, y, g
+        th.cuda.empty_cache()
+    y0 = th.randn(1, 128, 720, 1280, device=dev)
+    bias = th.randn(128, device=dev, requires_grad=True)
+    emit("bias_act fwd [1,128,720,1280] (in place)", lambda: F.BiasAct.apply(y0, bias.detach(), 1, 0.0),
+         nbytes=8.0 * y0.numel())
+    yy = F.BiasAct.apply(y0.clone().requires_grad_() * 1.0, bias, 1, 0.0)
+    g = th.randn_like(yy)
+    emit("bias_act bwd [1,128,720,1280]", lambda: th.autograd.grad(yy, [bias], g, retain_graph=True),
+         nbytes=12.0 * y0.numel())
+    coarse = th.randn(1, 256, 360, 640, device=dev, requires_grad=True)
+    left = th.randn(1, 128, 720, 1280, device=dev, requires_grad=True)
+    emit("upsample x2 + concat fwd (256 + 128 channels at 720p)",
+         lambda: F.UpsampleCat.apply(coarse.detach(), left.detach()),
+         nbytes=4.0 * (coarse.numel() + 2 * left.numel() + 4 * coarse.numel()))
+    out = F.UpsampleCat.apply(coarse, left)
+    g = th.randn_like(out)
+    emit("upsample x2 + concat bwd (gather adjoint)",
+         lambda: th.autograd.grad(out, [coarse], g, retain_graph=True),
+         nbytes=4.0 * (4 * coarse.numel() + coarse.numel()))
 
 
 if __name__ == "__main__":
