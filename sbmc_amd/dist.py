@@ -28,6 +28,7 @@ import torch as th
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from .models import _SampleMean
 from .utils import crop_like
 
 __all__ = ["SlabPartition", "halo_pad", "sharded_autoencoder", "ShardedDenoiser"]
@@ -199,7 +200,7 @@ class ShardedDenoiser(object):
         context = gfeatures
         for step in range(m.nsteps):
             features = m._embed(getattr(m, "embedding_{:02d}".format(step)), features, context)
-            reduced = features.mean(1)
+            reduced = _SampleMean.apply(features)
             context = sharded_autoencoder(getattr(m, "propagation_{:02d}".format(step)), reduced, part)
 
         p = (m.ksize - 1) // 2

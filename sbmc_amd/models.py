@@ -25,6 +25,21 @@ __all__ = ["Multisteps", "KPCN"]
 LOG = logging.getLogger(__name__)
 
 
+class _SampleMean(th.autograd.Function):
+    """features.mean(1) over the sample axis.  Backward hands autograd a broadcast VIEW of g / S
+    (divided on the small tensor) instead of the materialised [bs, S, c, h, w] tensor torch's
+    MeanBackward builds: the sum with the features' other gradient is then one pass, not three."""
+
+    @staticmethod
+    def forward(ctx, features):
+        ctx.shape = features.shape
+        return features.mean(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.shape[1]).unsqueeze(1).expand(ctx.shape)
+
+
 class Multisteps(nn.Module):
     """Sample-based Monte Carlo denoiser [Gharbi 2019].
 
@@ -106,7 +121,9 @@ class Multisteps(nn.Module):
         chunk = self.sample_chunk or spp
         outs = []
         for s0 in range(0, spp, chunk):
-            part = per_sample[:, s0:s0 + chunk]
+            # (no slicing when all samples go at once: SliceBackward would zero-fill and copy
+            # a whole [bs, spp, c, h, w] gradient)
+            part = per_sample if chunk >= spp else per_sample[:, s0:s0 + chunk]
             n = part.shape[1]
             out = None
             if module.pointwise_as_gemm:
@@ -174,7 +191,7 @@ class Multisteps(nn.Module):
         for step in range(self.nsteps):
             features = self._embed(getattr(self, "embedding_{:02d}".format(step)),
                                    features, context)
-            reduced = features.mean(1)
+            reduced = _SampleMean.apply(features)
             context = getattr(self, "propagation_{:02d}".format(step))(reduced)
 
         # -- per-sample kernel prediction + progressive splat ----------------------
