@@ -18,6 +18,12 @@ from helpers import close  # noqa: E402
 from sbmc_amd import functions as F  # noqa: E402
 
 
+def close_sum(a, ref, rtol, atol):
+    err = (a.double() - ref).abs().max().item()
+    bound = rtol * ref.abs().max().item() + atol
+    assert err <= bound, "max err %.3e > %.3e (scale %.3e)" % (err, bound, ref.abs().max().item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -63,9 +69,15 @@ def main():
             close(out, ref.float(), rtol=1e-5)
             if needx:
                 close(x2.grad, x.grad.float(), rtol=1e-5)
-            close(w2.grad, w.grad.float(), rtol=3e-5)
-            close(b2.grad, b.grad.float(), rtol=3e-5)
-            if tm:
+            # weight / bias / per-image context gradients are sums over up to B*hw terms of size
+            # ~|g| |x|: compare them relative to that sum's natural scale sqrt(#terms) as well, or a
+            # [1, 1] gradient that happens to cancel to ~0 fails on fp32 summation noise alone
+            red = (B * hw) ** 0.5
+            close_sum(w2.grad, w.grad, 3e-5, 1e-6 * red)
+            close_sum(b2.grad, b.grad, 3e-5, 1e-6 * red)
+            if tm == 1:
+                close_sum(t2.grad, t.grad, 3e-5, 1e-6 * (S * hw) ** 0.5)
+            elif tm == 2:
                 close(t2.grad, t.grad.float(), rtol=1e-5)
         except Exception:
             print("FAILED case:", tag, flush=True)
