@@ -310,13 +310,18 @@ SBMC_API int sbmc_pointwise_fwd_f32(const float *x, const float *w, const float 
  *                     (nb = b / s for t_mode 1 -- the per-image context gradient is the sum over g --
  *                      else 1; the bias gradient is the sum over g and nb)
  *     gt[b / s]     = sum over the s samples of a pixel of gz          (t_mode 2 only) [b / s, cout, hw]
- * groups = sbmc_pointwise_bwd_groups(b, s, t_mode, hw); the caller adds the partials up (no atomics).
+ * gmean (may be NULL; not with t_mode 2): [b / s_mean, cout, hw], the gradient of the mean of y over
+ * groups of s_mean consecutive batch elements (the per-pixel mean over samples that feeds the U-net):
+ * the kernel then works on gy[b] + gmean[b / s_mean] / s_mean, which saves the pass that would add them.
+ * groups = sbmc_pointwise_bwd_groups(b, s, t_mode, hw) -- with gmean and t_mode 0:
+ * sbmc_pointwise_bwd_groups(b, s_mean, 1, hw); the caller adds the partials up (no atomics).
  */
 SBMC_API int sbmc_pointwise_bwd_supported(int cin, int cout, long hw);
 SBMC_API int sbmc_pointwise_bwd_groups(int b, int s, int t_mode, long hw);
 SBMC_API int sbmc_pointwise_bwd_f32(const float *gy, const float *y, const float *x, const float *w,
-                           float *gx, float *gw_partial, float *gb_partial, float *gt, int b, int s,
-                           int cin, int cout, long hw, int t_mode, int act, float slope, void *stream);
+                           float *gx, float *gw_partial, float *gb_partial, float *gt,
+                           const float *gmean, int s_mean, int b, int s, int cin, int cout, long hw,
+                           int t_mode, int act, float slope, void *stream);
 
 /* ---- the U-net's up path: bilinear x2 upsampling + channel concatenation in one pass ---------
  * Reference sbmc/modules.py:300-320: F.interpolate(coarse, scale 2, "bilinear", align_corners=False)

@@ -110,7 +110,7 @@ def lib():
     handle.sbmc_pointwise_fwd_f32.argtypes = [p] * 5 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_supported.argtypes = [i, i, ctypes.c_long]
     handle.sbmc_pointwise_bwd_groups.argtypes = [i, i, i, ctypes.c_long]
-    handle.sbmc_pointwise_bwd_f32.argtypes = [p] * 8 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_pointwise_bwd_f32.argtypes = [p] * 9 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_upsample2x_cat_supported.argtypes = [i, i]
     handle.sbmc_upsample2x_cat_fwd_f32.argtypes = [p, p, p, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_bwd_f32.argtypes = [p, p, i, i, i, i, i, p]

@@ -247,17 +247,20 @@ struct PwBwdParams {
     float* gwp;          // [G, Cout, K] per-workgroup partial sums of gw
     float* gbp;          // [G, Bq, Cout] per-workgroup partial sums of gbias (zeroed by the host)
     float* gt;           // [B/S, Cout, hw] (t_mode 2) or nullptr
+    const float* gm;     // [B/Sm, Cout, hw] or nullptr: gradient of the mean of y over groups of Sm
+    int Sm;              //   consecutive batch elements; the kernel sees gy + gm[b / Sm] / Sm
     int B, S, K, Cout, Bq;
     unsigned hw, tiles_per_plane, nunits;
     int t_mode;
     float slope;
 };
 
-template <int KP, bool DX, bool TPIX>
+template <int KP, bool DX, bool TPIX, bool GM>
 __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
-    // gx of a tile is stored between the MFMAs of the next one; the per-pixel context variant has no
-    // registers left for that (16 more would spill) and stores it right away
-    constexpr bool PIPE = !TPIX;
+    // gx of a tile is stored between the MFMAs of the next one; the variants that carry 16 more
+    // registers (per-pixel context sums, mean-gradient tile) have none left for that and store it
+    // right away
+    constexpr bool PIPE = !TPIX && !GM;
     extern __shared__ float4 pw_lds[];
     float* lds = reinterpret_cast<float*>(pw_lds);
     constexpr int BUF = (128 + KP) * PB_PITCH;          // floats per pipeline stage: gz tile, then x tile
@@ -302,11 +305,14 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         return n;
     };
 
-    u32x4 pg[4], py[4], px[NX];
+    u32x4 pg[4], py[4], px[NX], pm[GM ? 4 : 1];
+    const float inv_sm = GM ? 1.f / (float)p.Sm : 0.f;
     auto issue = [&](Cursor c) {
         unsigned b, bq, p0;
         coords(c, b, bq, p0);
         const rsrc_t rg = make_rsrc_n(p.gy + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
+        const rsrc_t rm = make_rsrc_n(GM ? p.gm + (size_t)(b / (unsigned)p.Sm) * p.Cout * hw : p.gy,
+                                      (unsigned)p.Cout * hw * 4u);
         const rsrc_t ry = make_rsrc_n(p.y + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
         const rsrc_t rx = make_rsrc_n(p.x + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
         const bool colok = p0 + c4 < hw;
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             const unsigned off = (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB;
             pg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
             if (masked) py[i] = __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0);
+            if (GM) pm[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -354,6 +361,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 gv = __builtin_bit_cast(float4, pg[i]);
+            if (GM) {
+                const float4 m = __builtin_bit_cast(float4, pm[i]);
+                gv.x += m.x * inv_sm; gv.y += m.y * inv_sm; gv.z += m.z * inv_sm; gv.w += m.w * inv_sm;
+            }
             if (masked) {
                 const float4 v = __builtin_bit_cast(float4, py[i]);
                 gv.x = v.x > 0.f ? gv.x : gv.x * p.slope;
@@ -593,18 +604,23 @@ extern "C" int sbmc_pointwise_bwd_groups(int b, int s, int t_mode, long hw) {
 }
 
 extern "C" int sbmc_pointwise_bwd_f32(const float* gy, const float* y, const float* x, const float* w, float* gx,
-                                      float* gw_partial, float* gb_partial, float* gt, int b, int s, int cin,
-                                      int cout, long hw, int t_mode, int act, float slope, void* stream) {
+                                      float* gw_partial, float* gb_partial, float* gt, const float* gmean,
+                                      int s_mean, int b, int s, int cin, int cout, long hw, int t_mode, int act,
+                                      float slope, void* stream) {
     if (b < 0 || s < 1 || act < 0 || act > 2 || t_mode < 0 || t_mode > 2) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!sbmc_pointwise_bwd_supported(cin, cout, hw) || b % s || !gy || !x || !w || !gw_partial || !gb_partial ||
-        (act != 0 && !y) || (t_mode == 2 && !gt))
+        (act != 0 && !y) || (t_mode == 2 && !gt) || (gmean && (s_mean < 1 || b % s_mean || t_mode == 2)))
         return SBMC_HIP_EINVAL;
-    if ((uintptr_t)gy % 16 || (uintptr_t)x % 16 || (act != 0 && (uintptr_t)y % 16) || (t_mode == 2 && (uintptr_t)gt % 16))
+    if ((uintptr_t)gy % 16 || (uintptr_t)x % 16 || (act != 0 && (uintptr_t)y % 16) ||
+        (t_mode == 2 && (uintptr_t)gt % 16) || (uintptr_t)gmean % 16)
         return SBMC_HIP_EINVAL;
     PwBwdParams p;
     p.gy = gy; p.y = act != 0 ? y : gy; p.x = x; p.w = w; p.gx = gx; p.gwp = gw_partial; p.gbp = gb_partial; p.gt = gt;
-    p.B = b; p.S = t_mode ? s : 1; p.K = cin; p.Cout = cout;
+    p.gm = gmean; p.Sm = gmean ? s_mean : 1;
+    // walk order: the samples of a pixel tile one after the other when something per-pixel is shared
+    // between them (context term, mean gradient: its tile then stays in L2), else plain batch order
+    p.B = b; p.S = t_mode ? s : (gmean ? s_mean : 1); p.K = cin; p.Cout = cout;
     p.Bq = t_mode == 1 ? b / s : 1;
     p.hw = (unsigned)hw;
     p.tiles_per_plane = (unsigned)((hw + PB_NT - 1) / PB_NT);
@@ -617,7 +633,7 @@ extern "C" int sbmc_pointwise_bwd_f32(const float* gy, const float* y, const flo
     const size_t lds = (size_t)2 * (128 + kp) * PB_PITCH * sizeof(float);
 #define SBMC_PWB_LAUNCH2(KPV, DXV, TPV)                                                                  \
     do {                                                                                                 \
-        auto kern = pw_bwd_kernel<KPV, DXV, TPV>;                                                        \
+        auto kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true> : pw_bwd_kernel<KPV, DXV, TPV, false>; \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
         if (e == hipSuccess)                                                                             \

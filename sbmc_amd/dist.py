@@ -28,7 +28,6 @@ import torch as th
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from .models import _SampleMean
 from .utils import crop_like
 
 __all__ = ["SlabPartition", "halo_pad", "sharded_autoencoder", "ShardedDenoiser"]
@@ -199,8 +198,8 @@ class ShardedDenoiser(object):
         bs, spp, nf, h, w = features.shape
         context = gfeatures
         for step in range(m.nsteps):
-            features = m._embed(getattr(m, "embedding_{:02d}".format(step)), features, context)
-            reduced = _SampleMean.apply(features)
+            features, reduced = m._embed(getattr(m, "embedding_{:02d}".format(step)), features, context,
+                                         want_mean=True)
             context = sharded_autoencoder(getattr(m, "propagation_{:02d}".format(step)), reduced, part)
 
         p = (m.ksize - 1) // 2

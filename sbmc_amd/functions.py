@@ -379,82 +379,123 @@ class PointwiseLayer(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, t, s, act, slope):
-        x = x.contiguous()
-        w = w.contiguous()
-        bias = bias.contiguous()
-        B, cin, hw = x.shape
-        cout = w.shape[0]
-        t_mode = 0
-        if t is not None:
-            t = t.contiguous()
-            t_mode = 2 if (t.dim() == 3 and t.shape[2] == hw and hw > 1) else 1
-        y = x.new_empty(B, cout, hw)
-        dev = x.device
-        with th.cuda.device(dev), _timed("pointwise_fwd %dx%d" % (cout, cin), dev):
-            rc = _lib.lib().sbmc_pointwise_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
-                                                   _lib.ptr(t) if t is not None else None, _lib.ptr(y),
-                                                   B, s, cin, cout, hw, t_mode, act, slope,
-                                                   _lib.current_stream(dev))
-        _lib.check(rc, "pointwise_fwd")
-        ctx.cfg = (s, act, slope, t_mode, None if t is None else tuple(t.shape))
-        ctx.save_for_backward(x, w, y if act != 0 else None)
-        return y
+        return _pointwise_forward(ctx, x, w, bias, t, s, act, slope)
 
     @staticmethod
     def backward(ctx, gy):
-        s, act, slope, t_mode, tshape = ctx.cfg
-        x, w, y = ctx.saved_tensors
-        gy = gy.contiguous()
-        B, cout, hw = gy.shape
-        if y is None:
-            y = gy                                   # placeholder pointer, never read when linear
-        L = _lib.lib()
-        dev = gy.device
-        cin = x.shape[1]
-        if L.sbmc_pointwise_bwd_supported(cin, cout, hw):
-            # one pass: activation adjoint, both GEMMs, bias and context gradients
+        return _pointwise_backward(ctx, gy, None, 1) + (None, None, None)
+
+
+class PointwiseLayerMean(th.autograd.Function):
+    """`PointwiseLayer` that also returns the mean of y over groups of `mean_s` consecutive batch
+    elements (the per-pixel mean over samples that feeds the U-net, reference sbmc/models.py:179):
+    (y [B, cout, hw], ymean [B / mean_s, cout, hw]).  Both consumers' gradients arrive in ONE backward,
+    whose kernel reads gy[b] + gmean[b / mean_s] / mean_s directly: the [B, cout, hw] broadcast-add
+    pass autograd would otherwise run (7.5 GB at 720p x 8 spp) disappears."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, t, s, act, slope, mean_s):
+        y = _pointwise_forward(ctx, x, w, bias, t, s, act, slope)
+        ctx.mean_s = mean_s
+        B, cout, hw = y.shape
+        return y, y.view(B // mean_s, mean_s, cout, hw).mean(1)
+
+    @staticmethod
+    def backward(ctx, gy, gmean):
+        if gy is None:                       # only the mean was used
+            gy = (gmean / ctx.mean_s).repeat_interleave(ctx.mean_s, 0)
+            gmean = None
+        return _pointwise_backward(ctx, gy, gmean, ctx.mean_s) + (None, None, None, None)
+
+
+def _pointwise_forward(ctx, x, w, bias, t, s, act, slope):
+    x = x.contiguous()
+    w = w.contiguous()
+    bias = bias.contiguous()
+    B, cin, hw = x.shape
+    cout = w.shape[0]
+    t_mode = 0
+    if t is not None:
+        t = t.contiguous()
+        t_mode = 2 if (t.dim() == 3 and t.shape[2] == hw and hw > 1) else 1
+    y = x.new_empty(B, cout, hw)
+    dev = x.device
+    with th.cuda.device(dev), _timed("pointwise_fwd %dx%d" % (cout, cin), dev):
+        rc = _lib.lib().sbmc_pointwise_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
+                                               _lib.ptr(t) if t is not None else None, _lib.ptr(y),
+                                               B, s, cin, cout, hw, t_mode, act, slope,
+                                               _lib.current_stream(dev))
+    _lib.check(rc, "pointwise_fwd")
+    ctx.cfg = (s, act, slope, t_mode, None if t is None else tuple(t.shape))
+    ctx.save_for_backward(x, w, y if act != 0 else None)
+    return y
+
+
+def _pointwise_backward(ctx, gy, gmean, mean_s):
+    """-> (gx, gw, gbias, gt).  gmean: gradient of the group mean of y (or None)."""
+    s, act, slope, t_mode, tshape = ctx.cfg
+    x, w, y = ctx.saved_tensors
+    gy = gy.contiguous()
+    B, cout, hw = gy.shape
+    L = _lib.lib()
+    dev = gy.device
+    cin = x.shape[1]
+    fused = bool(L.sbmc_pointwise_bwd_supported(cin, cout, hw))
+    if gmean is not None and not (fused and t_mode != 2):
+        gy = gy + (gmean / mean_s).repeat_interleave(mean_s, 0)     # the kernels below take one gradient
+        gmean = None
+    if y is None:
+        y = gy                                   # placeholder pointer, never read when linear
+    if fused:
+        # one pass: activation adjoint, both GEMMs, bias and context gradients
+        if gmean is not None and t_mode == 0:
+            groups = L.sbmc_pointwise_bwd_groups(B, mean_s, 1, hw)     # the walk groups the samples of a pixel
+        else:
             groups = L.sbmc_pointwise_bwd_groups(B, s, t_mode, hw)
-            nb = B // s if t_mode == 1 else 1
-            gx = th.empty_like(x) if ctx.needs_input_grad[0] else None
-            gwp = gy.new_empty(groups, cout, cin)
-            gbp = gy.new_empty(groups, nb, cout)
-            gt = gy.new_empty(tshape) if t_mode == 2 else None
-            with th.cuda.device(dev), _timed("pointwise_bwd %dx%d%s" % (cout, cin, "" if gx is not None else " (no gx)"), dev):
-                rc = L.sbmc_pointwise_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(w),
-                                              _lib.ptr(gx) if gx is not None else None, _lib.ptr(gwp),
-                                              _lib.ptr(gbp), _lib.ptr(gt) if gt is not None else None,
-                                              B, s, cin, cout, hw, t_mode, act, slope,
-                                              _lib.current_stream(dev))
-            _lib.check(rc, "pointwise_bwd")
-            per_image = gbp.sum(0)                   # [nb, cout]
-            if t_mode == 1:
-                gt = per_image.view(tshape)
-            return gx, gwp.sum(0), per_image.sum(0), gt, None, None, None
-        gz = gy if (act == 0 and t_mode == 0) else th.empty_like(gy)   # linear: gz is gy, only sums needed
-        gt = None
-        with th.cuda.device(dev):
-            if t_mode == 0:
-                partial = gy.new_empty(B, cout, L.sbmc_bias_act_chunks(B, cout, hw))
-                rc = L.sbmc_bias_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gz), _lib.ptr(partial),
-                                             B, cout, hw, act, slope, _lib.current_stream(dev))
-            else:
-                b = B // s
-                gt = gy.new_empty(tshape) if t_mode == 2 else None
-                partial = gy.new_empty(b, cout, L.sbmc_bias_act_chunks(b, cout, hw))
-                rc = L.sbmc_ctx_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gz), _lib.ptr(gt),
-                                            _lib.ptr(partial), b, s, cout, hw, int(t_mode == 2), act, slope,
-                                            _lib.current_stream(dev))
+        nb = B // s if t_mode == 1 else 1
+        gx = th.empty_like(x) if ctx.needs_input_grad[0] else None
+        gwp = gy.new_empty(groups, cout, cin)
+        gbp = gy.new_empty(groups, nb, cout)
+        gt = gy.new_empty(tshape) if t_mode == 2 else None
+        if gmean is not None:
+            gmean = gmean.contiguous()
+        with th.cuda.device(dev), _timed("pointwise_bwd %dx%d%s" % (cout, cin, "" if gx is not None else " (no gx)"), dev):
+            rc = L.sbmc_pointwise_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(w),
+                                          _lib.ptr(gx) if gx is not None else None, _lib.ptr(gwp),
+                                          _lib.ptr(gbp), _lib.ptr(gt) if gt is not None else None,
+                                          _lib.ptr(gmean) if gmean is not None else None, mean_s,
+                                          B, s, cin, cout, hw, t_mode, act, slope,
+                                          _lib.current_stream(dev))
         _lib.check(rc, "pointwise_bwd")
-        per_image = partial.sum(2)
-        gbias = per_image.sum(0)
+        per_image = gbp.sum(0)                   # [nb, cout]
         if t_mode == 1:
             gt = per_image.view(tshape)
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = th.bmm(w.t().unsqueeze(0).expand(B, -1, -1), gz)
-        if ctx.needs_input_grad[1]:
-            gw = th.bmm(gz, x.transpose(1, 2)).sum(0)
-        return gx, gw, gbias, gt, None, None, None
+        return gx, gwp.sum(0), per_image.sum(0), gt
+    gz = gy if (act == 0 and t_mode == 0) else th.empty_like(gy)   # linear: gz is gy, only sums needed
+    gt = None
+    with th.cuda.device(dev):
+        if t_mode == 0:
+            partial = gy.new_empty(B, cout, L.sbmc_bias_act_chunks(B, cout, hw))
+            rc = L.sbmc_bias_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gz), _lib.ptr(partial),
+                                         B, cout, hw, act, slope, _lib.current_stream(dev))
+        else:
+            b = B // s
+            gt = gy.new_empty(tshape) if t_mode == 2 else None
+            partial = gy.new_empty(b, cout, L.sbmc_bias_act_chunks(b, cout, hw))
+            rc = L.sbmc_ctx_act_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gz), _lib.ptr(gt),
+                                        _lib.ptr(partial), b, s, cout, hw, int(t_mode == 2), act, slope,
+                                        _lib.current_stream(dev))
+    _lib.check(rc, "pointwise_bwd")
+    per_image = partial.sum(2)
+    gbias = per_image.sum(0)
+    if t_mode == 1:
+        gt = per_image.view(tshape)
+    gx = gw = None
+    if ctx.needs_input_grad[0]:
+        gx = th.bmm(w.t().unsqueeze(0).expand(B, -1, -1), gz)
+    if ctx.needs_input_grad[1]:
+        gw = th.bmm(gz, x.transpose(1, 2)).sum(0)
+    return gx, gw, gbias, gt
 
 
 def upsample_cat_supported(coarse, left):

@@ -112,14 +112,17 @@ class Multisteps(nn.Module):
                     if isinstance(m, ops.ConvChain):
                         m.fuse_bias_act = True
 
-    def _embed(self, module, per_sample, per_pixel):
+    def _embed(self, module, per_sample, per_pixel, want_mean=False):
         """Runs a 1x1 ConvChain on cat(per_sample[:, s], per_pixel) for every sample s.
 
-        per_sample [bs, spp, c, h, w], per_pixel [bs, c', h, w] -> [bs, spp, e, h, w]
+        per_sample [bs, spp, c, h, w], per_pixel [bs, c', h, w] -> [bs, spp, e, h, w]; with
+        want_mean: (that, its mean over the samples [bs, e, h, w]) -- the mean comes out of the
+        chain's last fused layer when it can, whose backward then takes both gradients at once.
         """
         bs, spp, c, h, w = per_sample.shape
         chunk = self.sample_chunk or spp
         outs = []
+        mean_out = [] if (want_mean and chunk >= spp) else None
         for s0 in range(0, spp, chunk):
             # (no slicing when all samples go at once: SliceBackward would zero-fill and copy
             # a whole [bs, spp, c, h, w] gradient)
@@ -128,14 +131,17 @@ class Multisteps(nn.Module):
             out = None
             if module.pointwise_as_gemm:
                 # context half of the first layer once per pixel, no concatenation
-                out = ops.pointwise_chain_with_context(module, part, per_pixel)
+                out = ops.pointwise_chain_with_context(module, part, per_pixel, mean_out)
             if out is None:
                 ctx = per_pixel.expand(bs, per_pixel.shape[1], h, w).unsqueeze(1).expand(
                     bs, n, per_pixel.shape[1], h, w)
                 flat = th.cat([part, ctx], 2).reshape(bs * n, c + per_pixel.shape[1], h, w)
                 out = module(flat)
             outs.append(out.view(bs, n, out.shape[1], h, w))
-        return outs[0] if len(outs) == 1 else th.cat(outs, 1)
+        features = outs[0] if len(outs) == 1 else th.cat(outs, 1)
+        if not want_mean:
+            return features
+        return features, (mean_out[0] if mean_out else _SampleMean.apply(features))
 
     def _predict_and_splat(self, features, context, radiance):
         """Kernel regression + splat of every sample (reference models.py:193-209).
@@ -189,9 +195,8 @@ class Multisteps(nn.Module):
         # bs > 1, where the reference's train path mis-tiles them).
         context = gfeatures          # [bs, ngf, 1, 1]: constant over the image at the first step
         for step in range(self.nsteps):
-            features = self._embed(getattr(self, "embedding_{:02d}".format(step)),
-                                   features, context)
-            reduced = _SampleMean.apply(features)
+            features, reduced = self._embed(getattr(self, "embedding_{:02d}".format(step)),
+                                            features, context, want_mean=True)
             context = getattr(self, "propagation_{:02d}".format(step))(reduced)
 
         # -- per-sample kernel prediction + progressive splat ----------------------

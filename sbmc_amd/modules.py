@@ -58,10 +58,12 @@ def _is_pointwise(conv):
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is not None)
 
 
-def _pointwise_gemm(conv, x, activation=None):
+def _pointwise_gemm(conv, x, activation=None, mean_s=0, mean_out=None):
     """conv(x) [+ activation] for a 1x1 convolution as y[b] = W @ x[b] on [B, Cin, H*W] (no
-    layout change), with bias and ReLU / LeakyReLU applied by one fused in-place HIP pass.
-    Returns (y, activation_was_applied)."""
+    layout change), with bias and ReLU / LeakyReLU fused (functions.PointwiseLayer).
+    Returns (y, activation_was_applied).  mean_s > 0 (only honoured when nothing is left to apply
+    after the fused layer): the mean of y over groups of mean_s batch elements is appended to
+    `mean_out` (functions.PointwiseLayerMean)."""
     if hasattr(conv, "weight_g"):   # old-style weight norm: w = g * v / ||v||, norm over dims 1..3
         w = th._weight_norm(conv.weight_v, conv.weight_g, 0)
     else:
@@ -75,7 +77,12 @@ def _pointwise_gemm(conv, x, activation=None):
     elif isinstance(activation, nn.LeakyReLU):
         act, slope = 2, float(activation.negative_slope)
     if funcs.pointwise_supported(x3, w.shape[0]):
-        y = funcs.PointwiseLayer.apply(x3, w.view(w.shape[0], c), conv.bias, None, 1, act, slope)
+        if mean_s and mean_out is not None and b % mean_s == 0 and (activation is None or act != 0):
+            y, m = funcs.PointwiseLayerMean.apply(x3, w.view(w.shape[0], c), conv.bias, None, 1, act, slope,
+                                                  mean_s)
+            mean_out.append(m.view(b // mean_s, w.shape[0], h, wd))
+        else:
+            y = funcs.PointwiseLayer.apply(x3, w.view(w.shape[0], c), conv.bias, None, 1, act, slope)
         return y.view(b, w.shape[0], h, wd), act != 0
     y = th.bmm(wmat, x3)
     if funcs.BiasAct.supported(y):
@@ -85,7 +92,7 @@ def _pointwise_gemm(conv, x, activation=None):
     return y.view(b, w.shape[0], h, wd), False
 
 
-def pointwise_chain_with_context(chain, per_sample, context):
+def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     """`chain(cat([per_sample[:, s], context], 1))` for every sample s of a 1x1 ConvChain, without
     building the concatenation: the first layer is linear, so its context half W_c @ context is
     computed once per pixel and added (with bias and activation) to the per-sample half
@@ -95,6 +102,8 @@ def pointwise_chain_with_context(chain, per_sample, context):
 
     per_sample [bs, S, cs, h, w], context [bs, cp, h, w] or [bs, cp, 1, 1] -> [bs*S, cout, h, w];
     returns None when the fused path does not apply (the caller then concatenates).
+    mean_out: a list; when the chain's last layer can deliver it, the mean of the output over the S
+    samples of every pixel ([bs, cout, h, w]) is appended (see functions.PointwiseLayerMean).
     """
     mods = list(chain.children())
     first = mods[0]
@@ -137,7 +146,7 @@ def pointwise_chain_with_context(chain, per_sample, context):
     # the rest of the chain, minus what has been consumed
     consumed = 1 if isinstance(first, ConvChain._ConvBNRelu) else (2 if act[0] != 0 else 1)
     rest = mods[consumed:]
-    return chain._run(rest, y) if rest else y
+    return chain._run(rest, y, mean_s=S, mean_out=mean_out) if rest else y
 
 
 class ConvChain(nn.Module):
@@ -223,7 +232,7 @@ class ConvChain(nn.Module):
             return None, False
         return funcs.BiasAct.apply(y, conv.bias, act, slope), act != 0
 
-    def _run(self, mods, x):
+    def _run(self, mods, x, mean_s=0, mean_out=None):
         gemm = self.pointwise_as_gemm and x.is_cuda
         i = 0
         while i < len(mods):
@@ -236,9 +245,12 @@ class ConvChain(nn.Module):
                     x = sub(x)
             elif gemm and isinstance(m, nn.Conv2d) and _is_pointwise(m):
                 nxt = mods[i] if i < len(mods) else None          # the chain's output activation
-                x, fused = _pointwise_gemm(m, x, nxt)
+                last = i + (1 if nxt is not None else 0) >= len(mods)
+                x, fused = _pointwise_gemm(m, x, nxt, mean_s if last else 0, mean_out)
                 if fused:
                     i += 1
+                elif nxt is not None and mean_out:
+                    mean_out.clear()                              # an activation is still to come
             elif (self.fuse_bias_act and x.is_cuda and x.dtype == th.float32
                   and isinstance(m, ConvChain._ConvBNRelu) and len(m.layer) == 2
                   and isinstance(m.layer[0], nn.Conv2d)):

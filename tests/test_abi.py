@@ -68,7 +68,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.sbmc_pointwise_bwd_supported(128, 128, hw) == 1 and lib.sbmc_pointwise_bwd_supported(128, 441, hw) == 0
     assert lib.sbmc_pointwise_fwd_f32(*([None] * 5), 2, 1, 129, 128, 64, 0, 1, 0.0, None) == -1
     assert lib.sbmc_pointwise_fwd_f32(*([None] * 5), 3, 2, 128, 128, 64, 1, 1, 0.0, None) == -1     # b % s
-    assert lib.sbmc_pointwise_bwd_f32(*([None] * 8), 2, 1, 128, 441, 64, 0, 1, 0.0, None) == -1
+    assert lib.sbmc_pointwise_bwd_f32(*([None] * 9), 1, 2, 1, 128, 441, 64, 0, 1, 0.0, None) == -1
     assert lib.sbmc_pointwise_fwd_f32(*([None] * 5), 0, 1, 128, 128, 64, 0, 1, 0.0, None) == 0
     assert lib.sbmc_bias_act_chunks(8, 128, hw) >= 1
 

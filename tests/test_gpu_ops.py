@@ -453,6 +453,41 @@ def test_pointwise_layer_kernel(shape):
         close(t2.grad, t.grad.float(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [
+    # B, mean_s, cin, cout, hw, act, needs gx
+    (8, 8, 128, 128, 1028, 1, True), (6, 3, 93, 128, 260, 0, False), (4, 2, 64, 32, 64, 2, True),
+    (4, 4, 128, 200, 132, 0, True),          # cout > 128: composed backward, gradients summed first
+])
+def test_pointwise_layer_with_sample_mean(shape):
+    """PointwiseLayerMean: (y, mean of y over groups of samples); one backward for both gradients
+    (the fused kernel reads gy + gmean / S) vs an fp64 restatement."""
+    from sbmc_amd import functions as F
+    B, ms, cin, cout, hw, act, needx = shape
+    slope = 0.01 if act == 2 else 0.0
+    th.manual_seed(sum(shape[:5]))
+    x0 = th.randn(B, cin, hw, device="cuda")
+    w0 = th.randn(cout, cin, device="cuda") / cin ** 0.5
+    b0 = th.randn(cout, device="cuda")
+    x, w, b = x0.double().requires_grad_(needx), w0.double().requires_grad_(), b0.double().requires_grad_()
+    pre = th.matmul(w, x) + b.view(1, -1, 1)
+    ref = pre if act == 0 else th.nn.functional.leaky_relu(pre, slope)
+    ref_mean = ref.view(B // ms, ms, cout, hw).mean(1)
+    g = th.randn(B, cout, hw, device="cuda") * (pre.detach().abs() > 1e-4).float()
+    gm = th.randn(B // ms, cout, hw, device="cuda")
+    if act:   # keep the mean's gradient away from the kink as well
+        gm = gm * (pre.detach().abs() > 1e-4).view(B // ms, ms, cout, hw).all(1).float()
+    th.autograd.backward([ref, ref_mean], [g.double(), gm.double()])
+    x2, w2, b2 = x0.clone().requires_grad_(needx), w0.clone().requires_grad_(), b0.clone().requires_grad_()
+    y, ym = F.PointwiseLayerMean.apply(x2, w2, b2, None, 1, act, slope, ms)
+    th.autograd.backward([y, ym], [g, gm])
+    close(y, ref.float(), rtol=1e-5)
+    close(ym, ref_mean.float(), rtol=1e-5)
+    if needx:
+        close(x2.grad, x.grad.float(), rtol=1e-5)
+    close(w2.grad, w.grad.float(), rtol=2e-5)
+    close(b2.grad, b.grad.float(), rtol=2e-5)
+
+
 def test_pointwise_chain_as_gemm_matches_convolution():
     """ConvChain(ksize=1) through the batched-GEMM + fused bias/activation path == the nn.Conv2d path."""
     from sbmc_amd import modules
