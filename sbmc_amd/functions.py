@@ -45,6 +45,14 @@ class _timed(object):
         return False
 
 
+def _require_f32(op, **tensors):
+    """The C ABI takes raw float pointers: anything but a float32 GPU tensor (a half tensor under
+    autocast, say) would be read or written out of bounds.  Fail loudly instead."""
+    for name, v in tensors.items():
+        if v is not None and (v.dtype != th.float32 or not v.is_cuda):
+            raise TypeError("%s: %s must be a float32 GPU tensor, got %s on %s" % (op, name, v.dtype, v.device))
+
+
 def _is_cuda(*args):
     """True if any argument lives on a GPU (reference functions.py:30-36)."""
     for arg in args:
@@ -268,6 +276,7 @@ class BiasAct(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, bias, act, slope):
+        _require_f32("BiasAct", y=y, bias=bias)
         b, c = y.shape[0], y.shape[1]
         hw = y[0, 0].numel()
         bias = bias.contiguous()
@@ -317,6 +326,7 @@ class CtxAct(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, t, bias, s, act, slope):
+        _require_f32("CtxAct", y=y, t=t, bias=bias)
         c = y.shape[1]
         b = y.shape[0] // s
         hw = y[0, 0].numel()
@@ -362,6 +372,7 @@ def pointwise_supported(x, cout):
         return False
     hw = x[0, 0].numel()
     return (x.data_ptr() % 16 == 0 and x.shape[0] <= 65535 and cout <= 65535
+            and not th.is_autocast_enabled()      # reduced-precision activations take the library path
             and bool(_lib.lib().sbmc_pointwise_supported(x.shape[1], cout, hw)))
 
 
@@ -409,6 +420,7 @@ class PointwiseLayerMean(th.autograd.Function):
 
 
 def _pointwise_forward(ctx, x, w, bias, t, s, act, slope):
+    _require_f32("PointwiseLayer", x=x, w=w, bias=bias, t=t)
     x = x.contiguous()
     w = w.contiguous()
     bias = bias.contiguous()
@@ -514,6 +526,7 @@ class UpsampleCat(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, coarse, left):
+        _require_f32("UpsampleCat", coarse=coarse, left=left)
         coarse = coarse.contiguous()
         left = left.contiguous()
         b, cu, h, w = coarse.shape

@@ -134,7 +134,7 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     xs = per_sample.reshape(bs * S, cs, h * w)
     ctx3 = context.reshape(bs, cp, -1)
     t = th.bmm(wt[:, cs:].unsqueeze(0).expand(bs, -1, -1), ctx3).contiguous()
-    if funcs.pointwise_supported(xs, cout):
+    if t.dtype == th.float32 and funcs.pointwise_supported(xs, cout):
         tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)
         y = funcs.PointwiseLayer.apply(xs, wt[:, :cs], conv.bias, tt, S, act[0], act[1])
         y = y.view(bs * S, cout, h, w)

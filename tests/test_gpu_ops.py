@@ -650,3 +650,30 @@ def test_upsample_cat_kernels(shape):
     close(cb.grad, ca.grad, rtol=1e-5)
     if cl:
         assert th.equal(lb.grad, la.grad)
+
+
+def test_fused_layers_refuse_half_tensors():
+    """The ctypes wrappers hand raw float pointers to the C ABI: a half tensor (autocast) must raise,
+    not be read out of bounds; under autocast the chains take the library path instead."""
+    from sbmc_amd import functions as F, modules
+    x = th.randn(2, 16, 64, device="cuda")
+    w = th.randn(8, 16, device="cuda")
+    b = th.randn(8, device="cuda")
+    with pytest.raises(TypeError):
+        F.PointwiseLayer.apply(x, w, b, th.randn(2, 8, 64, device="cuda").half(), 1, 1, 0.0)
+    with pytest.raises(TypeError):
+        F.PointwiseLayer.apply(x.half(), w, b, None, 1, 1, 0.0)
+    with pytest.raises(TypeError):
+        F.BiasAct.apply(th.randn(2, 8, 64, device="cuda").half(), b, 1, 0.0)
+    with th.autocast("cuda", dtype=th.float16):
+        assert not F.pointwise_supported(x, 8)
+        chain = modules.ConvChain(7 + 5, 9, ksize=1, width=16, depth=3, pad=False).cuda()
+        chain.pointwise_as_gemm = True
+        per_sample = th.randn(2, 4, 7, 12, 20, device="cuda")
+        ctx = th.randn(2, 5, 12, 20, device="cuda")
+        out = modules.pointwise_chain_with_context(chain, per_sample, ctx)
+        ref_in = th.cat([per_sample, ctx.unsqueeze(1).expand(2, 4, 5, 12, 20)], 2).reshape(8, 12, 12, 20)
+        chain.pointwise_as_gemm = False
+        ref = chain(ref_in)
+        if out is not None:
+            assert (out.float() - ref.float()).abs().max().item() <= 3e-2 * ref.float().abs().max().item()
