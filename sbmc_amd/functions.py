@@ -190,6 +190,10 @@ class SplatUpdate(th.autograd.Function):
         c = data.shape[1]
         if tuple(data.shape) != (bs, c, h, w):
             raise RuntimeError("data should be [bs, c, h, w] matching kernels [bs, k*k, h, w]")
+        _require_f32("SplatUpdate", data=data, sum_r=sum_r, sum_w=sum_w, max_w=max_w,
+                     kernels=None if kernels.dtype == th.float16 else kernels)
+        if kernels.dtype == th.float16 and (gather or not kernels.is_cuda or not _half_ok(c, k, h, w)):
+            raise TypeError("SplatUpdate: half logits are only taken by the k=21 strip kernels")
         data = data.contiguous()
         kernels = kernels.contiguous()
         first = sum_r is None
@@ -613,6 +617,9 @@ class SplatAll(th.autograd.Function):
         c = data.shape[2]
         if tuple(data.shape) != (bs, S, c, h, w):
             raise RuntimeError("data should be [bs, S, c, h, w] matching kernels [bs, S, k*k, h, w]")
+        _require_f32("SplatAll", data=data, kernels=None if kernels.dtype == th.float16 else kernels)
+        if kernels.dtype == th.float16 and (not kernels.is_cuda or not _half_ok(c, k, h, w)):
+            raise TypeError("SplatAll: half logits are only taken by the k=21 strip kernels")
         data = data.contiguous()
         kernels = kernels.contiguous()
         dev = data.device
