@@ -303,6 +303,12 @@ SBMC_API int sbmc_pointwise_supported(int cin, int cout, long hw);
 SBMC_API int sbmc_pointwise_fwd_f32(const float *x, const float *w, const float *bias, const float *t,
                            float *y, int b, int s, int cin, int cout, long hw, int t_mode, int act,
                            float slope, void *stream);
+/* The same forward with half-precision STORAGE ("fp16 activations", BASELINE configs[4]): y is
+ * _Float16, x is _Float16 (x_is_half = 1) or float (the network's fp32 inputs); w, bias, t stay
+ * float and all arithmetic is fp32 (fp32 MFMA).  Inference only: there is no half backward. */
+SBMC_API int sbmc_pointwise_fwd_f16(const void *x, int x_is_half, const float *w, const float *bias,
+                           const float *t, void *y, int b, int s, int cin, int cout, long hw,
+                           int t_mode, int act, float slope, void *stream);
 /* Backward of the same layer in one pass over gy, y (the forward output) and x; cout <= 128:
  *     gz = gy * act'(y);   gx[b] = w^T gz[b]   (gx may be NULL: not computed);
  *     gw_partial[g] = this workgroup's share of sum_b gz[b] x[b]^T     [groups, cout, cin]

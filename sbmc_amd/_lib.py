@@ -42,6 +42,7 @@ SYMBOLS = (
     "sbmc_ctx_act_bwd_f32",
     "sbmc_pointwise_supported",
     "sbmc_pointwise_fwd_f32",
+    "sbmc_pointwise_fwd_f16",
     "sbmc_pointwise_bwd_supported",
     "sbmc_pointwise_bwd_groups",
     "sbmc_pointwise_bwd_f32",
@@ -108,6 +109,7 @@ def lib():
     handle.sbmc_ctx_act_bwd_f32.argtypes = [p, p, p, p, p, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_supported.argtypes = [i, i, ctypes.c_long]
     handle.sbmc_pointwise_fwd_f32.argtypes = [p] * 5 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_pointwise_fwd_f16.argtypes = [p, i, p, p, p, p, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_supported.argtypes = [i, i, ctypes.c_long]
     handle.sbmc_pointwise_bwd_groups.argtypes = [i, i, i, ctypes.c_long]
     handle.sbmc_pointwise_bwd_f32.argtypes = [p] * 9 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]

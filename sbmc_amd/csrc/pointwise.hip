@@ -40,11 +40,11 @@ __device__ __forceinline__ rsrc_t make_rsrc_n(const void* base, unsigned bytes) 
 }
 
 struct PwFwdParams {
-    const float* x;      // [B, K, hw]
+    const void* x;       // [B, K, hw], float or _Float16 (template TI)
     const float* w;      // [Cout, K]
     const float* bias;   // [Cout]
     const float* t;      // context term: nullptr, [B/S, Cout] (t_mode 1) or [B/S, Cout, hw] (t_mode 2)
-    float* y;            // [B, Cout, hw]
+    void* y;             // [B, Cout, hw], float or _Float16 (template TO)
     int B, S, K, Cout;
     unsigned hw, tiles_per_plane, ntiles;
     int nrt;             // row tiles of 128 output channels
@@ -62,14 +62,23 @@ struct PwFwdParams {
 // Work assignment: workgroup g works on row tile (g / 8) % nrt of the pixel tiles
 // ((g / 8) / nrt) * 8 + g % 8 + i * (gridDim.x / nrt): the nrt workgroups that read the same
 // input tile sit on the same XCD (g % 8) and walk in step, so the tile comes from HBM once.
-template <int KP, int TMODE, int PH>
+//
+// TI / TO: storage type of x / y in HBM (float, or _Float16 for "fp16 activations": BASELINE
+// configs[4]); the LDS tile, the MFMAs and the epilogue are fp32 either way.
+template <int KP, int TMODE, int PH, typename TI, typename TO>
 __global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
     constexpr int NT = 64 * PH;                        // pixels per tile
+    constexpr bool HI = sizeof(TI) == 2, HO = sizeof(TO) == 2;
+    // staging: every thread moves 16 bytes of one row per pass = 4 float / 8 half pixels
+    constexpr int PXT = HI ? 8 : 4;                    // pixels per thread and pass
+    constexpr int RPP = 256 * PH / (NT / PXT);         // rows per pass
+    const TI* xg = static_cast<const TI*>(p.x);
+    TO* yg = static_cast<TO*>(p.y);
     extern __shared__ float4 pw_lds[];
     float* xs = reinterpret_cast<float*>(pw_lds);      // [2][KP][NT]
     constexpr int KS = KP / 2;                         // MFMA k-steps
     constexpr int NG = KS / PW_KGROUP;                 // scheduling groups per tile
-    constexpr int NLD = KP / 16;                       // float4 loads per thread per tile
+    constexpr int NLD = KP / RPP;                      // 16-byte loads per thread per tile
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int rb = wave & 3, ph = wave >> 2;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -82,8 +91,8 @@ __global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
     const int r0 = rt * 128 + rb * 32;
     const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
 
-    // staging role of this thread: float4 column c4 of rows srow + 16 i
-    const unsigned c4 = (threadIdx.x % (NT / 4)) * 4, srow = threadIdx.x / (NT / 4);
+    // staging role of this thread: pixels c4 .. c4 + PXT - 1 of rows srow + RPP i
+    const unsigned c4 = (threadIdx.x % (NT / PXT)) * PXT, srow = threadIdx.x / (NT / PXT);
 
     auto tile_coords = [&](unsigned tile, unsigned& b, unsigned& bq, unsigned& p0) {
         // samples of one pixel tile are adjacent in the walk: their context tile stays in L2
@@ -96,20 +105,29 @@ __global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
     auto issue_loads = [&](unsigned tile, u32x4 (&regs)[NLD]) {
         unsigned b, bq, p0;
         tile_coords(tile, b, bq, p0);
-        const rsrc_t rx = make_rsrc_n(p.x + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
+        const rsrc_t rx = make_rsrc_n(xg + (size_t)b * p.K * hw, (unsigned)p.K * hw * (unsigned)sizeof(TI));
         const bool colok = p0 + c4 < hw;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const unsigned k = srow + 16u * i;
-            const unsigned off = (colok && k < (unsigned)p.K) ? (k * hw + p0 + c4) * 4u : PW_OOB;
+            const unsigned k = srow + (unsigned)RPP * i;
+            const unsigned off = (colok && k < (unsigned)p.K) ? (k * hw + p0 + c4) * (unsigned)sizeof(TI) : PW_OOB;
             regs[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
         }
     };
     auto commit = [&](int buf, const u32x4 (&regs)[NLD]) {
         float* dst = xs + buf * (KP * NT);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            *reinterpret_cast<u32x4*>(dst + (srow + 16 * i) * NT + c4) = regs[i];
+        for (int i = 0; i < NLD; ++i) {
+            float* d = dst + (srow + RPP * i) * NT + c4;
+            if constexpr (HI) {
+                using h8 = __attribute__((ext_vector_type(8))) _Float16;
+                const h8 v = __builtin_bit_cast(h8, regs[i]);
+                *reinterpret_cast<float4*>(d) = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                *reinterpret_cast<float4*>(d + 4) = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+            } else {
+                *reinterpret_cast<u32x4*>(d) = regs[i];
+            }
+        }
     };
 
     // weight rows of this wave as MFMA A-operands: a[kk] = W[r0 + lane % 32][2 kk + lane / 32]
@@ -146,11 +164,15 @@ __global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
     for (int j = 0; j < 16; ++j) out0[j] = out1[j] = 0.f;
     unsigned b_prev = 0;                               // (uniform) batch element they belong to
     unsigned o_prev0 = PW_OOB, o_prev1 = PW_OOB;       // byte offset of register 0's element, or switched off
+    // (o_prev*: byte offsets for 4-byte elements; half outputs sit at half of them)
     auto store_prev = [&](int j) {
-        const rsrc_t ry_prev = make_rsrc_n(p.y + ((size_t)b_prev * p.Cout + r0) * hw, (unsigned)nrows * hw * 4u);
+        const rsrc_t ry_prev = make_rsrc_n(yg + ((size_t)b_prev * p.Cout + r0) * hw,
+                                           (unsigned)nrows * hw * (unsigned)sizeof(TO));
         const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
-        buf_store(out0[j], ry_prev, o_prev0 != PW_OOB ? o_prev0 + ro : PW_OOB, 0);
-        buf_store(out1[j], ry_prev, o_prev1 != PW_OOB ? o_prev1 + ro : PW_OOB, 0);
+        const unsigned a0 = o_prev0 != PW_OOB ? (o_prev0 + ro) / (HO ? 2u : 1u) : PW_OOB;
+        const unsigned a1 = o_prev1 != PW_OOB ? (o_prev1 + ro) / (HO ? 2u : 1u) : PW_OOB;
+        logit_store<TO>(out0[j], ry_prev, a0, 0);
+        logit_store<TO>(out1[j], ry_prev, a1, 0);
     };
 
     int buf = 0;
@@ -530,9 +552,9 @@ using namespace sbmc;
 
 extern "C" int sbmc_pointwise_supported(int cin, int cout, long hw) { return pw_dims_ok(cin, cout, hw) ? 1 : 0; }
 
-extern "C" int sbmc_pointwise_fwd_f32(const float* x, const float* w, const float* bias, const float* t, float* y,
-                                      int b, int s, int cin, int cout, long hw, int t_mode, int act, float slope,
-                                      void* stream) {
+template <typename TI, typename TO>
+static int pw_fwd_launch(const void* x, const float* w, const float* bias, const float* t, void* y, int b, int s,
+                         int cin, int cout, long hw, int t_mode, int act, float slope, void* stream) {
     if (b < 0 || s < 1 || act < 0 || act > 2 || t_mode < 0 || t_mode > 2) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!pw_dims_ok(cin, cout, hw) || b % s || !x || !w || !bias || !y || (t_mode && !t)) return SBMC_HIP_EINVAL;
@@ -565,8 +587,9 @@ extern "C" int sbmc_pointwise_fwd_f32(const float* x, const float* w, const floa
     hipError_t e = hipSuccess;
 #define SBMC_PW_LAUNCH(KPV)                                                                              \
     do {                                                                                                 \
-        auto kern = t_mode == 2 ? pw_fwd_kernel<KPV, 2, PW_FWD_PH>                                        \
-                                : (t_mode == 1 ? pw_fwd_kernel<KPV, 1, PW_FWD_PH> : pw_fwd_kernel<KPV, 0, PW_FWD_PH>); \
+        auto kern = t_mode == 2 ? pw_fwd_kernel<KPV, 2, PW_FWD_PH, TI, TO>                                \
+                                : (t_mode == 1 ? pw_fwd_kernel<KPV, 1, PW_FWD_PH, TI, TO>                 \
+                                               : pw_fwd_kernel<KPV, 0, PW_FWD_PH, TI, TO>);               \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
         if (e == hipSuccess)                                                                             \
@@ -581,6 +604,20 @@ extern "C" int sbmc_pointwise_fwd_f32(const float* x, const float* w, const floa
 #undef SBMC_PW_LAUNCH
     if (e != hipSuccess) return (int)e;
     return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_pointwise_fwd_f32(const float* x, const float* w, const float* bias, const float* t, float* y,
+                                      int b, int s, int cin, int cout, long hw, int t_mode, int act, float slope,
+                                      void* stream) {
+    return pw_fwd_launch<float, float>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream);
+}
+
+extern "C" int sbmc_pointwise_fwd_f16(const void* x, int x_is_half, const float* w, const float* bias, const float* t,
+                                      void* y, int b, int s, int cin, int cout, long hw, int t_mode, int act,
+                                      float slope, void* stream) {
+    if (x_is_half)
+        return pw_fwd_launch<_Float16, _Float16>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream);
+    return pw_fwd_launch<float, _Float16>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream);
 }
 
 static unsigned pw_bwd_grid(int b, int s, long hw, unsigned* nunits_out) {

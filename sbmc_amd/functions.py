@@ -380,6 +380,41 @@ def pointwise_supported(x, cout):
             and bool(_lib.lib().sbmc_pointwise_supported(x.shape[1], cout, hw)))
 
 
+def pointwise_half_supported(x, cout):
+    """True when `pointwise_half` applies: inference (no grad) under torch.autocast(float16) on the
+    GPU, x [B, cin, ...pixels] float32 or float16, dimensions the fused kernels take."""
+    if not (x.is_cuda and x.dtype in (th.float32, th.float16) and x.dim() >= 3 and x.numel() > 0):
+        return False
+    if th.is_grad_enabled() or not th.is_autocast_enabled() or th.get_autocast_gpu_dtype() != th.float16:
+        return False
+    hw = x[0, 0].numel()
+    return (x.data_ptr() % 16 == 0 and x.shape[0] <= 65535 and cout <= 65535
+            and bool(_lib.lib().sbmc_pointwise_supported(x.shape[1], cout, hw)))
+
+
+def pointwise_half(x, w, bias, t, s, act, slope):
+    """`PointwiseLayer` forward with half-precision storage: x float32 or float16, output float16;
+    w, bias and the context term t are float32, arithmetic is fp32 (inference; no autograd)."""
+    _require_f32("pointwise_half", w=w, bias=bias, t=t)
+    if not (x.is_cuda and x.dtype in (th.float32, th.float16)):
+        raise TypeError("pointwise_half: x must be a float32 or float16 GPU tensor")
+    x, w, bias = x.contiguous(), w.contiguous(), bias.contiguous()
+    B, cin, hw = x.shape
+    cout = w.shape[0]
+    t_mode = 0
+    if t is not None:
+        t = t.contiguous()
+        t_mode = 2 if (t.dim() == 3 and t.shape[2] == hw and hw > 1) else 1
+    y = th.empty(B, cout, hw, dtype=th.float16, device=x.device)
+    dev = x.device
+    with th.cuda.device(dev), _timed("pointwise_fwd_f16 %dx%d" % (cout, cin), dev):
+        rc = _lib.lib().sbmc_pointwise_fwd_f16(_lib.ptr(x), int(x.dtype == th.float16), _lib.ptr(w), _lib.ptr(bias),
+                                               _lib.ptr(t) if t is not None else None, _lib.ptr(y),
+                                               B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
+    _lib.check(rc, "pointwise_fwd_f16")
+    return y
+
+
 class PointwiseLayer(th.autograd.Function):
     """A whole 1x1-convolution layer in one pass: y[b] = act(w @ x[b] + bias (+ t[b // s])).
 

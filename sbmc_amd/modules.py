@@ -76,6 +76,9 @@ def _pointwise_gemm(conv, x, activation=None, mean_s=0, mean_out=None):
         act = 1
     elif isinstance(activation, nn.LeakyReLU):
         act, slope = 2, float(activation.negative_slope)
+    if funcs.pointwise_half_supported(x3, w.shape[0]):      # fp16 activations, inference
+        y = funcs.pointwise_half(x3, w.view(w.shape[0], c).float(), conv.bias.float(), None, 1, act, slope)
+        return y.view(b, w.shape[0], h, wd), act != 0
     if funcs.pointwise_supported(x3, w.shape[0]):
         if mean_s and mean_out is not None and b % mean_s == 0 and (activation is None or act != 0):
             y, m = funcs.PointwiseLayerMean.apply(x3, w.view(w.shape[0], c), conv.bias, None, 1, act, slope,
@@ -115,7 +118,10 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
         conv, act_mod = first, (mods[1] if len(mods) > 1 else None)
     else:
         return None
-    if not (_is_pointwise(conv) and per_sample.is_cuda and per_sample.dtype == th.float32):
+    if not (_is_pointwise(conv) and per_sample.is_cuda and per_sample.dtype in (th.float32, th.float16)):
+        return None
+    if per_sample.dtype == th.float16 and not funcs.pointwise_half_supported(per_sample.reshape(
+            per_sample.shape[0] * per_sample.shape[1], per_sample.shape[2], -1), conv.out_channels):
         return None
     act = 0, 0.0
     if isinstance(act_mod, nn.ReLU):
@@ -133,6 +139,15 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     cout = wt.shape[0]
     xs = per_sample.reshape(bs * S, cs, h * w)
     ctx3 = context.reshape(bs, cp, -1)
+    if funcs.pointwise_half_supported(xs, cout):             # fp16 activations, inference
+        with th.autocast("cuda", enabled=False):
+            t = th.bmm(wt[:, cs:].float().unsqueeze(0).expand(bs, -1, -1), ctx3.float()).contiguous()
+        tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)
+        y = funcs.pointwise_half(xs, wt[:, :cs].float(), conv.bias.float(), tt, S, act[0], act[1])
+        y = y.view(bs * S, cout, h, w)
+        consumed = 1 if isinstance(first, ConvChain._ConvBNRelu) else (2 if act[0] != 0 else 1)
+        rest = mods[consumed:]
+        return chain._run(rest, y) if rest else y
     t = th.bmm(wt[:, cs:].unsqueeze(0).expand(bs, -1, -1), ctx3).contiguous()
     if t.dtype == th.float32 and funcs.pointwise_supported(xs, cout):
         tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)

@@ -383,6 +383,15 @@ def test_multisteps_under_fp16_autocast():
     assert (out - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
     out.sum().backward()
     assert all(th.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    # inference: the 1x1 chains keep the fused kernels with half storage (functions.pointwise_half)
+    from sbmc_amd import functions as F
+    launches = []
+    F.enable_kernel_timing(launches)
+    with th.no_grad(), th.autocast("cuda", dtype=th.float16):
+        out_inf = model(batch)["radiance"]
+    F.enable_kernel_timing(None)
+    assert sum(n.startswith("pointwise_fwd_f16") for n, _, _ in launches) == 6     # 3 layers x 2 chains
+    assert (out_inf - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("act,slope", [(0, 0.0), (1, 0.0), (2, 0.01), (2, 0.2)])
@@ -677,3 +686,27 @@ def test_fused_layers_refuse_half_tensors():
         ref = chain(ref_in)
         if out is not None:
             assert (out.float() - ref.float()).abs().max().item() <= 3e-2 * ref.float().abs().max().item()
+
+
+@pytest.mark.parametrize("x_half", [False, True])
+@pytest.mark.parametrize("cfg", [(4, 2, 93, 128, 260, 2, 1), (2, 1, 128, 441, 132, 0, 0), (8, 8, 128, 128, 1028, 1, 2)])
+def test_pointwise_half_storage(cfg, x_half):
+    """Half-storage forward of the fused 1x1 layer (fp16 in HBM, fp32 arithmetic) vs the fp32 layer on
+    the same (half-rounded) inputs: equal up to the rounding of the fp16 output."""
+    from sbmc_amd import functions as F
+    B, S, cin, cout, hw, tm, act = cfg
+    slope = 0.01 if act == 2 else 0.0
+    th.manual_seed(sum(cfg))
+    x = th.randn(B, cin, hw, device="cuda")
+    if x_half:
+        x = x.half()
+    w = th.randn(cout, cin, device="cuda") / cin ** 0.5
+    b = th.randn(cout, device="cuda")
+    t = None if tm == 0 else (th.randn(B // S, cout, device="cuda") if tm == 1 else th.randn(B // S, cout, hw, device="cuda"))
+    ref = F.PointwiseLayer.apply(x.float(), w, b, t, S, act, slope)
+    with th.no_grad(), th.autocast("cuda", dtype=th.float16):
+        assert F.pointwise_half_supported(x, cout)
+        y = F.pointwise_half(x, w, b, t, S, act, slope)
+    assert y.dtype == th.float16
+    err = (y.float() - ref).abs().max().item()
+    assert err <= 1e-3 * ref.abs().max().item() + 1e-3, err
