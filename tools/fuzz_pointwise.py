@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    t0, n, fused_bwd = time.time(), 0, 0
+    t0, n, fused_bwd, halves = time.time(), 0, 0, 0
     while time.time() - t0 < args.seconds:
         S = int(rng.choice([1, 1, 2, 3, 8]))
         B = S * int(rng.choice([1, 1, 2, 3]))
@@ -79,12 +79,22 @@ def main():
                 close_sum(t2.grad, t.grad, 3e-5, 1e-6 * (S * hw) ** 0.5)
             elif tm == 2:
                 close(t2.grad, t.grad.float(), rtol=1e-5)
+            if n % 3 == 0:            # half-storage forward (inference) on the same case
+                xin = x0.half() if n % 2 else x0
+                refh = F.PointwiseLayer.apply(xin.float(), w0, b0, t0_, S, act, slope)
+                with th.no_grad(), th.autocast("cuda", dtype=th.float16):
+                    assert F.pointwise_half_supported(xin, cout)
+                    yh = F.pointwise_half(xin, w0, b0, t0_, S, act, slope)
+                errh = (yh.float() - refh).abs().max().item()
+                assert errh <= 1e-3 * refh.abs().max().item() + 1e-3, "half forward: %.3e" % errh
+                halves += 1
         except Exception:
             print("FAILED case:", tag, flush=True)
             raise
         n += 1
         fused_bwd += int(cout <= 128)
-    print("fuzz ok: %d random layers (%d with the fused backward) in %.0f s" % (n, fused_bwd, time.time() - t0))
+    print("fuzz ok: %d random layers (%d with the fused backward, %d half-storage forwards) in %.0f s" % (
+        n, fused_bwd, halves, time.time() - t0))
 
 
 if __name__ == "__main__":
