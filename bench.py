@@ -20,9 +20,12 @@ Workloads
          With the default workload this is also measured, after the timed region, and
          reported under "stages" together with the roofline figure of its dominant kernel.
 
-Multi-GPU (--gpus N under torch.distributed.run): ONE frame, split along H into N slabs
-(strong scaling).  model: per-layer halo exchange over RCCL (sbmc_amd/dist.py) + gradient
-all-reduce; splat: every rank splats the samples of its slab extended by the kernel radius.
+Multi-GPU (--gpus N): ONE frame, split along H into N slabs (strong scaling), one process per
+GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank; a plain
+`python bench.py --gpus N` starts the N ranks itself (re-executes through torch.distributed.run on
+127.0.0.1) and rank 0 prints the one JSON line.  model: U-net halo exchange + cross-rank merge of
+the splat's running state (sbmc_amd/dist.py) + gradient all-reduce; splat: every rank splats its
+own samples into its slab extended by the kernel radius and merges the overhang with its neighbours.
 """
 import argparse
 import gc
@@ -91,6 +94,23 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1, a free port) with the same arguments; rank 0's
+    JSON line goes to this process's stdout.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def make_splat_inputs(h, w, spp, k, device, seed):
     g = th.Generator(device="cpu").manual_seed(seed)
     rad = [th.empty(1, 3, h, w).exponential_(1.0, generator=g).to(device).requires_grad_()
@@ -150,11 +170,16 @@ def train_step(model, opt, loss_fn, batch):
 
 
 def cpu_baseline(args, device=None):
-    """Times the CPU port (torch-CPU convolutions + the oracle's splat operators behind the
-    same Python model code) on a bounded sample of the same workload.  For the model workload
-    the same seeded model and inputs are also run on the GPU, which gives the parity figures
-    of BASELINE.json's metric ("PSNR vs ref", SURVEY.md section 8d: 10*log10(1/MSE) after the
-    display curve x/(1+x), and the max relative error)."""
+    """Times the CPU port on a bounded sample of the same workload (rank 0, N=1 only).
+
+    model workload: the same Python model code with torch-CPU convolutions and the oracle's splat
+    operators behind the `*_cpu_float32` names, on a quarter-height crop of the real frame
+    (width x height/4, all samples): one warm-up training step, then 3 timed ones (1 if the warm-up
+    shows a step costs more than ~25 s on this host), median reported.  The op-level figure
+    (SURVEY.md 8d metric (i): the oracle's splat forward + backward alone, same crop) rides in the
+    same object.  The same seeded model and inputs are also run on the GPU, which gives the parity
+    figures of BASELINE.json's metric ("PSNR vs ref", SURVEY.md section 8d: 10*log10(1/MSE) after
+    the display curve x/(1+x), and the max relative error)."""
     from oracle import sbmc_oracle as orc
     from sbmc_amd import halide_ops
     orc.lib()
@@ -162,53 +187,74 @@ def cpu_baseline(args, device=None):
     threads = th.get_num_threads()
     th.manual_seed(0)
     parity = None
-    if args.workload == "model":
-        from sbmc_amd import Multisteps, losses
-        h = w = 128
-        halide_ops.register_cpu_ops_for_testing(orc)
-        try:
-            model = Multisteps(93, 3, ksize=k)
-            model.train()
-            state = {n: v.clone() for n, v in model.state_dict().items()}
-            opt = th.optim.Adam(model.parameters(), lr=1e-4)
-            batch = make_model_inputs(h, w, spp, "cpu", seed=1)
-            with th.no_grad():
-                ref_out = model(batch)["radiance"]
-            t0 = time.time()
-            train_step(model, opt, losses.TonemappedRelativeMSE(), batch)
-            dt = time.time() - t0
-        finally:
-            halide_ops.register_cpu_ops_for_testing(None)
-        if device is not None:
-            gmodel = Multisteps(93, 3, ksize=k)
-            gmodel.load_state_dict(state)
-            gmodel.to(device).train()
-            with th.no_grad():
-                out = gmodel({n: v.to(device) for n, v in batch.items()})["radiance"].cpu()
-            tm = lambda x: x.clamp(min=0) / (1 + x.clamp(min=0))  # noqa: E731
-            mse = ((tm(out) - tm(ref_out)) ** 2).mean().item()
-            parity = {
-                "psnr_db_vs_cpu_oracle": round(10 * __import__("math").log10(1.0 / max(mse, 1e-30)), 1),
-                "max_rel_err": float("%.3g" % ((out - ref_out).abs() / (ref_out.abs() + 1e-6)).max().item()),
-                "max_abs_err_over_max": float("%.3g" % ((out - ref_out).abs().max() / ref_out.abs().max()).item()),
-                "sample": "Multisteps forward, %dx%d, %d spp, k=%d, GPU (HIP splat + MIOpen/rocBLAS) "
-                          "vs CPU (oracle splat + torch-CPU convs)" % (w, h, spp, k)}
-        what = "Multisteps training step (torch-CPU convs + oracle splat ops)"
-    else:
-        h, w, spp = min(360, args.height), args.width, min(spp, 4)
+    h, w = max(2 * k + 2, (args.height // 4) // 4 * 4), args.width
+
+    # op level: S progressive updates + normalise + backward on the oracle (C operators + torch-CPU glue)
+    def splat_cpu_once():
         rad = [th.empty(1, 3, h, w).exponential_(1.0).requires_grad_() for _ in range(spp)]
         logits = [th.randn(1, k * k, h, w).requires_grad_() for _ in range(spp)]
         d_out = th.randn(1, 3, h, w)
-        t0 = time.time()
+        t0 = time.perf_counter()
         splat_step(lambda d, kk, a, b, m: orc.progressive_kernel_apply(d, kk, a, b, m, splat=True),
                    rad, logits, d_out)
-        dt = time.time() - t0
-        what = "oracle splat fwd+bwd (C ops + torch-CPU composition)"
+        return time.perf_counter() - t0
+    splat_cpu_once()                                    # warm-up (thread pool, page faults)
+    sdts = sorted(splat_cpu_once() for _ in range(3))
+    splat_dt = sdts[1]
+    op = {"value": round(spp * h * w / splat_dt / 1e6, 4), "unit": "Msamples/s",
+          "sample": "oracle splat fwd+bwd (%d x progressive_kernel_apply + normalise + backward) on %dx%d, "
+                    "%d spp, k=%d: median of 3 after 1 warm-up = %.2f s" % (spp, w, h, spp, k, splat_dt)}
+    if args.workload != "model":
+        base = dict(op)
+        base.update({"cores": threads, "kind": "port"})
+        base["sample"] += " on %d threads (host has %d logical cpus)" % (threads, os.cpu_count())
+        return base, None
+
+    from sbmc_amd import Multisteps, losses
+    halide_ops.register_cpu_ops_for_testing(orc)
+    try:
+        model = Multisteps(93, 3, ksize=k)
+        model.train()
+        state = {n: v.clone() for n, v in model.state_dict().items()}
+        opt = th.optim.Adam(model.parameters(), lr=1e-4)
+        batch = make_model_inputs(h, w, spp, "cpu", seed=1)
+        with th.no_grad():
+            ref_out = model(batch)["radiance"]
+        loss_fn = losses.TonemappedRelativeMSE()
+        t0 = time.perf_counter()
+        train_step(model, opt, loss_fn, batch)           # warm-up: oneDNN primitives, Adam state
+        warm = time.perf_counter() - t0
+        ntimed = 3 if warm < 25.0 else 1
+        dts = []
+        for _ in range(ntimed):
+            t0 = time.perf_counter()
+            train_step(model, opt, loss_fn, batch)
+            dts.append(time.perf_counter() - t0)
+        dt = sorted(dts)[len(dts) // 2]
+    finally:
+        halide_ops.register_cpu_ops_for_testing(None)
+    if device is not None:
+        gmodel = Multisteps(93, 3, ksize=k)
+        gmodel.load_state_dict(state)
+        gmodel.to(device).train()
+        with th.no_grad():
+            out = gmodel({n: v.to(device) for n, v in batch.items()})["radiance"].cpu()
+        tm = lambda x: x.clamp(min=0) / (1 + x.clamp(min=0))  # noqa: E731
+        mse = ((tm(out) - tm(ref_out)) ** 2).mean().item()
+        parity = {
+            "psnr_db_vs_cpu_oracle": round(10 * __import__("math").log10(1.0 / max(mse, 1e-30)), 1),
+            "max_rel_err": float("%.3g" % ((out - ref_out).abs() / (ref_out.abs() + 1e-6)).max().item()),
+            "max_abs_err_over_max": float("%.3g" % ((out - ref_out).abs().max() / ref_out.abs().max()).item()),
+            "sample": "Multisteps forward, %dx%d, %d spp, k=%d, GPU (HIP splat + MIOpen/rocBLAS) "
+                      "vs CPU (oracle splat + torch-CPU convs)" % (w, h, spp, k)}
     base = {
         "value": round(spp * h * w / dt / 1e6, 4), "unit": "Msamples/s",
         "cores": threads, "kind": "port",
-        "sample": "%s on %dx%d, %d spp, k=%d: %.1f s on %d threads (host has %d logical cpus)" % (
-            what, w, h, spp, k, dt, threads, os.cpu_count()),
+        "sample": "Multisteps training step (torch-CPU convs + oracle splat ops) on a %dx%d crop (full width, "
+                  "quarter height) of the frame, %d spp, k=%d: 1 warm-up step (%.1f s) + %d timed, median "
+                  "%.1f s, on %d threads (host has %d logical cpus)" % (
+                      w, h, spp, k, warm, ntimed, dt, threads, os.cpu_count()),
+        "splat_op": op,
     }
     return base, parity
 
@@ -218,9 +264,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py "
-                         "--gpus %d ..." % (args.gpus, args.gpus))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not th.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X)")
     # test hooks (single-GPU dry run of the multi-rank code path): all ranks on device 0 over gloo
@@ -245,8 +292,9 @@ def main():
     pad = (K - 1) // 2
     is_model = args.workload in ("model", "infer")
     infer = args.workload == "infer"
-    steps = args.steps if args.steps is not None else (3 if is_model else 10)
-    warmup = args.warmup if args.warmup is not None else (2 if is_model else 3)
+    # SURVEY.md 8d protocol: >= 5 warm-up and >= 20 timed iterations (whole run: a few minutes)
+    steps = args.steps if args.steps is not None else 20
+    warmup = args.warmup if args.warmup is not None else 5
     if is_model:
         # the first TWO steps carry one-time work (MIOpen solver selection forward and backward,
         # Adam state allocation, caching-allocator growth): never time them
@@ -276,16 +324,24 @@ def main():
         gc.collect()
         gc.freeze()
         functions.enable_kernel_timing(store if events_inside else None)
+        marks = [th.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]   # one per step boundary
+        stream = th.cuda.current_stream(device)
         t0 = time.perf_counter()
         for i in range(nsteps):
+            marks[i].record(stream)
             step_fn()
             if os.environ.get("SBMC_BENCH_VERBOSE"):   # debugging aid: adds a sync per step
                 th.cuda.synchronize(device)
                 print("step %d: %.1f ms since start" % (i, (time.perf_counter() - t0) * 1e3),
                       file=sys.stderr, flush=True)
+        marks[nsteps].record(stream)
         sync()
         dt = time.perf_counter() - t0
         functions.enable_kernel_timing(None)
+        # per-step device time between the boundary events (no extra synchronisation): the median
+        # SURVEY.md 8d asks for; `value` stays the whole-region figure the driver's contract defines
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) * 1e-3 for i in range(nsteps))
+        med = per_step[nsteps // 2] if nsteps % 2 else 0.5 * (per_step[nsteps // 2 - 1] + per_step[nsteps // 2])
         if store is not None and not events_inside:
             functions.enable_kernel_timing(store)
             for _ in range(2):
@@ -293,9 +349,11 @@ def main():
             sync()
             functions.enable_kernel_timing(None)
         if world > 1:
-            t = th.tensor([dt], dtype=th.float64, device=device if backend == "nccl" else "cpu")
+            t = th.tensor([dt, med], dtype=th.float64, device=device if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
+            dt, med = t[0].item(), t[1].item()
+        timed.median = med
+        timed.spread = (per_step[0], per_step[-1])
         return dt
 
     part = sdist.SlabPartition(H, world, rank)
@@ -333,6 +391,7 @@ def main():
             def step():
                 runner.train_step(opt, loss_fn, batch)
         dt = timed(step, warmup, steps, timings, events_inside=False)
+        med_s, spread = timed.median, timed.spread
         model_timings = timings
         del batch
         # rows the splat kernels see on this rank (the slab plus the kernel radius at inner edges)
@@ -342,6 +401,7 @@ def main():
         s0, s1 = max(0, part.y0 - pad), min(H, part.y1 + pad)
         rad, logits, d_out = make_splat_inputs(s1 - s0, W, S, K, device, seed=1234 + rank)
         dt = timed(lambda: splat_step(update, rad, logits, d_out), warmup, steps, timings)
+        med_s, spread = timed.median, timed.spread
         local_px = (s1 - s0) * W
 
     # ---------------------------------------------------------------- splat stages (N=1, model)
@@ -352,12 +412,13 @@ def main():
         timings = []
         update = modules.ProgressiveKernelApply(splat=True)
         rad, logits, d_out = make_splat_inputs(H, W, S, K, device, seed=1234)
-        sdt = timed(lambda: splat_step(update, rad, logits, d_out), 3, 10, timings)
+        sdt = timed(lambda: splat_step(update, rad, logits, d_out), 5, 20, timings)
         local_px = H * W
         stage = {"workload": "splat fwd+bwd only, reference module API: %d x ProgressiveKernelApply("
                              "splat=True) + normalise + backward" % S,
-                 "value": round(S * H * W / (sdt / 10) / 1e6, 2), "unit": "Msamples/s",
-                 "ms_per_step": round(sdt / 10 * 1e3, 3), "steps": 10, "warmup": 3}
+                 "value": round(S * H * W / (sdt / 20) / 1e6, 2), "unit": "Msamples/s",
+                 "ms_per_step": round(sdt / 20 * 1e3, 3), "ms_per_step_median": round(timed.median * 1e3, 3),
+                 "steps": 20, "warmup": 5}
         # the same work the way Multisteps issues it: all samples in one launch per kernel
         all_rad = th.stack([r.detach() for r in rad], 1).requires_grad_()
         all_log = th.stack([t.detach() for t in logits], 1).requires_grad_()
@@ -369,11 +430,12 @@ def main():
                 all_log.grad = None
                 sr, sw, _ = functions.SplatAll.apply(all_rad, all_log)
                 (sr / (sw + 1e-8)).backward(d_out)
-            adt = timed(all_step, 3, 10, timings)
+            adt = timed(all_step, 5, 20, timings)
             stage_all = {"workload": "splat fwd+bwd only, as Multisteps issues it: functions.SplatAll "
                                      "(all %d samples per launch) + normalise + backward" % S,
-                         "value": round(S * H * W / (adt / 10) / 1e6, 2), "unit": "Msamples/s",
-                         "ms_per_step": round(adt / 10 * 1e3, 3), "steps": 10, "warmup": 3}
+                         "value": round(S * H * W / (adt / 20) / 1e6, 2), "unit": "Msamples/s",
+                         "ms_per_step": round(adt / 20 * 1e3, 3), "ms_per_step_median": round(timed.median * 1e3, 3),
+                 "steps": 20, "warmup": 5}
             # informational: the same with fp16 logit storage (BASELINE configs[4] "fp16 activations";
             # NOT the fp32 metric -- reported separately, never mixed into `value`)
             all_log16 = all_log.detach().half().requires_grad_()
@@ -385,11 +447,12 @@ def main():
                 all_log16.grad = None
                 sr, sw, _ = functions.SplatAll.apply(all_rad, all_log16)
                 (sr / (sw + 1e-8)).backward(d_out)
-            hdt = timed(all_step16, 3, 10, timings)
+            hdt = timed(all_step16, 5, 20, timings)
             stage_f16 = {"workload": "as splat_all_samples but with fp16 logit / logit-gradient storage "
                                      "(fp32 arithmetic)", "dtype": "f16 storage, f32 math",
-                         "value": round(S * H * W / (hdt / 10) / 1e6, 2), "unit": "Msamples/s",
-                         "ms_per_step": round(hdt / 10 * 1e3, 3), "steps": 10, "warmup": 3}
+                         "value": round(S * H * W / (hdt / 20) / 1e6, 2), "unit": "Msamples/s",
+                         "ms_per_step": round(hdt / 20 * 1e3, 3), "ms_per_step_median": round(timed.median * 1e3, 3),
+                 "steps": 20, "warmup": 5}
 
     # per-call device time of the fused operators (events on the launch stream)
     per = {}
@@ -431,6 +494,9 @@ def main():
                 "fwd only" if infer else "fwd+bwd", W, H, S, K, K),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
+            "ms_per_step_median": round(med_s * 1e3, 3),
+            "ms_per_step_min_max": [round(spread[0] * 1e3, 3), round(spread[1] * 1e3, 3)],
+            "value_at_median": round(S * H * W / med_s / 1e6, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16 activations, f32 splat math" if (infer and args.fp16_activations) else "f32",
             "data": "synthetic",
@@ -468,8 +534,15 @@ def main():
                 "kernel": "sbmc::splat_bwd_strip_kernel<21,3> (%d sample(s) per launch; the timed call "
                           "also holds its per-pixel state pre-pass, ~1-3%%)" % kb["samples_per_launch"],
                 "bound": "hbm", "achieved": kb["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(kb["GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "traffic_source": src, "alg_bytes_per_launch": kb["alg_bytes"],
+                "frac": round(kb["GBps"] / HBM_PEAK_GBPS, 4),
+                # PMC counters cannot be read from inside the run: `traffic` is null here; the figure
+                # below comes from the committed rocprofv3 --pmc passes of this same kernel and size
+                "traffic": None,
+                "traffic_profiled": None if traffic is None else {
+                    "hbm_bytes_per_launch": traffic, "source": "profiles/" + src,
+                    "note": "separate rocprofv3 --pmc passes of this command (tools/prof.sh), per "
+                            "1-sample launch x samples per launch; not measured in this run"},
+                "alg_bytes_per_launch": kb["alg_bytes"],
                 "avg_launch_ms": kb["avg_ms"],
             }
         if world == 1 and not args.no_cpu_baseline and not infer:

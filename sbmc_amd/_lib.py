@@ -6,6 +6,7 @@ raises -- loudly -- instead of degrading to a slow path.
 """
 import ctypes
 import os
+import warnings
 
 import torch  # noqa: F401  (must be loaded first: brings in the HIP runtime the library binds to)
 
@@ -65,14 +66,26 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH) and LIB_PATH == _DEFAULT_LIB_PATH:
-        # not built yet (fresh checkout: *.so is git-ignored): build the real thing with hipcc.
-        # This is a build step, not a fallback -- if hipcc is unavailable the error below stands.
+    if LIB_PATH == _DEFAULT_LIB_PATH:
+        # not built yet (fresh checkout: *.so is git-ignored) or older than its sources: build the
+        # real thing with hipcc.  This is a build step, not a fallback -- a compile error is the
+        # error the user sees.
+        from . import build as _build
         try:
-            from . import build as _build
-            _build.build()
-        except Exception:
-            pass
+            stale = _build.is_stale()
+        except OSError:
+            stale = not os.path.exists(LIB_PATH)     # installed without sources: take the .so as is
+        if stale:
+            try:
+                _build.build()
+            except Exception as e:
+                if not os.path.exists(LIB_PATH):
+                    raise HipExtensionMissing(
+                        "%s is not built and building it failed (%s: %s). Build it with `python -m "
+                        "sbmc_amd.build` (hipcc, gfx950); sbmc_amd has no CPU or PyTorch fallback for "
+                        "its operators." % (LIB_PATH, type(e).__name__, e)) from e
+                warnings.warn("%s is older than its sources and rebuilding it failed (%s: %s); "
+                              "loading the stale library" % (LIB_PATH, type(e).__name__, e))
     if not os.path.exists(LIB_PATH):
         raise HipExtensionMissing(
             "%s not found: build it with `python -m sbmc_amd.build` (hipcc, gfx950). "

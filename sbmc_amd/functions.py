@@ -274,7 +274,9 @@ class BiasAct(th.autograd.Function):
 
     @staticmethod
     def supported(y):
-        hw = y[0, 0].numel() if y.dim() >= 2 and y.numel() else 0
+        if y.dim() < 2 or y.numel() == 0:
+            return False          # (the C ABI treats an empty batch as a no-op; torch handles it here)
+        hw = y[0, 0].numel()
         return (y.is_cuda and y.dtype == th.float32 and y.is_contiguous() and hw % 4 == 0
                 and y.data_ptr() % 16 == 0 and y.shape[0] <= 65535 and y.shape[1] <= 65535)
 
@@ -385,7 +387,7 @@ def pointwise_half_supported(x, cout):
     GPU, x [B, cin, ...pixels] float32 or float16, dimensions the fused kernels take."""
     if not (x.is_cuda and x.dtype in (th.float32, th.float16) and x.dim() >= 3 and x.numel() > 0):
         return False
-    if th.is_grad_enabled() or not th.is_autocast_enabled() or th.get_autocast_gpu_dtype() != th.float16:
+    if th.is_grad_enabled() or not th.is_autocast_enabled() or th.get_autocast_dtype("cuda") != th.float16:
         return False
     hw = x[0, 0].numel()
     return (x.data_ptr() % 16 == 0 and x.shape[0] <= 65535 and cout <= 65535

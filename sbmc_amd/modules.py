@@ -244,7 +244,9 @@ class ConvChain(nn.Module):
             act, slope = 2, float(activation.negative_slope)
         y = th.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if not funcs.BiasAct.supported(y):
-            return None, False
+            # (odd plane sizes, channels_last results, empty batches) the convolution is done: finish
+            # with torch's bias add instead of running the module -- and the convolution -- again
+            return y + conv.bias.view(1, -1, 1, 1), False
         return funcs.BiasAct.apply(y, conv.bias, act, slope), act != 0
 
     def _run(self, mods, x, mean_s=0, mean_out=None):

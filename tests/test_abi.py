@@ -94,3 +94,20 @@ def test_product_never_imports_the_oracle():
         assert "sbmc_oracle" not in src, path
     for path in glob.glob(os.path.join(ROOT, "sbmc_amd", "csrc", "*")):
         assert "oracle" not in open(path).read(), path
+
+
+def test_product_never_installs_a_host_implementation():
+    """`halide_ops.register_cpu_ops_for_testing` is a test-harness seam: no product module (package or
+    scripts) may call it -- with the oracle or with anything else -- so the `*_cpu_float32` names can
+    only ever resolve inside a test or bench.py's cpu_baseline leg."""
+    import glob
+    files = glob.glob(os.path.join(ROOT, "sbmc_amd", "**", "*.py"), recursive=True)
+    files += glob.glob(os.path.join(ROOT, "scripts", "*.py"))
+    for path in files:
+        src = open(path).read()
+        uses = [m.start() for m in re.finditer(r"register_cpu_ops_for_testing|_CPU_OPS\s*=", src)]
+        if path.endswith(os.path.join("sbmc_amd", "halide_ops.py")):
+            # the definition, its docstring mention and the two assignments inside it: nothing else
+            assert len(re.findall(r"register_cpu_ops_for_testing\s*\(", src)) == 1, path
+            continue
+        assert not uses, "%s touches the test-only host-op seam" % path
