@@ -394,15 +394,37 @@ def main():
         med_s, spread = timed.median, timed.spread
         model_timings = timings
         del batch
-        # rows the splat kernels see on this rank (the slab plus the kernel radius at inner edges)
-        local_px = (min(H, part.y1 + pad) - max(0, part.y0 - pad)) * W if world > 1 else H * W
-    else:
+        # source pixels whose logits this rank's splat kernels stream (its own rows: the overhang of the
+        # running state is exchanged, nothing is recomputed)
+        local_px = part.rows * W
+    elif world == 1:
         update = modules.ProgressiveKernelApply(splat=True)
-        s0, s1 = max(0, part.y0 - pad), min(H, part.y1 + pad)
-        rad, logits, d_out = make_splat_inputs(s1 - s0, W, S, K, device, seed=1234 + rank)
+        rad, logits, d_out = make_splat_inputs(H, W, S, K, device, seed=1234)
         dt = timed(lambda: splat_step(update, rad, logits, d_out), warmup, steps, timings)
         med_s, spread = timed.median, timed.spread
-        local_px = (s1 - s0) * W
+        local_px = H * W
+    else:
+        # every rank splats the samples of its own rows into its slab extended by the kernel radius,
+        # exchanges the overhang rows of the running state with its neighbours and merges them
+        # (sbmc_amd/dist.py), normalises and runs the backward -- no other communication
+        rad, logits, d_out = make_splat_inputs(part.rows, W, S, K, device, seed=1234 + rank)
+        all_rad = th.stack([r.detach() for r in rad], 1).requires_grad_()
+        all_log = th.stack([t.detach() for t in logits], 1).requires_grad_()
+        del rad, logits
+        slab = (pad if part.has_up else 0, pad if part.has_down else 0, not part.has_up, not part.has_down)
+        if part.min_rows < pad or not functions.splat_slab_supported(all_rad, all_log, slab[0], slab[1]):
+            raise SystemExit("bench.py --workload splat --gpus %d: slabs of %d rows are not supported" % (
+                world, part.rows))
+
+        def slab_step():
+            all_rad.grad = None
+            all_log.grad = None
+            st = functions.SplatAll.apply(all_rad, all_log, *slab)
+            sr, sw, _ = sdist.merge_overhang(st[0], st[1], st[2], pad, part)
+            (sr / (sw + 1e-8)).backward(d_out)
+        dt = timed(slab_step, warmup, steps, timings)
+        med_s, spread = timed.median, timed.spread
+        local_px = part.rows * W
 
     # ---------------------------------------------------------------- splat stages (N=1, model)
     stage = stage_all = stage_f16 = None
@@ -500,6 +522,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16 activations, f32 splat math" if (infer and args.fp16_activations) else "f32",
             "data": "synthetic",
+            "world_size": world if world == 1 else dist.get_world_size(),
+            "backend": None if world == 1 else dist.get_backend(),
             "config": {
                 "workload": "Multisteps(93,3,ksize=%d) forward only (eval, no_grad)" % K if infer else
                             "Multisteps(93,3,ksize=%d) training step: fwd + TonemappedRelativeMSE + bwd "
@@ -508,8 +532,10 @@ def main():
                             "backward" % S,
                 "height": H, "width": W, "spp": S, "ksize": K, "batch": 1,
                 "parallelism": "single GPU" if world == 1 else
-                               ("H-slabs x%d, halo exchange + grad all-reduce" % world if is_model else
-                                "H-slabs x%d (+%d halo rows/side)" % (world, pad)),
+                               ("H-slabs x%d: U-net halo exchange, cross-rank merge of the splat state (%d "
+                                "overhang rows), one flat gradient all-reduce" % (world, pad) if is_model else
+                                "H-slabs x%d: own samples splatted into slab + %d overhang rows/side, running "
+                                "state exchanged and merged" % (world, pad)),
             },
         }
         if stage is not None:

@@ -41,7 +41,7 @@ extern "C" {
 #define SBMC_API
 #endif
 
-#define SBMC_HIP_ABI_VERSION 1
+#define SBMC_HIP_ABI_VERSION 2
 #define SBMC_HIP_EINVAL (-1)
 /* largest channel count the fused/plain kernels take in one call */
 #define SBMC_HIP_MAX_CHANNELS 8
@@ -220,6 +220,58 @@ SBMC_API int sbmc_splat_all_bwd_f32(const float *data, const float *kernels,
                            const float *d_sum_r, const float *d_sum_w, const float *d_max_w,
                            float *d_data, float *d_kernels, float *scratch,
                            int bs, int s, int c, int h, int w, int k, void *stream);
+
+/*
+ * Row-slab form of the all-samples splat: ONE frame sharded along H over several GPUs (new
+ * functionality; the reference's closest analogue is the overlapped tiling
+ * of scripts/denoise.py:54-93).  A rank holds the h rows of its slab -- radiance and logits of its
+ * own samples only -- and splats them into a destination slab of hd = top + h + bot rows:
+ * destination row r is source row r - top, `top` / `bot` (0 <= . <= (k-1)/2) are the overhang rows
+ * that belong to the neighbouring ranks.  Source rows beyond a slab edge:
+ *   zero_top / zero_bot = 1  the edge is the image edge: the taps beyond it are the zero-filled
+ *                            taps of Scatter2Gather (logit 0, data 0 -- src/scatter2gather.cpp:34-47),
+ *                            counted in the running softmax exactly as in the whole-frame calls;
+ *   zero_top / zero_bot = 0  the rows belong to a neighbouring slab, whose rank accounts for them:
+ *                            they contribute nothing here.
+ * Every destination pixel's state is then the log-sum-exp partial over this rank's sources; the
+ * ranks exchange the overhang rows and merge them with the rule of sbmc/modules.py:450-471
+ * (sbmc_amd/dist.py), which reproduces the whole-frame state up to fp32 rounding.
+ *   1. sbmc_splat_slab_fwd_f32: n = bs*S images; part_r [n,c,hd,w], part_w / part_m / atap [n,hd,w]
+ *      (part_m = the per-sample max, as kmax in the whole-frame call);
+ *   2. sbmc_splat_merge_fwd_f32 with h := hd folds the S partial states (unchanged);
+ *   3. sbmc_splat_slab_bwd_f32: as sbmc_splat_all_bwd_f32; run_*, part_m, atap and the upstream
+ *      gradients live on the hd destination rows, data / kernels / d_data / d_kernels on the h
+ *      source rows; scratch: sbmc_splat_update_bwd_scratch_bytes(bs*S, c, hd, w, k) bytes.
+ * Whole frame == (top, bot, zero_top, zero_bot) = (0, 0, 1, 1).  Strip kernels only:
+ * sbmc_splat_slab_supported(c, k, h, w, top, bot) == 1, else SBMC_HIP_EINVAL (the caller then
+ * halo-pads the inputs and uses the whole-frame calls on the padded slab).
+ */
+SBMC_API int sbmc_splat_slab_supported(int c, int k, int h, int w, int top, int bot);
+
+SBMC_API int sbmc_splat_slab_fwd_f32(const float *data, const float *kernels,
+                            float *part_r, float *part_w, float *part_m, int32_t *atap,
+                            int n, int c, int h, int w, int k,
+                            int top, int bot, int zero_top, int zero_bot, void *stream);
+
+SBMC_API int sbmc_splat_slab_bwd_f32(const float *data, const float *kernels,
+                            const float *part_m, const int32_t *atap,
+                            const float *run_r, const float *run_w, const float *run_m,
+                            const float *d_sum_r, const float *d_sum_w, const float *d_max_w,
+                            float *d_data, float *d_kernels, float *scratch,
+                            int bs, int s, int c, int h, int w, int k, int top, int bot, void *stream);
+
+/* the same with half logits / logit gradients (see the fp16 block below) */
+SBMC_API int sbmc_splat_slab_fwd_f16(const float *data, const void *kernels,
+                            float *part_r, float *part_w, float *part_m, int32_t *atap,
+                            int n, int c, int h, int w, int k,
+                            int top, int bot, int zero_top, int zero_bot, void *stream);
+
+SBMC_API int sbmc_splat_slab_bwd_f16(const float *data, const void *kernels,
+                            const float *part_m, const int32_t *atap,
+                            const float *run_r, const float *run_w, const float *run_m,
+                            const float *d_sum_r, const float *d_sum_w, const float *d_max_w,
+                            float *d_data, void *d_kernels, float *scratch,
+                            int bs, int s, int c, int h, int w, int k, int top, int bot, void *stream);
 
 /*
  * fp16 logits ("fp16 activations", BASELINE.json configs[4]).  Same calls as

@@ -29,6 +29,11 @@ SYMBOLS = (
     "sbmc_splat_all_supported",
     "sbmc_splat_merge_fwd_f32",
     "sbmc_splat_all_bwd_f32",
+    "sbmc_splat_slab_supported",
+    "sbmc_splat_slab_fwd_f32",
+    "sbmc_splat_slab_bwd_f32",
+    "sbmc_splat_slab_fwd_f16",
+    "sbmc_splat_slab_bwd_f16",
     "sbmc_splat_f16_supported",
     "sbmc_splat_update_fwd_f16",
     "sbmc_splat_update_bwd_f16",
@@ -51,7 +56,7 @@ SYMBOLS = (
     "sbmc_upsample2x_cat_fwd_f32",
     "sbmc_upsample2x_cat_bwd_f32",
 )
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_CHANNELS = 8
 
 _LIB = None
@@ -109,6 +114,11 @@ def lib():
     handle.sbmc_splat_f16_supported.argtypes = [i] * 4
     handle.sbmc_splat_merge_fwd_f32.argtypes = [p] * 9 + [i] * 5 + [p]
     handle.sbmc_splat_all_bwd_f32.argtypes = [p] * 13 + [i] * 6 + [p]
+    handle.sbmc_splat_slab_supported.argtypes = [i] * 6
+    handle.sbmc_splat_slab_fwd_f32.argtypes = [p] * 6 + [i] * 9 + [p]
+    handle.sbmc_splat_slab_bwd_f32.argtypes = [p] * 13 + [i] * 8 + [p]
+    handle.sbmc_splat_slab_fwd_f16.argtypes = handle.sbmc_splat_slab_fwd_f32.argtypes
+    handle.sbmc_splat_slab_bwd_f16.argtypes = handle.sbmc_splat_slab_bwd_f32.argtypes
     handle.sbmc_splat_update_fwd_f16.argtypes = handle.sbmc_splat_update_fwd_f32.argtypes
     handle.sbmc_splat_update_bwd_f16.argtypes = handle.sbmc_splat_update_bwd_f32.argtypes
     handle.sbmc_splat_all_bwd_f16.argtypes = handle.sbmc_splat_all_bwd_f32.argtypes

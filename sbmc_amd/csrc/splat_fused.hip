@@ -91,6 +91,12 @@ struct SplatFwdParams {
     int32_t* atap_out;
     int bs, h, w, k;
     int ntx, nty;
+    // row-slab form (strip kernels only; hd == h, top == 0, zero_top == zero_bot == 1 is the whole
+    // frame): data / kernels hold the slab's own h source rows, the outputs hd = top + h + bottom
+    // destination rows; destination row r is source row r - top.  A slab edge that is the image
+    // edge (zero_*) sees Scatter2Gather's zero-filled taps beyond it; beyond an inner edge the
+    // taps belong to the neighbouring slab and contribute nothing here.
+    int hd, top, zero_top, zero_bot;
 };
 
 // ------------------------------------------------------------------ tile forward
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     const int lane = threadIdx.x & 63;
     const long item = (long)logical_block_id() * V2_WAVES + wv;
     const int nseg = p.ntx;
-    const long per_img = (long)p.h * nseg;
+    const long per_img = (long)p.hd * nseg;   // one item per 64-pixel strip of a DESTINATION row
     if (item >= per_img * p.bs) return;  // whole wave; no block-level barrier is used below
     // readfirstlane: the divisions run on the VALU; force the (uniform) results back to
     // SGPRs so that every address below is "SGPR base + lane" (global_load saddr form)
@@ -239,7 +245,8 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     const int X0 = __builtin_amdgcn_readfirstlane((rem % nseg) * TX);
     const int X = X0 + lane;
     const bool xact = X < p.w;
-    const size_t hw = (size_t)p.h * p.w;
+    const size_t hw = (size_t)p.h * p.w;      // source planes
+    const size_t hwd = (size_t)p.hd * p.w;    // destination planes (== hw unless this is a row slab)
     const size_t pix = (size_t)Y * p.w + (xact ? X : p.w - 1);
     const bool first = (p.sum_r_in == nullptr);
     float* buf = lds + wv * (C * V2_ROW);
@@ -264,8 +271,9 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     // border strips: lane's source column X+dx-P is inside the image for dx in [dx_lo, dx_hi)
     const int dx_lo = P - X, dx_hi = p.w + P - X;
 
-    auto load_row = [&](int dy, float (&v)[K], float (&s)[2 * C]) {
-        const int ys = Y + dy - P;
+    // returns false when the row contributes nothing (it lies in a neighbouring slab)
+    auto load_row = [&](int dy, float (&v)[K], float (&s)[2 * C]) -> bool {
+        const int ys = Y - p.top + dy - P;
         const bool yin = (ys >= 0) && (ys < p.h);  // wave-uniform
         if constexpr (GATHER) {
             const rsrc_t rs = make_rsrc(S + ((size_t)(dy * K) * hw + (size_t)Y * p.w + (size_t)X0));
@@ -279,14 +287,15 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
                 s[2 * c] = (yin && inA) ? dr[colA] : 0.f;
                 s[2 * c + 1] = (yin && inB) ? dr[colB] : 0.f;
             }
-            return;
+            return true;
         }
         if (!yin) {
+            if (!(ys < 0 ? p.zero_top : p.zero_bot)) return false;
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) v[dx] = 0.f;
 #pragma unroll
             for (int j = 0; j < 2 * C; ++j) s[j] = 0.f;
-            return;
+            return true;
         }
         // tap dx of this row: plane (2P-dy)*K + (K-1-dx), row ys, column X0-P+dx+lane
         //   = rowmin + (K-1-dx) * (hw-1) + lane,  rowmin = address of tap K-1, lane 0
@@ -307,6 +316,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
             s[2 * c] = inA ? dr[colA] : 0.f;
             s[2 * c + 1] = inB ? dr[colB] : 0.f;
         }
+        return true;
     };
     auto step = [&](int dy, const float (&v)[K], const float (&s)[2 * C]) {
         wave_lds_sync();  // previous row's reads are done before its slots are overwritten
@@ -324,12 +334,12 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     float v[K], s[2 * C];
 #pragma unroll 1
     for (int dy = 0; dy < K; ++dy) {
-        load_row(dy, v, s);
+        if (!load_row(dy, v, s)) continue;   // wave-uniform
         step(dy, v, s);
     }
 
     if (xact) {
-        const size_t o = (size_t)n * hw + pix;
+        const size_t o = (size_t)n * hwd + pix;
         float M = m;  // == kmax here
         if (!first) {
             const float Mp = p.max_w_in[o];
@@ -338,14 +348,14 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
             accw = p.sum_w_in[o] * sigma + accw * tau;
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                acc[c] = p.sum_r_in[((size_t)n * C + c) * hw + pix] * sigma + acc[c] * tau;
+                acc[c] = p.sum_r_in[((size_t)n * C + c) * hwd + pix] * sigma + acc[c] * tau;
         }
         p.sum_w_out[o] = accw;
         p.max_w_out[o] = M;
-        p.kmax_out[o] = kmax;
+        if (p.kmax_out) p.kmax_out[o] = kmax;
         p.atap_out[o] = atap;
 #pragma unroll
-        for (int c = 0; c < C; ++c) p.sum_r_out[((size_t)n * C + c) * hw + pix] = acc[c];
+        for (int c = 0; c < C; ++c) p.sum_r_out[((size_t)n * C + c) * hwd + pix] = acc[c];
     }
 }
 
@@ -369,9 +379,10 @@ struct SplatBwdParams {
     float* d_sum_r_in;         // or null
     float* d_sum_w_in;
     float* d_max_w_in;
-    float* scratch;            // tile: d_kmax [bs, h, w];  strip: destination records [bs, h, w, REC]
+    float* scratch;            // tile: d_kmax [bs, h, w];  strip: destination records [bs, hd, w, REC]
     int bs, c, h, w, k;
     int ntx, nty;
+    int hd, top;               // row-slab form (splat_bwd_strip_kernel only), see SplatFwdParams
 };
 
 // Per-pixel state adjoint (everything in modules.py:450-457,470-471 that is not a
@@ -546,7 +557,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
     }
     const LT* S = static_cast<const LT*>(p.kernels) + (size_t)n * K * K * hw + (size_t)ys * p.w + X0;
     LT* dS = static_cast<LT*>(p.d_kernels) + (size_t)n * K * K * hw + (size_t)ys * p.w + X0;
-    const float4* rec = reinterpret_cast<const float4*>(p.scratch) + (size_t)n * hw * 2;
+    const float4* rec = reinterpret_cast<const float4*>(p.scratch) + (size_t)n * p.hd * p.w * 2;
     const unsigned voff = active ? (unsigned)lane * (unsigned)sizeof(LT) : BUF_OOB;  // sample-less lanes: loads 0, stores dropped
     const unsigned plane_stride = (unsigned)hw * (unsigned)sizeof(LT);
 
@@ -563,8 +574,8 @@ __global__ __launch_bounds__(V2_WAVES * TX, 8) void splat_bwd_strip_kernel(Splat
         for (int kx = 0; kx < K; ++kx) s[kx] = logit_load<LT, AUX_BWD_LD>(rs, voff, (unsigned)kx * plane_stride);
     };
     auto step = [&](int ky, const float (&s)[K]) {
-        const int yd = ys + ky - P;
-        const bool yin = (yd >= 0) && (yd < p.h);  // wave-uniform
+        const int yd = ys + p.top + ky - P;         // destination row (of the slab's hd rows)
+        const bool yin = (yd >= 0) && (yd < p.hd);  // wave-uniform
         float4 a0 = fill0, a1 = zero4, b0 = fill0, b1 = zero4;
         if (yin) {
             const float4* rrow = rec + (size_t)yd * p.w * 2;
@@ -962,19 +973,23 @@ static int splat_update_fwd_impl(const float* data, const void* kernels,
                                  float* max_w_out, float* kmax_out,
                                  int32_t* atap_out,
                                  int bs, int c, int h, int w, int k,
-                                 void* stream) {
+                                 void* stream, int top = 0, int bot = 0, int zero_top = 1, int zero_bot = 1) {
     if (bad_splat_dims(bs, c, h, w, k)) return SBMC_HIP_EINVAL;
     const int nin = (sum_r_in != nullptr) + (sum_w_in != nullptr) + (max_w_in != nullptr);
     if (nin != 0 && nin != 3) return SBMC_HIP_EINVAL;  // modules.py:431-435
+    const bool slab = top != 0 || bot != 0 || !zero_top || !zero_bot;
+    if (top < 0 || bot < 0 || top > (k - 1) / 2 || bot > (k - 1) / 2) return SBMC_HIP_EINVAL;
+    const int hd = top + h + bot;
+    if (slab && !strip_ok(c, k, hd, w, sizeof(LT) != 4)) return SBMC_HIP_EINVAL;   // strip kernels only
     if (bs == 0 || h == 0 || w == 0) return 0;
-    if (!data || !kernels || !sum_r_out || !sum_w_out || !max_w_out || !kmax_out || !atap_out)
+    if (!data || !kernels || !sum_r_out || !sum_w_out || !max_w_out || !atap_out || (!kmax_out && !slab))
         return SBMC_HIP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int variant = splat_variant();
-    if (variant > 0 && strip_ok(c, k, h, w, sizeof(LT) != 4)) {
+    const int variant = slab ? 1 : splat_variant();
+    if (variant > 0 && strip_ok(c, k, hd, w, sizeof(LT) != 4)) {
         SplatFwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out,
-                         max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), h};
-        const long items = (long)bs * h * p.ntx;
+                         max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), h, hd, top, zero_top, zero_bot};
+        const long items = (long)bs * hd * p.ntx;
         const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
         SBMC_LAUNCH_STRIP(splat_fwd_strip_kernel, grid, s, p);
         return (int)hipGetLastError();
@@ -983,7 +998,7 @@ static int splat_update_fwd_impl(const float* data, const void* kernels,
     const size_t lds = fwd_tile_lds_bytes(c, k);
     if (lds > 64 * 1024) return SBMC_HIP_EINVAL;
     SplatFwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out,
-                     max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), tiles_y(h, FWD_TY)};
+                     max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), tiles_y(h, FWD_TY), h, 0, 1, 1};
     const unsigned grid = (unsigned)bs * p.ntx * p.nty;
     SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_fwd_tile_kernel<C>), dim3(grid),
                                           dim3(FWD_TY * TX), lds, s, p));
@@ -1021,7 +1036,7 @@ static int splat_update_bwd_impl(const float* data, const void* kernels,
     if (variant > 0 && strip_ok(c, k, h, w, sizeof(LT) != 4)) {
         SplatBwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out,
                          kmax, atap, d_sum_r_out, d_sum_w_out, d_max_w_out, d_data, d_kernels,
-                         d_sum_r_in, d_sum_w_in, d_max_w_in, scratch, bs, c, h, w, k, tiles_x(w), h};
+                         d_sum_r_in, d_sum_w_in, d_max_w_in, scratch, bs, c, h, w, k, tiles_x(w), h, h, 0};
         SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_bwd_state_kernel<C, true>), dim3(egrid), dim3(256), 0, s, p));
         int err = (int)hipGetLastError();
         if (err) return err;
@@ -1037,7 +1052,7 @@ static int splat_update_bwd_impl(const float* data, const void* kernels,
     SplatBwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out,
                      kmax, atap, d_sum_r_out, d_sum_w_out, d_max_w_out, d_data, d_kernels,
                      d_sum_r_in, d_sum_w_in, d_max_w_in, scratch,
-                     bs, c, h, w, k, tiles_x(w), tiles_y(h, BWD_TY)};
+                     bs, c, h, w, k, tiles_x(w), tiles_y(h, BWD_TY), h, 0};
     SBMC_DISPATCH_C(c, hipLaunchKernelGGL((splat_bwd_state_kernel<C, false>), dim3(egrid), dim3(256), 0, s, p));
     int err = (int)hipGetLastError();
     if (err) return err;
@@ -1078,15 +1093,17 @@ static int splat_all_bwd_impl(const float* data, const void* kernels,
                               const float* run_r, const float* run_w, const float* run_m,
                               const float* d_sum_r, const float* d_sum_w, const float* d_max_w,
                               float* d_data, void* d_kernels, float* scratch,
-                              int bs, int s, int c, int h, int w, int k, void* stream) {
-    if (bs < 0 || s < 1 || h < 0 || w < 0 || c < 1 || !strip_ok(c, k, h, w, sizeof(LT) != 4)) return SBMC_HIP_EINVAL;
+                              int bs, int s, int c, int h, int w, int k, void* stream, int top = 0, int bot = 0) {
+    if (top < 0 || bot < 0 || h < 0 || top > (k - 1) / 2 || bot > (k - 1) / 2) return SBMC_HIP_EINVAL;
+    const int hd = top + h + bot;   // the per-pixel quantities (state, records) live on the destination rows
+    if (bs < 0 || s < 1 || w < 0 || c < 1 || !strip_ok(c, k, hd, w, sizeof(LT) != 4)) return SBMC_HIP_EINVAL;
     if (bs == 0 || h == 0 || w == 0) return 0;
     if (!data || !kernels || !part_m || !atap || !run_r || !run_w || !run_m || !d_sum_r || !d_sum_w ||
         !d_max_w || !d_data || !d_kernels || !scratch)
         return SBMC_HIP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SplatChainParams cp{part_m, atap, run_r, run_w, run_m, d_sum_r, d_sum_w, d_max_w, scratch, bs, s, h, w};
-    const size_t total = (size_t)bs * h * w;
+    SplatChainParams cp{part_m, atap, run_r, run_w, run_m, d_sum_r, d_sum_w, d_max_w, scratch, bs, s, hd, w};
+    const size_t total = (size_t)bs * hd * w;
     unsigned egrid = (unsigned)((total + 255) / 256);
     if (egrid > 8192) egrid = 8192;
     SBMC_DISPATCH_C4(c, hipLaunchKernelGGL((splat_chain_bwd_kernel<C>), dim3(egrid), dim3(256), 0, st, cp));
@@ -1096,6 +1113,7 @@ static int splat_all_bwd_impl(const float* data, const void* kernels,
     SplatBwdParams p{};
     p.data = data; p.kernels = kernels; p.d_data = d_data; p.d_kernels = d_kernels; p.scratch = scratch;
     p.bs = bs * s; p.c = c; p.h = h; p.w = w; p.k = k; p.ntx = tiles_x(w); p.nty = h;
+    p.hd = hd; p.top = top;
     const long items = (long)p.bs * h * p.ntx;
     const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
     SBMC_LAUNCH_STRIP(splat_bwd_strip_kernel, grid, st, p);
@@ -1121,7 +1139,7 @@ extern "C" int sbmc_gather_update_fwd_f32(const float* data, const float* kernel
         return SBMC_HIP_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     SplatFwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out,
-                     max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), h};
+                     max_w_out, kmax_out, atap_out, bs, h, w, k, tiles_x(w), h, h, 0, 1, 1};
     const long items = (long)bs * h * p.ntx;
     const unsigned grid = (unsigned)((items + V2_WAVES - 1) / V2_WAVES);
     SBMC_LAUNCH_STRIP(splat_fwd_strip_kernel, grid, s, p, true);
@@ -1149,7 +1167,7 @@ extern "C" int sbmc_gather_update_bwd_f32(const float* data, const float* kernel
     hipStream_t s = (hipStream_t)stream;
     SplatBwdParams p{data, kernels, sum_r_in, sum_w_in, max_w_in, sum_r_out, sum_w_out, max_w_out,
                      kmax, atap, d_sum_r_out, d_sum_w_out, d_max_w_out, d_data, d_kernels,
-                     d_sum_r_in, d_sum_w_in, d_max_w_in, scratch, bs, c, h, w, k, tiles_x(w), h};
+                     d_sum_r_in, d_sum_w_in, d_max_w_in, scratch, bs, c, h, w, k, tiles_x(w), h, h, 0};
     const size_t total = (size_t)bs * h * w;
     unsigned egrid = (unsigned)((total + 255) / 256);
     if (egrid > 8192) egrid = 8192;
@@ -1205,6 +1223,35 @@ extern "C" int sbmc_splat_all_bwd_f16(const float* data, const void* kernels, SP
                                       void* d_kernels, float* scratch, int bs, int s, int c, int h, int w,
                                       int k, void* stream) {
     return splat_all_bwd_impl<_Float16>(data, kernels, SPLAT_ALL_PASS, d_data, d_kernels, scratch, bs, s, c, h, w, k, stream);
+}
+
+// ---- row-slab form (one frame sharded along H over several GPUs)
+extern "C" int sbmc_splat_slab_supported(int c, int k, int h, int w, int top, int bot) {
+    if (h < 1 || w < 1 || top < 0 || bot < 0 || k < 1 || (k % 2) == 0) return 0;
+    if (top > (k - 1) / 2 || bot > (k - 1) / 2) return 0;
+    return strip_ok(c, k, top + h + bot, w) ? 1 : 0;
+}
+#define SPLAT_SLAB_FWD_ARGS float *part_r, float *part_w, float *part_m, int32_t *atap, int n, int c, int h, int w, \
+                            int k, int top, int bot, int zero_top, int zero_bot, void *stream
+extern "C" int sbmc_splat_slab_fwd_f32(const float* data, const float* kernels, SPLAT_SLAB_FWD_ARGS) {
+    return splat_update_fwd_impl<float>(data, kernels, nullptr, nullptr, nullptr, part_r, part_w, part_m, nullptr,
+                                        atap, n, c, h, w, k, stream, top, bot, zero_top != 0, zero_bot != 0);
+}
+extern "C" int sbmc_splat_slab_fwd_f16(const float* data, const void* kernels, SPLAT_SLAB_FWD_ARGS) {
+    return splat_update_fwd_impl<_Float16>(data, kernels, nullptr, nullptr, nullptr, part_r, part_w, part_m, nullptr,
+                                           atap, n, c, h, w, k, stream, top, bot, zero_top != 0, zero_bot != 0);
+}
+extern "C" int sbmc_splat_slab_bwd_f32(const float* data, const float* kernels, SPLAT_ALL_ARGS, float* d_data,
+                                       float* d_kernels, float* scratch, int bs, int s, int c, int h, int w,
+                                       int k, int top, int bot, void* stream) {
+    return splat_all_bwd_impl<float>(data, kernels, SPLAT_ALL_PASS, d_data, d_kernels, scratch, bs, s, c, h, w, k,
+                                     stream, top, bot);
+}
+extern "C" int sbmc_splat_slab_bwd_f16(const float* data, const void* kernels, SPLAT_ALL_ARGS, float* d_data,
+                                       void* d_kernels, float* scratch, int bs, int s, int c, int h, int w,
+                                       int k, int top, int bot, void* stream) {
+    return splat_all_bwd_impl<_Float16>(data, kernels, SPLAT_ALL_PASS, d_data, d_kernels, scratch, bs, s, c, h, w, k,
+                                        stream, top, bot);
 }
 
 extern "C" int sbmc_hip_abi_version(void) { return SBMC_HIP_ABI_VERSION; }

@@ -12,12 +12,16 @@ tiling of scripts/denoise.py:54-93, which recomputes a 256-px halo per tile).  D
   is padded or dropped, so the convolutions' own zero padding acts exactly as in the
   single-GPU model.  2x2 max-pools are local because slab boundaries are multiples of 4
   rows; the bilinear x2 upsample takes 1 halo row of the coarse map;
-* the splat: the regressor's inputs (per-sample embeddings, pixel context, radiance) are
-  halo-padded by the kernel radius p, logits are predicted for slab + 2p source rows and the
-  fused kernels run on that extended slab; destination rows of the halo are dropped
-  (running-softmax state never crosses ranks);
+* the splat: the running state (sum_r, sum_w, max_w) is an associative log-sum-exp monoid
+  (reference sbmc/modules.py:450-471), so every rank predicts kernels for, and splats, its OWN
+  samples only -- into a destination slab extended by the kernel radius p towards its
+  neighbours (`functions.SplatAll` in its row-slab form) -- then sends the p overhang rows of
+  the state (c + 2 channels x p rows x W, 256 KB at 720p) to the neighbour that owns them, which
+  merges them into its own rows with the reference's merge rule: one neighbour exchange per
+  frame and direction, nothing recomputed.  (Slabs thinner than p rows, or gather kernels: the
+  regressor's inputs are halo-padded by p instead and the halo's destination rows dropped.)
 * training: the loss is the global mean (each rank contributes its rows); parameter
-  gradients are summed with one flattened all-reduce.
+  gradients live in one flat buffer (every `.grad` is a view of it) summed by ONE all-reduce.
 
 `halo_pad` is a `torch.autograd.Function`: its backward sends the gradient of the halo
 rows back to the rank that owns them, so autograd over the sharded graph equals autograd
@@ -39,7 +43,7 @@ class SlabPartition(object):
     Slab boundaries are multiples of `align` rows (4: two 2x2 poolings in the U-net)."""
 
     def __init__(self, height, world, rank, align=4, group=None):
-        self.height, self.world, self.rank, self.group = height, world, rank, group
+        self.height, self.world, self.rank, self.group, self.align = height, world, rank, group, align
         if world > 1 and height % align != 0:
             raise ValueError("sharded path needs the frame height to be a multiple of %d" % align)
         units = height // align if world > 1 else height
@@ -54,6 +58,13 @@ class SlabPartition(object):
     @property
     def rows(self):
         return self.y1 - self.y0
+
+    @property
+    def min_rows(self):
+        """Rows of the thinnest slab of the partition (the same number on every rank)."""
+        if self.world == 1:
+            return self.height
+        return (self.height // self.align // self.world) * self.align
 
     def peer(self, delta):
         r = self.rank + delta
@@ -176,6 +187,59 @@ def sharded_autoencoder(autoencoder, x, part):
     return _level(autoencoder.net, x, part)
 
 
+class _OverhangExchange(th.autograd.Function):
+    """state [bs, c+2, top + rows + bot, w] (this rank's log-sum-exp partial on its extended slab)
+    -> (own [bs, c+2, rows, w], from_up [bs, c+2, p, w], from_down [bs, c+2, p, w]): the overhang
+    rows go to the neighbours that own them, theirs for this rank's edge rows come back (an empty
+    tensor where there is no neighbour).  Pure communication (linear): backward returns the
+    gradient of what was received to its sender."""
+
+    @staticmethod
+    def forward(ctx, state, p, part):
+        top = p if part.has_up else 0
+        bot = p if part.has_down else 0
+        hd = state.shape[-2]
+        ctx.part, ctx.p = part, p
+        from_up, from_down = _exchange(part, state[..., :top, :], state[..., hd - bot:, :])
+        none = state.new_zeros(state.shape[:-2] + (0, state.shape[-1]))
+        return (state[..., top:hd - bot, :].contiguous(),
+                none if from_up is None else from_up, none if from_down is None else from_down)
+
+    @staticmethod
+    def backward(ctx, g_own, g_up, g_down):
+        part, p = ctx.part, ctx.p
+        shape = g_own.shape[:-2] + (p, g_own.shape[-1])
+        g_up = g_own.new_zeros(shape) if g_up is None else g_up
+        g_down = g_own.new_zeros(shape) if g_down is None else g_down
+        back_up, back_down = _exchange(part, g_up, g_down)
+        pieces = [t for t in (back_up, g_own, back_down) if t is not None]
+        return (th.cat(pieces, -2) if len(pieces) > 1 else g_own), None, None
+
+
+def _merge_rows(state, other, r0, r1, c):
+    """Rows [r0, r1) of `state` (+)= `other`, the merge of two running-softmax states (reference
+    sbmc/modules.py:450-471): M = max(m1, m2), sum = sum1 * exp(m1 - M) + sum2 * exp(m2 - M).
+    Channels: c of sum_r, sum_w, max_w."""
+    a = state[..., r0:r1, :]
+    m = th.max(a[:, c + 1:], other[:, c + 1:])
+    sa, sb = th.exp(a[:, c + 1:] - m), th.exp(other[:, c + 1:] - m)
+    merged = th.cat([a[:, :c + 1] * sa + other[:, :c + 1] * sb, m], 1)
+    return th.cat([state[..., :r0, :], merged, state[..., r1:, :]], -2)
+
+
+def merge_overhang(sum_r, sum_w, max_w, p, part):
+    """The cross-rank step of the sharded splat.  In: this rank's partial state on
+    its slab extended by p rows towards every neighbour; out: the complete state of its own rows."""
+    c = sum_r.shape[1]
+    own, from_up, from_down = _OverhangExchange.apply(th.cat([sum_r, sum_w, max_w], 1), p, part)
+    rows = own.shape[-2]
+    if part.has_up:
+        own = _merge_rows(own, from_up, 0, p, c)
+    if part.has_down:
+        own = _merge_rows(own, from_down, rows - p, rows, c)
+    return own[:, :c], own[:, c:c + 1], own[:, c + 1:]
+
+
 class ShardedDenoiser(object):
     """Runs a `Multisteps` model on this rank's slab of one frame.
 
@@ -184,8 +248,13 @@ class ShardedDenoiser(object):
     target_image [bs, 3, rows, w].
     """
 
-    def __init__(self, model, part):
+    def __init__(self, model, part, merge_state=None):
         self.model, self.part = model, part
+        p = (model.ksize - 1) // 2
+        possible = model.splat and part.world > 1 and part.min_rows >= p
+        # merge_state=False forces the halo-recompute form of the splat (kept for the comparison)
+        self.merge_state = possible if merge_state is None else (bool(merge_state) and possible)
+        self._flat = None
 
     def forward(self, batch):
         m, part = self.model, self.part
@@ -203,6 +272,16 @@ class ShardedDenoiser(object):
             context = sharded_autoencoder(getattr(m, "propagation_{:02d}".format(step)), reduced, part)
 
         p = (m.ksize - 1) // 2
+        if self.merge_state:
+            # every rank splats its own samples; the p overhang rows of the state cross the link
+            slab = (p if part.has_up else 0, p if part.has_down else 0, not part.has_up, not part.has_down)
+            sum_r, sum_w, max_w = m._predict_and_splat(features, context, radiance.contiguous(), slab=slab)
+            sum_r, sum_w, max_w = merge_overhang(sum_r, sum_w, max_w, p, part)
+            output = sum_r / (sum_w + m.eps)
+            # only the invalid border of the true image goes (reference models.py:215-216)
+            top = 0 if part.has_up else p
+            bot = 0 if part.has_down else p
+            return {"radiance": output[..., top:output.shape[-2] - bot, p:-p]}
         features = halo_pad(features, p, part)
         context = halo_pad(context, p, part)
         radiance = halo_pad(radiance, p, part)
@@ -221,31 +300,43 @@ class ShardedDenoiser(object):
         bot = 0 if self.part.has_down else p
         return target[..., top:target.shape[-2] - bot, p:-p]
 
+    def _flat_grads(self):
+        """One flat fp32 buffer holding every parameter gradient (each `.grad` is a view of it) plus
+        one slot for the loss: the cross-rank sum is ONE all-reduce of this buffer, no packing."""
+        params = [q for q in self.model.parameters() if q.requires_grad]
+        if self._flat is None or any(q.grad is None or q.grad.data_ptr() != v.data_ptr()
+                                     for q, v in zip(params, self._views)):
+            n = sum(q.numel() for q in params)
+            self._flat = th.zeros(n + 1, dtype=th.float32, device=params[0].device)
+            self._views, off = [], 0
+            for q in params:
+                v = self._flat[off:off + q.numel()].view_as(q)
+                q.grad = v
+                self._views.append(v)
+                off += q.numel()
+        return self._flat
+
     def train_step(self, optimizer, loss_fn, batch, clip=1000):
         """The reference training step (sbmc/interfaces.py:78-105) on the sharded frame.
         `loss_fn` must be a mean over pixels (all of sbmc_amd.losses are)."""
         part = self.part
-        optimizer.zero_grad()
+        flat = self._flat_grads()
+        flat.zero_()                                   # == optimizer.zero_grad(), keeping the views
         out = self.forward(batch)["radiance"]
         tgt = self.target_rows(batch["target_image"])
         count = th.tensor([float(out.numel())])
         if part.world > 1:
             count = _all_reduce_sum(count, part)
         loss = loss_fn(out, tgt) * (out.numel() / count.item())   # this rank's share of the global mean
-        loss.backward()
-        params = [q for q in self.model.parameters() if q.grad is not None]
-        total = loss.detach().clone()
+        loss.backward()                                # accumulates into the views, in place
+        flat[-1] = loss.detach()
         if part.world > 1:
-            flat = th.cat([q.grad.reshape(-1) for q in params] + [total.reshape(1)])
-            flat = _all_reduce_sum(flat, part)
-            off = 0
-            for q in params:
-                n = q.grad.numel()
-                q.grad.copy_(flat[off:off + n].view_as(q.grad))
-                off += n
-            total = flat[off]
+            summed = _all_reduce_sum(flat, part)       # in place over RCCL; a new tensor when staged
+            if summed.data_ptr() != flat.data_ptr():
+                flat.copy_(summed)
+        total = flat[-1]
         if not th.isfinite(total).item():
             raise RuntimeError("non-finite loss")
         th.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
         optimizer.step()
-        return total
+        return total.clone()

@@ -13,7 +13,7 @@ from . import _lib
 from . import halide_ops as ops
 
 __all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported",
-           "SplatAll", "splat_all_supported", "splat_all_supported_dims", "gather_update_supported", "BiasAct", "CtxAct"]
+           "SplatAll", "splat_all_supported", "splat_all_supported_dims", "splat_slab_supported", "gather_update_supported", "BiasAct", "CtxAct"]
 
 
 # Optional per-call device timing (used by bench.py for the roofline figure): when a list
@@ -629,6 +629,18 @@ def splat_all_supported(data, kernels):
     return bool(_lib.lib().sbmc_splat_all_supported(int(data.shape[2]), k, int(h), int(w)))
 
 
+def splat_slab_supported(data, kernels, top, bot):
+    """True when `SplatAll` takes data [bs, S, c, h, w] / kernels [bs, S, k*k, h, w] in its row-slab
+    form with `top` / `bot` overhang rows (the strip kernels)."""
+    if not splat_all_supported(data, kernels):
+        return False
+    k = int(round(kernels.shape[2] ** 0.5))
+    h, w = kernels.shape[-2:]
+    if kernels.dtype == th.float16 and not _half_ok(data.shape[2], k, top + h + bot, w):
+        return False
+    return bool(_lib.lib().sbmc_splat_slab_supported(int(data.shape[2]), k, int(h), int(w), int(top), int(bot)))
+
+
 class SplatAll(th.autograd.Function):
     """All S progressive splat updates of a frame in three launches per direction.
 
@@ -643,50 +655,64 @@ class SplatAll(th.autograd.Function):
     Args:
       data(th.Tensor)[bs, S, c, h, w]: sample radiance.
       kernels(th.Tensor)[bs, S, k*k, h, w]: per-sample splat kernel logits.
+      top, bot(int), zero_top, zero_bot(bool): row-slab form (one frame sharded along H,
+        sbmc_amd/dist.py; include/sbmc_hip.h "Row-slab form"): the tensors hold one slab's own h
+        rows, the state comes out on top + h + bot destination rows; an edge with zero_* = False is
+        shared with a neighbouring slab, whose sources contribute nothing here.  Defaults = the
+        whole frame.
     Returns:
-      sum_r[bs, c, h, w], sum_w[bs, 1, h, w], max_w[bs, 1, h, w].
+      sum_r[bs, c, hd, w], sum_w[bs, 1, hd, w], max_w[bs, 1, hd, w], hd = top + h + bot.
     """
 
     @staticmethod
-    def forward(ctx, data, kernels):
+    def forward(ctx, data, kernels, top=0, bot=0, zero_top=True, zero_bot=True):
         bs, S, k2, h, w = kernels.shape
         k = int(round(k2 ** 0.5))
         c = data.shape[2]
         if tuple(data.shape) != (bs, S, c, h, w):
             raise RuntimeError("data should be [bs, S, c, h, w] matching kernels [bs, S, k*k, h, w]")
         _require_f32("SplatAll", data=data, kernels=None if kernels.dtype == th.float16 else kernels)
-        if kernels.dtype == th.float16 and (not kernels.is_cuda or not _half_ok(c, k, h, w)):
+        slab = bool(top or bot or not zero_top or not zero_bot)
+        hd = top + h + bot
+        if kernels.dtype == th.float16 and (not kernels.is_cuda or not _half_ok(c, k, hd, w)):
             raise TypeError("SplatAll: half logits are only taken by the k=21 strip kernels")
         data = data.contiguous()
         kernels = kernels.contiguous()
         dev = data.device
-        part_r = th.empty_like(data)
-        part_w = data.new_empty(bs, S, h, w)
-        part_m = data.new_empty(bs, S, h, w)
-        kmax = data.new_empty(bs, S, h, w)
-        atap = th.empty(bs, S, h, w, dtype=th.int32, device=dev)
+        part_r = data.new_empty(bs, S, c, hd, w)
+        part_w = data.new_empty(bs, S, hd, w)
+        part_m = data.new_empty(bs, S, hd, w)
+        atap = th.empty(bs, S, hd, w, dtype=th.int32, device=dev)
         lib = _lib.lib()
         with th.cuda.device(dev):
             half = kernels.dtype == th.float16
             with _timed("splat_update_fwd_all_f16" if half else "splat_update_fwd_all", dev):
-                rc = (lib.sbmc_splat_update_fwd_f16 if half else lib.sbmc_splat_update_fwd_f32)(
-                    _lib.ptr(data), _lib.ptr(kernels), None, None, None,
-                    _lib.ptr(part_r), _lib.ptr(part_w), _lib.ptr(part_m), _lib.ptr(kmax), _lib.ptr(atap),
-                    bs * S, c, h, w, k, _lib.current_stream(dev))
+                if slab:
+                    rc = (lib.sbmc_splat_slab_fwd_f16 if half else lib.sbmc_splat_slab_fwd_f32)(
+                        _lib.ptr(data), _lib.ptr(kernels),
+                        _lib.ptr(part_r), _lib.ptr(part_w), _lib.ptr(part_m), _lib.ptr(atap),
+                        bs * S, c, h, w, k, int(top), int(bot), int(bool(zero_top)), int(bool(zero_bot)),
+                        _lib.current_stream(dev))
+                else:
+                    kmax = data.new_empty(bs, S, h, w)
+                    rc = (lib.sbmc_splat_update_fwd_f16 if half else lib.sbmc_splat_update_fwd_f32)(
+                        _lib.ptr(data), _lib.ptr(kernels), None, None, None,
+                        _lib.ptr(part_r), _lib.ptr(part_w), _lib.ptr(part_m), _lib.ptr(kmax), _lib.ptr(atap),
+                        bs * S, c, h, w, k, _lib.current_stream(dev))
             _lib.check(rc, "splat_update_fwd (all samples)")
-            sum_r = data.new_empty(bs, c, h, w)
-            sum_w = data.new_empty(bs, 1, h, w)
-            max_w = data.new_empty(bs, 1, h, w)
-            run_r = th.empty_like(data)
-            run_w = data.new_empty(bs, S, h, w)
-            run_m = data.new_empty(bs, S, h, w)
+            sum_r = data.new_empty(bs, c, hd, w)
+            sum_w = data.new_empty(bs, 1, hd, w)
+            max_w = data.new_empty(bs, 1, hd, w)
+            run_r = th.empty_like(part_r)
+            run_w = data.new_empty(bs, S, hd, w)
+            run_m = data.new_empty(bs, S, hd, w)
             rc = lib.sbmc_splat_merge_fwd_f32(
                 _lib.ptr(part_r), _lib.ptr(part_w), _lib.ptr(part_m),
                 _lib.ptr(sum_r), _lib.ptr(sum_w), _lib.ptr(max_w),
                 _lib.ptr(run_r), _lib.ptr(run_w), _lib.ptr(run_m),
-                bs, S, c, h, w, _lib.current_stream(dev))
+                bs, S, c, hd, w, _lib.current_stream(dev))
             _lib.check(rc, "splat_merge_fwd")
-        ctx.k = k
+        ctx.k, ctx.slab = k, (int(top), int(bot))
         ctx.save_for_backward(data, kernels, part_m, atap, run_r, run_w, run_m)
         return sum_r, sum_w, max_w
 
@@ -694,22 +720,28 @@ class SplatAll(th.autograd.Function):
     def backward(ctx, d_r, d_w, d_m):
         data, kernels, part_m, atap, run_r, run_w, run_m = ctx.saved_tensors
         bs, S, c, h, w = data.shape
+        top, bot = ctx.slab
+        hd = top + h + bot
         dev = data.device
-        d_r = data.new_zeros(bs, c, h, w) if d_r is None else d_r.contiguous()
-        d_w = data.new_zeros(bs, 1, h, w) if d_w is None else d_w.contiguous()
-        d_m = data.new_zeros(bs, 1, h, w) if d_m is None else d_m.contiguous()
+        d_r = data.new_zeros(bs, c, hd, w) if d_r is None else d_r.contiguous()
+        d_w = data.new_zeros(bs, 1, hd, w) if d_w is None else d_w.contiguous()
+        d_m = data.new_zeros(bs, 1, hd, w) if d_m is None else d_m.contiguous()
         d_data = th.empty_like(data)
         d_kernels = th.empty_like(kernels)
-        nbytes = _lib.lib().sbmc_splat_update_bwd_scratch_bytes(bs * S, c, h, w, ctx.k)
+        nbytes = _lib.lib().sbmc_splat_update_bwd_scratch_bytes(bs * S, c, hd, w, ctx.k)
         scratch = data.new_empty((nbytes + 3) // 4)
         half = kernels.dtype == th.float16
-        bwd = _lib.lib().sbmc_splat_all_bwd_f16 if half else _lib.lib().sbmc_splat_all_bwd_f32
-        with th.cuda.device(dev), _timed("splat_update_bwd_all_f16" if half else "splat_update_bwd_all", dev):
-            rc = bwd(
-                _lib.ptr(data), _lib.ptr(kernels), _lib.ptr(part_m), _lib.ptr(atap),
+        L = _lib.lib()
+        args = (_lib.ptr(data), _lib.ptr(kernels), _lib.ptr(part_m), _lib.ptr(atap),
                 _lib.ptr(run_r), _lib.ptr(run_w), _lib.ptr(run_m),
                 _lib.ptr(d_r), _lib.ptr(d_w), _lib.ptr(d_m),
-                _lib.ptr(d_data), _lib.ptr(d_kernels), _lib.ptr(scratch),
-                bs, S, c, h, w, ctx.k, _lib.current_stream(dev))
+                _lib.ptr(d_data), _lib.ptr(d_kernels), _lib.ptr(scratch), bs, S, c, h, w, ctx.k)
+        with th.cuda.device(dev), _timed("splat_update_bwd_all_f16" if half else "splat_update_bwd_all", dev):
+            if top or bot:
+                rc = (L.sbmc_splat_slab_bwd_f16 if half else L.sbmc_splat_slab_bwd_f32)(
+                    *args, top, bot, _lib.current_stream(dev))
+            else:
+                rc = (L.sbmc_splat_all_bwd_f16 if half else L.sbmc_splat_all_bwd_f32)(
+                    *args, _lib.current_stream(dev))
         _lib.check(rc, "splat_all_bwd")
-        return d_data, d_kernels
+        return d_data, d_kernels, None, None, None, None

@@ -143,32 +143,56 @@ class Multisteps(nn.Module):
             return features
         return features, (mean_out[0] if mean_out else _SampleMean.apply(features))
 
-    def _predict_and_splat(self, features, context, radiance):
+    def _predict_and_splat(self, features, context, radiance, slab=None):
         """Kernel regression + splat of every sample (reference models.py:193-209).
 
         features [bs, spp, e, h, w], context [bs, c, h, w], radiance [bs, spp, 3, h, w] ->
         running state (sum_r, sum_w, max_w) after the last sample.
+        slab = (top, bot, zero_top, zero_bot): the tensors are one row slab of a frame sharded along
+        H (sbmc_amd/dist.py); the state then comes out on top + h + bot rows, see functions.SplatAll.
         """
         bs, spp, _, h, w = features.shape
-        if self.batch_samples and self.splat and self.kernel_update.fused:
+        top, bot, zero_top, zero_bot = slab or (0, 0, True, True)
+        all_kernels = None
+        if (self.batch_samples and self.splat and self.kernel_update.fused and radiance.is_cuda
+                and radiance.dtype == th.float32
+                and funcs.splat_all_supported_dims(radiance.shape[2], self.ksize, top + h + bot, w)):
             # all samples at once: one regressor pass over bs*spp images, three splat launches
             # per direction instead of 2-3 per sample (functions.SplatAll)
-            if (radiance.is_cuda and radiance.dtype == th.float32
-                    and funcs.splat_all_supported_dims(radiance.shape[2], self.ksize, h, w)):
-                kernels = ops.pointwise_chain_with_context(self.kernel_regressor, features, context) \
-                    if self.kernel_regressor.pointwise_as_gemm else None
-                if kernels is None:
-                    ctx = context.unsqueeze(1).expand(bs, spp, context.shape[1], h, w)
-                    flat = th.cat([features, ctx], 2).reshape(bs * spp, -1, h, w)
-                    kernels = self.kernel_regressor(flat)
-                kernels = kernels.view(bs, spp, kernels.shape[1], h, w)
-                return funcs.SplatAll.apply(radiance, kernels)
+            kernels = ops.pointwise_chain_with_context(self.kernel_regressor, features, context) \
+                if self.kernel_regressor.pointwise_as_gemm else None
+            if kernels is None:
+                ctx = context.unsqueeze(1).expand(bs, spp, context.shape[1], h, w)
+                flat = th.cat([features, ctx], 2).reshape(bs * spp, -1, h, w)
+                kernels = self.kernel_regressor(flat)
+            kernels = kernels.view(bs, spp, kernels.shape[1], h, w)
+            supported = (lambda kk: funcs.splat_slab_supported(radiance, kk, top, bot)) if slab else \
+                (lambda kk: funcs.splat_all_supported(radiance, kk))
+            if kernels.dtype != th.float32 and not supported(kernels):
+                kernels = kernels.float()     # half logits where only the fp32 strip kernels apply (k != 21)
+            if supported(kernels):
+                return funcs.SplatAll.apply(radiance, kernels, top, bot, zero_top, zero_bot)
+            all_kernels = kernels             # predicted already: the per-sample loop below consumes them
+        # per-sample loop, as the reference.  A row slab is handled by padding: rows that belong to a
+        # neighbouring slab get logit -1e30 (weight exp(-1e30 - max) = 0, i.e. no contribution) deep
+        # enough that no destination row kept below sees Scatter2Gather's zero fill across an inner edge
+        p = (self.ksize - 1) // 2
+        pt = 0 if zero_top else top + p
+        pb = 0 if zero_bot else bot + p
         sum_r, sum_w, max_w = None, None, None
         for sp in range(spp):
-            f = th.cat([features[:, sp], context], 1)
-            kernels = self.kernel_regressor(f)
+            if all_kernels is not None:
+                kernels = all_kernels[:, sp]
+            else:
+                kernels = self.kernel_regressor(th.cat([features[:, sp], context], 1))
             r = crop_like(radiance[:, sp], kernels)
+            if pt or pb:
+                kernels = th.nn.functional.pad(kernels, (0, 0, pt, pb), value=-1e30)
+                r = th.nn.functional.pad(r, (0, 0, pt, pb))
             sum_r, sum_w, max_w = self.kernel_update(r, kernels, sum_r, sum_w, max_w)
+        if slab:
+            r0, r1 = pt - top, pt + h + bot
+            sum_r, sum_w, max_w = sum_r[..., r0:r1, :], sum_w[..., r0:r1, :], max_w[..., r0:r1, :]
         return sum_r, sum_w, max_w
 
     def forward(self, samples):

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# MIOpen's exhaustive "find" costs minutes per new convolution shape at 1280x720; its FAST mode (what
+# bench.py uses) picks solvers from the heuristics in seconds.  Read by MIOpen at the first convolution.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -50,3 +50,67 @@ def multisteps_from_golden(device="cpu"):
     model.load_state_dict(sd, strict=True)
     batch = {k[3:]: t(g[k], device) for k in g.files if k.startswith("in.")}
     return g, model.to(device), batch
+
+
+def gather_logits_fp64(kernels):
+    """Scatter2Gather (reference src/scatter2gather.cpp:34-47) restated with torch slicing, any
+    dtype (used in float64): kernels [bs, k*k, h, w] sample-centred -> [bs, k*k, h, w] gather layout,
+    out[dy*k+dx, Y, X] = in[(2p-dy)*k + (2p-dx), Y+dy-p, X+dx-p], 0 outside the image."""
+    bs, k2, h, w = kernels.shape
+    k = int(round(k2 ** 0.5))
+    p = (k - 1) // 2
+    padded = th.nn.functional.pad(kernels.view(bs, k, k, h, w), (p, p, p, p))
+    rows = []
+    for dy in range(k):
+        for dx in range(k):
+            rows.append(padded[:, 2 * p - dy, 2 * p - dx, dy:dy + h, dx:dx + w])
+    return th.stack(rows, 1)
+
+
+def progressive_fp64(datas, kerns, grads=None, splat=True):
+    """The reference's ProgressiveKernelApply chain (sbmc/modules.py:422-471) in float64 torch ops:
+    the "truth" two fp32 implementations are both measured against where their own 1e-5 agreement is
+    limited by cancellation (the routed arg-max element of d_kernels).
+    Returns (state, d_datas, d_kerns) like helpers.run_progressive (gradients None without grads)."""
+    datas = [d.detach().double().requires_grad_() for d in datas]
+    kerns = [k.detach().double().requires_grad_() for k in kerns]
+    sr = sw = mw = None
+    for d, kk in zip(datas, kerns):
+        bs, k2, h, w = kk.shape
+        k = int(round(k2 ** 0.5))
+        p = (k - 1) // 2
+        g = gather_logits_fp64(kk) if splat else kk
+        kmax = g.max(1, keepdim=True)[0]
+        new_max = kmax if sr is None else th.max(kmax, mw)
+        wts = th.exp(g - new_max)
+        dpad = th.nn.functional.pad(d, (p, p, p, p))
+        new_r = th.zeros_like(d)
+        for dy in range(k):
+            for dx in range(k):
+                new_r = new_r + wts[:, dy * k + dx:dy * k + dx + 1] * dpad[:, :, dy:dy + h, dx:dx + w]
+        new_w = wts.sum(1, keepdim=True)
+        if sr is None:
+            sr, sw, mw = new_r, new_w, new_max
+        else:
+            sc = th.exp(mw - new_max)
+            sr, sw, mw = sr * sc + new_r, sw * sc + new_w, new_max
+    if grads is None:
+        return (sr, sw, mw), None, None
+    th.autograd.backward([sr, sw, mw], [g.double() for g in grads])
+    return (sr, sw, mw), [d.grad for d in datas], [k.grad for k in kerns]
+
+
+def no_worse_than(a, ref32, truth, rtol=1e-5, slack=2.0, what=""):
+    """|a - truth| <= rtol-bound, OR no worse than `slack` x the error the reference-order fp32
+    computation (`ref32`, the oracle) itself makes against the float64 truth, element by element max.
+    For quantities whose fp32 value is a difference of two long sums: both implementations round, so
+    demanding 1e-5 of their mutual difference would test rounding luck, not correctness."""
+    a = a.detach().cpu().double()
+    ref32 = ref32.detach().cpu().double()
+    truth = truth.detach().cpu().double()
+    scale = truth.abs().max().item()
+    err = (a - truth).abs().max().item()
+    ref_err = (ref32 - truth).abs().max().item()
+    bound = max(rtol * scale, slack * ref_err)
+    assert err <= bound, "%s: err vs fp64 %.3e > max(%.1e * scale = %.3e, %.1f x oracle's own fp32 error %.3e)" % (
+        what, err, rtol, rtol * scale, slack, ref_err)

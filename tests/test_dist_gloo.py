@@ -29,7 +29,7 @@ def _close(a, b, rtol, what):
     assert err <= rtol * max(scale, 1e-30) + 1e-12, "%s: err %.3e scale %.3e" % (what, err, scale)
 
 
-def _worker(rank, world, port, height, train):
+def _worker(rank, world, port, height, train, merge_state):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -66,7 +66,8 @@ def _worker(rank, world, port, height, train):
         part = sdist.SlabPartition(height, world, rank)
         slab = {k: (v if k == "global_features" else v[..., part.y0:part.y1, :].contiguous())
                 for k, v in full.items()}
-        runner = sdist.ShardedDenoiser(model, part)
+        runner = sdist.ShardedDenoiser(model, part, merge_state=merge_state)
+        assert runner.merge_state == merge_state
         p = (ks - 1) // 2
         lo = max(part.y0, p) - p                      # this rank's rows in output coordinates
         hi = min(part.y1, height - p) - p
@@ -85,9 +86,13 @@ def _worker(rank, world, port, height, train):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height,train", [(2, 32, False), (2, 32, True), (3, 48, True)])
-def test_sharded_denoiser_equals_full_frame(world, height, train):
-    mp.spawn(_worker, args=(world, _free_port(), height, train), nprocs=world, join=True)
+# merge_state=True: every rank splats its own samples and the overhang rows of the running state are
+# exchanged and merged; False: the halo-recompute form (inputs padded by the kernel radius)
+@pytest.mark.parametrize("world,height,train,merge_state", [
+    (2, 32, False, True), (2, 32, True, True), (3, 48, True, True), (3, 36, False, True),
+    (2, 32, True, False), (3, 48, False, False)])
+def test_sharded_denoiser_equals_full_frame(world, height, train, merge_state):
+    mp.spawn(_worker, args=(world, _free_port(), height, train, merge_state), nprocs=world, join=True)
 
 
 def test_slab_partition():

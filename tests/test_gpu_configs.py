@@ -1,0 +1,201 @@
+"""GPU, BASELINE.json configurations at their FULL sizes (1280x720, k = 21), whole model.
+
+The CPU oracle cannot run these sizes in test time, so each configuration is checked through
+properties that do not depend on the size (SURVEY.md section 8c / the task's parity rules):
+
+  configs[1]  1280x720, 4 spp, Multisteps forward (eval): tiled == untiled in the valid region
+              (the harness of scripts/denoise.py), invariance under a permutation of the samples,
+              train-mode forward == eval-mode forward (reference models.py:136-209: two code paths,
+              one set of numbers), a full-width band of the splat stage vs the oracle on the model's OWN
+              predicted kernels;
+  configs[2]  1280x720, 8 spp, one training step (reference interfaces.py:78-105): finite loss and
+              gradients for every parameter, the loss equals the loss of the eval forward, the first
+              Adam step moves every parameter by at most lr;
+  configs[4]  1280x720, 32 spp, fused splat vs the Scatter2Gather + KernelWeighting dual path, the
+              fp16-logit path vs the fp32 path on the same half-rounded logits, a full-width band
+              vs the oracle at 32 spp.
+(configs[3], 3840x2160 on 8 GPUs, needs the 8-GPU node; its single-GPU parts are in
+test_gpu_fullsize.py::test_4k_* and its sharded logic in test_dist_gloo.py / test_dist_gpu.py /
+test_gpu_slab.py.)
+"""
+import os
+import sys
+
+import pytest
+import torch as th
+
+from helpers import close
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H, W, K = 720, 1280, 21
+P = (K - 1) // 2
+
+
+def _bench():
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+@pytest.fixture(scope="module")
+def model():
+    from sbmc_amd import Multisteps
+    th.manual_seed(0)
+    return Multisteps(93, 3, ksize=K).cuda()
+
+
+def test_config1_forward_720p_4spp_properties(model, oracle):
+    from sbmc_amd import denoise, functions as F
+    batch = _bench().make_model_inputs(H, W, 4, "cuda", seed=7)
+    batch.pop("target_image")
+    model.train(False)
+    with th.no_grad():
+        out = model(batch)["radiance"]
+        assert tuple(out.shape) == (1, 3, H - 2 * P, W - 2 * P)
+        assert th.isfinite(out).all()
+        scale = out.abs().max().item()
+
+        # (a) the two code paths of the reference (eval parks tensors on the host, train does not) give
+        #     the same numbers; here both are one batched path: bit-identical
+        model.train(True)
+        out_train = model(batch)["radiance"]
+        model.train(False)
+        assert th.equal(out_train, out)
+
+        # (b) permuting the samples permutes nothing in the result (mean over samples, splat sums)
+        perm = th.tensor([2, 0, 3, 1], device="cuda")
+        pb = {"radiance": batch["radiance"][:, perm].contiguous(), "features": batch["features"][:, perm].contiguous(),
+              "global_features": batch["global_features"]}
+        close(model(pb)["radiance"], out, rtol=1e-5, what="sample permutation")
+
+        # (c) tiled == untiled inside the valid region (scripts/denoise.py harness; tiles start at multiples
+        #     of 4 so that the U-net's poolings see the same phase, overlap 128 > the model's reach)
+        batch["low_spp"] = batch["radiance"].mean(1)
+        whole = denoise.denoise_frame(model, batch, tile_size=4096, tile_pad=0)
+        tiled = denoise.denoise_frame(model, batch, tile_size=768, tile_pad=128)
+        assert len(denoise.split_tiles(batch, 768, 128)) == 2
+        err = (tiled - whole)[..., P:-P, P:-P].abs().max().item()
+        assert err <= 1e-5 * scale, "tiled vs untiled: %.3e (scale %.3e)" % (err, scale)
+
+        # (d) the splat stage on the kernels the model itself predicts, full width, vs the oracle: rows
+        #     [300, 348) of the frame as an independent 48-row problem (sources and destinations of the band)
+        feats, ctx = batch["features"], batch["global_features"]
+        for step in range(model.nsteps):
+            feats, red = model._embed(getattr(model, "embedding_%02d" % step), feats, ctx, want_mean=True)
+            ctx = getattr(model, "propagation_%02d" % step)(red)
+        band = slice(300, 348)
+        fb, cb = feats[..., band, :].contiguous(), ctx[..., band, :].contiguous()
+        rb = batch["radiance"][..., band, :].contiguous()
+        from sbmc_amd import modules as ops
+        kernels = ops.pointwise_chain_with_context(model.kernel_regressor, fb, cb).view(1, 4, K * K, 48, W)
+        sr, sw, mw = F.SplatAll.apply(rb, kernels)
+    st = (None, None, None)
+    kc, rc = kernels.cpu(), rb.cpu()
+    for s in range(4):
+        st = oracle.progressive_kernel_apply(rc[:, s], kc[:, s], *st, splat=True)
+    for a, b, n in zip((sr, sw, mw), st, ("sum_r", "sum_w", "max_w")):
+        close(a, b, what="band " + n)
+    close(sr / (sw + 1e-8), st[0] / (st[1] + 1e-8), what="band output")
+
+
+def test_config2_training_step_720p_8spp(model):
+    from sbmc_amd import losses
+    from sbmc_amd.utils import crop_like
+    bench = _bench()
+    batch = bench.make_model_inputs(H, W, 8, "cuda", seed=8)
+    loss_fn = losses.TonemappedRelativeMSE()
+    model.train(False)
+    with th.no_grad():
+        out = model(batch)["radiance"]
+        eval_loss = loss_fn(out, crop_like(batch["target_image"], out)).item()
+    del out
+    model.train(True)
+    before = [q.detach().clone() for q in model.parameters()]
+    lr = 1e-4
+    opt = th.optim.Adam(model.parameters(), lr=lr, fused=True)
+    loss = bench.train_step(model, opt, loss_fn, batch).item()
+    assert loss == pytest.approx(eval_loss, rel=1e-6)
+    total = 0.0
+    for (name, q), old in zip(model.named_parameters(), before):
+        assert q.grad is not None and th.isfinite(q.grad).all(), name
+        total += float(q.grad.double().pow(2).sum())
+        # first Adam step: |delta| = lr * |g| / (|g| + eps) <= lr
+        assert (q.detach() - old).abs().max().item() <= lr * 1.001, name
+    assert 0.0 < total ** 0.5 < 1000.0          # non-trivial gradient, below the clipping threshold
+    # every chain's first layer got a gradient through the splat: the kernels matter
+    g = model.kernel_regressor.prediction
+    assert (g.weight_v.grad.abs().max().item() > 0) if hasattr(g, "weight_v") else (g.weight.grad.abs().max().item() > 0)
+    model.zero_grad(set_to_none=True)
+
+
+def _splat_inputs(spp, seed, h=H, half=False):
+    g = th.Generator().manual_seed(seed)
+    rad = th.empty(1, spp, 3, h, W).exponential_(1.0, generator=g)
+    ker = th.empty(1, spp, K * K, h, W, dtype=th.float16 if half else th.float32)
+    for s in range(spp):                                   # one sample at a time: bounded host memory
+        ker[0, s] = th.randn(K * K, h, W, generator=g)
+    return rad, ker
+
+
+def test_config4_32spp_720p_fused_vs_dual_path():
+    """32 spp at 1280x720: the fused all-samples splat vs the reference's dual path (Scatter2Gather, then
+    KernelWeighting, per sample; sbmc/modules.py:422-471) built from the boundary-level HIP operators."""
+    from sbmc_amd import functions as F, modules
+    rad, ker = _splat_inputs(32, 41)
+    rad, ker = rad.cuda(), ker.cuda()
+    with th.no_grad():
+        sr, sw, mw = F.SplatAll.apply(rad, ker)
+        dual = modules.ProgressiveKernelApply(splat=True, fused=False)
+        st = (None, None, None)
+        for s in range(32):
+            st = dual(rad[:, s], ker[:, s], *st)
+    close(mw, st[2], what="max_w")
+    close(sw, st[1], what="sum_w")
+    close(sr, st[0], what="sum_r")
+    close(sr / (sw + 1e-8), st[0] / (st[1] + 1e-8), what="output")
+
+
+def test_config4_fp16_logits_720p():
+    """fp16 activations (logit storage) at 1280x720: forward at 32 spp, backward at 8 spp, vs the fp32
+    kernels on the same half-rounded logits (fp32 arithmetic in both: 1e-5; d_kernels: half rounding)."""
+    from sbmc_amd import functions as F
+    rad, ker = _splat_inputs(32, 42, half=True)
+    rad, ker = rad.cuda(), ker.cuda()
+    with th.no_grad():
+        a = F.SplatAll.apply(rad, ker)
+        b = F.SplatAll.apply(rad, ker.float())
+    for x, y, n in zip(a, b, ("sum_r", "sum_w", "max_w")):
+        close(x, y, what="32 spp " + n)
+    del a, b
+    d_out = th.randn(1, 3, H, W, device="cuda")
+    r16, k16 = rad[:, :8].clone().requires_grad_(), ker[:, :8].clone().requires_grad_()
+    r32, k32 = rad[:, :8].clone().requires_grad_(), ker[:, :8].float().requires_grad_()
+    for r, kk in ((r16, k16), (r32, k32)):
+        sr, sw, _ = F.SplatAll.apply(r, kk)
+        (sr / (sw + 1e-8)).backward(d_out)
+    close(r16.grad, r32.grad, what="d_radiance")
+    assert k16.grad.dtype == th.float16
+    err = (k16.grad.float() - k32.grad).abs().max().item()
+    assert err <= 1e-3 * k32.grad.abs().max().item(), err      # one half rounding (2^-11) of the stored gradient
+
+
+def test_config4_32spp_full_width_band_vs_oracle(oracle):
+    """32 progressive updates on a full-width (1280 px) band of 24 rows vs the oracle, values and gradients."""
+    from sbmc_amd import functions as F
+    rad, ker = _splat_inputs(32, 43, h=24)
+    d_out = th.randn(1, 3, 24, W)
+    ro, ko = rad.clone().requires_grad_(), ker.clone().requires_grad_()
+    st = (None, None, None)
+    for s in range(32):
+        st = oracle.progressive_kernel_apply(ro[:, s], ko[:, s], *st, splat=True)
+    (st[0] / (st[1] + 1e-8)).backward(d_out)
+    rg, kg = rad.cuda().requires_grad_(), ker.cuda().requires_grad_()
+    sr, sw, mw = F.SplatAll.apply(rg, kg)
+    (sr / (sw + 1e-8)).backward(d_out.cuda())
+    for a, b, n in zip((sr, sw, mw), st, ("sum_r", "sum_w", "max_w")):
+        close(a, b, what=n)
+    close(rg.grad, ro.grad, what="d_radiance")
+    close(kg.grad, ko.grad, what="d_kernels")

@@ -7,6 +7,8 @@ products are compared with an abs-scaled bound: |a - b| <= 1e-5 * max|b| + 1e-5 
 import pytest
 import torch as th
 
+from helpers import no_worse_than, progressive_fp64
+
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
@@ -612,9 +614,13 @@ def test_fused_gather_update_vs_oracle(oracle, bs, c, h, w, k, spp):
     out, dd, dk = _progressive(modules.ProgressiveKernelApply(splat=False), datas, kerns, grads, "cuda")
     for a, b, n in zip(out, ref_out, ("sum_r", "sum_w", "max_w")):
         close(a, b, what=n)
+    # d_kernels: the element that receives the routed max-gradient is a difference of two k*k-term sums
+    # in BOTH fp32 implementations; it is held to 1e-5 of the float64 restatement of the same graph, or to
+    # twice the oracle's own fp32 error against it, whichever is larger (helpers.no_worse_than)
+    _, _, dk64 = progressive_fp64(datas, kerns, grads, splat=False)
     for s in range(spp):
         close(dd[s], ref_dd[s], what="d_data[%d]" % s)
-        close(dk[s], ref_dk[s], rtol=5e-5, what="d_kernels[%d]" % s)
+        no_worse_than(dk[s], ref_dk[s], dk64[s], what="d_kernels[%d]" % s)
 
 
 def test_fused_gather_running_max_branches(oracle):
@@ -633,8 +639,9 @@ def test_fused_gather_running_max_branches(oracle):
     out, dd, dk = _progressive(modules.ProgressiveKernelApply(splat=False), datas, kerns, grads, "cuda")
     for a, b in zip(out, ref_out):
         close(a, b)
+    _, _, dk64 = progressive_fp64(datas, kerns, grads, splat=False)
     for s in range(4):
-        close(dd[s], ref_dd[s]); close(dk[s], ref_dk[s], rtol=5e-5)
+        close(dd[s], ref_dd[s]); no_worse_than(dk[s], ref_dk[s], dk64[s], what="d_kernels[%d]" % s)
 
 
 @pytest.mark.parametrize("shape", [(1, 3, 2, 1, 2), (2, 5, 3, 7, 10), (1, 16, 8, 45, 64), (3, 4, 0, 6, 4), (1, 2, 2, 1, 6)])
