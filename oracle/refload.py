@@ -46,6 +46,7 @@ def _install_ttools_stub():
     tt = types.ModuleType("ttools")
     tt._sbmc_stub = True
     tt.get_logger = logging.getLogger
+    tt.ModelInterface = type("ModelInterface", (object,), {})   # base class of sbmc/interfaces.py:35 (not in tree)
     mods = types.ModuleType("ttools.modules")
     imops = types.ModuleType("ttools.modules.image_operators")
     imops.crop_like = _crop_like
@@ -80,4 +81,16 @@ def load_reference(ops_module=None):
     # reference models.py uses an undefined LOG in its error paths (models.py:62,66)
     pkg.Multisteps = pkg.models.Multisteps
     pkg.KPCN = pkg.models.KPCN
+    pkg.losses_mod = pkg.losses
     return pkg
+
+
+def load_reference_interfaces(pkg):
+    """Adds the reference's sbmc/interfaces.py (training step: loss, clip, Adam) to `pkg`."""
+    path = os.path.join(REFERENCE_ROOT, "sbmc", "interfaces.py")
+    spec = importlib.util.spec_from_file_location("sbmc.interfaces", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["sbmc.interfaces"] = mod
+    spec.loader.exec_module(mod)
+    pkg.interfaces = mod
+    return mod

@@ -32,13 +32,14 @@ import torch as th
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libsbmc_oracle.so")
 _SRC = os.path.join(_HERE, "sbmc_oracle.c")
+_INC = os.path.join(_HERE, "sbmc_oracle_ops.inc")
 _LIB = None
 
 
 def build(force=False):
     """Compile ``sbmc_oracle.c`` into ``libsbmc_oracle.so`` (gcc + OpenMP)."""
     stale = (not os.path.exists(_SO)
-             or os.path.getmtime(_SO) < os.path.getmtime(_SRC))
+             or os.path.getmtime(_SO) < max(os.path.getmtime(_SRC), os.path.getmtime(_INC)))
     if force or stale:
         subprocess.check_call(["make", "-s", "-B", "-C", _HERE])
     return _SO
@@ -54,21 +55,32 @@ def lib():
         _LIB.sbmc_oracle_kernel_weighting.argtypes = [fp, fp, fp, fp, i, i, i, i, i, i]
         _LIB.sbmc_oracle_kernel_weighting_grad.argtypes = [fp] * 7 + [i] * 6
         _LIB.sbmc_oracle_scatter2gather.argtypes = [fp, fp, i, i, i, i, i]
+        _LIB.sbmc_oracle_kernel_weighting_f64.argtypes = _LIB.sbmc_oracle_kernel_weighting.argtypes
+        _LIB.sbmc_oracle_kernel_weighting_grad_f64.argtypes = _LIB.sbmc_oracle_kernel_weighting_grad.argtypes
+        _LIB.sbmc_oracle_scatter2gather_f64.argtypes = _LIB.sbmc_oracle_scatter2gather.argtypes
         for f in (_LIB.sbmc_oracle_kernel_weighting,
                   _LIB.sbmc_oracle_kernel_weighting_grad,
-                  _LIB.sbmc_oracle_scatter2gather):
+                  _LIB.sbmc_oracle_scatter2gather,
+                  _LIB.sbmc_oracle_kernel_weighting_f64,
+                  _LIB.sbmc_oracle_kernel_weighting_grad_f64,
+                  _LIB.sbmc_oracle_scatter2gather_f64):
             f.restype = ctypes.c_int
     return _LIB
 
 
 def _chk(*tensors):
+    """Returns "" for float32 tensors (the oracle proper: the reference ops are *_float32) or "_f64"
+    for float64 ones (the same expressions evaluated in double: the tests' yardstick where two fp32
+    implementations are both limited by cancellation -- never compared as "the reference")."""
+    dt = tensors[0].dtype
     for t in tensors:
         if t.is_cuda:
             raise RuntimeError("the oracle only runs on host tensors")
-        if t.dtype != th.float32:
-            raise RuntimeError("the oracle is float32 only (reference ops are *_float32)")
+        if t.dtype != dt or dt not in (th.float32, th.float64):
+            raise RuntimeError("the oracle takes float32 tensors (or all-float64 ones for its double evaluation)")
         if not t.is_contiguous():
             raise RuntimeError("the oracle expects contiguous tensors")
+    return "" if dt == th.float32 else "_f64"
 
 
 def _p(t):
@@ -77,21 +89,21 @@ def _p(t):
 
 # -- the six names of sbmc.halide_ops (reference setup.py:65-84) --------------
 def scatter2gather_cpu_float32(weights, output):
-    _chk(weights, output)
+    sfx = _chk(weights, output)
     bs, kh, kw, h, w = weights.shape
     assert output.shape == weights.shape
-    rc = lib().sbmc_oracle_scatter2gather(_p(weights), _p(output), bs, h, w, kh, kw)
+    rc = getattr(lib(), "sbmc_oracle_scatter2gather" + sfx)(_p(weights), _p(output), bs, h, w, kh, kw)
     if rc:
         raise RuntimeError("sbmc_oracle_scatter2gather failed (%d)" % rc)
 
 
 def kernel_weighting_cpu_float32(data, weights, output, sum_w):
-    _chk(data, weights, output, sum_w)
+    sfx = _chk(data, weights, output, sum_w)
     bs, c, h, w = data.shape
     _, kh, kw, _, _ = weights.shape
     assert weights.shape == (bs, kh, kw, h, w)
     assert output.shape == data.shape and sum_w.shape == (bs, h, w)
-    rc = lib().sbmc_oracle_kernel_weighting(
+    rc = getattr(lib(), "sbmc_oracle_kernel_weighting" + sfx)(
         _p(data), _p(weights), _p(output), _p(sum_w), bs, c, h, w, kh, kw)
     if rc:
         raise RuntimeError("sbmc_oracle_kernel_weighting failed (%d)" % rc)
@@ -99,10 +111,10 @@ def kernel_weighting_cpu_float32(data, weights, output, sum_w):
 
 def kernel_weighting_grad_cpu_float32(data, weights, sum_w, d_output, d_sum_w,
                                       d_data, d_weights):
-    _chk(data, weights, sum_w, d_output, d_sum_w, d_data, d_weights)
+    sfx = _chk(data, weights, sum_w, d_output, d_sum_w, d_data, d_weights)
     bs, c, h, w = data.shape
     _, kh, kw, _, _ = weights.shape
-    rc = lib().sbmc_oracle_kernel_weighting_grad(
+    rc = getattr(lib(), "sbmc_oracle_kernel_weighting_grad" + sfx)(
         _p(data), _p(weights), _p(sum_w), _p(d_output), _p(d_sum_w),
         _p(d_data), _p(d_weights), bs, c, h, w, kh, kw)
     if rc:

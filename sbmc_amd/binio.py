@@ -37,6 +37,9 @@ N_BT = 5
 NUM_FEATURES = SAMPLE_FEATURES + 4 * PATH_DEPTH + 2 * PATH_DEPTH + N_BT * PATH_DEPTH  # 93
 GLOBAL_LABELS = ("aperture_radius", "focus_distance", "fov")   # datasets.py:312
 I_DIFFUSE, I_SPECULAR = 5, 8                                   # datasets.py:319-323
+I_NORMAL, I_DEPTH, I_ALBEDO = 14, 18, 24                       # g-buffer labels, datasets.py:326-335
+C_DIFFUSE, C_SPECULAR, C_ALBEDO = 0, 3, 6                      # pixel-data channels, datasets.py:300-306
+MODES = ("sbmc", "kpcn", "raw")
 
 _LZ4 = None
 
@@ -175,13 +178,69 @@ def read_header(fid):
                 aperture_radius=aperture, fov=fov, scene_radius=scene_radius)
 
 
-def read_tile(path, spp=None, preprocess=True):
-    """One tile as the reference's TilesDataset yields it in "sbmc" mode (all feature groups).
+def _gradients(buf):
+    """[c, h, w] -> [2c, h, w]: backward differences along x then y, zero in the first column / row
+    (datasets.py:858-874)."""
+    dx = np.pad(buf[:, :, 1:] - buf[:, :, :-1], [[0, 0], [0, 0], [1, 0]], mode="constant")
+    dy = np.pad(buf[:, 1:] - buf[:, :-1], [[0, 0], [1, 0], [0, 0]], mode="constant")
+    return np.concatenate([dx, dy], 0)
 
-    Returns a dict with block_x, block_y, global_features [3,1,1], image_data [15,ts,ts],
-    image_data_var, target_image [3,ts,ts], features [spp,93,ts,ts], radiance [spp,3,ts,ts],
-    low_spp [3,ts,ts], spp, scene_radius, header.
+
+def preprocess_kpcn(tile):
+    """A raw tile (read_tile(..., mode="raw")) in the format [Bako2017]'s denoiser expects: per-pixel
+    means / variances of the samples, albedo-demodulated diffuse, log specular and their gradients
+    (the reference's TilesDataset._preprocess_kpcn, datasets.py:780-856).  27 input channels per branch."""
+    f, tgt = tile["features"], tile["image_data"]
+    spp = f.shape[0]
+    depth = f[:, I_DEPTH:I_DEPTH + 1].mean(0)
+    depth_v = f[:, I_DEPTH:I_DEPTH + 1].var(0)
+    max_depth = depth.max()
+    if max_depth > 0:
+        depth = depth / max_depth
+        depth_v = depth_v / (max_depth * max_depth * spp)
+    depth = np.clip(depth, 0, 1)
+
+    def stats(i):
+        return f[:, i:i + 3].mean(0), f[:, i:i + 3].var(0).mean(0, keepdims=True) / spp
+    albedo, albedo_v = stats(I_ALBEDO)
+    albedo = albedo + 0.00316
+    albedo_sqr = (albedo * albedo).mean(0, keepdims=True)
+    diffuse, diffuse_v = stats(I_DIFFUSE)
+    diffuse = np.maximum(diffuse, 0)
+    specular, specular_v = stats(I_SPECULAR)
+    specular = np.maximum(specular, 0)
+    diffuse = diffuse / albedo
+    diffuse_v = diffuse_v / albedo_sqr
+    specular = np.log(1 + specular)
+    specular_v = specular_v / (((1 + specular) * (1 + specular)).mean(0, keepdims=True) + 1e-5)
+    normals, normals_v = stats(I_NORMAL)
+    normals_g, depth_g, albedo_g = _gradients(normals), _gradients(depth), _gradients(albedo)
+    common = [normals_g, normals_v, depth_g, depth_v, albedo_g, albedo_v]
+    out = {
+        "kpcn_diffuse_in": np.concatenate([diffuse] + common + [_gradients(diffuse), diffuse_v], 0),
+        "kpcn_specular_in": np.concatenate([specular] + common + [_gradients(specular), specular_v], 0),
+        "kpcn_diffuse_buffer": diffuse, "kpcn_specular_buffer": specular, "kpcn_albedo": albedo,
+    }
+    for k in ("target_image", "low_spp", "spp", "block_x", "block_y", "header", "global_features",
+              "scene_radius", "path"):
+        if k in tile:
+            out[k] = tile[k]
+    return out
+
+
+def read_tile(path, spp=None, preprocess=True, mode="sbmc"):
+    """One tile as the reference's TilesDataset yields it (datasets.py:395-411).
+
+    mode "sbmc" (all feature groups): a dict with block_x, block_y, global_features [3,1,1],
+    image_data [15,ts,ts], image_data_var, target_image [3,ts,ts], features [spp,93,ts,ts], radiance
+    [spp,3,ts,ts], low_spp [3,ts,ts], spp, scene_radius, header; the radiance features log-compressed
+    (`_preprocess_standard`) unless preprocess=False or mode "raw".  mode "kpcn": `preprocess_kpcn`.
     """
+    if mode not in MODES:
+        raise RuntimeError("Unknown dataset loading mode %s" % mode)
+    if mode != "sbmc":
+        raw = read_tile(path, spp, preprocess=False)
+        return preprocess_kpcn(raw) if mode == "kpcn" else raw
     with open(path, "rb") as fid:
         hdr = read_header(fid)
         ts = hdr["tile_size"]
@@ -221,12 +280,13 @@ def read_tile(path, spp=None, preprocess=True):
     return out
 
 
-def read_scene(folder, spp=None):
-    """All tiles of one scene folder assembled into full-frame arrays (FullImagesDataset)."""
+def read_scene(folder, spp=None, mode="sbmc"):
+    """All tiles of one scene folder assembled into full-frame arrays (FullImagesDataset,
+    datasets.py:930-964: every tile is preprocessed on its own, then pasted)."""
     files = sorted(f for f in os.listdir(folder) if f.endswith(".bin"))
     if not files:
         raise RuntimeError("Empty dataset")
-    first = read_tile(os.path.join(folder, files[0]), spp)
+    first = read_tile(os.path.join(folder, files[0]), spp, mode=mode)
     hdr = first["header"]
     ts, w, h = hdr["tile_size"], hdr["image_width"], hdr["image_height"]
     keys = [k for k, v in first.items() if isinstance(v, np.ndarray) and v.ndim >= 3
@@ -236,7 +296,7 @@ def read_scene(folder, spp=None):
     frame["scene_radius"] = first["scene_radius"]
     frame["header"] = hdr
     for f in files:
-        tile = first if f == files[0] else read_tile(os.path.join(folder, f), spp)
+        tile = first if f == files[0] else read_tile(os.path.join(folder, f), spp, mode=mode)
         th_ = tile["header"]
         for k in ("version", "tile_size", "image_width", "image_height", "sample_count"):
             if th_[k] != hdr[k]:

@@ -71,10 +71,67 @@ def denoise_frame(model, batch, tile_size=1024, tile_pad=256, kpcn_mode=False):
     return out_radiance
 
 
+def denoise_frame_sharded(model, batch, part, gather=True):
+    """One frame on several GPUs: this rank denoises the rows [part.y0, part.y1) of the frame with
+    `dist.ShardedDenoiser` (U-net halo exchange + cross-rank merge of the splat state) and -- with
+    gather=True -- every rank returns the whole [bs, 3, H, W] frame (zero border of (ksize-1)/2 pixels,
+    as `denoise_frame`).  `batch` holds the WHOLE frame on every rank; only the slab is moved through the
+    network.  The multi-GPU counterpart of the tile loop of scripts/denoise.py:142-165 (tiles -> ranks,
+    nothing recomputed in the overlap)."""
+    import torch.distributed as dist
+    from . import dist as sdist
+    p = (model.ksize - 1) // 2
+    slab = {k: (v if k in UNCHANGED_KEYS else v[..., part.y0:part.y1, :].contiguous())
+            for k, v in batch.items() if k in ("radiance", "features") + UNCHANGED_KEYS}
+    with th.no_grad():
+        out = sdist.ShardedDenoiser(model, part)(slab)["radiance"]
+    h, w = batch["radiance"].shape[-2:]
+    lo, hi = max(part.y0, p), min(part.y1, h - p)          # frame rows this rank's output covers
+    assert out.shape[-2] == hi - lo
+    if not gather:
+        return out, lo, hi
+    rows_max = -(-h // part.world) + 4
+    mine = out.new_zeros(out.shape[:-2] + (rows_max, out.shape[-1]))
+    mine[..., :hi - lo, :] = out
+    staged = mine.is_cuda and dist.get_backend(part.group) != "nccl"
+    send = mine.cpu() if staged else mine
+    parts = [th.empty_like(send) for _ in range(part.world)]
+    dist.all_gather(parts, send, group=part.group)
+    frame = out.new_zeros(out.shape[:-2] + (h, w))
+    for r in range(part.world):
+        pr = sdist.SlabPartition(h, part.world, r, group=part.group)
+        a, b = max(pr.y0, p), min(pr.y1, h - p)
+        frame[..., a:b, p:w - p] = parts[r][..., :b - a, :].to(frame.device)
+    return frame
+
+
+def find_checkpoint(path):
+    """`path` is a checkpoint file, or -- like the reference's --checkpoint -- a folder whose most
+    recent *.pth is taken (ttools.Checkpointer.load_latest, scripts/denoise.py:107,133-134)."""
+    import glob
+    import os
+    if os.path.isdir(path):
+        files = sorted(glob.glob(os.path.join(path, "*.pth")), key=os.path.getmtime)
+        if not files:
+            raise RuntimeError("no checkpoint (*.pth) in %s" % path)
+        return files[-1]
+    return path
+
+
+def load_meta(path):
+    """The `meta` dict stored next to the weights ({"model_params", "data_params", "kpcn_mode"} as
+    scripts/train.py writes it; reference scripts/train.py:84-86, scripts/denoise.py:107-123), {} for
+    a bare state dict."""
+    obj = th.load(find_checkpoint(path), map_location="cpu")
+    if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):
+        return obj.get("meta", {}) or {}
+    return {}
+
+
 def load_checkpoint(path, model):
     """Loads a state-dict checkpoint: either a bare state dict or {"model": sd, "meta": {...}}.
     (The reference goes through ttools.Checkpointer, whose on-disk format is not in its tree.)"""
-    obj = th.load(path, map_location="cpu")
+    obj = th.load(find_checkpoint(path), map_location="cpu")
     meta = {}
     if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict):
         meta = obj.get("meta", {}) or {}

@@ -86,36 +86,42 @@ class TilesDataset(th.utils.data.Dataset):
     """`.bin` tiles under root/<scene>/*.bin (folder mode of the reference's TilesDataset,
     sbmc/datasets.py:243-300) in "sbmc" mode with every feature group."""
 
-    def __init__(self, path, spp=None):
+    KEYS = {"sbmc": ("radiance", "features", "global_features", "target_image", "low_spp"),
+            "kpcn": ("kpcn_diffuse_in", "kpcn_specular_in", "kpcn_diffuse_buffer", "kpcn_specular_buffer",
+                     "kpcn_albedo", "target_image", "low_spp")}
+
+    def __init__(self, path, spp=None, mode="sbmc"):
+        if mode not in self.KEYS:
+            LOG.error("Unknown dataset loading mode %s", mode)
+            raise RuntimeError("Unknown dataset loading mode %s" % mode)
         self.files = sorted(glob.glob(os.path.join(path, "*", "*.bin")))
         if not self.files:
             LOG.error("Dataset is empty, please check the file format / folder structure.")
             raise RuntimeError("Empty dataset")
-        self.spp = spp
-        self.num_features = binio.NUM_FEATURES
+        self.spp, self.mode = spp, mode
+        self.num_features = 27 if mode == "kpcn" else binio.NUM_FEATURES     # datasets.py:413-419
         self.num_global_features = len(binio.GLOBAL_LABELS)
 
     def __len__(self):
         return len(self.files)
 
     def __getitem__(self, idx):
-        tile = binio.read_tile(self.files[idx], self.spp)
-        return {k: th.from_numpy(np.ascontiguousarray(tile[k]))
-                for k in ("radiance", "features", "global_features", "target_image", "low_spp")}
+        tile = binio.read_tile(self.files[idx], self.spp, mode=self.mode)
+        return {k: th.from_numpy(np.ascontiguousarray(tile[k])) for k in self.KEYS[self.mode]}
 
 
 class MultiSampleCountDataset(th.utils.data.ConcatDataset):
     """Every tile at every sample count 2..spp (reference sbmc/datasets.py:1015-1043); the
     sample dimension varies between items, so use batch_size = 1."""
 
-    def __init__(self, path, spp=None):
+    def __init__(self, path, spp=None, mode="sbmc"):
         if spp is None:
             LOG.error("MultiSampleCountDataset requires a number of spps")
             raise RuntimeError("spp not provided.")
         if spp < 2:
             LOG.error("MultiSampleCountDataset needs at least 2spp")
             raise RuntimeError("spp too low to randomize sample count, should be at least 2.")
-        parts = [TilesDataset(path, spp=s) for s in range(2, spp + 1)]
+        parts = [TilesDataset(path, spp=s, mode=mode) for s in range(2, spp + 1)]
         super(MultiSampleCountDataset, self).__init__(parts)
         self.num_features = parts[0].num_features
         self.num_global_features = parts[0].num_global_features

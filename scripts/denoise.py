@@ -1,13 +1,20 @@
 #!/usr/bin/env python
-"""Denoise one scene folder of `.bin` sample tiles with a Multisteps checkpoint (counterpart of
-the reference's scripts/denoise.py:96-194 for the SBMC model; same flags, int-typed tile args).
+"""Denoise one scene folder of `.bin` sample tiles with a trained checkpoint (counterpart of the
+reference's scripts/denoise.py:96-194; same flags, int-typed tile arguments).
 
-    python scripts/denoise.py --input <scene folder> --checkpoint <file.pth> --output out.npy \
-        [--spp N] [--tile_size 1024] [--tile_pad 256] [--ksize 21] [--width 128]
+    python scripts/denoise.py --input <scene folder> --checkpoint <file.pth | folder> --output out.exr \
+        [--spp N] [--tile_size 1024] [--tile_pad 256]
 
-Writes the denoised radiance as .npy ([H, W, 3] float32) and, when Pillow is present, a
-clipped 8-bit .png next to it (the reference writes .exr + .png through pyexr / skimage,
-neither of which exists here).
+Like the reference, everything about the model comes from the checkpoint's `meta`
+(scripts/denoise.py:107-123): `kpcn_mode` selects [Bako2017]'s KPCN over the sample-based
+`Multisteps`, `model_params` (ksize, gather, pixel; written by scripts/train.py) configure it and
+`data_params["spp"]` is the default sample count.  `--ksize/--gather/--pixel/--kpcn_mode` override the
+meta (needed for bare state-dict checkpoints).  Output: `<output>.exr` (float32 OpenEXR) + a clipped 8-bit
+`.png` next to it, as the reference (:166-173); an `--output` ending in `.npy` saves the array instead.
+
+Several GPUs: start it through `python -m torch.distributed.run --nproc-per-node N scripts/denoise.py ...`;
+the frame is then cut into N row slabs, one per rank (tiles -> ranks: halo exchange instead of the
+overlapped tiles' recomputation, sbmc_amd/dist.py), and rank 0 writes the result.
 """
 import argparse
 import logging
@@ -19,57 +26,107 @@ import numpy as np
 import torch as th
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from sbmc_amd import Multisteps, binio, denoise  # noqa: E402
+from sbmc_amd import KPCN, Multisteps, binio, denoise, imageio  # noqa: E402
 
 LOG = logging.getLogger("denoise")
+
+
+def build_model(meta, args):
+    """The network the checkpoint was trained as (reference scripts/denoise.py:116-123 + train.py:56-70)."""
+    params = dict(meta.get("model_params") or {})
+    kpcn_mode = bool(meta.get("kpcn_mode", False)) if args.kpcn_mode is None else args.kpcn_mode
+    ksize = args.ksize if args.ksize is not None else int(params.get("ksize", 21))
+    if kpcn_mode:
+        LOG.info("Using [Bako2017] denoiser.")
+        return KPCN(27, ksize=ksize), True
+    gather = args.gather if args.gather is not None else bool(params.get("gather", False))
+    pixel = args.pixel if args.pixel is not None else bool(params.get("pixel", False))
+    width = args.width if args.width is not None else int(params.get("width", 128))
+    for k in ("gather", "pixel"):
+        if getattr(args, k) is not None and k in params and bool(params[k]) != getattr(args, k):
+            LOG.warning("--%s overrides the checkpoint's model_params[%r] = %r", k, k, params[k])
+    return Multisteps(binio.NUM_FEATURES, len(binio.GLOBAL_LABELS), ksize=ksize, splat=not gather,
+                      pixel=pixel, width=width, embedding_width=width), False
+
+
+def save_output(path, img):
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    if path.endswith(".npy"):
+        np.save(path, img)
+        return
+    imageio.write_exr(path, img)
+    png = os.path.splitext(path)[0] + ".png"
+    imageio.write_png(png, (np.clip(img, 0, 1) * 255).astype(np.uint8))
 
 
 def main(args):
     start = time.time()
     if not os.path.isdir(args.input):
         raise ValueError("input {} does not exist".format(args.input))
-    frame = binio.read_scene(args.input, spp=args.spp)
-    LOG.info("frame %dx%d, %d spp", frame["header"]["image_width"], frame["header"]["image_height"],
-             frame["features"].shape[0])
-    model = Multisteps(binio.NUM_FEATURES, len(binio.GLOBAL_LABELS), ksize=args.ksize,
-                       width=args.width, embedding_width=args.width)
+    if not th.cuda.is_available():
+        raise SystemExit("sbmc_amd runs its operators on MI355X only; no GPU is visible")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, th.cuda.device_count())
+    device = th.device("cuda", local_rank)
+    th.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("SBMC_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+
+    meta = denoise.load_meta(args.checkpoint) if args.checkpoint else {}
+    spp = args.spp if args.spp else (meta.get("data_params") or {}).get("spp")
+    model, kpcn_mode = build_model(meta, args)
+    LOG.info("Loading model %s", args.checkpoint)
     if args.checkpoint:
         denoise.load_checkpoint(args.checkpoint, model)
     else:
         LOG.warning("no checkpoint given: running with the seeded random initialisation")
     model.train(False)
-    if not th.cuda.is_available():
-        raise SystemExit("sbmc_amd runs its operators on MI355X only; no GPU is visible")
-    device = th.device("cuda")
     model.to(device)
-    batch = {k: th.from_numpy(np.ascontiguousarray(frame[k])).unsqueeze(0).to(device)
-             for k in ("radiance", "features", "global_features", "low_spp")}
+
+    frame = binio.read_scene(args.input, spp=spp, mode="kpcn" if kpcn_mode else "sbmc")
+    hdr = frame["header"]
+    LOG.info("Denoising input %dx%d with %s spp", hdr["image_width"], hdr["image_height"], spp or hdr["sample_count"])
+    keys = denoise.TILED_KEYS + denoise.UNCHANGED_KEYS + ("low_spp",)
+    batch = {k: th.from_numpy(np.ascontiguousarray(frame[k])).unsqueeze(0).to(device) for k in keys if k in frame}
     LOG.info("setup time %.1f ms", (time.time() - start) * 1000)
     th.cuda.synchronize()
     start = time.time()
-    out = denoise.denoise_frame(model, batch, args.tile_size, args.tile_pad)
+    if world > 1 and not kpcn_mode:
+        from sbmc_amd import dist as sdist
+        part = sdist.SlabPartition(hdr["image_height"], world, rank)
+        out = denoise.denoise_frame_sharded(model, batch, part)
+    else:
+        out = denoise.denoise_frame(model, batch, args.tile_size, args.tile_pad, kpcn_mode=kpcn_mode)
     th.cuda.synchronize()
-    LOG.info("denoising time %.1f ms", (time.time() - start) * 1000)
-    img = out[0].cpu().numpy().transpose(1, 2, 0)
-    os.makedirs(os.path.dirname(os.path.abspath(args.output)), exist_ok=True)
-    np.save(args.output, img)
-    try:
-        from PIL import Image
-        Image.fromarray((np.clip(img, 0, 1) * 255).astype(np.uint8)).save(
-            os.path.splitext(args.output)[0] + ".png")
-    except ImportError:
-        pass
+    LOG.info("    denoising time %.1f ms", (time.time() - start) * 1000)
+    if rank == 0:
+        save_output(args.output, out[0].cpu().numpy().transpose(1, 2, 0))
+    if world > 1:
+        dist.destroy_process_group()
+    return out
 
 
-if __name__ == "__main__":
+def parser():
     p = argparse.ArgumentParser()
     p.add_argument("--input", required=True, help="scene folder containing the sample .bin tiles")
-    p.add_argument("--checkpoint", default=None, help="state-dict checkpoint (.pth)")
-    p.add_argument("--output", required=True, help="output .npy")
+    p.add_argument("--checkpoint", default=None, help="checkpoint file (.pth) or folder holding it")
+    p.add_argument("--output", required=True, help="output .exr (a .png preview is written next to it) or .npy")
     p.add_argument("--spp", type=int, default=None, help="number of samples to use as input")
     p.add_argument("--tile_size", type=int, default=1024)
     p.add_argument("--tile_pad", type=int, default=256)
-    p.add_argument("--ksize", type=int, default=21)
-    p.add_argument("--width", type=int, default=128)
+    # overrides of the checkpoint's meta (None = take the meta / the reference's defaults)
+    p.add_argument("--ksize", type=int, default=None)
+    p.add_argument("--width", type=int, default=None)
+    p.add_argument("--gather", action="store_true", default=None)
+    p.add_argument("--pixel", action="store_true", default=None)
+    p.add_argument("--kpcn_mode", action="store_true", default=None)
+    return p
+
+
+if __name__ == "__main__":
     logging.basicConfig(level=logging.INFO)
-    main(p.parse_args())
+    main(parser().parse_args())

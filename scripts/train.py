@@ -3,7 +3,7 @@
 scripts/train.py:33-152 for the sample-based model; visdom / progress-bar callbacks dropped).
 
     python scripts/train.py --data <root> --checkpoint_dir <dir> [--val_data <root>] [--spp 8]
-        [--ksize 21] [--gather] [--pixel] [--lr 1e-4] [--bs 1] [--num_epochs 1]
+        [--ksize 21] [--gather] [--pixel] [--kpcn_mode] [--lr 1e-4] [--bs 1] [--num_epochs 1]
 """
 import argparse
 import logging
@@ -15,7 +15,7 @@ import torch as th
 from torch.utils.data import DataLoader
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from sbmc_amd import Multisteps, interfaces  # noqa: E402
+from sbmc_amd import KPCN, Multisteps, interfaces  # noqa: E402
 
 
 def main(args):
@@ -23,21 +23,25 @@ def main(args):
     th.manual_seed(0)
     if not th.cuda.is_available():
         raise SystemExit("sbmc_amd runs its operators on MI355X only; no GPU is visible")
+    mode = "kpcn" if args.kpcn_mode else "sbmc"          # reference scripts/train.py:39-41
     if args.randomize_spp:
         if args.bs != 1:
             raise RuntimeError("Training with randomized spp is only valid for batch_size=1")
-        data = interfaces.MultiSampleCountDataset(args.data, spp=args.spp)
+        data = interfaces.MultiSampleCountDataset(args.data, spp=args.spp, mode=mode)
     else:
-        data = interfaces.TilesDataset(args.data, spp=args.spp)
-    model = Multisteps(data.num_features, data.num_global_features, ksize=args.ksize,
-                       splat=not args.gather, pixel=args.pixel)
+        data = interfaces.TilesDataset(args.data, spp=args.spp, mode=mode)
+    if args.kpcn_mode:                                    # reference scripts/train.py:58-60
+        model = KPCN(data.num_features, ksize=args.ksize)
+    else:
+        model = Multisteps(data.num_features, data.num_global_features, ksize=args.ksize,
+                           splat=not args.gather, pixel=args.pixel)
     loader = DataLoader(data, batch_size=args.bs, num_workers=args.num_worker_threads, shuffle=True)
     val_loader = None
     if args.val_data:
-        val_loader = DataLoader(interfaces.TilesDataset(args.val_data, spp=args.spp),
+        val_loader = DataLoader(interfaces.TilesDataset(args.val_data, spp=args.spp, mode=mode),
                                 batch_size=args.bs, num_workers=1, shuffle=False)
     meta = dict(model_params=dict(ksize=args.ksize, gather=args.gather, pixel=args.pixel),
-                kpcn_mode=False, data_params=dict(spp=args.spp))
+                kpcn_mode=args.kpcn_mode, data_params=dict(spp=args.spp))
     interface = interfaces.SampleBasedDenoiserInterface(model, lr=args.lr, cuda=True)
     ckpt = interfaces.Checkpointer(args.checkpoint_dir, model, interface.optimizer, meta=meta)
     extras, _ = ckpt.load_latest()
@@ -55,6 +59,7 @@ if __name__ == "__main__":
     p.add_argument("--ksize", type=int, default=21)
     p.add_argument("--gather", action="store_true")
     p.add_argument("--pixel", action="store_true")
+    p.add_argument("--kpcn_mode", action="store_true", help="train [Bako2017]'s KPCN baseline instead")
     p.add_argument("--constant_spp", dest="randomize_spp", action="store_false", default=True)
     p.add_argument("--lr", type=float, default=1e-4)
     p.add_argument("--bs", type=int, default=1)

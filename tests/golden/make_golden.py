@@ -284,7 +284,61 @@ def gen_bin(ref_root):
     save("bin_scene_expected.npz", out)
 
 
+def gen_interface(ref):
+    """Two training steps of the reference's SampleBasedDenoiserInterface (sbmc/interfaces.py:78-105: loss,
+    backward, grad-norm clip 1000, Adam(1e-4)) on the model and batch of multisteps.npz; commits the returned
+    loss / rmse of each step and the parameters after each Adam step."""
+    itf = refload.load_reference_interfaces(ref)
+    g = np.load(os.path.join(HERE, "multisteps.npz"))
+    nf, ngf, width, ew, ks, nsteps = [int(v) for v in g["meta"]]
+    model = ref.models.Multisteps(nf, ngf, width=width, embedding_width=ew, ksize=ks, nsteps=nsteps)
+    model.load_state_dict({k[3:]: th.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+    model.train(True)
+    iface = itf.SampleBasedDenoiserInterface(model, lr=1e-4, cuda=False)
+    out = {}
+    for step in (1, 2):
+        batch = {k[3:]: th.from_numpy(g[k]).clone() for k in g.files if k.startswith("in.")}
+        stats = iface.backward(batch, iface.forward(batch))
+        out["step%d.loss" % step] = np.float64(stats["loss"])
+        out["step%d.rmse" % step] = np.float64(stats["rmse"])
+        for k, v in model.state_dict().items():
+            out["step%d.sd.%s" % (step, k)] = npy(v.detach().clone())
+    save("interface.npz", out)
+
+
+def gen_bin_kpcn(ref_root):
+    """The committed scene (tests/golden/bin_scene, written by sbmc_amd.binio) read by the REFERENCE's
+    sbmc/datasets.py in "kpcn" mode ([Bako2017] preprocessing, datasets.py:780-856)."""
+    import importlib.util
+    import types
+    from sbmc_amd import binio
+    scene_root = os.path.join(HERE, "bin_scene")
+    lz4 = types.ModuleType("lz4")
+    frame = types.ModuleType("lz4.frame")
+    frame.decompress = lambda buf: binio.lz4f_decompress(buf, None)
+    lz4.frame = frame
+    sys.modules["lz4"], sys.modules["lz4.frame"] = lz4, frame
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    spec = importlib.util.spec_from_file_location("ref_datasets", os.path.join(ref_root, "sbmc", "datasets.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    ds = mod.FullImagesDataset(scene_root, spp=3, mode="kpcn")
+    item = ds[0]
+    assert ds.num_features == 27
+    for k in ("kpcn_diffuse_in", "kpcn_specular_in", "kpcn_diffuse_buffer", "kpcn_specular_buffer", "kpcn_albedo",
+              "target_image", "low_spp"):
+        out["spp3." + k] = np.asarray(item[k])
+    save("bin_scene_kpcn_expected.npz", out)
+
+
 def main():
+    if "--round2" in sys.argv:        # the fixtures added in round 2 only (leaves the others untouched)
+        ref = refload.load_reference()
+        gen_interface(ref)
+        gen_bin_kpcn(refload.REFERENCE_ROOT)
+        return
     if not refload.available():
         raise SystemExit("reference tree not available: fixtures can only be regenerated in the "
                          "authoring container")
@@ -297,6 +351,8 @@ def main():
     gen_kpcn(ref)
     gen_multisteps_odd(ref)
     gen_bin(refload.REFERENCE_ROOT)
+    gen_interface(ref)
+    gen_bin_kpcn(refload.REFERENCE_ROOT)
 
 
 if __name__ == "__main__":

@@ -68,7 +68,25 @@ def gather_logits_fp64(kernels):
 
 
 def progressive_fp64(datas, kerns, grads=None, splat=True):
-    """The reference's ProgressiveKernelApply chain (sbmc/modules.py:422-471) in float64 torch ops:
+    """The reference's ProgressiveKernelApply chain (sbmc/modules.py:422-471) evaluated in float64 by the
+    oracle's double instantiation of its operators (oracle/sbmc_oracle_ops.inc, OpenMP: fast enough for
+    full-width bands).  Same contract as `progressive_fp64_torch`, against which it is checked on the CPU."""
+    from oracle import sbmc_oracle as orc
+    orc.lib()
+    datas = [d.detach().double().requires_grad_() for d in datas]
+    kerns = [k.detach().double().requires_grad_() for k in kerns]
+    st = (None, None, None)
+    for d, kk in zip(datas, kerns):
+        st = orc.progressive_kernel_apply(d, kk, *st, splat=splat)
+    if grads is None:
+        return st, None, None
+    th.autograd.backward(list(st), [g.double() for g in grads])
+    return st, [d.grad for d in datas], [k.grad for k in kerns]
+
+
+def progressive_fp64_torch(datas, kerns, grads=None, splat=True):
+    """The reference's ProgressiveKernelApply chain (sbmc/modules.py:422-471) in float64 torch ops only
+    (no native code at all; slow: small frames):
     the "truth" two fp32 implementations are both measured against where their own 1e-5 agreement is
     limited by cancellation (the routed arg-max element of d_kernels).
     Returns (state, d_datas, d_kerns) like helpers.run_progressive (gradients None without grads)."""

@@ -148,3 +148,21 @@ def test_oracle_matches_committed_golden_ops(oracle):
         assert th.equal(wts.grad, th.from_numpy(g[tag + ".d_weights"]))
         x = th.from_numpy(g[tag + ".s2g_in"])
         assert th.equal(oracle.Scatter2Gather.apply(x), th.from_numpy(g[tag + ".s2g_out"]))
+
+
+def test_float64_evaluation_of_the_oracle_agrees_with_pure_torch(oracle):
+    """The oracle's double instantiation (the tests' yardstick for cancellation-limited gradients) vs an
+    independent pure-torch float64 restatement, and the float32 oracle within fp32 rounding of both."""
+    from helpers import progressive_fp64, progressive_fp64_torch, run_progressive
+    th.manual_seed(3)
+    for splat, k in ((True, 5), (False, 3), (True, 7)):
+        d = [th.rand(1, 3, 9, 13) for _ in range(3)]
+        kk = [th.randn(1, k * k, 9, 13) * 2 for _ in range(3)]
+        g = [th.randn(1, 3, 9, 13), th.randn(1, 1, 9, 13), th.randn(1, 1, 9, 13)]
+        a, da, ka = progressive_fp64(d, kk, g, splat=splat)
+        b, db, kb = progressive_fp64_torch(d, kk, g, splat=splat)
+        for x, y in zip(list(a) + da + ka, list(b) + db + kb):
+            assert (x - y).abs().max().item() <= 1e-12 * max(1.0, y.abs().max().item())
+        o, do, ko = run_progressive(lambda *args: oracle.progressive_kernel_apply(*args, splat=splat), d, kk, g, "cpu")
+        for x, y in zip(list(o) + do + ko, list(a) + da + ka):
+            assert (x.double() - y).abs().max().item() <= 1e-5 * max(1.0, y.abs().max().item())
