@@ -22,7 +22,7 @@ full = bench.make_model_inputs(H, W, S, dev, seed=1234)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     th.manual_seed(0)
     model = Multisteps(93, 3, ksize=K).to(dev).train()
-    opt = th.optim.Adam(model.parameters(), lr=1e-4)
+    opt = th.optim.Adam(model.parameters(), lr=1e-4, fused=True)   # as bench.py
     loss_fn = losses.TonemappedRelativeMSE()
     rank = world // 2 if world > 1 else 0          # an interior rank (halos on both sides)
     part = sdist.SlabPartition(H, world, rank)
