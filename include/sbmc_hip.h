@@ -93,6 +93,24 @@ SBMC_API int sbmc_kernel_weighting_bwd_f32(const float *data, const float *weigh
                                   void *stream);
 
 /*
+ * The same three operators with half-precision storage -- what the reference's naming scheme
+ * (setup.py:65-84: `<op>_{cpu,cuda}_<dtype>`) would call `scatter2gather_cuda_float16`,
+ * `kernel_weighting_cuda_float16`, `kernel_weighting_grad_cuda_float16` (the
+ * reference only instantiates float32).  EVERY tensor of a call is IEEE half (torch.float16), same
+ * shapes and semantics; products and sums are formed in fp32 and rounded once on the store.
+ * scatter2gather_f16 is a pure permutation: bit exact.
+ */
+SBMC_API int sbmc_scatter2gather_f16(const void *weights, void *output,
+                            int bs, int h, int w, int kh, int kw, void *stream);
+SBMC_API int sbmc_kernel_weighting_fwd_f16(const void *data, const void *weights,
+                                  void *output, void *sum_w,
+                                  int bs, int c, int h, int w, int kh, int kw, void *stream);
+SBMC_API int sbmc_kernel_weighting_bwd_f16(const void *data, const void *weights,
+                                  const void *sum_w, const void *d_output,
+                                  const void *d_sum_w, void *d_data, void *d_weights,
+                                  int bs, int c, int h, int w, int kh, int kw, void *stream);
+
+/*
  * 1 if sbmc_splat_update_{fwd,bwd}_f32 accept this (channels, kernel size): k odd,
  * 1 <= c <= SBMC_HIP_MAX_CHANNELS and the LDS halo tiles fit; 0 otherwise (the
  * caller then composes scatter2gather + kernel_weighting instead).
@@ -357,7 +375,7 @@ SBMC_API int sbmc_pointwise_fwd_f32(const float *x, const float *w, const float 
                            float slope, void *stream);
 /* The same forward with half-precision STORAGE ("fp16 activations", BASELINE configs[4]): y is
  * _Float16, x is _Float16 (x_is_half = 1) or float (the network's fp32 inputs); w, bias, t stay
- * float and all arithmetic is fp32 (fp32 MFMA).  Inference only: there is no half backward. */
+ * float and all arithmetic is fp32 (fp32 MFMA).  Backward: sbmc_pointwise_bwd_f16 below. */
 SBMC_API int sbmc_pointwise_fwd_f16(const void *x, int x_is_half, const float *w, const float *bias,
                            const float *t, void *y, int b, int s, int cin, int cout, long hw,
                            int t_mode, int act, float slope, void *stream);
@@ -379,6 +397,15 @@ SBMC_API int sbmc_pointwise_bwd_groups(int b, int s, int t_mode, long hw);
 SBMC_API int sbmc_pointwise_bwd_f32(const float *gy, const float *y, const float *x, const float *w,
                            float *gx, float *gw_partial, float *gb_partial, float *gt,
                            const float *gmean, int s_mean, int b, int s, int cin, int cout, long hw,
+                           int t_mode, int act, float slope, void *stream);
+
+/* The same backward with half-precision STORAGE (training under torch.autocast(float16), SURVEY.md row
+ * N4): gy, y, gmean are _Float16; x and gx are _Float16 (x_is_half = 1) or float (a chain's first
+ * layer, whose input is the network's fp32 features); w, gw_partial, gb_partial and gt stay float, every
+ * product and sum is fp32 (fp32 MFMA), gx is rounded once on the store. */
+SBMC_API int sbmc_pointwise_bwd_f16(const void *gy, const void *y, const void *x, int x_is_half, const float *w,
+                           void *gx, float *gw_partial, float *gb_partial, float *gt,
+                           const void *gmean, int s_mean, int b, int s, int cin, int cout, long hw,
                            int t_mode, int act, float slope, void *stream);
 
 /* ---- the U-net's up path: bilinear x2 upsampling + channel concatenation in one pass ---------

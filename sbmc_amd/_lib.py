@@ -22,6 +22,9 @@ SYMBOLS = (
     "sbmc_scatter2gather_f32",
     "sbmc_kernel_weighting_fwd_f32",
     "sbmc_kernel_weighting_bwd_f32",
+    "sbmc_scatter2gather_f16",
+    "sbmc_kernel_weighting_fwd_f16",
+    "sbmc_kernel_weighting_bwd_f16",
     "sbmc_splat_update_supported",
     "sbmc_splat_update_bwd_scratch_bytes",
     "sbmc_splat_update_fwd_f32",
@@ -52,6 +55,7 @@ SYMBOLS = (
     "sbmc_pointwise_bwd_supported",
     "sbmc_pointwise_bwd_groups",
     "sbmc_pointwise_bwd_f32",
+    "sbmc_pointwise_bwd_f16",
     "sbmc_upsample2x_cat_supported",
     "sbmc_upsample2x_cat_fwd_f32",
     "sbmc_upsample2x_cat_bwd_f32",
@@ -106,6 +110,9 @@ def lib():
     handle.sbmc_scatter2gather_f32.argtypes = [p, p, i, i, i, i, i, p]
     handle.sbmc_kernel_weighting_fwd_f32.argtypes = [p] * 4 + [i] * 6 + [p]
     handle.sbmc_kernel_weighting_bwd_f32.argtypes = [p] * 7 + [i] * 6 + [p]
+    handle.sbmc_scatter2gather_f16.argtypes = handle.sbmc_scatter2gather_f32.argtypes
+    handle.sbmc_kernel_weighting_fwd_f16.argtypes = handle.sbmc_kernel_weighting_fwd_f32.argtypes
+    handle.sbmc_kernel_weighting_bwd_f16.argtypes = handle.sbmc_kernel_weighting_bwd_f32.argtypes
     handle.sbmc_splat_update_supported.argtypes = [i, i]
     handle.sbmc_splat_update_fwd_f32.argtypes = [p] * 10 + [i] * 5 + [p]
     handle.sbmc_splat_update_bwd_f32.argtypes = [p] * 19 + [i] * 5 + [p]
@@ -136,6 +143,8 @@ def lib():
     handle.sbmc_pointwise_bwd_supported.argtypes = [i, i, ctypes.c_long]
     handle.sbmc_pointwise_bwd_groups.argtypes = [i, i, i, ctypes.c_long]
     handle.sbmc_pointwise_bwd_f32.argtypes = [p] * 9 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_pointwise_bwd_f16.argtypes = [p, p, p, i, p, p, p, p, p, p, i, i, i, i, i, ctypes.c_long, i, i,
+                                              ctypes.c_float, p]
     handle.sbmc_upsample2x_cat_supported.argtypes = [i, i]
     handle.sbmc_upsample2x_cat_fwd_f32.argtypes = [p, p, p, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_bwd_f32.argtypes = [p, p, i, i, i, i, i, p]

@@ -58,19 +58,20 @@ __device__ __forceinline__ TileCoord decode_tile(int ntx, int nty, int ty_rows) 
 
 // Cooperative load of a haloed tile of one [H, W] plane into LDS.
 //   dst[r * tw + cc] = inside ? src[(ys0 + r) * W + xs0 + cc] : fill
+template <typename T>
 __device__ __forceinline__ void stage_plane(float* __restrict__ dst,
-                                            const float* __restrict__ src,
+                                            const T* __restrict__ src,
                                             int h, int w, int ys0, int xs0,
                                             int th, int tw, float fill) {
     const int nthreads = blockDim.x;
     for (int r = threadIdx.x / TX; r < th; r += nthreads / TX) {
         const int ys = ys0 + r;
         const bool yin = (ys >= 0) && (ys < h);
-        const float* row = src + (size_t)(yin ? ys : 0) * w;
+        const T* row = src + (size_t)(yin ? ys : 0) * w;
         for (int cc = threadIdx.x % TX; cc < tw; cc += TX) {
             const int xs = xs0 + cc;
             const bool in = yin && (xs >= 0) && (xs < w);
-            dst[r * tw + cc] = in ? row[xs] : fill;
+            dst[r * tw + cc] = in ? (float)row[xs] : fill;
         }
     }
 }

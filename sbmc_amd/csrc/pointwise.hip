@@ -260,16 +260,39 @@ __global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
 constexpr int PB_NT = 64;
 constexpr int PB_PITCH = 66;
 
+// 4 consecutive pixels of one row as they sit in HBM: 16 bytes of float or 8 bytes of _Float16
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+template <typename T> struct Pack4 { using type = u32x4; };
+template <> struct Pack4<_Float16> { using type = u32x2; };
+template <typename T>
+__device__ __forceinline__ typename Pack4<T>::type load4(rsrc_t r, unsigned off) {
+    if constexpr (sizeof(T) == 4) return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    else return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+}
+template <typename T>
+__device__ __forceinline__ float4 unpack4(typename Pack4<T>::type v) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(float4, v);
+    } else {
+        using h4 = __attribute__((ext_vector_type(4))) _Float16;
+        const h4 h = __builtin_bit_cast(h4, v);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+}
+
+// TA: storage type of gy, y, gm (the layer's output side); TXT: of x and gx (its input side) -- float, or
+// _Float16 for training under torch.autocast(float16) ("fp16 activations").  w, the
+// partial sums gwp / gbp and the context gradient gt are fp32; so is every product and sum.
 struct PwBwdParams {
-    const float* gy;     // [B, Cout, hw]
-    const float* y;      // [B, Cout, hw] (forward output; unused when linear)
-    const float* x;      // [B, K, hw]
+    const void* gy;      // [B, Cout, hw]
+    const void* y;       // [B, Cout, hw] (forward output; unused when linear)
+    const void* x;       // [B, K, hw]
     const float* w;      // [Cout, K]
-    float* gx;           // [B, K, hw] or nullptr
+    void* gx;            // [B, K, hw] or nullptr
     float* gwp;          // [G, Cout, K] per-workgroup partial sums of gw
     float* gbp;          // [G, Bq, Cout] per-workgroup partial sums of gbias (zeroed by the host)
     float* gt;           // [B/S, Cout, hw] (t_mode 2) or nullptr
-    const float* gm;     // [B/Sm, Cout, hw] or nullptr: gradient of the mean of y over groups of Sm
+    const void* gm;      // [B/Sm, Cout, hw] or nullptr: gradient of the mean of y over groups of Sm
     int Sm;              //   consecutive batch elements; the kernel sees gy + gm[b / Sm] / Sm
     int B, S, K, Cout, Bq;
     unsigned hw, tiles_per_plane, nunits;
@@ -277,8 +300,14 @@ struct PwBwdParams {
     float slope;
 };
 
-template <int KP, bool DX, bool TPIX, bool GM>
+template <int KP, bool DX, bool TPIX, bool GM, typename TA = float, typename TXT = float>
 __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
+    const TA* gy_g = static_cast<const TA*>(p.gy);
+    const TA* y_g = static_cast<const TA*>(p.y);
+    const TA* gm_g = static_cast<const TA*>(p.gm);
+    const TXT* x_g = static_cast<const TXT*>(p.x);
+    TXT* gx_g = static_cast<TXT*>(p.gx);
+    constexpr unsigned SA = (unsigned)sizeof(TA), SX = (unsigned)sizeof(TXT);
     // gx of a tile is stored between the MFMAs of the next one; the variants that carry 16 more
     // registers (per-pixel context sums, mean-gradient tile) have none left for that and store it
     // right away
@@ -327,30 +356,31 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         return n;
     };
 
-    u32x4 pg[4], py[4], px[NX], pm[GM ? 4 : 1];
+    typename Pack4<TA>::type pg[4], py[4], pm[GM ? 4 : 1];
+    typename Pack4<TXT>::type px[NX];
     const float inv_sm = GM ? 1.f / (float)p.Sm : 0.f;
     auto issue = [&](Cursor c) {
         unsigned b, bq, p0;
         coords(c, b, bq, p0);
-        const rsrc_t rg = make_rsrc_n(p.gy + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
-        const rsrc_t rm = make_rsrc_n(GM ? p.gm + (size_t)(b / (unsigned)p.Sm) * p.Cout * hw : p.gy,
-                                      (unsigned)p.Cout * hw * 4u);
-        const rsrc_t ry = make_rsrc_n(p.y + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
-        const rsrc_t rx = make_rsrc_n(p.x + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
+        const rsrc_t rg = make_rsrc_n(gy_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * SA);
+        const rsrc_t rm = make_rsrc_n(GM ? gm_g + (size_t)(b / (unsigned)p.Sm) * p.Cout * hw : gy_g,
+                                      (unsigned)p.Cout * hw * SA);
+        const rsrc_t ry = make_rsrc_n(y_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * SA);
+        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * SX);
         const bool colok = p0 + c4 < hw;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned r = srow + 32u * i;
-            const unsigned off = (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB;
-            pg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
-            if (masked) py[i] = __builtin_amdgcn_raw_buffer_load_b128(ry, off, 0, 0);
-            if (GM) pm[i] = __builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0);
+            const unsigned off = (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * SA : PW_OOB;
+            pg[i] = load4<TA>(rg, off);
+            if (masked) py[i] = load4<TA>(ry, off);
+            if (GM) pm[i] = load4<TA>(rm, off);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const unsigned r = srow + 32u * i;
-            const unsigned off = (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * 4u : PW_OOB;
-            px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+            const unsigned off = (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * SX : PW_OOB;
+            px[i] = load4<TXT>(rx, off);
         }
     };
 
@@ -382,13 +412,13 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         float* xst = gzs + 128 * PB_PITCH;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float4 gv = __builtin_bit_cast(float4, pg[i]);
+            float4 gv = unpack4<TA>(pg[i]);
             if (GM) {
-                const float4 m = __builtin_bit_cast(float4, pm[i]);
+                const float4 m = unpack4<TA>(pm[i]);
                 gv.x += m.x * inv_sm; gv.y += m.y * inv_sm; gv.z += m.z * inv_sm; gv.w += m.w * inv_sm;
             }
             if (masked) {
-                const float4 v = __builtin_bit_cast(float4, py[i]);
+                const float4 v = unpack4<TA>(py[i]);
                 gv.x = v.x > 0.f ? gv.x : gv.x * p.slope;
                 gv.y = v.y > 0.f ? gv.y : gv.y * p.slope;
                 gv.z = v.z > 0.f ? gv.z : gv.z * p.slope;
@@ -404,7 +434,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const float4 xv = __builtin_bit_cast(float4, px[i]);
+            const float4 xv = unpack4<TXT>(px[i]);
             float2* d = reinterpret_cast<float2*>(xst + (srow + 32 * i) * PB_PITCH + c4);
             d[0] = make_float2(xv.x, xv.y);
             d[1] = make_float2(xv.z, xv.w);
@@ -445,10 +475,11 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     unsigned b_prev = 0, o_prev = PW_OOB;
     const int kr0 = rb * 32;
     const int nkrows = p.K - kr0 < 32 ? (p.K - kr0 > 0 ? p.K - kr0 : 0) : 32;
+    // (o_prev: byte offset for 4-byte elements; half outputs sit at half of it)
     auto store_prev = [&](int j) {
-        const rsrc_t rgx = make_rsrc_n(p.gx + ((size_t)b_prev * p.K + kr0) * hw, (unsigned)nkrows * hw * 4u);
+        const rsrc_t rgx = make_rsrc_n(gx_g + ((size_t)b_prev * p.K + kr0) * hw, (unsigned)nkrows * hw * SX);
         const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
-        buf_store(out[j], rgx, o_prev != PW_OOB ? o_prev + ro : PW_OOB, 0);
+        logit_store<TXT>(out[j], rgx, o_prev != PW_OOB ? (o_prev + ro) / (4u / SX) : PW_OOB, 0);
     };
 
     int buf = 0;
@@ -640,17 +671,18 @@ extern "C" int sbmc_pointwise_bwd_groups(int b, int s, int t_mode, long hw) {
     return (int)pw_bwd_grid(b, t_mode ? s : 1, hw, nullptr);
 }
 
-extern "C" int sbmc_pointwise_bwd_f32(const float* gy, const float* y, const float* x, const float* w, float* gx,
-                                      float* gw_partial, float* gb_partial, float* gt, const float* gmean,
-                                      int s_mean, int b, int s, int cin, int cout, long hw, int t_mode, int act,
-                                      float slope, void* stream) {
+template <typename TA, typename TXT>
+static int pw_bwd_launch(const void* gy, const void* y, const void* x, const float* w, void* gx,
+                         float* gw_partial, float* gb_partial, float* gt, const void* gmean,
+                         int s_mean, int b, int s, int cin, int cout, long hw, int t_mode, int act,
+                         float slope, void* stream) {
     if (b < 0 || s < 1 || act < 0 || act > 2 || t_mode < 0 || t_mode > 2) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!sbmc_pointwise_bwd_supported(cin, cout, hw) || b % s || !gy || !x || !w || !gw_partial || !gb_partial ||
         (act != 0 && !y) || (t_mode == 2 && !gt) || (gmean && (s_mean < 1 || b % s_mean || t_mode == 2)))
         return SBMC_HIP_EINVAL;
     if ((uintptr_t)gy % 16 || (uintptr_t)x % 16 || (act != 0 && (uintptr_t)y % 16) ||
-        (t_mode == 2 && (uintptr_t)gt % 16) || (uintptr_t)gmean % 16)
+        (t_mode == 2 && (uintptr_t)gt % 16) || (uintptr_t)gmean % 16 || (uintptr_t)gx % 16)
         return SBMC_HIP_EINVAL;
     PwBwdParams p;
     p.gy = gy; p.y = act != 0 ? y : gy; p.x = x; p.w = w; p.gx = gx; p.gwp = gw_partial; p.gbp = gb_partial; p.gt = gt;
@@ -670,7 +702,8 @@ extern "C" int sbmc_pointwise_bwd_f32(const float* gy, const float* y, const flo
     const size_t lds = (size_t)2 * (128 + kp) * PB_PITCH * sizeof(float);
 #define SBMC_PWB_LAUNCH2(KPV, DXV, TPV)                                                                  \
     do {                                                                                                 \
-        auto kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true> : pw_bwd_kernel<KPV, DXV, TPV, false>; \
+        auto kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, TA, TXT>                       \
+                                    : pw_bwd_kernel<KPV, DXV, TPV, false, TA, TXT>;                       \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
         if (e == hipSuccess)                                                                             \
@@ -691,4 +724,23 @@ extern "C" int sbmc_pointwise_bwd_f32(const float* gy, const float* y, const flo
 #undef SBMC_PWB_LAUNCH2
     if (e != hipSuccess) return (int)e;
     return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_pointwise_bwd_f32(const float* gy, const float* y, const float* x, const float* w, float* gx,
+                                      float* gw_partial, float* gb_partial, float* gt, const float* gmean,
+                                      int s_mean, int b, int s, int cin, int cout, long hw, int t_mode, int act,
+                                      float slope, void* stream) {
+    return pw_bwd_launch<float, float>(gy, y, x, w, gx, gw_partial, gb_partial, gt, gmean, s_mean, b, s, cin, cout,
+                                       hw, t_mode, act, slope, stream);
+}
+
+extern "C" int sbmc_pointwise_bwd_f16(const void* gy, const void* y, const void* x, int x_is_half, const float* w,
+                                      void* gx, float* gw_partial, float* gb_partial, float* gt, const void* gmean,
+                                      int s_mean, int b, int s, int cin, int cout, long hw, int t_mode, int act,
+                                      float slope, void* stream) {
+    if (x_is_half)
+        return pw_bwd_launch<_Float16, _Float16>(gy, y, x, w, gx, gw_partial, gb_partial, gt, gmean, s_mean, b, s,
+                                                 cin, cout, hw, t_mode, act, slope, stream);
+    return pw_bwd_launch<_Float16, float>(gy, y, x, w, gx, gw_partial, gb_partial, gt, gmean, s_mean, b, s, cin,
+                                          cout, hw, t_mode, act, slope, stream);
 }

@@ -79,7 +79,9 @@ class Scatter2Gather(th.autograd.Function):
         data = data.contiguous()
         output = th.empty_like(data)
         if _is_cuda(data):
-            ops.scatter2gather_cuda_float32(data, output)
+            # the reference has float32 only; half tensors take the `_float16` instantiation
+            (ops.scatter2gather_cuda_float16 if data.dtype == th.float16 else ops.scatter2gather_cuda_float32)(
+                data, output)
         else:
             ops.scatter2gather_cpu_float32(data, output)
         return output
@@ -90,7 +92,8 @@ class Scatter2Gather(th.autograd.Function):
         d_output = d_output.contiguous()
         d_data = th.empty_like(d_output)
         if _is_cuda(d_output):
-            ops.scatter2gather_cuda_float32(d_output, d_data)
+            (ops.scatter2gather_cuda_float16 if d_output.dtype == th.float16 else ops.scatter2gather_cuda_float32)(
+                d_output, d_data)
         else:
             ops.scatter2gather_cpu_float32(d_output, d_data)
         return d_data
@@ -118,7 +121,10 @@ class KernelWeighting(th.autograd.Function):
         output = th.empty_like(data)
         sum_w = data.new_empty(bs, h, w)
         if _is_cuda(data, weights):
-            ops.kernel_weighting_cuda_float32(data, weights, output, sum_w)
+            if data.dtype == th.float16 and weights.dtype == th.float16:
+                ops.kernel_weighting_cuda_float16(data, weights, output, sum_w)
+            else:
+                ops.kernel_weighting_cuda_float32(data, weights, output, sum_w)
         else:
             ops.kernel_weighting_cpu_float32(data, weights, output, sum_w)
         ctx.save_for_backward(data, weights, sum_w)
@@ -132,8 +138,12 @@ class KernelWeighting(th.autograd.Function):
         d_data = th.empty_like(data)
         d_weights = th.empty_like(weights)
         if _is_cuda(d_output, d_sum_w):
-            ops.kernel_weighting_grad_cuda_float32(
-                data, weights, sum_w, d_output, d_sum_w, d_data, d_weights)
+            if data.dtype == th.float16 and weights.dtype == th.float16:
+                ops.kernel_weighting_grad_cuda_float16(
+                    data, weights, sum_w, d_output.half(), d_sum_w.half(), d_data, d_weights)
+            else:
+                ops.kernel_weighting_grad_cuda_float32(
+                    data, weights, sum_w, d_output, d_sum_w, d_data, d_weights)
         else:
             ops.kernel_weighting_grad_cpu_float32(
                 data, weights, sum_w, d_output, d_sum_w, d_data, d_weights)
@@ -383,11 +393,11 @@ def pointwise_supported(x, cout):
 
 
 def pointwise_half_supported(x, cout):
-    """True when `pointwise_half` applies: inference (no grad) under torch.autocast(float16) on the
-    GPU, x [B, cin, ...pixels] float32 or float16, dimensions the fused kernels take."""
+    """True when the half-storage form of `PointwiseLayer` applies: under torch.autocast(float16) on the
+    GPU (inference or training), x [B, cin, ...pixels] float32 or float16, dimensions the fused kernels take."""
     if not (x.is_cuda and x.dtype in (th.float32, th.float16) and x.dim() >= 3 and x.numel() > 0):
         return False
-    if th.is_grad_enabled() or not th.is_autocast_enabled() or th.get_autocast_dtype("cuda") != th.float16:
+    if not th.is_autocast_enabled() or th.get_autocast_dtype("cuda") != th.float16:
         return False
     hw = x[0, 0].numel()
     return (x.data_ptr() % 16 == 0 and x.shape[0] <= 65535 and cout <= 65535
@@ -396,7 +406,8 @@ def pointwise_half_supported(x, cout):
 
 def pointwise_half(x, w, bias, t, s, act, slope):
     """`PointwiseLayer` forward with half-precision storage: x float32 or float16, output float16;
-    w, bias and the context term t are float32, arithmetic is fp32 (inference; no autograd)."""
+    w, bias and the context term t are float32, arithmetic is fp32.  No autograd here: training goes
+    through `PointwiseLayer.apply(..., half=True)`."""
     _require_f32("pointwise_half", w=w, bias=bias, t=t)
     if not (x.is_cuda and x.dtype in (th.float32, th.float16)):
         raise TypeError("pointwise_half: x must be a float32 or float16 GPU tensor")
@@ -430,12 +441,15 @@ class PointwiseLayer(th.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w, bias, t, s, act, slope):
-        return _pointwise_forward(ctx, x, w, bias, t, s, act, slope)
+    def forward(ctx, x, w, bias, t, s, act, slope, half=False):
+        """half=True ("fp16 activations", torch.autocast(float16)): y is float16, x float16 or float32 (a
+        chain's first layer); w, bias, t stay float32 and so does all arithmetic; backward likewise
+        (sbmc_pointwise_{fwd,bwd}_f16)."""
+        return _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half)
 
     @staticmethod
     def backward(ctx, gy):
-        return _pointwise_backward(ctx, gy, None, 1) + (None, None, None)
+        return _pointwise_backward(ctx, gy, None, 1) + (None, None, None, None)
 
 
 class PointwiseLayerMean(th.autograd.Function):
@@ -446,8 +460,8 @@ class PointwiseLayerMean(th.autograd.Function):
     pass autograd would otherwise run (7.5 GB at 720p x 8 spp) disappears."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, t, s, act, slope, mean_s):
-        y = _pointwise_forward(ctx, x, w, bias, t, s, act, slope)
+    def forward(ctx, x, w, bias, t, s, act, slope, mean_s, half=False):
+        y = _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half)
         ctx.mean_s = mean_s
         B, cout, hw = y.shape
         return y, y.view(B // mean_s, mean_s, cout, hw).mean(1)
@@ -457,11 +471,13 @@ class PointwiseLayerMean(th.autograd.Function):
         if gy is None:                       # only the mean was used
             gy = (gmean / ctx.mean_s).repeat_interleave(ctx.mean_s, 0)
             gmean = None
-        return _pointwise_backward(ctx, gy, gmean, ctx.mean_s) + (None, None, None, None)
+        return _pointwise_backward(ctx, gy, gmean, ctx.mean_s) + (None, None, None, None, None)
 
 
-def _pointwise_forward(ctx, x, w, bias, t, s, act, slope):
-    _require_f32("PointwiseLayer", x=x, w=w, bias=bias, t=t)
+def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False):
+    _require_f32("PointwiseLayer", w=w, bias=bias, t=t, x=None if half else x)
+    if half and not (x.is_cuda and x.dtype in (th.float32, th.float16)):
+        raise TypeError("PointwiseLayer(half): x must be a float32 or float16 GPU tensor")
     x = x.contiguous()
     w = w.contiguous()
     bias = bias.contiguous()
@@ -471,15 +487,21 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope):
     if t is not None:
         t = t.contiguous()
         t_mode = 2 if (t.dim() == 3 and t.shape[2] == hw and hw > 1) else 1
-    y = x.new_empty(B, cout, hw)
+    y = th.empty(B, cout, hw, dtype=th.float16 if half else th.float32, device=x.device)
     dev = x.device
-    with th.cuda.device(dev), _timed("pointwise_fwd %dx%d" % (cout, cin), dev):
-        rc = _lib.lib().sbmc_pointwise_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
-                                               _lib.ptr(t) if t is not None else None, _lib.ptr(y),
-                                               B, s, cin, cout, hw, t_mode, act, slope,
-                                               _lib.current_stream(dev))
+    L = _lib.lib()
+    with th.cuda.device(dev), _timed("pointwise_fwd%s %dx%d" % ("_f16" if half else "", cout, cin), dev):
+        if half:
+            rc = L.sbmc_pointwise_fwd_f16(_lib.ptr(x), int(x.dtype == th.float16), _lib.ptr(w), _lib.ptr(bias),
+                                          _lib.ptr(t) if t is not None else None, _lib.ptr(y),
+                                          B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
+        else:
+            rc = L.sbmc_pointwise_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
+                                          _lib.ptr(t) if t is not None else None, _lib.ptr(y),
+                                          B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
     _lib.check(rc, "pointwise_fwd")
     ctx.cfg = (s, act, slope, t_mode, None if t is None else tuple(t.shape))
+    ctx.half = half
     ctx.save_for_backward(x, w, y if act != 0 else None)
     return y
 
@@ -488,14 +510,16 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
     """-> (gx, gw, gbias, gt).  gmean: gradient of the group mean of y (or None)."""
     s, act, slope, t_mode, tshape = ctx.cfg
     x, w, y = ctx.saved_tensors
-    gy = gy.contiguous()
+    half = ctx.half
+    adt = th.float16 if half else th.float32          # storage type of the layer's output side
+    gy = gy.to(adt).contiguous()
     B, cout, hw = gy.shape
     L = _lib.lib()
     dev = gy.device
     cin = x.shape[1]
     fused = bool(L.sbmc_pointwise_bwd_supported(cin, cout, hw))
     if gmean is not None and not (fused and t_mode != 2):
-        gy = gy + (gmean / mean_s).repeat_interleave(mean_s, 0)     # the kernels below take one gradient
+        gy = gy + (gmean / mean_s).repeat_interleave(mean_s, 0).to(adt)   # the kernels below take one gradient
         gmean = None
     if y is None:
         y = gy                                   # placeholder pointer, never read when linear
@@ -507,23 +531,44 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
             groups = L.sbmc_pointwise_bwd_groups(B, s, t_mode, hw)
         nb = B // s if t_mode == 1 else 1
         gx = th.empty_like(x) if ctx.needs_input_grad[0] else None
-        gwp = gy.new_empty(groups, cout, cin)
-        gbp = gy.new_empty(groups, nb, cout)
-        gt = gy.new_empty(tshape) if t_mode == 2 else None
+        gwp = w.new_empty(groups, cout, cin)
+        gbp = w.new_empty(groups, nb, cout)
+        gt = w.new_empty(tshape) if t_mode == 2 else None
         if gmean is not None:
-            gmean = gmean.contiguous()
-        with th.cuda.device(dev), _timed("pointwise_bwd %dx%d%s" % (cout, cin, "" if gx is not None else " (no gx)"), dev):
-            rc = L.sbmc_pointwise_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), _lib.ptr(w),
-                                          _lib.ptr(gx) if gx is not None else None, _lib.ptr(gwp),
-                                          _lib.ptr(gbp), _lib.ptr(gt) if gt is not None else None,
-                                          _lib.ptr(gmean) if gmean is not None else None, mean_s,
-                                          B, s, cin, cout, hw, t_mode, act, slope,
-                                          _lib.current_stream(dev))
+            gmean = gmean.to(adt).contiguous()
+        with th.cuda.device(dev), _timed("pointwise_bwd%s %dx%d%s" % ("_f16" if half else "", cout, cin,
+                                                                      "" if gx is not None else " (no gx)"), dev):
+            tail = (_lib.ptr(w), _lib.ptr(gx) if gx is not None else None, _lib.ptr(gwp),
+                    _lib.ptr(gbp), _lib.ptr(gt) if gt is not None else None,
+                    _lib.ptr(gmean) if gmean is not None else None, mean_s,
+                    B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
+            if half:
+                rc = L.sbmc_pointwise_bwd_f16(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), int(x.dtype == th.float16), *tail)
+            else:
+                rc = L.sbmc_pointwise_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), *tail)
         _lib.check(rc, "pointwise_bwd")
         per_image = gbp.sum(0)                   # [nb, cout]
         if t_mode == 1:
             gt = per_image.view(tshape)
         return gx, gwp.sum(0), per_image.sum(0), gt
+    if half:
+        # wider than the fused backward takes (the 441-channel logits): activation adjoint and the sums in
+        # torch, the two products as half GEMMs with fp32 accumulation (rocBLAS / hipBLASLt)
+        gz = gy if act == 0 else th.where(y > 0, gy, gy * slope)
+        gzf = gz.float()
+        gbias = gzf.sum((0, 2))
+        gt = None
+        if t_mode == 1:
+            gt = gzf.view(B // s, s, cout, hw).sum((1, 3)).view(tshape)
+        elif t_mode == 2:
+            gt = gzf.view(B // s, s, cout, hw).sum(1)
+        gx = gw = None
+        with th.autocast("cuda", enabled=False):
+            if ctx.needs_input_grad[0]:
+                gx = th.bmm(w.half().t().unsqueeze(0).expand(B, -1, -1), gz).to(x.dtype)
+            if ctx.needs_input_grad[1]:
+                gw = th.bmm(gz, x.half().transpose(1, 2)).float().sum(0)
+        return gx, gw, gbias, gt
     gz = gy if (act == 0 and t_mode == 0) else th.empty_like(gy)   # linear: gz is gy, only sums needed
     gt = None
     with th.cuda.device(dev):

@@ -76,16 +76,14 @@ def _pointwise_gemm(conv, x, activation=None, mean_s=0, mean_out=None):
         act = 1
     elif isinstance(activation, nn.LeakyReLU):
         act, slope = 2, float(activation.negative_slope)
-    if funcs.pointwise_half_supported(x3, w.shape[0]):      # fp16 activations, inference
-        y = funcs.pointwise_half(x3, w.view(w.shape[0], c).float(), conv.bias.float(), None, 1, act, slope)
-        return y.view(b, w.shape[0], h, wd), act != 0
-    if funcs.pointwise_supported(x3, w.shape[0]):
+    half = funcs.pointwise_half_supported(x3, w.shape[0])   # fp16 activations (torch.autocast(float16))
+    if half or funcs.pointwise_supported(x3, w.shape[0]):
+        wm, bias = w.view(w.shape[0], c).float(), conv.bias.float()
         if mean_s and mean_out is not None and b % mean_s == 0 and (activation is None or act != 0):
-            y, m = funcs.PointwiseLayerMean.apply(x3, w.view(w.shape[0], c), conv.bias, None, 1, act, slope,
-                                                  mean_s)
+            y, m = funcs.PointwiseLayerMean.apply(x3, wm, bias, None, 1, act, slope, mean_s, half)
             mean_out.append(m.view(b // mean_s, w.shape[0], h, wd))
         else:
-            y = funcs.PointwiseLayer.apply(x3, w.view(w.shape[0], c), conv.bias, None, 1, act, slope)
+            y = funcs.PointwiseLayer.apply(x3, wm, bias, None, 1, act, slope, half)
         return y.view(b, w.shape[0], h, wd), act != 0
     y = th.bmm(wmat, x3)
     if funcs.BiasAct.supported(y):
@@ -143,11 +141,11 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
         with th.autocast("cuda", enabled=False):
             t = th.bmm(wt[:, cs:].float().unsqueeze(0).expand(bs, -1, -1), ctx3.float()).contiguous()
         tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)
-        y = funcs.pointwise_half(xs, wt[:, :cs].float(), conv.bias.float(), tt, S, act[0], act[1])
+        y = funcs.PointwiseLayer.apply(xs, wt[:, :cs].float(), conv.bias.float(), tt, S, act[0], act[1], True)
         y = y.view(bs * S, cout, h, w)
         consumed = 1 if isinstance(first, ConvChain._ConvBNRelu) else (2 if act[0] != 0 else 1)
         rest = mods[consumed:]
-        return chain._run(rest, y) if rest else y
+        return chain._run(rest, y, mean_s=S, mean_out=mean_out) if rest else y
     t = th.bmm(wt[:, cs:].unsqueeze(0).expand(bs, -1, -1), ctx3).contiguous()
     if t.dtype == th.float32 and funcs.pointwise_supported(xs, cout):
         tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)

@@ -717,3 +717,141 @@ def test_pointwise_half_storage(cfg, x_half):
     assert y.dtype == th.float16
     err = (y.float() - ref).abs().max().item()
     assert err <= 1e-3 * ref.abs().max().item() + 1e-3, err
+
+
+@pytest.mark.parametrize("bs,c,h,w,k", SHAPES)
+def test_float16_boundary_operators_vs_oracle(oracle, bs, c, h, w, k):
+    """`*_cuda_float16`: the three boundary operators on torch.float16 tensors vs the
+    oracle on the same half-rounded inputs.  Scatter2Gather is a permutation (bit exact); the sums are
+    formed in fp32 and rounded once on the store, so they agree with the rounded fp32 result to one half ulp
+    (2^-11 relative) plus the fp32 bound."""
+    from sbmc_amd import functions as F, halide_ops
+    th.manual_seed(40 + k)
+    x = th.randn(bs, k, k, h, w).half()
+    out = F.Scatter2Gather.apply(x.cuda())
+    assert out.dtype == th.float16
+    assert th.equal(out.cpu(), oracle.Scatter2Gather.apply(x.float()).half())
+
+    data = (th.rand(bs, c, h, w) * 2).half()
+    wts = th.randn(bs, k, k, h, w).half()
+    g_out, g_sw = th.randn(bs, c, h, w).half(), th.randn(bs, h, w).half()
+    dr, wr = data.float().requires_grad_(), wts.float().requires_grad_()
+    ro, rs = oracle.KernelWeighting.apply(dr, wr)
+    th.autograd.backward([ro, rs], [g_out.float(), g_sw.float()])
+    dg, wg = data.cuda().requires_grad_(), wts.cuda().requires_grad_()
+    o, s = F.KernelWeighting.apply(dg, wg)
+    assert o.dtype == th.float16 and s.dtype == th.float16
+    th.autograd.backward([o, s], [g_out.cuda(), g_sw.cuda()])
+
+    def half_close(a, b, what):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        bound = 2.0 ** -10 * b.abs() + 1e-5 * b.abs().max().item() + 1e-7
+        assert ((a - b).abs() <= bound).all(), "%s: max err %.3e" % (what, (a - b).abs().max().item())
+    half_close(o, ro, "output"); half_close(s, rs, "sum_w")
+    half_close(dg.grad, dr.grad, "d_data"); half_close(wg.grad, wr.grad, "d_weights")
+    # the C-ABI shim refuses mixed dtypes instead of reading out of bounds
+    with pytest.raises(RuntimeError):
+        halide_ops.kernel_weighting_cuda_float16(data.cuda(), wts.cuda().float(), o.detach(), s.detach())
+    with pytest.raises(RuntimeError):
+        halide_ops.scatter2gather_cuda_float32(x.cuda(), th.empty_like(x.cuda()))
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, S, cin, cout, hw, t_mode, act, x_half, with_mean
+    (4, 2, 93, 128, 260, 1, 1, False, False),     # a chain's first layer: fp32 features in, per-image context
+    (8, 4, 128, 128, 1028, 2, 2, True, False),    # per-pixel context, leaky relu
+    (6, 3, 128, 96, 516, 0, 1, True, True),       # last embedding layer: also returns the mean over samples
+    (2, 1, 128, 441, 132, 0, 0, True, False),     # the logits layer (wider than the fused backward: GEMM path)
+])
+def test_pointwise_half_training(cfg):
+    """Half-storage forward AND backward of the fused 1x1 layer (training under torch.autocast(float16),
+    SURVEY.md row N4) vs fp32 torch on exactly the values the kernel sees (half-rounded x / gy, the sign of
+    the half y): y and gx to one half rounding, the fp32 outputs (gw, gbias, gt) to the fp32 bound."""
+    from sbmc_amd import functions as F
+    B, S, cin, cout, hw, tm, act, x_half, with_mean = cfg
+    slope = 0.01 if act == 2 else 0.0
+    th.manual_seed(sum(int(v) for v in cfg))
+    x = th.randn(B, cin, hw, device="cuda")
+    x = x.half() if x_half else x
+    w = (th.randn(cout, cin, device="cuda") / cin ** 0.5).requires_grad_()
+    b = th.randn(cout, device="cuda").requires_grad_()
+    t = None if tm == 0 else (th.randn(B // S, cout, device="cuda") if tm == 1 else th.randn(B // S, cout, hw, device="cuda"))
+    if t is not None:
+        t.requires_grad_()
+    xg = x.clone().requires_grad_()
+    if with_mean:
+        y, ym = F.PointwiseLayerMean.apply(xg, w, b, t, S, act, slope, S, True)
+    else:
+        y = F.PointwiseLayer.apply(xg, w, b, t, S, act, slope, True)
+    assert y.dtype == th.float16
+    gy = th.randn(B, cout, hw, device="cuda").half()
+    gm = th.randn(B // S, cout, hw, device="cuda").half() if with_mean else None
+    th.autograd.backward([y, ym] if with_mean else [y], [gy, gm] if with_mean else [gy])
+
+    # fp32 reference on the same values
+    xr = x.float()
+    pre = th.einsum("oc,bcp->bop", w.detach(), xr) + b.detach().view(1, -1, 1)
+    if tm == 1:
+        pre = pre + t.detach().repeat_interleave(S, 0).unsqueeze(-1)
+    elif tm == 2:
+        pre = pre + t.detach().repeat_interleave(S, 0)
+    yr = pre if act == 0 else th.where(pre > 0, pre, pre * slope)
+    assert (y.float() - yr).abs().max().item() <= 2.0 ** -10 * yr.abs().max().item() + 1e-3
+    g = gy.float()
+    if with_mean:
+        g = g + gm.float().repeat_interleave(S, 0) / S
+    gz = g if act == 0 else th.where(y > 0, g, g * slope)
+    close(w.grad, th.einsum("bop,bcp->oc", gz, xr), rtol=2e-5 if cout <= 128 else 2e-3, what="gw")
+    close(b.grad, gz.sum((0, 2)), rtol=2e-5, what="gbias")
+    gxr = th.einsum("oc,bop->bcp", w.detach(), gz)
+    if cout <= 128:
+        assert xg.grad.dtype == x.dtype
+        tol = 2.0 ** -10 if x_half else 1e-5
+        assert (xg.grad.float() - gxr).abs().max().item() <= tol * gxr.abs().max().item() + 1e-6
+    else:                                            # half GEMM operands (w rounded to half)
+        assert (xg.grad.float() - gxr).abs().max().item() <= 4e-3 * gxr.abs().max().item()
+    if tm == 1:
+        close(t.grad, gz.view(B // S, S, cout, hw).sum((1, 3)), rtol=2e-5, what="gt (per image)")
+    elif tm == 2:
+        close(t.grad, gz.view(B // S, S, cout, hw).sum(1), rtol=1e-5, what="gt (per pixel)")
+
+
+def test_multisteps_trains_under_fp16_autocast_on_the_fused_kernels():
+    """A training step under torch.autocast(float16): the per-sample chains stay on the fused MFMA kernels
+    (half storage, forward and backward), the splat takes half logits; gradients agree with the fp32 step to
+    fp16 accuracy."""
+    from sbmc_amd import Multisteps, functions as F, losses
+    from sbmc_amd.utils import crop_like
+    th.manual_seed(33)
+    model = Multisteps(12, 3, width=32, embedding_width=32, ksize=21, nsteps=2).cuda().train()
+    g = th.Generator().manual_seed(34)
+    batch = {"radiance": th.empty(1, 3, 3, 48, 72).exponential_(1.0, generator=g).cuda(),
+             "features": th.rand(1, 3, 12, 48, 72, generator=g).cuda(),
+             "global_features": th.rand(1, 3, 1, 1, generator=g).cuda()}
+    tgt = th.empty(1, 3, 48, 72).exponential_(1.0, generator=g).cuda()
+    loss_fn = losses.TonemappedRelativeMSE()
+    out = model(batch)["radiance"]
+    loss32 = loss_fn(out, crop_like(tgt, out))
+    loss32.backward()
+    ref = {k: q.grad.clone() for k, q in model.named_parameters()}
+    model.zero_grad()
+    store = []
+    F.enable_kernel_timing(store)
+    try:
+        with th.autocast("cuda", dtype=th.float16):
+            out = model(batch)["radiance"]
+            loss16 = loss_fn(out.float(), crop_like(tgt, out))
+        loss16.backward()
+    finally:
+        F.enable_kernel_timing(None)
+    names = {n.split(" ")[0] for n, _, _ in store}
+    assert "pointwise_fwd_f16" in names and "pointwise_bwd_f16" in names, names       # the fused half kernels ran
+    assert "splat_update_fwd_all_f16" in names and "splat_update_bwd_all_f16" in names, names
+    assert abs(loss16.item() - loss32.item()) <= 2e-2 * abs(loss32.item())
+    worst = 0.0
+    for k, q in model.named_parameters():
+        assert q.grad is not None and th.isfinite(q.grad).all(), k
+        denom = ref[k].abs().max().item()
+        if denom > 0:
+            worst = max(worst, (q.grad - ref[k]).abs().max().item() / denom)
+    assert worst <= 0.1, worst            # fp16 activations / gradients end to end (no loss scaling here)
