@@ -87,8 +87,9 @@ def parse():
     ap.add_argument("--spp", type=int, default=8)
     ap.add_argument("--ksize", type=int, default=21)
     ap.add_argument("--fp16-activations", action="store_true",
-                    help="infer only, informational (BASELINE configs[4]): run the network under "
-                         "torch.autocast(float16); splat arithmetic stays fp32. Never the fp32 metric.")
+                    help="informational (BASELINE configs[4]): run the network under torch.autocast(float16) "
+                         "(infer, or the single-GPU training step); splat arithmetic stays fp32. Never the "
+                         "fp32 metric.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true")
     return ap.parse_args()
@@ -154,11 +155,15 @@ def make_model_inputs(h, w, spp, device, seed, rows=None):
             "global_features": gf.to(device), "target_image": tgt.contiguous().to(device)}
 
 
-def train_step(model, opt, loss_fn, batch):
-    """The reference training step, sbmc/interfaces.py:78-105."""
+def train_step(model, opt, loss_fn, batch, fp16=False):
+    """The reference training step, sbmc/interfaces.py:78-105.  fp16 (informational, never the fp32
+    metric): the network runs under torch.autocast(float16) -- half activations end to end, fp32 splat
+    arithmetic, fp32 loss and optimizer."""
     from sbmc_amd.utils import crop_like
     opt.zero_grad()
-    out = model(batch)["radiance"]
+    with th.autocast("cuda", dtype=th.float16, enabled=fp16):
+        out = model(batch)["radiance"]
+    out = out.float()
     tgt = crop_like(batch["target_image"], out)
     loss = loss_fn(out, tgt)
     loss.backward()
@@ -383,7 +388,7 @@ def main():
             batch = make_model_inputs(H, W, S, device, seed=1234)
 
             def step():
-                train_step(model, opt, loss_fn, batch)
+                train_step(model, opt, loss_fn, batch, fp16=args.fp16_activations)
         else:
             batch = make_model_inputs(H, W, S, device, seed=1234, rows=(part.y0, part.y1))
             runner = sdist.ShardedDenoiser(model, part)
@@ -520,7 +525,7 @@ def main():
             "ms_per_step_min_max": [round(spread[0] * 1e3, 3), round(spread[1] * 1e3, 3)],
             "value_at_median": round(S * H * W / med_s / 1e6, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16 activations, f32 splat math" if (infer and args.fp16_activations) else "f32",
+            "dtype": "f16 activations, f32 splat math" if (is_model and args.fp16_activations) else "f32",
             "data": "synthetic",
             "world_size": world if world == 1 else dist.get_world_size(),
             "backend": None if world == 1 else dist.get_backend(),

@@ -422,6 +422,16 @@ SBMC_API int sbmc_upsample2x_cat_fwd_f32(const float *coarse, const float *left,
 SBMC_API int sbmc_upsample2x_cat_bwd_f32(const float *gout, float *gcoarse, int b, int cu, int cl,
                                 int h, int w, void *stream);
 
+/* Row-slab form (one frame sharded along H, sbmc_amd/dist.py): coarse / gcoarse hold hc = top + h + bot
+ * rows whose first `top` and last `bot` (0 or 1) are the neighbouring slabs' edge rows; left / out / gout
+ * are the 2h fine rows of this slab.  The edge clamp of the interpolation acts at true image borders
+ * (top == 0 / bot == 0) only; gcoarse of a halo row holds this slab's share of its gradient (the caller
+ * returns it to its owner).  (top, bot) = (0, 0) is the whole-frame call. */
+SBMC_API int sbmc_upsample2x_cat_slab_fwd_f32(const float *coarse, const float *left, float *out, int b,
+                                     int cu, int cl, int hc, int w, int top, int bot, void *stream);
+SBMC_API int sbmc_upsample2x_cat_slab_bwd_f32(const float *gout, float *gcoarse, int b, int cu, int cl,
+                                     int hc, int w, int top, int bot, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,9 +15,14 @@
 namespace sbmc {
 
 // one thread: 4 consecutive output pixels of one row of one (b, c) plane
+// Row-slab form (one frame sharded along H, sbmc_amd/dist.py): `coarse` holds hc = top + h + bot rows,
+// the first `top` / last `bot` (0 or 1) of which are the neighbouring slabs' edge rows; the output is the
+// 2h fine rows of this slab, i.e. rows 2 top .. 2 top + 2h of the upsampled padded map.  The edge clamp
+// of the interpolation therefore only ever acts at a true image border (top == 0 / bot == 0).
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict__ coarse, const float* __restrict__ left,
-                                                       float* __restrict__ out, int cu, int cl, int h, int w,
-                                                       size_t total4) {
+                                                       float* __restrict__ out, int cu, int cl, int hc, int w,
+                                                       int top, int bot, size_t total4) {
+    const int h = hc - top - bot;
     const int W = 2 * w, H = 2 * h, W4 = W / 4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4;
          idx += (size_t)gridDim.x * blockDim.x) {
@@ -32,15 +37,16 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
             v = reinterpret_cast<const float4*>(left + ((b * cl + (c - cu)) * H + y) * (size_t)W)[q];
         } else {
             // rows: y even -> (i-1: .25, i: .75), y odd -> (i: .75, i+1: .25), clamped
-            const int i = y >> 1;
+            const int yf = y + 2 * top;             // row of the upsampled (padded) coarse map
+            const int i = yf >> 1;
             int r0, r1;
             float l1;                               // weight of r1
-            if (y == 0) { r0 = 0; r1 = 0; l1 = 0.f; }
-            else if (y & 1) { r0 = i; r1 = i + 1 < h ? i + 1 : i; l1 = 0.25f; }
+            if (yf == 0) { r0 = 0; r1 = 0; l1 = 0.f; }
+            else if (yf & 1) { r0 = i; r1 = i + 1 < hc ? i + 1 : i; l1 = 0.25f; }
             else { r0 = i - 1; r1 = i; l1 = 0.75f; }
             const float l0 = 1.f - l1;
-            const float* p0 = coarse + ((b * cu + c) * h + r0) * (size_t)w;
-            const float* p1 = coarse + ((b * cu + c) * h + r1) * (size_t)w;
+            const float* p0 = coarse + ((b * cu + c) * hc + r0) * (size_t)w;
+            const float* p1 = coarse + ((b * cu + c) * hc + r1) * (size_t)w;
             // columns 4q .. 4q+3 come from coarse columns 2q-1 .. 2q+2
             const int j = 2 * q;
             const int jm = j > 0 ? j - 1 : 0, jp = j + 2 < w ? j + 2 : w - 1;
@@ -68,28 +74,32 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float* __restrict_
 // one thread: two adjacent coarse pixels (i, 2q), (i, 2q + 1) of one (b, c) plane: their 4 x 6 fine
 // neighbourhood is one aligned float4 plus one pixel on each side per row
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gcoarse,
-                                                       int cu, int cl, int h, int w, size_t total2) {
+                                                       int cu, int cl, int hc, int w, int top, int bot,
+                                                       size_t total2) {
+    const int h = hc - top - bot;
     const int W = 2 * w, H = 2 * h, w2 = w / 2;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total2;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(idx % w2);
         size_t rest = idx / w2;
-        const int i = (int)(rest % h);
-        rest /= h;
+        const int i = (int)(rest % hc);             // coarse row (of the hc padded rows)
+        rest /= hc;
         const int c = (int)(rest % cu);
         const size_t b = rest / cu;
         const float* g = gout + ((b * (cu + cl) + c) * H) * (size_t)W;
         // fine rows 2i-1 .. 2i+2 with weights .25 .75 .75 .25; a partner that falls off the image
         // was clamped to this row / column in the forward, so its weight comes back here
         float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-        if (i == 0) { wy[0] = 0.f; wy[1] = 1.f; }
-        if (i == h - 1) { wy[3] = 0.f; wy[2] = 1.f; }
+        if (i == 0 && top == 0) { wy[0] = 0.f; wy[1] = 1.f; }            // true image borders only
+        if (i == hc - 1 && bot == 0) { wy[3] = 0.f; wy[2] = 1.f; }
         const bool first = q == 0, last = q == w2 - 1;
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy) {
             if (wy[dy] == 0.f) continue;
-            const float* row = g + (size_t)(2 * i - 1 + dy) * W + 4 * q;
+            const int y = 2 * i - 1 + dy - 2 * top;   // fine row of this slab; outside: another slab's share
+            if (y < 0 || y >= H) continue;
+            const float* row = g + (size_t)y * W + 4 * q;
             const float4 m = *reinterpret_cast<const float4*>(row);       // fine columns 4q .. 4q+3
             const float lft = first ? 0.f : row[-1], rgt = last ? 0.f : row[4];
             // coarse column 2q   <- fine 4q-1 (.25), 4q (.75, or 1 at the left edge), 4q+1 (.75), 4q+2 (.25)
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float* __restrict_
             a0 += wy[dy] * s0;
             a1 += wy[dy] * s1;
         }
-        *reinterpret_cast<float2*>(gcoarse + ((b * cu + c) * h + i) * (size_t)w + 2 * q) = make_float2(a0, a1);
+        *reinterpret_cast<float2*>(gcoarse + ((b * cu + c) * hc + i) * (size_t)w + 2 * q) = make_float2(a0, a1);
     }
 }
 
@@ -109,26 +119,47 @@ using namespace sbmc;
 
 extern "C" int sbmc_upsample2x_cat_supported(int h, int w) { return (h >= 1 && w >= 2 && w % 2 == 0) ? 1 : 0; }
 
-extern "C" int sbmc_upsample2x_cat_fwd_f32(const float* coarse, const float* left, float* out, int b, int cu, int cl,
-                                           int h, int w, void* stream) {
-    if (b < 0 || cu < 1 || cl < 0 || !sbmc_upsample2x_cat_supported(h, w)) return SBMC_HIP_EINVAL;
+static int upcat_fwd_impl(const float* coarse, const float* left, float* out, int b, int cu, int cl,
+                          int hc, int w, int top, int bot, void* stream) {
+    const int h = hc - top - bot;
+    if (b < 0 || cu < 1 || cl < 0 || top < 0 || top > 1 || bot < 0 || bot > 1 || !sbmc_upsample2x_cat_supported(h, w))
+        return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!coarse || !out || (cl > 0 && !left) || (uintptr_t)out % 16 || (uintptr_t)left % 16) return SBMC_HIP_EINVAL;
     const size_t total4 = (size_t)b * (cu + cl) * (2 * (size_t)h) * (2 * (size_t)w / 4);
     const size_t blocks = (total4 + 255) / 256;
     hipLaunchKernelGGL(upcat_fwd_kernel, dim3((unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16)), dim3(256), 0,
-                       (hipStream_t)stream, coarse, left, out, cu, cl, h, w, total4);
+                       (hipStream_t)stream, coarse, left, out, cu, cl, hc, w, top, bot, total4);
     return (int)hipGetLastError();
 }
 
-extern "C" int sbmc_upsample2x_cat_bwd_f32(const float* gout, float* gcoarse, int b, int cu, int cl, int h, int w,
-                                           void* stream) {
-    if (b < 0 || cu < 1 || cl < 0 || !sbmc_upsample2x_cat_supported(h, w)) return SBMC_HIP_EINVAL;
+static int upcat_bwd_impl(const float* gout, float* gcoarse, int b, int cu, int cl, int hc, int w, int top, int bot,
+                          void* stream) {
+    const int h = hc - top - bot;
+    if (b < 0 || cu < 1 || cl < 0 || top < 0 || top > 1 || bot < 0 || bot > 1 || !sbmc_upsample2x_cat_supported(h, w))
+        return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!gout || !gcoarse || (uintptr_t)gout % 16 || (uintptr_t)gcoarse % 8) return SBMC_HIP_EINVAL;
-    const size_t total2 = (size_t)b * cu * h * (w / 2);
+    const size_t total2 = (size_t)b * cu * hc * (w / 2);
     const size_t blocks = (total2 + 255) / 256;
     hipLaunchKernelGGL(upcat_bwd_kernel, dim3((unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16)), dim3(256), 0,
-                       (hipStream_t)stream, gout, gcoarse, cu, cl, h, w, total2);
+                       (hipStream_t)stream, gout, gcoarse, cu, cl, hc, w, top, bot, total2);
     return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_upsample2x_cat_fwd_f32(const float* coarse, const float* left, float* out, int b, int cu, int cl,
+                                           int h, int w, void* stream) {
+    return upcat_fwd_impl(coarse, left, out, b, cu, cl, h, w, 0, 0, stream);
+}
+extern "C" int sbmc_upsample2x_cat_bwd_f32(const float* gout, float* gcoarse, int b, int cu, int cl, int h, int w,
+                                           void* stream) {
+    return upcat_bwd_impl(gout, gcoarse, b, cu, cl, h, w, 0, 0, stream);
+}
+extern "C" int sbmc_upsample2x_cat_slab_fwd_f32(const float* coarse, const float* left, float* out, int b, int cu,
+                                                int cl, int hc, int w, int top, int bot, void* stream) {
+    return upcat_fwd_impl(coarse, left, out, b, cu, cl, hc, w, top, bot, stream);
+}
+extern "C" int sbmc_upsample2x_cat_slab_bwd_f32(const float* gout, float* gcoarse, int b, int cu, int cl, int hc,
+                                                int w, int top, int bot, void* stream) {
+    return upcat_bwd_impl(gout, gcoarse, b, cu, cl, hc, w, top, bot, stream);
 }

@@ -32,6 +32,7 @@ import torch as th
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import functions as funcs
 from .utils import crop_like
 
 __all__ = ["SlabPartition", "halo_pad", "sharded_autoencoder", "ShardedDenoiser"]
@@ -144,10 +145,27 @@ def halo_pad(x, r, part):
     return _HaloPad.apply(x, r, part)
 
 
+class _CropRows(th.autograd.Function):
+    """y[..., top : h - bot, :] whose backward is ONE zero-padding pass (torch's slice backward fills a
+    zero tensor and then copies the gradient into it: two passes over every U-net activation)."""
+
+    @staticmethod
+    def forward(ctx, y, top, bot):
+        ctx.pad = (top, bot)
+        return y[..., top:y.shape[-2] - bot, :]
+
+    @staticmethod
+    def backward(ctx, g):
+        top, bot = ctx.pad
+        return F.pad(g, (0, 0, top, bot)), None, None
+
+
 def _crop_halo(y, r, part):
     top = r if part.has_up else 0
     bot = r if part.has_down else 0
-    return y[..., top:y.shape[-2] - bot, :]
+    if top == 0 and bot == 0:
+        return y
+    return _CropRows.apply(y, top, bot)
 
 
 def _reach(chain):
@@ -174,6 +192,10 @@ def _level(level, x, part):
         raise RuntimeError("sharded path needs an even number of rows at every U-net level")
     coarse = _level(level.next_level, level.downsample(left), part)
     padded = halo_pad(coarse, 1, part)
+    top, bot = int(part.has_up), int(part.has_down)
+    if funcs.upsample_cat_supported(padded, left, top, bot):
+        # one pass, the upsampled tensor never exists (functions.UpsampleCat in its row-slab form)
+        return _chain(level.right, funcs.UpsampleCat.apply(padded, left, top, bot), part)
     up = F.interpolate(padded, size=(2 * padded.shape[-2], left.shape[-1]), mode="bilinear",
                        align_corners=False)
     up = _crop_halo(up, 2, part)

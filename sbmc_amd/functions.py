@@ -596,49 +596,54 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
     return gx, gw, gbias, gt
 
 
-def upsample_cat_supported(coarse, left):
-    """True when `UpsampleCat` applies: fp32 GPU tensors, `left` exactly twice the size of `coarse`."""
+def upsample_cat_supported(coarse, left, top=0, bot=0):
+    """True when `UpsampleCat` applies: fp32 GPU tensors, `left` exactly twice the size of `coarse` (minus
+    its `top` + `bot` halo rows in the row-slab form)."""
     return (coarse.is_cuda and left.is_cuda and coarse.dtype == th.float32 and left.dtype == th.float32
             and coarse.dim() == 4 and left.dim() == 4 and coarse.shape[0] == left.shape[0]
-            and left.shape[2] == 2 * coarse.shape[2] and left.shape[3] == 2 * coarse.shape[3]
+            and top in (0, 1) and bot in (0, 1)
+            and left.shape[2] == 2 * (coarse.shape[2] - top - bot) and left.shape[3] == 2 * coarse.shape[3]
             and coarse.numel() > 0 and not th.is_autocast_enabled()
-            and bool(_lib.lib().sbmc_upsample2x_cat_supported(coarse.shape[2], coarse.shape[3])))
+            and bool(_lib.lib().sbmc_upsample2x_cat_supported(coarse.shape[2] - top - bot, coarse.shape[3])))
 
 
 class UpsampleCat(th.autograd.Function):
     """th.cat([F.interpolate(coarse, scale_factor=2, mode="bilinear", align_corners=False), left], 1)
     in one pass (csrc/resample.hip); backward: a gather for the upsampling adjoint (PyTorch scatters
-    with atomics), the gradient of `left` is a channel slice of the incoming gradient."""
+    with atomics), the gradient of `left` is a channel slice of the incoming gradient.
+    top, bot (0 or 1): row-slab form -- `coarse` carries that many halo rows of the neighbouring slabs
+    above / below, the result covers this slab's own rows only (sbmc_amd/dist.py)."""
 
     @staticmethod
-    def forward(ctx, coarse, left):
+    def forward(ctx, coarse, left, top=0, bot=0):
         _require_f32("UpsampleCat", coarse=coarse, left=left)
         coarse = coarse.contiguous()
         left = left.contiguous()
-        b, cu, h, w = coarse.shape
+        b, cu, hc, w = coarse.shape
         cl = left.shape[1]
+        h = hc - top - bot
         out = coarse.new_empty(b, cu + cl, 2 * h, 2 * w)
         dev = coarse.device
         with th.cuda.device(dev):
-            rc = _lib.lib().sbmc_upsample2x_cat_fwd_f32(_lib.ptr(coarse), _lib.ptr(left), _lib.ptr(out),
-                                                        b, cu, cl, h, w, _lib.current_stream(dev))
+            rc = _lib.lib().sbmc_upsample2x_cat_slab_fwd_f32(_lib.ptr(coarse), _lib.ptr(left), _lib.ptr(out),
+                                                             b, cu, cl, hc, w, top, bot, _lib.current_stream(dev))
         _lib.check(rc, "upsample2x_cat_fwd")
-        ctx.dims = (b, cu, cl, h, w)
+        ctx.dims = (b, cu, cl, hc, w, top, bot)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        b, cu, cl, h, w = ctx.dims
+        b, cu, cl, hc, w, top, bot = ctx.dims
         g = g.contiguous()
         gcoarse = None
         if ctx.needs_input_grad[0]:
-            gcoarse = g.new_empty(b, cu, h, w)
+            gcoarse = g.new_empty(b, cu, hc, w)
             dev = g.device
             with th.cuda.device(dev):
-                rc = _lib.lib().sbmc_upsample2x_cat_bwd_f32(_lib.ptr(g), _lib.ptr(gcoarse), b, cu, cl, h, w,
-                                                            _lib.current_stream(dev))
+                rc = _lib.lib().sbmc_upsample2x_cat_slab_bwd_f32(_lib.ptr(g), _lib.ptr(gcoarse), b, cu, cl, hc, w,
+                                                                 top, bot, _lib.current_stream(dev))
             _lib.check(rc, "upsample2x_cat_bwd")
-        return gcoarse, (g[:, cu:] if ctx.needs_input_grad[1] else None)
+        return gcoarse, (g[:, cu:] if ctx.needs_input_grad[1] else None), None, None
 
 
 def gather_update_supported(data, kernels):

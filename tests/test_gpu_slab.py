@@ -140,3 +140,29 @@ def test_half_logit_slab(oracle):
     out = sharded_state(rad.cuda(), kern.cuda(), [(0, 20), (20, 40)], p)
     for a, b, name in zip(out, st, ("sum_r", "sum_w", "max_w")):
         close(a, b, what=name)
+
+
+@pytest.mark.parametrize("top,bot", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("shape", [(1, 5, 3, 6, 10), (2, 16, 8, 11, 64)])
+def test_upsample_cat_row_slab(shape, top, bot):
+    """UpsampleCat in its row-slab form (coarse map carrying the neighbours' edge rows) vs
+    F.interpolate on the padded map + crop + cat -- what dist._level did before -- forward and backward."""
+    import torch.nn.functional as nnf
+    from sbmc_amd import functions as F
+    b, cu, cl, h, w = shape
+    hc = h + top + bot
+    th.manual_seed(sum(shape) + top + 2 * bot)
+    c0 = th.randn(b, cu, hc, w, device="cuda")
+    l0 = th.randn(b, cl, 2 * h, 2 * w, device="cuda")
+    ca, la = c0.clone().requires_grad_(), l0.clone().requires_grad_()
+    up = nnf.interpolate(ca, scale_factor=2, mode="bilinear", align_corners=False)
+    ref = th.cat([up[..., 2 * top:2 * hc - 2 * bot, :], la], 1)
+    g = th.randn_like(ref)
+    ref.backward(g)
+    cb, lb = c0.clone().requires_grad_(), l0.clone().requires_grad_()
+    assert F.upsample_cat_supported(cb, lb, top, bot)
+    out = F.UpsampleCat.apply(cb, lb, top, bot)
+    out.backward(g)
+    close(out, ref, rtol=1e-6, what="output")
+    close(cb.grad, ca.grad, rtol=1e-5, what="d_coarse")
+    assert th.equal(lb.grad, la.grad)
