@@ -17,11 +17,13 @@
 // summation order only.
 #include "common.hpp"
 #include "../../include/sbmc_hip.h"
+#include <stdlib.h>
 
 namespace sbmc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 constexpr int PW_FWD_PH = 2;        // pixel halves per workgroup: 2 = one 8-wave workgroup per CU, 128-pixel tiles
                                     // (1 = two 4-wave workgroups per CU on 64-pixel tiles: measured equal)
@@ -247,6 +249,195 @@ __global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The forward for half activations on the f16 matrix pipe ("fp16 activations", BASELINE configs[4]):
+// x and y are _Float16 in HBM, the weights are rounded to half once (what torch.autocast does to a
+// convolution's weight), products are exact and accumulate in fp32 (v_mfma_f32_32x32x8_f16), bias /
+// context term / activation in fp32 on the accumulators.  At 8x the fp32 MFMA rate the layer is purely
+// HBM-bound at half the bytes of the fp32 layer.
+//
+// The B operand of the f16 MFMA wants, per lane, 4 CONSECUTIVE k of one pixel -- the planar activations
+// are k-major (a row per channel).  The transpose happens on the way into LDS: a staging thread loads a
+// 4 (channels) x 4 (pixels) block as four 8-byte row pieces, transposes it in registers and writes four
+// 8-byte {k, k+1, k+2, k+3} entries; the LDS image of a tile is [K/4][NT] such entries, so an operand
+// fetch is one conflict-free ds_read_b64 per lane (lanes = consecutive pixels).
+// Same persistent tile walk and software pipeline as pw_fwd_kernel.
+using h4 = __attribute__((ext_vector_type(4))) _Float16;
+
+template <int KP, int TMODE>
+__global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
+    constexpr int NT = 128;                            // pixels per tile
+    constexpr int KQ = KP / 4;                         // channel quads
+    constexpr int KS = KP / 8;                         // MFMA k-steps
+    constexpr int NPASS = (KQ + 15) / 16;              // staging passes: 16 quads x 32 pixel groups per pass
+    const _Float16* xg = static_cast<const _Float16*>(p.x);
+    _Float16* yg = static_cast<_Float16*>(p.y);
+    extern __shared__ float4 pw_lds[];
+    u32x2* xs = reinterpret_cast<u32x2*>(pw_lds);      // [2][KQ][NT] entries of 4 halves
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int rb = wave & 3, ph = wave >> 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const unsigned hw = p.hw;
+
+    const unsigned g = blockIdx.x, slot = g / NUM_XCD;
+    const int rt = (int)(slot % (unsigned)p.nrt);
+    const unsigned first = (slot / (unsigned)p.nrt) * NUM_XCD + g % NUM_XCD;
+    const unsigned stride = gridDim.x / (unsigned)p.nrt;
+    const int r0 = rt * 128 + rb * 32;
+    const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
+
+    // staging role: pixels 4 pg .. 4 pg + 3 of the channel quads sq + 16 i
+    const unsigned pg = threadIdx.x & 31, sq = threadIdx.x >> 5;
+
+    auto tile_coords = [&](unsigned tile, unsigned& b, unsigned& bq, unsigned& p0) {
+        const unsigned s = tile % (unsigned)p.S, rest = tile / (unsigned)p.S;
+        const unsigned pt = rest % p.tiles_per_plane;
+        bq = rest / p.tiles_per_plane;
+        b = bq * (unsigned)p.S + s;
+        p0 = pt * NT;
+    };
+    auto issue_loads = [&](unsigned tile, u32x2 (&regs)[NPASS][4]) {
+        unsigned b, bq, p0;
+        tile_coords(tile, b, bq, p0);
+        const rsrc_t rx = make_rsrc_n(xg + (size_t)b * p.K * hw, (unsigned)p.K * hw * 2u);
+        const bool colok = p0 + 4 * pg < hw;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned k = 4u * (sq + 16u * i) + r;
+                const unsigned off = (colok && k < (unsigned)p.K) ? (k * hw + p0 + 4 * pg) * 2u : PW_OOB;
+                regs[i][r] = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
+            }
+        }
+    };
+    auto commit = [&](int buf, const u32x2 (&regs)[NPASS][4]) {
+        u32x2* dst = xs + buf * (KQ * NT);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const unsigned q = sq + 16u * i;
+            if (q < (unsigned)KQ) {
+                const h4 a0 = __builtin_bit_cast(h4, regs[i][0]), a1 = __builtin_bit_cast(h4, regs[i][1]);
+                const h4 a2 = __builtin_bit_cast(h4, regs[i][2]), a3 = __builtin_bit_cast(h4, regs[i][3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h4 o;
+                    o[0] = a0[j]; o[1] = a1[j]; o[2] = a2[j]; o[3] = a3[j];
+                    dst[q * NT + 4 * pg + j] = __builtin_bit_cast(u32x2, o);
+                }
+            }
+        }
+    };
+
+    // weight rows of this wave as f16 A-operands: a[kk][i] = W[r0 + lane % 32][8 kk + 4 (lane / 32) + i]
+    h4 a[KS];
+    {
+        const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
+        const int row = r0 + l31;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 8 * kk + 4 * lhi + i;
+                const bool ok = row < p.Cout && k < p.K;
+                a[kk][i] = (_Float16)buf_load(rw, ok ? (unsigned)(row * p.K + k) * 4u : PW_OOB, 0);
+            }
+        }
+    }
+    float bias[16];
+    {
+        const rsrc_t rbias = make_rsrc_n(p.bias, (unsigned)p.Cout * 4u);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            bias[j] = buf_load(rbias, (unsigned)(r0 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * 4u, 0);
+    }
+
+    u32x2 pre[NPASS][4];
+    unsigned tile = first;
+    if (tile < p.ntiles) {
+        issue_loads(tile, pre);
+        commit(0, pre);
+    }
+    __syncthreads();
+
+    f32x16 out0, out1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) out0[j] = out1[j] = 0.f;
+    unsigned b_prev = 0;
+    unsigned o_prev0 = PW_OOB, o_prev1 = PW_OOB;       // byte offsets for 4-byte elements; halves sit at half of them
+    auto store_prev = [&](int j) {
+        const rsrc_t ry_prev = make_rsrc_n(yg + ((size_t)b_prev * p.Cout + r0) * hw, (unsigned)nrows * hw * 2u);
+        const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
+        logit_store<_Float16>(out0[j], ry_prev, o_prev0 != PW_OOB ? (o_prev0 + ro) / 2u : PW_OOB, 0);
+        logit_store<_Float16>(out1[j], ry_prev, o_prev1 != PW_OOB ? (o_prev1 + ro) / 2u : PW_OOB, 0);
+    };
+
+    int buf = 0;
+    for (; tile < p.ntiles; tile += stride, buf ^= 1) {
+        const unsigned next = tile + stride;
+        if (next < p.ntiles) issue_loads(next, pre);
+
+        unsigned b, bq, p0;
+        tile_coords(tile, b, bq, p0);
+        const unsigned col = p0 + ph * 64 + l31;
+        const unsigned o0 = (col < hw && nrows > 0) ? (4u * lhi * hw + col) * 4u : PW_OOB;
+        const unsigned o1 = (col + 32 < hw && nrows > 0) ? (4u * lhi * hw + col + 32) * 4u : PW_OOB;
+
+        f32x16 acc0, acc1;
+        {
+            const rsrc_t rt1 = make_rsrc_n(TMODE == 1 ? p.t + (size_t)bq * p.Cout : p.bias, (unsigned)p.Cout * 4u);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float v = bias[j];
+                if (TMODE == 1) v += buf_load(rt1, (unsigned)(r0 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * 4u, 0);
+                acc0[j] = v;
+                acc1[j] = v;
+            }
+        }
+        f32x16 t0, t1;
+        if (TMODE == 2) {
+            const rsrc_t rt2 = make_rsrc_n(p.t + ((size_t)bq * p.Cout + r0) * hw, (unsigned)nrows * hw * 4u);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
+                t0[j] = buf_load(rt2, o0 != PW_OOB ? o0 + ro : PW_OOB, 0);
+                t1[j] = buf_load(rt2, o1 != PW_OOB ? o1 + ro : PW_OOB, 0);
+            }
+        }
+
+        const u32x2* xb = xs + buf * (KQ * NT) + lhi * NT + ph * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const h4 b0 = __builtin_bit_cast(h4, xb[(2 * kk) * NT]);
+            const h4 b1 = __builtin_bit_cast(h4, xb[(2 * kk) * NT + 32]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(a[kk], b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(a[kk], b1, acc1, 0, 0, 0);
+            if (kk < 16) store_prev(kk);
+        }
+#pragma unroll
+        for (int j = KS; j < 16; ++j) store_prev(j);
+
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v0 = acc0[j], v1 = acc1[j];
+            if (TMODE == 2) {
+                v0 += t0[j];
+                v1 += t1[j];
+            }
+            out0[j] = v0 > 0.f ? v0 : v0 * p.slope;
+            out1[j] = v1 > 0.f ? v1 : v1 * p.slope;
+        }
+        b_prev = __builtin_amdgcn_readfirstlane(b);
+        o_prev0 = o0;
+        o_prev1 = o1;
+
+        if (next < p.ntiles) commit(buf ^ 1, pre);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) store_prev(j);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of the layer in ONE pass over gy, y and x (cout <= 128):
 //   gz = gy * act'(y)                      (never written to HBM)
 //   gx[b]  = w^T @ gz[b]                    (MFMA, reduction over cout)
@@ -261,7 +452,6 @@ constexpr int PB_NT = 64;
 constexpr int PB_PITCH = 66;
 
 // 4 consecutive pixels of one row as they sit in HBM: 16 bytes of float or 8 bytes of _Float16
-using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 template <typename T> struct Pack4 { using type = u32x4; };
 template <> struct Pack4<_Float16> { using type = u32x2; };
 template <typename T>
@@ -616,6 +806,34 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
     if (grid > need) grid = (unsigned)need;
     if (grid < unit) grid = unit;
     hipError_t e = hipSuccess;
+    if constexpr (sizeof(TI) == 2 && sizeof(TO) == 2) {
+        // half in, half out: the f16 matrix pipe (weights rounded to half); SBMC_HIP_PW_F16MFMA=0 keeps
+        // the fp32-MFMA kernel (development knob, not part of the ABI)
+        const char* knob = getenv("SBMC_HIP_PW_F16MFMA");
+        if (!knob || atoi(knob) != 0) {
+            const size_t hlds = (size_t)2 * (kp / 4) * 128 * 8;
+            unsigned hgrid = (unsigned)(2 * cus) / unit * unit;      // two workgroups per CU when they fit
+            if (hgrid > need) hgrid = (unsigned)need;
+            if (hgrid < unit) hgrid = unit;
+#define SBMC_PWH_LAUNCH(KPV)                                                                             \
+    do {                                                                                                 \
+        auto kern = t_mode == 2 ? pw_fwd_h_kernel<KPV, 2> : (t_mode == 1 ? pw_fwd_h_kernel<KPV, 1> : pw_fwd_h_kernel<KPV, 0>); \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds);                  \
+        if (e == hipSuccess)                                                                             \
+            hipLaunchKernelGGL(kern, dim3(hgrid), dim3(512), hlds, (hipStream_t)stream, p);              \
+    } while (0)
+            switch (kp) {
+                case 32: SBMC_PWH_LAUNCH(32); break;
+                case 64: SBMC_PWH_LAUNCH(64); break;
+                case 96: SBMC_PWH_LAUNCH(96); break;
+                default: SBMC_PWH_LAUNCH(128); break;
+            }
+#undef SBMC_PWH_LAUNCH
+            if (e != hipSuccess) return (int)e;
+            return (int)hipGetLastError();
+        }
+    }
 #define SBMC_PW_LAUNCH(KPV)                                                                              \
     do {                                                                                                 \
         auto kern = t_mode == 2 ? pw_fwd_kernel<KPV, 2, PW_FWD_PH, TI, TO>                                \
