@@ -271,8 +271,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     // border strips: lane's source column X+dx-P is inside the image for dx in [dx_lo, dx_hi)
     const int dx_lo = P - X, dx_hi = p.w + P - X;
 
-    // returns false when the row contributes nothing (it lies in a neighbouring slab)
-    auto load_row = [&](int dy, float (&v)[K], float (&s)[2 * C]) -> bool {
+    auto load_row = [&](int dy, float (&v)[K], float (&s)[2 * C]) {
         const int ys = Y - p.top + dy - P;
         const bool yin = (ys >= 0) && (ys < p.h);  // wave-uniform
         if constexpr (GATHER) {
@@ -287,15 +286,14 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
                 s[2 * c] = (yin && inA) ? dr[colA] : 0.f;
                 s[2 * c + 1] = (yin && inB) ? dr[colB] : 0.f;
             }
-            return true;
+            return;
         }
-        if (!yin) {
-            if (!(ys < 0 ? p.zero_top : p.zero_bot)) return false;
+        if (!yin) {   // beyond an IMAGE edge (rows beyond an inner slab edge are never visited, see below)
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) v[dx] = 0.f;
 #pragma unroll
             for (int j = 0; j < 2 * C; ++j) s[j] = 0.f;
-            return true;
+            return;
         }
         // tap dx of this row: plane (2P-dy)*K + (K-1-dx), row ys, column X0-P+dx+lane
         //   = rowmin + (K-1-dx) * (hw-1) + lane,  rowmin = address of tap K-1, lane 0
@@ -316,7 +314,6 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
             s[2 * c] = inA ? dr[colA] : 0.f;
             s[2 * c + 1] = inB ? dr[colB] : 0.f;
         }
-        return true;
     };
     auto step = [&](int dy, const float (&v)[K], const float (&s)[2 * C]) {
         wave_lds_sync();  // previous row's reads are done before its slots are overwritten
@@ -332,9 +329,13 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     // (A register double-buffer that prefetches row dy+1 while row dy is reduced was tried:
     // it costs ~40 VGPRs, i.e. 2-3 waves/SIMD of occupancy, and measured slower.)
     float v[K], s[2 * C];
+    // kernel rows whose source row lies beyond an INNER slab edge belong to the neighbouring slab and are
+    // not visited at all (scalar loop bounds; whole frame: 0 .. K)
+    const int dy_lo = p.zero_top ? 0 : max(0, P + p.top - Y);
+    const int dy_hi = p.zero_bot ? K : min(K, p.h + P + p.top - Y);
 #pragma unroll 1
-    for (int dy = 0; dy < K; ++dy) {
-        if (!load_row(dy, v, s)) continue;   // wave-uniform
+    for (int dy = dy_lo; dy < dy_hi; ++dy) {
+        load_row(dy, v, s);
         step(dy, v, s);
     }
 

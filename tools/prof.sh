@@ -13,7 +13,7 @@ mkdir -p $out $sum
 cd /tmp && export TMPDIR=/tmp
 export MIOPEN_FIND_MODE=FAST
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/splat -o splat -- python $root/bench.py --workload splat --steps 5 --warmup 2 --no-cpu-baseline > $out/splat.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/model -o model -- python $root/bench.py --workload model --steps 2 --warmup 1 --no-cpu-baseline --no-stages > $out/model.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/model -o model -- python $root/bench.py --workload model --steps 6 --warmup 3 --no-cpu-baseline --no-stages > $out/model.log 2>&1
 i=0
 for pmc in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
