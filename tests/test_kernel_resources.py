@@ -14,7 +14,14 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def splat_kernels():
     import kernel_resources
     rows = kernel_resources.resources(os.path.join(ROOT, "sbmc_amd", "csrc", "splat_fused.hip"))
-    return {r["name"].split("(")[0].replace("void ", ""): r for r in rows}
+    out = {r["name"].split("(")[0].replace("void ", ""): r for r in rows}
+    # binutils' c++filt does not know _Float16 (DF16_): those instantiations keep their mangled names
+    for r in rows:
+        if "splat_fwd_strip_kernelILi21ELi3EDF16_Lb0E" in r["name"]:
+            out["sbmc::splat_fwd_strip_kernel<21, 3, _Float16, false>"] = r
+        if "splat_bwd_strip_kernelILi21ELi3EDF16_E" in r["name"]:
+            out["sbmc::splat_bwd_strip_kernel<21, 3, _Float16>"] = r
+    return out
 
 
 @pytest.mark.parametrize("name,min_occupancy", [
