@@ -432,6 +432,29 @@ SBMC_API int sbmc_upsample2x_cat_slab_fwd_f32(const float *coarse, const float *
 SBMC_API int sbmc_upsample2x_cat_slab_bwd_f32(const float *gout, float *gcoarse, int b, int cu, int cl,
                                      int hc, int w, int top, int bot, void *stream);
 
+/* ---- channels-last (NHWC) forms of the glue around the U-nets' 3x3 convolutions (csrc/nhwc_ops.hip) ----
+ * MIOpen's fastest fp32 3x3 solvers on gfx950 are NHWC-native; with the U-net's activations kept
+ * channels-last between its convolutions MIOpen stops transposing every input and output.  Tensors here
+ * are [pixels = b*h*w, c] (bias_act) or [b, h, w, c] (upsample), c multiples of 4, 16-byte aligned.
+ *   bias_act_nhwc fwd (in place): y = act(y + bias[c]);
+ *   bwd: gx = gy * act'(y) (gx may alias gy), partial[j, c] = sums over the pixels of workgroup j,
+ *        j < sbmc_bias_act_nhwc_chunks(pixels, c); the bias gradient is the sum over j (no atomics);
+ *        only where sbmc_bias_act_nhwc_supported(c) == 1 (c / 4 divides 256);
+ *   upsample2x_cat_nhwc: as sbmc_upsample2x_cat_* (reference sbmc/modules.py:300-320); the backward also
+ *        writes the skip connection's gradient gleft = gout[..., cu:] as a contiguous tensor (either
+ *        output pointer may be NULL: not computed). */
+SBMC_API int sbmc_bias_act_nhwc_supported(int c);
+SBMC_API int sbmc_bias_act_nhwc_chunks(long pixels, int c);
+SBMC_API int sbmc_bias_act_nhwc_fwd_f32(float *y, const float *bias, long pixels, int c, int act, float slope,
+                               void *stream);
+SBMC_API int sbmc_bias_act_nhwc_bwd_f32(const float *gy, const float *y, float *gx, float *partial, long pixels,
+                               int c, int act, float slope, void *stream);
+SBMC_API int sbmc_upsample2x_cat_nhwc_supported(int cu, int cl, int h, int w);
+SBMC_API int sbmc_upsample2x_cat_nhwc_fwd_f32(const float *coarse, const float *left, float *out, int b, int cu,
+                                     int cl, int h, int w, void *stream);
+SBMC_API int sbmc_upsample2x_cat_nhwc_bwd_f32(const float *gout, float *gcoarse, float *gleft, int b, int cu,
+                                     int cl, int h, int w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

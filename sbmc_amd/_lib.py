@@ -61,6 +61,13 @@ SYMBOLS = (
     "sbmc_upsample2x_cat_bwd_f32",
     "sbmc_upsample2x_cat_slab_fwd_f32",
     "sbmc_upsample2x_cat_slab_bwd_f32",
+    "sbmc_bias_act_nhwc_supported",
+    "sbmc_bias_act_nhwc_chunks",
+    "sbmc_bias_act_nhwc_fwd_f32",
+    "sbmc_bias_act_nhwc_bwd_f32",
+    "sbmc_upsample2x_cat_nhwc_supported",
+    "sbmc_upsample2x_cat_nhwc_fwd_f32",
+    "sbmc_upsample2x_cat_nhwc_bwd_f32",
 )
 ABI_VERSION = 2
 MAX_CHANNELS = 8
@@ -152,6 +159,13 @@ def lib():
     handle.sbmc_upsample2x_cat_bwd_f32.argtypes = [p, p, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_slab_fwd_f32.argtypes = [p, p, p, i, i, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_slab_bwd_f32.argtypes = [p, p, i, i, i, i, i, i, i, p]
+    handle.sbmc_bias_act_nhwc_supported.argtypes = [i]
+    handle.sbmc_bias_act_nhwc_chunks.argtypes = [ctypes.c_long, i]
+    handle.sbmc_bias_act_nhwc_fwd_f32.argtypes = [p, p, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_bias_act_nhwc_bwd_f32.argtypes = [p, p, p, p, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_upsample2x_cat_nhwc_supported.argtypes = [i, i, i, i]
+    handle.sbmc_upsample2x_cat_nhwc_fwd_f32.argtypes = [p, p, p, i, i, i, i, i, p]
+    handle.sbmc_upsample2x_cat_nhwc_bwd_f32.argtypes = [p, p, p, i, i, i, i, i, p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t

@@ -1,0 +1,228 @@
+// Channels-last (NHWC) forms of the memory-bound glue around the U-nets' 3x3 convolutions.
+//
+// MIOpen's fastest fp32 3x3 solvers on gfx950 (ConvAsmImplicitGemmGTCDynamic{Fwd,Bwd,Wrw}XdlopsNHWC) are
+// NHWC-native: fed NCHW tensors they transpose every input and output (36 ms of a 527 ms training step at
+// 1280x720, `batched_transpose_*`).  With the U-net's activations kept channels-last between its
+// convolutions those transposes disappear -- provided the glue between the convolutions speaks NHWC too:
+//   bias + ReLU / LeakyReLU behind every convolution (reference sbmc/modules.py:154-175)   -> bias_act_nhwc_*
+//   bilinear x2 upsampling + concatenation with the skip connection (modules.py:300-320)   -> upcat_nhwc_*
+// Same arithmetic as the planar kernels of bias_act.hip / resample.hip; a pixel's channels are contiguous,
+// so a thread owns one float4 of channels of one pixel and neighbouring lanes neighbouring channels.
+// HBM-bound, one pass per direction, no atomics (bias gradient: per-workgroup partial sums, added up by
+// the caller).
+#include "common.hpp"
+#include "../../include/sbmc_hip.h"
+
+namespace sbmc {
+
+__device__ __forceinline__ float nact(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// y [pixels, C] in place; one thread = one float4 of channels of one pixel
+__global__ __launch_bounds__(256) void bias_act_nhwc_fwd_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                               size_t total4, int c4n, float slope, int linear) {
+    float4* y4 = reinterpret_cast<float4*>(y);
+    const float4* b4 = reinterpret_cast<const float4*>(bias);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 bv = b4[i % (size_t)c4n];
+        float4 v = y4[i];
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (!linear) { v.x = nact(v.x, slope); v.y = nact(v.y, slope); v.z = nact(v.z, slope); v.w = nact(v.w, slope); }
+        y4[i] = v;
+    }
+}
+
+// gx = gy * act'(y); partial[chunk, C] = this workgroup's sums of gx per channel.
+// 256 threads = (256 / c4n) pixel lanes x c4n channel quads; c4n must divide 256.
+__global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                               float* __restrict__ gx, float* __restrict__ partial,
+                                                               size_t pixels, int c4n, float slope, int linear) {
+    __shared__ float4 red[256];
+    const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n, npl = 256 / c4n;
+    const size_t per = (pixels + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per;
+    const size_t p1 = p0 + per < pixels ? p0 + per : pixels;
+    const bool store = !(linear && gx == gy);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t px = p0 + pl; px < p1; px += npl) {
+        const size_t i = px * c4n + cq;
+        float4 g = reinterpret_cast<const float4*>(gy)[i];
+        if (!linear) {
+            const float4 v = reinterpret_cast<const float4*>(y)[i];
+            g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
+            g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
+        }
+        if (store) reinterpret_cast<float4*>(gx)[i] = g;
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (pl == 0) {
+        for (int j = 1; j < npl; ++j) {
+            const float4 o = red[j * c4n + cq];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        reinterpret_cast<float4*>(partial)[(size_t)blockIdx.x * c4n + cq] = acc;
+    }
+}
+
+// out[b, y, x, :cu] = bilinear x2 of coarse[b, :, :, :cu] (align_corners = False), out[b, y, x, cu:] = left
+__global__ __launch_bounds__(256) void upcat_nhwc_fwd_kernel(const float* __restrict__ coarse, const float* __restrict__ left,
+                                                            float* __restrict__ out, int cu4, int cl4, int h, int w,
+                                                            size_t total4) {
+    const int W = 2 * w, H = 2 * h, ct4 = cu4 + cl4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % ct4);
+        size_t rest = idx / ct4;
+        const int x = (int)(rest % W);
+        rest /= W;
+        const int y = (int)(rest % H);
+        const size_t b = rest / H;
+        float4 v;
+        if (q >= cu4) {
+            v = reinterpret_cast<const float4*>(left)[((b * H + y) * W + x) * (size_t)cl4 + (q - cu4)];
+        } else {
+            // source coordinate 0.5 * dst - 0.25 clamped at 0: even dst -> (i-1: .25, i: .75), odd -> (i: .75, i+1: .25)
+            int r0, r1, c0, c1;
+            float ly, lx;                                     // weights of r1 / c1
+            const int i = y >> 1, j = x >> 1;
+            if (y == 0) { r0 = r1 = 0; ly = 0.f; } else if (y & 1) { r0 = i; r1 = i + 1 < h ? i + 1 : i; ly = 0.25f; } else { r0 = i - 1; r1 = i; ly = 0.75f; }
+            if (x == 0) { c0 = c1 = 0; lx = 0.f; } else if (x & 1) { c0 = j; c1 = j + 1 < w ? j + 1 : j; lx = 0.25f; } else { c0 = j - 1; c1 = j; lx = 0.75f; }
+            const float4* cz = reinterpret_cast<const float4*>(coarse) + (b * h) * (size_t)w * cu4 + q;
+            const float4 a = cz[((size_t)r0 * w + c0) * cu4], bq = cz[((size_t)r0 * w + c1) * cu4];
+            const float4 c = cz[((size_t)r1 * w + c0) * cu4], d = cz[((size_t)r1 * w + c1) * cu4];
+            const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+            v.x = w00 * a.x + w01 * bq.x + w10 * c.x + w11 * d.x;
+            v.y = w00 * a.y + w01 * bq.y + w10 * c.y + w11 * d.y;
+            v.z = w00 * a.z + w01 * bq.z + w10 * c.z + w11 * d.z;
+            v.w = w00 * a.w + w01 * bq.w + w10 * c.w + w11 * d.w;
+        }
+        reinterpret_cast<float4*>(out)[idx] = v;
+    }
+}
+
+// gcoarse[b, i, j, :] = sum over the <= 4x4 fine neighbours, separable weights {.25, .75, .75, .25}, a partner
+// that fell off the image was clamped onto the border row / column in the forward: its weight comes back there.
+// gleft (may be null) = gout[..., cu:] as a contiguous tensor.
+__global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gcoarse,
+                                                            int cu4, int cl4, int h, int w, size_t total4) {
+    const int W = 2 * w, H = 2 * h, ct4 = cu4 + cl4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cu4);
+        size_t rest = idx / cu4;
+        const int j = (int)(rest % w);
+        rest /= w;
+        const int i = (int)(rest % h);
+        const size_t b = rest / h;
+        float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+        if (i == 0) { wy[0] = 0.f; wy[1] = 1.f; }
+        if (i == h - 1) { wy[3] = 0.f; wy[2] = 1.f; }
+        if (j == 0) { wx[0] = 0.f; wx[1] = 1.f; }
+        if (j == w - 1) { wx[3] = 0.f; wx[2] = 1.f; }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* g = reinterpret_cast<const float4*>(gout) + (b * H) * (size_t)W * ct4 + q;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            if (wy[dy] == 0.f) continue;
+            const int yy = 2 * i - 1 + dy;
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                if (wx[dx] == 0.f) continue;
+                const int xx = 2 * j - 1 + dx;
+                const float4 v = g[((size_t)yy * W + xx) * ct4];
+                const float wt = wy[dy] * wx[dx];
+                acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+            }
+        }
+        reinterpret_cast<float4*>(gcoarse)[idx] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void slice_channels_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                 int ct4, int c0_4, int cn4, size_t total4) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t px = idx / cn4;
+        const int q = (int)(idx % cn4);
+        reinterpret_cast<float4*>(dst)[idx] = reinterpret_cast<const float4*>(src)[px * ct4 + c0_4 + q];
+    }
+}
+
+static inline unsigned grid_for(size_t n) {
+    const size_t blocks = (n + 255) / 256;
+    return (unsigned)(blocks < 65536 * 8 ? (blocks ? blocks : 1) : 65536 * 8);
+}
+
+}  // namespace sbmc
+
+using namespace sbmc;
+
+extern "C" int sbmc_bias_act_nhwc_supported(int c) {
+    return (c >= 4 && c % 4 == 0 && c / 4 <= 256 && 256 % (c / 4) == 0) ? 1 : 0;
+}
+
+extern "C" int sbmc_bias_act_nhwc_chunks(long pixels, int c) {
+    if (pixels <= 0 || c <= 0) return 1;
+    const long rows = 256 / (c / 4 > 0 ? c / 4 : 1);          // pixels one pass of a workgroup covers
+    long want = pixels / (rows * 16);                          // >= 16 passes per workgroup
+    if (want < 1) want = 1;
+    if (want > 2048) want = 2048;
+    return (int)want;
+}
+
+extern "C" int sbmc_bias_act_nhwc_fwd_f32(float* y, const float* bias, long pixels, int c, int act, float slope,
+                                          void* stream) {
+    if (pixels < 0 || c < 0 || act < 0 || act > 2) return SBMC_HIP_EINVAL;
+    if (pixels == 0 || c == 0) return 0;
+    if (!y || !bias || !sbmc_bias_act_nhwc_supported(c) || (uintptr_t)y % 16 || (uintptr_t)bias % 16) return SBMC_HIP_EINVAL;
+    const size_t total4 = (size_t)pixels * (c / 4);
+    hipLaunchKernelGGL(bias_act_nhwc_fwd_kernel, dim3(grid_for(total4 / 4 + 1)), dim3(256), 0, (hipStream_t)stream, y,
+                       bias, total4, c / 4, act == 1 ? 0.f : slope, act == 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_bias_act_nhwc_bwd_f32(const float* gy, const float* y, float* gx, float* partial, long pixels,
+                                          int c, int act, float slope, void* stream) {
+    if (pixels < 0 || c < 0 || act < 0 || act > 2) return SBMC_HIP_EINVAL;
+    if (pixels == 0 || c == 0) return 0;
+    if (!gy || !y || !gx || !partial || !sbmc_bias_act_nhwc_supported(c)) return SBMC_HIP_EINVAL;
+    if ((uintptr_t)gy % 16 || (uintptr_t)y % 16 || (uintptr_t)gx % 16 || (uintptr_t)partial % 16) return SBMC_HIP_EINVAL;
+    hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel, dim3((unsigned)sbmc_bias_act_nhwc_chunks(pixels, c)), dim3(256), 0,
+                       (hipStream_t)stream, gy, y, gx, partial, (size_t)pixels, c / 4, act == 1 ? 0.f : slope, act == 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_upsample2x_cat_nhwc_supported(int cu, int cl, int h, int w) {
+    return (cu >= 4 && cu % 4 == 0 && cl >= 0 && cl % 4 == 0 && h >= 1 && w >= 1) ? 1 : 0;
+}
+
+extern "C" int sbmc_upsample2x_cat_nhwc_fwd_f32(const float* coarse, const float* left, float* out, int b, int cu,
+                                                int cl, int h, int w, void* stream) {
+    if (b < 0 || !sbmc_upsample2x_cat_nhwc_supported(cu, cl, h, w)) return SBMC_HIP_EINVAL;
+    if (b == 0) return 0;
+    if (!coarse || !out || (cl > 0 && !left) || (uintptr_t)coarse % 16 || (uintptr_t)out % 16 || (uintptr_t)left % 16)
+        return SBMC_HIP_EINVAL;
+    const size_t total4 = (size_t)b * (2 * (size_t)h) * (2 * (size_t)w) * ((cu + cl) / 4);
+    hipLaunchKernelGGL(upcat_nhwc_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, coarse, left,
+                       out, cu / 4, cl / 4, h, w, total4);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_upsample2x_cat_nhwc_bwd_f32(const float* gout, float* gcoarse, float* gleft, int b, int cu, int cl,
+                                                int h, int w, void* stream) {
+    if (b < 0 || !sbmc_upsample2x_cat_nhwc_supported(cu, cl, h, w)) return SBMC_HIP_EINVAL;
+    if (b == 0) return 0;
+    if (!gout || (!gcoarse && !gleft) || (uintptr_t)gout % 16 || (uintptr_t)gcoarse % 16 || (uintptr_t)gleft % 16)
+        return SBMC_HIP_EINVAL;
+    if (gcoarse) {
+        const size_t total4 = (size_t)b * h * w * (cu / 4);
+        hipLaunchKernelGGL(upcat_nhwc_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, gout,
+                           gcoarse, cu / 4, cl / 4, h, w, total4);
+        const int err = (int)hipGetLastError();
+        if (err) return err;
+    }
+    if (gleft && cl > 0) {
+        const size_t total4 = (size_t)b * (2 * (size_t)h) * (2 * (size_t)w) * (cl / 4);
+        hipLaunchKernelGGL(slice_channels_nhwc_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, gout,
+                           gleft, (cu + cl) / 4, cu / 4, cl / 4, total4);
+    }
+    return (int)hipGetLastError();
+}

@@ -604,6 +604,7 @@ def upsample_cat_supported(coarse, left, top=0, bot=0):
             and top in (0, 1) and bot in (0, 1)
             and left.shape[2] == 2 * (coarse.shape[2] - top - bot) and left.shape[3] == 2 * coarse.shape[3]
             and coarse.numel() > 0 and not th.is_autocast_enabled()
+            and coarse.is_contiguous() and left.is_contiguous()       # planar [b, c, h, w]; NHWC: UpsampleCatNHWC
             and bool(_lib.lib().sbmc_upsample2x_cat_supported(coarse.shape[2] - top - bot, coarse.shape[3])))
 
 
@@ -644,6 +645,101 @@ class UpsampleCat(th.autograd.Function):
                                                                  top, bot, _lib.current_stream(dev))
             _lib.check(rc, "upsample2x_cat_bwd")
         return gcoarse, (g[:, cu:] if ctx.needs_input_grad[1] else None), None, None
+
+
+def _is_channels_last(t):
+    """A 4-d tensor whose memory order is [b, h, w, c] (and not also plain contiguous in [b, c, h, w])."""
+    return (t.dim() == 4 and t.is_contiguous(memory_format=th.channels_last)
+            and (t.shape[1] > 1 and t.shape[2] * t.shape[3] > 1))
+
+
+class BiasActNHWC(th.autograd.Function):
+    """`BiasAct` for a channels-last activation (the U-nets' convolutions in NHWC, csrc/nhwc_ops.hip):
+    y [b, c, h, w] with memory order [b, h, w, c], modified in place; backward in one pass as well."""
+
+    @staticmethod
+    def supported(y):
+        return (y.is_cuda and y.dtype == th.float32 and y.numel() > 0 and _is_channels_last(y)
+                and y.data_ptr() % 16 == 0 and bool(_lib.lib().sbmc_bias_act_nhwc_supported(int(y.shape[1]))))
+
+    @staticmethod
+    def forward(ctx, y, bias, act, slope):
+        _require_f32("BiasActNHWC", y=y, bias=bias)
+        b, c, h, w = y.shape
+        bias = bias.contiguous()
+        dev = y.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_bias_act_nhwc_fwd_f32(_lib.ptr(y), _lib.ptr(bias), b * h * w, c, act, slope,
+                                                       _lib.current_stream(dev))
+        _lib.check(rc, "bias_act_nhwc_fwd")
+        ctx.mark_dirty(y)
+        ctx.act, ctx.slope = act, slope
+        if act != 0:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous(memory_format=th.channels_last)
+        y = ctx.saved_tensors[0] if ctx.act != 0 else gy
+        b, c, h, w = gy.shape
+        gx = th.empty_like(gy, memory_format=th.channels_last)
+        L = _lib.lib()
+        partial = gy.new_empty(L.sbmc_bias_act_nhwc_chunks(b * h * w, c), c)
+        dev = gy.device
+        with th.cuda.device(dev):
+            rc = L.sbmc_bias_act_nhwc_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gx), _lib.ptr(partial),
+                                              b * h * w, c, ctx.act, ctx.slope, _lib.current_stream(dev))
+        _lib.check(rc, "bias_act_nhwc_bwd")
+        return gx, partial.sum(0), None, None
+
+
+def upsample_cat_nhwc_supported(coarse, left):
+    return (coarse.is_cuda and left.is_cuda and coarse.dtype == th.float32 and left.dtype == th.float32
+            and coarse.dim() == 4 and left.dim() == 4 and coarse.shape[0] == left.shape[0]
+            and left.shape[2] == 2 * coarse.shape[2] and left.shape[3] == 2 * coarse.shape[3]
+            and coarse.numel() > 0 and not th.is_autocast_enabled()
+            and _is_channels_last(coarse) and _is_channels_last(left)
+            and coarse.data_ptr() % 16 == 0 and left.data_ptr() % 16 == 0
+            and bool(_lib.lib().sbmc_upsample2x_cat_nhwc_supported(coarse.shape[1], left.shape[1],
+                                                                   coarse.shape[2], coarse.shape[3])))
+
+
+class UpsampleCatNHWC(th.autograd.Function):
+    """`UpsampleCat` on channels-last tensors (result channels-last too): one pass per direction, the
+    backward also delivers the skip connection's gradient as a contiguous tensor."""
+
+    @staticmethod
+    def forward(ctx, coarse, left):
+        _require_f32("UpsampleCatNHWC", coarse=coarse, left=left)
+        b, cu, h, w = coarse.shape
+        cl = left.shape[1]
+        out = th.empty(b, cu + cl, 2 * h, 2 * w, dtype=coarse.dtype, device=coarse.device,
+                       memory_format=th.channels_last)
+        dev = coarse.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_upsample2x_cat_nhwc_fwd_f32(_lib.ptr(coarse), _lib.ptr(left), _lib.ptr(out),
+                                                             b, cu, cl, h, w, _lib.current_stream(dev))
+        _lib.check(rc, "upsample2x_cat_nhwc_fwd")
+        ctx.dims = (b, cu, cl, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, cu, cl, h, w = ctx.dims
+        g = g.contiguous(memory_format=th.channels_last)
+        gcoarse = gleft = None
+        if ctx.needs_input_grad[0]:
+            gcoarse = th.empty(b, cu, h, w, dtype=g.dtype, device=g.device, memory_format=th.channels_last)
+        if ctx.needs_input_grad[1]:
+            gleft = th.empty(b, cl, 2 * h, 2 * w, dtype=g.dtype, device=g.device, memory_format=th.channels_last)
+        if gcoarse is not None or gleft is not None:
+            dev = g.device
+            with th.cuda.device(dev):
+                rc = _lib.lib().sbmc_upsample2x_cat_nhwc_bwd_f32(_lib.ptr(g), _lib.ptr(gcoarse), _lib.ptr(gleft),
+                                                                 b, cu, cl, h, w, _lib.current_stream(dev))
+            _lib.check(rc, "upsample2x_cat_nhwc_bwd")
+        return gcoarse, gleft
 
 
 def gather_update_supported(data, kernels):

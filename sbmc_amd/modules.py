@@ -162,6 +162,63 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     return chain._run(rest, y, mean_s=S, mean_out=mean_out) if rest else y
 
 
+_LAYOUT_DECISIONS = {}
+
+
+def unet_channels_last(net, x):
+    """Should this U-net run channels-last on this input?  MEASURED, once per (channels, height, width,
+    training?) and process: one 3x3 convolution of the net's width at the input's resolution, forward (and
+    backward when gradients are on), in both layouts.  With the find records of `sbmc_amd.miopen_db` MIOpen
+    picks its NHWC implicit-GEMM solvers and channels-last wins by the NCHW<->NHWC transposes it no longer
+    needs; without a matching record (another GPU, MIOpen build or frame size) its heuristic choice for
+    channels-last fp32 can be many times slower, and the U-net stays planar.
+    SBMC_UNET_LAYOUT = nchw | nhwc overrides the measurement."""
+    import os
+    mode = os.environ.get("SBMC_UNET_LAYOUT", "auto").lower()
+    if (mode == "nchw" or not x.is_cuda or x.dtype != th.float32 or x.dim() != 4 or th.is_autocast_enabled()
+            or x.shape[1] % 4 or x.numel() == 0):
+        return False
+    if mode == "nhwc":
+        return True
+    grad = th.is_grad_enabled() and any(q.requires_grad for q in net.parameters())
+    key = (x.device.index, x.shape[0], x.shape[1], x.shape[2], x.shape[3], grad)
+    if key not in _LAYOUT_DECISIONS:
+        _LAYOUT_DECISIONS[key] = _measure_layouts(x.shape, x.device, grad)
+    return _LAYOUT_DECISIONS[key]
+
+
+def _measure_layouts(shape, device, grad):
+    b, c, h, w = shape
+    times = {}
+    with th.enable_grad():
+        for cl in (False, True):
+            xin = th.zeros(b, c, h, w, device=device)
+            wt = th.zeros(c, c, 3, 3, device=device)
+            if cl:
+                xin = xin.contiguous(memory_format=th.channels_last)
+                wt = wt.contiguous(memory_format=th.channels_last)
+            xin.requires_grad_(grad)
+            wt.requires_grad_(grad)
+
+            def run():
+                y = F.conv2d(xin, wt, None, 1, 1)
+                if grad:
+                    y.backward(y.detach())
+                    xin.grad = wt.grad = None
+            run()                                   # solver selection / kernel load
+            th.cuda.synchronize(device)
+            t0, t1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+            t0.record()
+            run()
+            run()
+            t1.record()
+            th.cuda.synchronize(device)
+            times[cl] = t0.elapsed_time(t1)
+            del xin, wt
+    LOG.debug("U-net layout at %s: planar %.2f ms, channels-last %.2f ms", tuple(shape), times[False], times[True])
+    return times[True] < 0.97 * times[False]
+
+
 class ConvChain(nn.Module):
     """A stack of ``depth`` convolutions: (depth-1) x [conv, (norm), activation] + conv.
 
@@ -240,6 +297,14 @@ class ConvChain(nn.Module):
             act = 1
         elif isinstance(activation, nn.LeakyReLU):
             act, slope = 2, float(activation.negative_slope)
+        if funcs._is_channels_last(x):
+            # the U-net runs channels-last (Autoencoder.forward): MIOpen's NHWC solvers without any layout
+            # change around them, bias + activation by the NHWC pass
+            w = w.contiguous(memory_format=th.channels_last)
+            y = th.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if funcs.BiasActNHWC.supported(y):
+                return funcs.BiasActNHWC.apply(y, conv.bias, act, slope), act != 0
+            return y + conv.bias.view(1, -1, 1, 1), False
         y = th.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if not funcs.BiasAct.supported(y):
             # (odd plane sizes, channels_last results, empty batches) the convolution is done: finish
@@ -350,6 +415,10 @@ class Autoencoder(nn.Module):
         self.add_module("net", coarser)
 
     def forward(self, x):
+        if unet_channels_last(self, x):
+            # channels-last between the convolutions (MIOpen's NHWC-native solvers need no transposes then),
+            # planar again for the per-sample 1x1 kernels that consume the result
+            return self.net(x.contiguous(memory_format=th.channels_last)).contiguous()
         return self.net(x)
 
     class _Level(nn.Module):
@@ -386,6 +455,8 @@ class Autoencoder(nn.Module):
             if self.is_last:
                 return left
             coarse = self.next_level(self.downsample(left))
+            if funcs.upsample_cat_nhwc_supported(coarse, left):
+                return self.right(funcs.UpsampleCatNHWC.apply(coarse, left))
             if funcs.upsample_cat_supported(coarse, left):
                 return self.right(funcs.UpsampleCat.apply(coarse, left))   # one pass, same values
             up = F.interpolate(coarse, size=left.shape[-2:], mode="bilinear",
