@@ -146,6 +146,43 @@ __global__ __launch_bounds__(256) void slice_channels_nhwc_kernel(const float* _
     }
 }
 
+// Batched 2-d transpose src[b][R][Cn] -> dst[b][Cn][R] through a 64 x 64 LDS tile (both sides move float4s):
+// planar -> channels-last is (R, Cn) = (c, h*w), channels-last -> planar (h*w, c).  torch's generic strided
+// copy does the same conversion at 0.5-1.5 TB/s (1.9 ms for a [128, 720, 1280] map); this one runs at the
+// copy rate.  R and Cn multiples of 4.
+constexpr int TT = 64;
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int R, int Cn, int tiles_r, int tiles_c) {
+    __shared__ float tile[TT][TT + 1];
+    unsigned blk = blockIdx.x;
+    const int tc = blk % tiles_c; blk /= tiles_c;
+    const int tr = blk % tiles_r;
+    const size_t b = blk / tiles_r;
+    const int r0 = tr * TT, c0 = tc * TT;
+    const float* s = src + b * (size_t)R * Cn;
+    float* d = dst + b * (size_t)R * Cn;
+    const int q = threadIdx.x % 16, line = threadIdx.x / 16;          // float4 column, row within a pass of 16
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + line + 16 * i, c = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R && c < Cn) v = *reinterpret_cast<const float4*>(s + (size_t)r * Cn + c);
+        float* t = &tile[line + 16 * i][4 * q];
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + line + 16 * i, r = r0 + 4 * q;               // output row c, columns r .. r + 3
+        if (c < Cn && r < R) {
+            float4 v;
+            v.x = tile[4 * q + 0][line + 16 * i]; v.y = tile[4 * q + 1][line + 16 * i];
+            v.z = tile[4 * q + 2][line + 16 * i]; v.w = tile[4 * q + 3][line + 16 * i];
+            *reinterpret_cast<float4*>(d + (size_t)c * R + r) = v;
+        }
+    }
+}
+
 static inline unsigned grid_for(size_t n) {
     const size_t blocks = (n + 255) / 256;
     return (unsigned)(blocks < 65536 * 8 ? (blocks ? blocks : 1) : 65536 * 8);
@@ -224,5 +261,17 @@ extern "C" int sbmc_upsample2x_cat_nhwc_bwd_f32(const float* gout, float* gcoars
         hipLaunchKernelGGL(slice_channels_nhwc_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, gout,
                            gleft, (cu + cl) / 4, cu / 4, cl / 4, total4);
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_transpose2d_f32(const float* src, float* dst, int b, int rows, int cols, void* stream) {
+    if (b < 0 || rows < 0 || cols < 0) return SBMC_HIP_EINVAL;
+    if (b == 0 || rows == 0 || cols == 0) return 0;
+    if (!src || !dst || rows % 4 || cols % 4 || (uintptr_t)src % 16 || (uintptr_t)dst % 16) return SBMC_HIP_EINVAL;
+    const int tr = (rows + TT - 1) / TT, tc = (cols + TT - 1) / TT;
+    const unsigned long long blocks = (unsigned long long)b * tr * tc;
+    if (blocks > 0x7fffffffull) return SBMC_HIP_EINVAL;
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, rows,
+                       cols, tr, tc);
     return (int)hipGetLastError();
 }

@@ -653,6 +653,81 @@ def _is_channels_last(t):
             and (t.shape[1] > 1 and t.shape[2] * t.shape[3] > 1))
 
 
+class ToChannelsLast(th.autograd.Function):
+    """x [b, c, h, w] planar -> the same tensor in channels-last memory order (and back in the backward), by
+    the LDS-tile transpose of csrc/nhwc_ops.hip instead of torch's generic strided copy."""
+
+    @staticmethod
+    def supported(x):
+        return (x.is_cuda and x.dtype == th.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() > 0
+                and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+    @staticmethod
+    def forward(ctx, x):
+        b, c, h, w = x.shape
+        out = th.empty(b, c, h, w, dtype=x.dtype, device=x.device, memory_format=th.channels_last)
+        dev = x.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_transpose2d_f32(_lib.ptr(x), _lib.ptr(out), b, c, h * w, _lib.current_stream(dev))
+        _lib.check(rc, "transpose2d")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return FromChannelsLast.apply(g.contiguous(memory_format=th.channels_last))
+
+
+class FromChannelsLast(th.autograd.Function):
+    """The inverse: a channels-last [b, c, h, w] tensor -> planar contiguous."""
+
+    @staticmethod
+    def supported(x):
+        return (x.is_cuda and x.dtype == th.float32 and _is_channels_last(x) and x.numel() > 0
+                and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+    @staticmethod
+    def forward(ctx, x):
+        b, c, h, w = x.shape
+        out = th.empty(b, c, h, w, dtype=x.dtype, device=x.device)
+        dev = x.device
+        with th.cuda.device(dev):
+            rc = _lib.lib().sbmc_transpose2d_f32(_lib.ptr(x), _lib.ptr(out), b, h * w, c, _lib.current_stream(dev))
+        _lib.check(rc, "transpose2d")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return ToChannelsLast.apply(g) if ToChannelsLast.supported(g) else g.contiguous(memory_format=th.channels_last)
+
+
+class ContextProductNHWC(th.autograd.Function):
+    """t[b] = w @ ctx[b] for a CHANNELS-LAST context map ctx [bs, cp, h, w] (memory [bs, h*w, cp]) and w [cout, cp]
+    -> t [bs, cout, h*w] planar: the context half of a 1x1 chain's first layer (modules.pointwise_chain_with_context)
+    reading the U-net's channels-last result in place.  Backward returns the context gradient channels-last too
+    (the GEMM writes [h*w, cp] rows), which is what the U-net's backward wants: no layout copy either way."""
+
+    @staticmethod
+    def forward(ctx, context, w):
+        bs, cp, h, wd = context.shape
+        rows = context.permute(0, 2, 3, 1).reshape(bs, h * wd, cp)          # a view of the channels-last memory
+        ctx.save_for_backward(rows, w)
+        ctx.dims = (bs, cp, h, wd)
+        return th.bmm(w.unsqueeze(0).expand(bs, -1, -1), rows.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, gt):
+        rows, w = ctx.saved_tensors
+        bs, cp, h, wd = ctx.dims
+        g_context = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_rows = th.bmm(gt.transpose(1, 2), w.unsqueeze(0).expand(bs, -1, -1))   # [bs, hw, cp]: channels-last
+            g_context = g_rows.view(bs, h, wd, cp).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            g_w = th.bmm(gt, rows).sum(0)
+        return g_context, g_w
+
+
 class BiasActNHWC(th.autograd.Function):
     """`BiasAct` for a channels-last activation (the U-nets' convolutions in NHWC, csrc/nhwc_ops.hip):
     y [b, c, h, w] with memory order [b, h, w, c], modified in place; backward in one pass as well."""

@@ -111,6 +111,7 @@ class Multisteps(nn.Module):
                 for m in getattr(self, "propagation_{:02d}".format(step)).modules():
                     if isinstance(m, ops.ConvChain):
                         m.fuse_bias_act = True
+                getattr(self, "propagation_{:02d}".format(step)).keep_channels_last = True
 
     def _embed(self, module, per_sample, per_pixel, want_mean=False):
         """Runs a 1x1 ConvChain on cat(per_sample[:, s], per_pixel) for every sample s.

@@ -136,17 +136,25 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     wt = wt.view(wt.shape[0], cs + cp)
     cout = wt.shape[0]
     xs = per_sample.reshape(bs * S, cs, h * w)
-    ctx3 = context.reshape(bs, cp, -1)
+    nhwc_ctx = funcs._is_channels_last(context) and context.dtype == th.float32 and h * w > 1
+    ctx3 = None if nhwc_ctx else context.reshape(bs, cp, -1)
+
+    def context_term(wc):
+        # the U-net may hand its result over channels-last: the product then reads it in place and returns
+        # the context gradient channels-last as well (functions.ContextProductNHWC)
+        if nhwc_ctx:
+            return funcs.ContextProductNHWC.apply(context, wc.contiguous())
+        return th.bmm(wc.unsqueeze(0).expand(bs, -1, -1), ctx3.to(wc.dtype))
     if funcs.pointwise_half_supported(xs, cout):             # fp16 activations, inference
         with th.autocast("cuda", enabled=False):
-            t = th.bmm(wt[:, cs:].float().unsqueeze(0).expand(bs, -1, -1), ctx3.float()).contiguous()
+            t = context_term(wt[:, cs:].float()).contiguous()
         tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)
         y = funcs.PointwiseLayer.apply(xs, wt[:, :cs].float(), conv.bias.float(), tt, S, act[0], act[1], True)
         y = y.view(bs * S, cout, h, w)
         consumed = 1 if isinstance(first, ConvChain._ConvBNRelu) else (2 if act[0] != 0 else 1)
         rest = mods[consumed:]
         return chain._run(rest, y, mean_s=S, mean_out=mean_out) if rest else y
-    t = th.bmm(wt[:, cs:].unsqueeze(0).expand(bs, -1, -1), ctx3).contiguous()
+    t = context_term(wt[:, cs:]).contiguous()
     if t.dtype == th.float32 and funcs.pointwise_supported(xs, cout):
         tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)
         y = funcs.PointwiseLayer.apply(xs, wt[:, :cs], conv.bias, tt, S, act[0], act[1])
@@ -414,11 +422,19 @@ class Autoencoder(nn.Module):
                 activation=activation, pooling=pooling)
         self.add_module("net", coarser)
 
+    #: hand the result back in channels-last memory order when the U-net ran that way (Multisteps sets it: its
+    #: consumer, the context product of the next 1x1 chain, reads either layout without a copy)
+    keep_channels_last = False
+
     def forward(self, x):
         if unet_channels_last(self, x):
-            # channels-last between the convolutions (MIOpen's NHWC-native solvers need no transposes then),
-            # planar again for the per-sample 1x1 kernels that consume the result
-            return self.net(x.contiguous(memory_format=th.channels_last)).contiguous()
+            # channels-last between the convolutions: MIOpen's NHWC-native solvers need no transposes then
+            xin = funcs.ToChannelsLast.apply(x) if funcs.ToChannelsLast.supported(x) \
+                else x.contiguous(memory_format=th.channels_last)
+            y = self.net(xin)
+            if self.keep_channels_last:
+                return y
+            return funcs.FromChannelsLast.apply(y) if funcs.FromChannelsLast.supported(y) else y.contiguous()
         return self.net(x)
 
     class _Level(nn.Module):
