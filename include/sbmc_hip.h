@@ -457,6 +457,11 @@ SBMC_API int sbmc_upsample2x_cat_nhwc_fwd_f32(const float *coarse, const float *
                                      int cl, int h, int w, void *stream);
 SBMC_API int sbmc_upsample2x_cat_nhwc_bwd_f32(const float *gout, float *gcoarse, float *gleft, int b, int cu,
                                      int cl, int h, int w, void *stream);
+/* row-slab form of the two (see sbmc_upsample2x_cat_slab_*): coarse / gcoarse hold hc = top + h + bot rows */
+SBMC_API int sbmc_upsample2x_cat_nhwc_slab_fwd_f32(const float *coarse, const float *left, float *out, int b,
+                                          int cu, int cl, int hc, int w, int top, int bot, void *stream);
+SBMC_API int sbmc_upsample2x_cat_nhwc_slab_bwd_f32(const float *gout, float *gcoarse, float *gleft, int b,
+                                          int cu, int cl, int hc, int w, int top, int bot, void *stream);
 
 #ifdef __cplusplus
 }

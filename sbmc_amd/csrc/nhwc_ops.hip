@@ -66,9 +66,12 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __r
 }
 
 // out[b, y, x, :cu] = bilinear x2 of coarse[b, :, :, :cu] (align_corners = False), out[b, y, x, cu:] = left
+// Row-slab form (sbmc_amd/dist.py): coarse holds hc = top + h + bot rows, the first `top` / last `bot` (0 or 1)
+// being the neighbouring slabs' edge rows; out / left are the 2h fine rows of this slab (see resample.hip).
 __global__ __launch_bounds__(256) void upcat_nhwc_fwd_kernel(const float* __restrict__ coarse, const float* __restrict__ left,
-                                                            float* __restrict__ out, int cu4, int cl4, int h, int w,
-                                                            size_t total4) {
+                                                            float* __restrict__ out, int cu4, int cl4, int hc, int w,
+                                                            int top, int bot, size_t total4) {
+    const int h = hc - top - bot;
     const int W = 2 * w, H = 2 * h, ct4 = cu4 + cl4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(idx % ct4);
@@ -84,10 +87,11 @@ __global__ __launch_bounds__(256) void upcat_nhwc_fwd_kernel(const float* __rest
             // source coordinate 0.5 * dst - 0.25 clamped at 0: even dst -> (i-1: .25, i: .75), odd -> (i: .75, i+1: .25)
             int r0, r1, c0, c1;
             float ly, lx;                                     // weights of r1 / c1
-            const int i = y >> 1, j = x >> 1;
-            if (y == 0) { r0 = r1 = 0; ly = 0.f; } else if (y & 1) { r0 = i; r1 = i + 1 < h ? i + 1 : i; ly = 0.25f; } else { r0 = i - 1; r1 = i; ly = 0.75f; }
+            const int yf = y + 2 * top;                       // row of the upsampled (padded) coarse map
+            const int i = yf >> 1, j = x >> 1;
+            if (yf == 0) { r0 = r1 = 0; ly = 0.f; } else if (yf & 1) { r0 = i; r1 = i + 1 < hc ? i + 1 : i; ly = 0.25f; } else { r0 = i - 1; r1 = i; ly = 0.75f; }
             if (x == 0) { c0 = c1 = 0; lx = 0.f; } else if (x & 1) { c0 = j; c1 = j + 1 < w ? j + 1 : j; lx = 0.25f; } else { c0 = j - 1; c1 = j; lx = 0.75f; }
-            const float4* cz = reinterpret_cast<const float4*>(coarse) + (b * h) * (size_t)w * cu4 + q;
+            const float4* cz = reinterpret_cast<const float4*>(coarse) + (b * hc) * (size_t)w * cu4 + q;
             const float4 a = cz[((size_t)r0 * w + c0) * cu4], bq = cz[((size_t)r0 * w + c1) * cu4];
             const float4 c = cz[((size_t)r1 * w + c0) * cu4], d = cz[((size_t)r1 * w + c1) * cu4];
             const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
@@ -104,18 +108,20 @@ __global__ __launch_bounds__(256) void upcat_nhwc_fwd_kernel(const float* __rest
 // that fell off the image was clamped onto the border row / column in the forward: its weight comes back there.
 // gleft (may be null) = gout[..., cu:] as a contiguous tensor.
 __global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gcoarse,
-                                                            int cu4, int cl4, int h, int w, size_t total4) {
+                                                            int cu4, int cl4, int hc, int w, int top, int bot,
+                                                            size_t total4) {
+    const int h = hc - top - bot;
     const int W = 2 * w, H = 2 * h, ct4 = cu4 + cl4;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(idx % cu4);
         size_t rest = idx / cu4;
         const int j = (int)(rest % w);
         rest /= w;
-        const int i = (int)(rest % h);
-        const size_t b = rest / h;
+        const int i = (int)(rest % hc);                      // coarse row (of the hc padded rows)
+        const size_t b = rest / hc;
         float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-        if (i == 0) { wy[0] = 0.f; wy[1] = 1.f; }
-        if (i == h - 1) { wy[3] = 0.f; wy[2] = 1.f; }
+        if (i == 0 && top == 0) { wy[0] = 0.f; wy[1] = 1.f; }            // true image borders only
+        if (i == hc - 1 && bot == 0) { wy[3] = 0.f; wy[2] = 1.f; }
         if (j == 0) { wx[0] = 0.f; wx[1] = 1.f; }
         if (j == w - 1) { wx[3] = 0.f; wx[2] = 1.f; }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -123,7 +129,8 @@ __global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const float* __rest
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy) {
             if (wy[dy] == 0.f) continue;
-            const int yy = 2 * i - 1 + dy;
+            const int yy = 2 * i - 1 + dy - 2 * top;           // fine row of this slab; outside: another slab's share
+            if (yy < 0 || yy >= H) continue;
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx) {
                 if (wx[dx] == 0.f) continue;
@@ -231,28 +238,32 @@ extern "C" int sbmc_upsample2x_cat_nhwc_supported(int cu, int cl, int h, int w) 
     return (cu >= 4 && cu % 4 == 0 && cl >= 0 && cl % 4 == 0 && h >= 1 && w >= 1) ? 1 : 0;
 }
 
-extern "C" int sbmc_upsample2x_cat_nhwc_fwd_f32(const float* coarse, const float* left, float* out, int b, int cu,
-                                                int cl, int h, int w, void* stream) {
-    if (b < 0 || !sbmc_upsample2x_cat_nhwc_supported(cu, cl, h, w)) return SBMC_HIP_EINVAL;
+static int upcat_nhwc_fwd_impl(const float* coarse, const float* left, float* out, int b, int cu, int cl, int hc,
+                               int w, int top, int bot, void* stream) {
+    const int h = hc - top - bot;
+    if (b < 0 || top < 0 || top > 1 || bot < 0 || bot > 1 || !sbmc_upsample2x_cat_nhwc_supported(cu, cl, h, w))
+        return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!coarse || !out || (cl > 0 && !left) || (uintptr_t)coarse % 16 || (uintptr_t)out % 16 || (uintptr_t)left % 16)
         return SBMC_HIP_EINVAL;
     const size_t total4 = (size_t)b * (2 * (size_t)h) * (2 * (size_t)w) * ((cu + cl) / 4);
     hipLaunchKernelGGL(upcat_nhwc_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, coarse, left,
-                       out, cu / 4, cl / 4, h, w, total4);
+                       out, cu / 4, cl / 4, hc, w, top, bot, total4);
     return (int)hipGetLastError();
 }
 
-extern "C" int sbmc_upsample2x_cat_nhwc_bwd_f32(const float* gout, float* gcoarse, float* gleft, int b, int cu, int cl,
-                                                int h, int w, void* stream) {
-    if (b < 0 || !sbmc_upsample2x_cat_nhwc_supported(cu, cl, h, w)) return SBMC_HIP_EINVAL;
+static int upcat_nhwc_bwd_impl(const float* gout, float* gcoarse, float* gleft, int b, int cu, int cl, int hc, int w,
+                               int top, int bot, void* stream) {
+    const int h = hc - top - bot;
+    if (b < 0 || top < 0 || top > 1 || bot < 0 || bot > 1 || !sbmc_upsample2x_cat_nhwc_supported(cu, cl, h, w))
+        return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!gout || (!gcoarse && !gleft) || (uintptr_t)gout % 16 || (uintptr_t)gcoarse % 16 || (uintptr_t)gleft % 16)
         return SBMC_HIP_EINVAL;
     if (gcoarse) {
-        const size_t total4 = (size_t)b * h * w * (cu / 4);
+        const size_t total4 = (size_t)b * hc * w * (cu / 4);
         hipLaunchKernelGGL(upcat_nhwc_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, gout,
-                           gcoarse, cu / 4, cl / 4, h, w, total4);
+                           gcoarse, cu / 4, cl / 4, hc, w, top, bot, total4);
         const int err = (int)hipGetLastError();
         if (err) return err;
     }
@@ -262,6 +273,23 @@ extern "C" int sbmc_upsample2x_cat_nhwc_bwd_f32(const float* gout, float* gcoars
                            gleft, (cu + cl) / 4, cu / 4, cl / 4, total4);
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_upsample2x_cat_nhwc_fwd_f32(const float* coarse, const float* left, float* out, int b, int cu,
+                                                int cl, int h, int w, void* stream) {
+    return upcat_nhwc_fwd_impl(coarse, left, out, b, cu, cl, h, w, 0, 0, stream);
+}
+extern "C" int sbmc_upsample2x_cat_nhwc_bwd_f32(const float* gout, float* gcoarse, float* gleft, int b, int cu, int cl,
+                                                int h, int w, void* stream) {
+    return upcat_nhwc_bwd_impl(gout, gcoarse, gleft, b, cu, cl, h, w, 0, 0, stream);
+}
+extern "C" int sbmc_upsample2x_cat_nhwc_slab_fwd_f32(const float* coarse, const float* left, float* out, int b, int cu,
+                                                     int cl, int hc, int w, int top, int bot, void* stream) {
+    return upcat_nhwc_fwd_impl(coarse, left, out, b, cu, cl, hc, w, top, bot, stream);
+}
+extern "C" int sbmc_upsample2x_cat_nhwc_slab_bwd_f32(const float* gout, float* gcoarse, float* gleft, int b, int cu,
+                                                     int cl, int hc, int w, int top, int bot, void* stream) {
+    return upcat_nhwc_bwd_impl(gout, gcoarse, gleft, b, cu, cl, hc, w, top, bot, stream);
 }
 
 extern "C" int sbmc_transpose2d_f32(const float* src, float* dst, int b, int rows, int cols, void* stream) {

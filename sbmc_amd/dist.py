@@ -121,6 +121,21 @@ class _HaloPad(th.autograd.Function):
         if x.shape[-2] < r:
             raise RuntimeError("slab of %d rows is thinner than the halo (%d)" % (x.shape[-2], r))
         from_up, from_down = _exchange(part, x[..., :r, :], x[..., -r:, :])
+        if funcs._is_channels_last(x):
+            # keep the U-net's channels-last order: with one image per rank a run of rows is one contiguous
+            # block of [row, column, channel] memory, so the body is a plain copy and the halo rows (which
+            # travel in planar order) are the only elements that get re-ordered
+            top = r if from_up is not None else 0
+            bot = r if from_down is not None else 0
+            h = x.shape[-2]
+            out = th.empty(x.shape[:-2] + (top + h + bot, x.shape[-1]), dtype=x.dtype, device=x.device,
+                           memory_format=th.channels_last)
+            out[..., top:top + h, :].copy_(x)
+            if from_up is not None:
+                out[..., :top, :].copy_(from_up)
+            if from_down is not None:
+                out[..., top + h:, :].copy_(from_down)
+            return out
         pieces = [t for t in (from_up, x, from_down) if t is not None]
         return th.cat(pieces, -2) if len(pieces) > 1 else x.clone()
 
@@ -193,6 +208,8 @@ def _level(level, x, part):
     coarse = _level(level.next_level, level.downsample(left), part)
     padded = halo_pad(coarse, 1, part)
     top, bot = int(part.has_up), int(part.has_down)
+    if funcs.upsample_cat_nhwc_supported(padded, left, top, bot):
+        return _chain(level.right, funcs.UpsampleCatNHWC.apply(padded, left, top, bot), part)
     if funcs.upsample_cat_supported(padded, left, top, bot):
         # one pass, the upsampled tensor never exists (functions.UpsampleCat in its row-slab form)
         return _chain(level.right, funcs.UpsampleCat.apply(padded, left, top, bot), part)
@@ -203,9 +220,23 @@ def _level(level, x, part):
 
 
 def sharded_autoencoder(autoencoder, x, part):
-    """`modules.Autoencoder.forward` on a row slab (exact, see the module docstring)."""
+    """`modules.Autoencoder.forward` on a row slab (exact, see the module docstring).  Like the whole-frame
+    U-net it runs channels-last when that measures faster for this slab's shape (modules.unet_channels_last:
+    MIOpen's NHWC solvers, given find records for the shape; cropping rows of a channels-last map is free)."""
     if part.world == 1:
         return autoencoder(x)
+    from . import modules as ops
+    # (ranks may decide differently -- an edge rank convolves a different height: the exchange is
+    # layout-agnostic, correctness does not depend on the ranks agreeing)
+    reach = _reach(autoencoder.net.left)
+    rows = x.shape[-2] + reach * (int(part.has_up) + int(part.has_down))     # what the first chain convolves
+    if ops.unet_channels_last(autoencoder, x, rows=rows):
+        xin = funcs.ToChannelsLast.apply(x) if funcs.ToChannelsLast.supported(x) \
+            else x.contiguous(memory_format=th.channels_last)
+        y = _level(autoencoder.net, xin, part)
+        if autoencoder.keep_channels_last:
+            return y
+        return funcs.FromChannelsLast.apply(y) if funcs.FromChannelsLast.supported(y) else y.contiguous()
     return _level(autoencoder.net, x, part)
 
 

@@ -173,13 +173,14 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
 _LAYOUT_DECISIONS = {}
 
 
-def unet_channels_last(net, x):
+def unet_channels_last(net, x, rows=None):
     """Should this U-net run channels-last on this input?  MEASURED, once per (channels, height, width,
     training?) and process: one 3x3 convolution of the net's width at the input's resolution, forward (and
     backward when gradients are on), in both layouts.  With the find records of `sbmc_amd.miopen_db` MIOpen
     picks its NHWC implicit-GEMM solvers and channels-last wins by the NCHW<->NHWC transposes it no longer
     needs; without a matching record (another GPU, MIOpen build or frame size) its heuristic choice for
     channels-last fp32 can be many times slower, and the U-net stays planar.
+    rows: measure at this height instead of x's (a row slab is convolved together with its halo rows).
     SBMC_UNET_LAYOUT = nchw | nhwc overrides the measurement."""
     import os
     mode = os.environ.get("SBMC_UNET_LAYOUT", "auto").lower()
@@ -189,9 +190,10 @@ def unet_channels_last(net, x):
     if mode == "nhwc":
         return True
     grad = th.is_grad_enabled() and any(q.requires_grad for q in net.parameters())
-    key = (x.device.index, x.shape[0], x.shape[1], x.shape[2], x.shape[3], grad)
+    shape = (x.shape[0], x.shape[1], int(rows) if rows else x.shape[2], x.shape[3])
+    key = (x.device.index,) + shape + (grad,)
     if key not in _LAYOUT_DECISIONS:
-        _LAYOUT_DECISIONS[key] = _measure_layouts(x.shape, x.device, grad)
+        _LAYOUT_DECISIONS[key] = _measure_layouts(shape, x.device, grad)
     return _LAYOUT_DECISIONS[key]
 
 

@@ -28,8 +28,9 @@ def _close(a, b, rtol, what):
     assert err <= rtol * max(scale, 1e-30) + 1e-12, "%s: err %.3e scale %.3e" % (what, err, scale)
 
 
-def _worker(rank, world, port, height):
+def _worker(rank, world, port, height, layout="auto"):
     sys.path.insert(0, ROOT)
+    os.environ["SBMC_UNET_LAYOUT"] = layout
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -75,5 +76,9 @@ def _worker(rank, world, port, height):
         dist.destroy_process_group()
 
 
-def test_sharded_denoiser_on_device_kernels():
-    mp.spawn(_worker, args=(2, _free_port(), 64), nprocs=2, join=True)
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_sharded_denoiser_on_device_kernels(layout):
+    """layout: the U-nets planar, or channels-last (MIOpen NHWC solvers, NHWC glue kernels in their
+    row-slab forms, layout-preserving halo padding) -- forced, so that both run whatever the measurement
+    would pick on this box."""
+    mp.spawn(_worker, args=(2, _free_port(), 64, layout), nprocs=2, join=True)

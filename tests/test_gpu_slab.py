@@ -166,3 +166,28 @@ def test_upsample_cat_row_slab(shape, top, bot):
     close(out, ref, rtol=1e-6, what="output")
     close(cb.grad, ca.grad, rtol=1e-5, what="d_coarse")
     assert th.equal(lb.grad, la.grad)
+
+
+@pytest.mark.parametrize("top,bot", [(1, 1), (1, 0), (0, 1)])
+@pytest.mark.parametrize("shape", [(1, 8, 4, 6, 10), (1, 16, 8, 11, 64)])
+def test_upsample_cat_row_slab_channels_last(shape, top, bot):
+    """The channels-last form of the same (the U-nets run NHWC when that measures faster)."""
+    import torch.nn.functional as nnf
+    from sbmc_amd import functions as F
+    b, cu, cl, h, w = shape
+    hc = h + top + bot
+    th.manual_seed(sum(shape) + top + 2 * bot)
+    c0 = th.randn(b, cu, hc, w, device="cuda").contiguous(memory_format=th.channels_last)
+    l0 = th.randn(b, cl, 2 * h, 2 * w, device="cuda").contiguous(memory_format=th.channels_last)
+    ca, la = c0.clone().requires_grad_(), l0.clone().requires_grad_()
+    up = nnf.interpolate(ca, scale_factor=2, mode="bilinear", align_corners=False)
+    ref = th.cat([up[..., 2 * top:2 * hc - 2 * bot, :], la], 1)
+    g = th.randn_like(ref)
+    ref.backward(g)
+    cb, lb = c0.clone().requires_grad_(), l0.clone().requires_grad_()
+    assert F.upsample_cat_nhwc_supported(cb, lb, top, bot)
+    out = F.UpsampleCatNHWC.apply(cb, lb, top, bot)
+    out.backward(g)
+    close(out, ref, rtol=1e-6, what="output")
+    close(cb.grad, ca.grad, rtol=1e-5, what="d_coarse")
+    close(lb.grad, la.grad, rtol=0, what="d_left")

@@ -1,6 +1,6 @@
 """Produces the MIOpen find records shipped in sbmc_amd/miopen_db/ (run on an MI355X through gpurun):
 
-    MIOPEN_FIND_MODE=1 MIOPEN_USER_DB_PATH=<dir> python tools/make_miopen_db.py [--layout nhwc|nchw] [--ranks N] [--4k]
+    MIOPEN_FIND_MODE=1 MIOPEN_USER_DB_PATH=<dir> python tools/make_miopen_db.py [--layout nhwc|nchw] [--ranks N [--rank R]] [--4k]
 
 One training step (forward + backward: all three convolution directions) of Multisteps(93,3) at 1280x720 with
 MIOpen's full find, so that MIOpen writes what it measured for every convolution configuration of the U-nets
@@ -18,6 +18,7 @@ from sbmc_amd import Multisteps, losses
 from sbmc_amd import dist as sdist
 
 ranks = int(sys.argv[sys.argv.index("--ranks") + 1]) if "--ranks" in sys.argv else 1
+rank = int(sys.argv[sys.argv.index("--rank") + 1]) if "--rank" in sys.argv else ranks // 2
 H, W = (2160, 3840) if "--4k" in sys.argv else (720, 1280)
 dev = th.device("cuda")
 th.manual_seed(0)
@@ -31,11 +32,11 @@ if ranks == 1:
 else:
     sdist._exchange = lambda part, a, b: (th.zeros_like(a) if part.has_up else None, th.zeros_like(b) if part.has_down else None)
     sdist._all_reduce_sum = lambda t, part: t.cuda() if not t.is_cuda else t
-    part = sdist.SlabPartition(H, ranks, ranks // 2)
+    part = sdist.SlabPartition(H, ranks, rank)
     batch = bench.make_model_inputs(H, W, 8, dev, seed=1, rows=(part.y0, part.y1))
     sdist.ShardedDenoiser(model, part).train_step(opt, loss_fn, batch)
 th.cuda.synchronize()
-print("find + one step (%s, %d rank(s), %dx%d): %.0f s" % (layout, ranks, W, H, time.time() - t0), flush=True)
+print("find + one step (%s, rank %d of %d, %dx%d): %.0f s" % (layout, rank, ranks, W, H, time.time() - t0), flush=True)
 for f in os.listdir(os.environ["MIOPEN_USER_DB_PATH"]):
     p = os.path.join(os.environ["MIOPEN_USER_DB_PATH"], f)
     print(f, os.path.getsize(p), "bytes", sum(1 for _ in open(p)) if f.endswith(".txt") else "")
