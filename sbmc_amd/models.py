@@ -62,9 +62,10 @@ class Multisteps(nn.Module):
             (rocBLAS / hipBLASLt) instead of MIOpen convolutions: same arithmetic, no layout
             change, ~7% faster training step at 720p.  Not a reference argument.
             The same switch makes the U-nets run their 3x3 convolutions without bias followed by
-            one fused in-place bias / activation pass per direction (functions.BiasAct).
-            (NHWC activations for the U-nets were measured too: MIOpen's heuristic solver
-            choice for NHWC fp32 made the step 5x slower, so the backbone stays NCHW.)
+            one fused in-place bias / activation pass per direction (functions.BiasAct / BiasActNHWC),
+            and lets them run channels-last where that MEASURES faster (modules.unet_channels_last:
+            MIOpen's NHWC solvers, given the find records of sbmc_amd.miopen_db), handing their result
+            to the next 1x1 chain without a layout copy.
     """
 
     def __init__(self, n_features, n_global_features, width=128,
