@@ -448,6 +448,10 @@ __global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
 // banks); pitch 65 is conflict-free for both but needs dword staging stores -- measured 4 % slower.
 // Same software pipeline as the forward: next tile's gy / y / x in flight during the MFMAs, the
 // previous tile's gx stored between them.
+#ifndef PW_BWD_PIPE
+#define PW_BWD_PIPE 0     // 1 = keep a tile's gx in registers and store it between the next tile's MFMAs: 16 more
+                          // live registers = 10-12 spilled VGPRs at 2 waves/SIMD; measured 4.98 ms vs 4.66 ms without
+#endif
 constexpr int PB_NT = 64;
 constexpr int PB_PITCH = 66;
 
@@ -498,10 +502,9 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     const TXT* x_g = static_cast<const TXT*>(p.x);
     TXT* gx_g = static_cast<TXT*>(p.gx);
     constexpr unsigned SA = (unsigned)sizeof(TA), SX = (unsigned)sizeof(TXT);
-    // gx of a tile is stored between the MFMAs of the next one; the variants that carry 16 more
-    // registers (per-pixel context sums, mean-gradient tile) have none left for that and store it
-    // right away
-    constexpr bool PIPE = !TPIX && !GM;
+    // gx of a tile is stored right away.  (PW_BWD_PIPE = 1 holds it back and stores it between the MFMAs of
+    // the next tile, as the forward does with y: here that costs spills, see the knob.)
+    constexpr bool PIPE = PW_BWD_PIPE && !TPIX && !GM;
     extern __shared__ float4 pw_lds[];
     float* lds = reinterpret_cast<float*>(pw_lds);
     constexpr int BUF = (128 + KP) * PB_PITCH;          // floats per pipeline stage: gz tile, then x tile
