@@ -377,10 +377,11 @@ class ShardedDenoiser(object):
         flat.zero_()                                   # == optimizer.zero_grad(), keeping the views
         out = self.forward(batch)["radiance"]
         tgt = self.target_rows(batch["target_image"])
-        count = th.tensor([float(out.numel())])
-        if part.world > 1:
-            count = _all_reduce_sum(count, part)
-        loss = loss_fn(out, tgt) * (out.numel() / count.item())   # this rank's share of the global mean
+        # this rank's share of the global mean: the frame's output size is known from the partition (the
+        # model crops (ksize-1)/2 pixels on every side), no collective and no host synchronisation needed
+        p = (self.model.ksize - 1) // 2
+        total = out.shape[0] * out.shape[1] * (part.height - 2 * p) * out.shape[-1]
+        loss = loss_fn(out, tgt) * (out.numel() / float(total))
         loss.backward()                                # accumulates into the views, in place
         flat[-1] = loss.detach()
         if part.world > 1:
@@ -388,7 +389,7 @@ class ShardedDenoiser(object):
             if summed.data_ptr() != flat.data_ptr():
                 flat.copy_(summed)
         total = flat[-1]
-        if not th.isfinite(total).item():
+        if not th.isfinite(total).item():              # the step's one host synchronisation (reference guard)
             raise RuntimeError("non-finite loss")
         th.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
         optimizer.step()
