@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC counters of the fused 1x1-layer kernels (one counter group per run, kernel-trace only):
-# HBM traffic, MFMA busy cycles, LDS bank conflicts.  Summary -> gpurun_out/profiles_pw/r01_pointwise_pmc.txt
+# HBM traffic, MFMA busy cycles, LDS bank conflicts.  Summary -> gpurun_out/profiles_pw/r02_pointwise_pmc.txt
 root=/root/repo
 out=$root/gpurun_out/prof_pw
 sum=$root/gpurun_out/profiles_pw
@@ -11,7 +11,7 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   i=$((i+1))
   rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $out/p$i -o p -- python $root/tools/bench_pointwise.py --notest --time --bwd > $out/p$i.log 2>&1
 done
-python - $out $sum/r01_pointwise_pmc.txt <<'PY'
+python - $out $sum/r02_pointwise_pmc.txt <<'PY'
 import collections, csv, glob, os, sys
 root, dst = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: [0.0, 0])
