@@ -1,0 +1,41 @@
+"""bench.py as the driver calls it: `python bench.py --gpus N ...` must start its own ranks and print ONE JSON
+line on rank 0.  Two ranks on ONE GPU over gloo (test hooks SBMC_BENCH_BACKEND / SBMC_BENCH_SINGLE_DEVICE):
+everything but the RCCL transport, on a tiny frame."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--height", "64", "--width", "96", "--spp", "2", "--ksize", "5", "--steps", "2", "--warmup", "2",
+         "--no-cpu-baseline", "--no-stages"]
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         env=e, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    d = _run(SMALL)
+    assert d["n_gpus"] == 1 and d["world_size"] == 1 and d["value"] > 0 and d["unit"] == "Msamples/s"
+    assert d["steps"] == 2 and d["higher_is_better"] is True and d["dtype"] == "f32"
+    assert d["ms_per_step_median"] > 0 and len(d["ms_per_step_min_max"]) == 2
+
+
+@pytest.mark.parametrize("workload", ["model", "splat", "infer"])
+def test_bench_starts_its_own_ranks(workload):
+    d = _run(["--gpus", "2", "--workload", workload] + SMALL,
+             env={"SBMC_BENCH_BACKEND": "gloo", "SBMC_BENCH_SINGLE_DEVICE": "1"})
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo"
+    assert d["value"] > 0 and d["scaling"] == "strong"
+    assert "H-slabs x2" in d["config"]["parallelism"]
