@@ -184,26 +184,28 @@ def unet_channels_last(net, x, rows=None):
     SBMC_UNET_LAYOUT = nchw | nhwc overrides the measurement."""
     import os
     mode = os.environ.get("SBMC_UNET_LAYOUT", "auto").lower()
-    if (mode == "nchw" or not x.is_cuda or x.dtype != th.float32 or x.dim() != 4 or th.is_autocast_enabled()
-            or x.shape[1] % 4 or x.numel() == 0):
+    half = th.is_autocast_enabled() and th.get_autocast_dtype("cuda") == th.float16
+    if (mode == "nchw" or not x.is_cuda or x.dim() != 4 or x.shape[1] % 4 or x.numel() == 0
+            or x.dtype not in (th.float32, th.float16) or (th.is_autocast_enabled() and not half)):
         return False
     if mode == "nhwc":
         return True
     grad = th.is_grad_enabled() and any(q.requires_grad for q in net.parameters())
     shape = (x.shape[0], x.shape[1], int(rows) if rows else x.shape[2], x.shape[3])
-    key = (x.device.index,) + shape + (grad,)
+    dtype = th.float16 if (half or x.dtype == th.float16) else th.float32     # what MIOpen will convolve in
+    key = (x.device.index,) + shape + (grad, dtype)
     if key not in _LAYOUT_DECISIONS:
-        _LAYOUT_DECISIONS[key] = _measure_layouts(shape, x.device, grad)
+        _LAYOUT_DECISIONS[key] = _measure_layouts(shape, x.device, grad, dtype)
     return _LAYOUT_DECISIONS[key]
 
 
-def _measure_layouts(shape, device, grad):
+def _measure_layouts(shape, device, grad, dtype=th.float32):
     b, c, h, w = shape
     times = {}
-    with th.enable_grad():
+    with th.enable_grad(), th.autocast("cuda", enabled=False):
         for cl in (False, True):
-            xin = th.zeros(b, c, h, w, device=device)
-            wt = th.zeros(c, c, 3, 3, device=device)
+            xin = th.zeros(b, c, h, w, device=device, dtype=dtype)
+            wt = th.zeros(c, c, 3, 3, device=device, dtype=dtype)
             if cl:
                 xin = xin.contiguous(memory_format=th.channels_last)
                 wt = wt.contiguous(memory_format=th.channels_last)

@@ -1,6 +1,6 @@
 """Produces the MIOpen find records shipped in sbmc_amd/miopen_db/ (run on an MI355X through gpurun):
 
-    MIOPEN_FIND_MODE=1 MIOPEN_USER_DB_PATH=<dir> python tools/make_miopen_db.py [--layout nhwc|nchw] [--ranks N [--rank R]] [--4k]
+    MIOPEN_FIND_MODE=1 MIOPEN_USER_DB_PATH=<dir> python tools/make_miopen_db.py [--layout nhwc|nchw] [--ranks N [--rank R]] [--4k] [--fp16]
 
 One training step (forward + backward: all three convolution directions) of Multisteps(93,3) at 1280x720 with
 MIOpen's full find, so that MIOpen writes what it measured for every convolution configuration of the U-nets
@@ -26,9 +26,10 @@ model = Multisteps(93, 3, ksize=21).to(dev).train()
 opt = th.optim.Adam(model.parameters(), lr=1e-4, fused=True)
 loss_fn = losses.TonemappedRelativeMSE()
 t0 = time.time()
+fp16 = "--fp16" in sys.argv          # records for the half convolutions of torch.autocast(float16)
 if ranks == 1:
     batch = bench.make_model_inputs(H, W, 8, dev, seed=1)
-    bench.train_step(model, opt, loss_fn, batch)
+    bench.train_step(model, opt, loss_fn, batch, fp16=fp16)
 else:
     sdist._exchange = lambda part, a, b: (th.zeros_like(a) if part.has_up else None, th.zeros_like(b) if part.has_down else None)
     sdist._all_reduce_sum = lambda t, part: t.cuda() if not t.is_cuda else t
