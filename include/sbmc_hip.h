@@ -462,6 +462,11 @@ SBMC_API int sbmc_upsample2x_cat_nhwc_slab_fwd_f32(const float *coarse, const fl
                                           int cu, int cl, int hc, int w, int top, int bot, void *stream);
 SBMC_API int sbmc_upsample2x_cat_nhwc_slab_bwd_f32(const float *gout, float *gcoarse, float *gleft, int b,
                                           int cu, int cl, int hc, int w, int top, int bot, void *stream);
+/* the same on _Float16 tensors (fp16 activations under torch.autocast): half storage, fp32 interpolation */
+SBMC_API int sbmc_upsample2x_cat_nhwc_slab_fwd_f16(const void *coarse, const void *left, void *out, int b,
+                                          int cu, int cl, int hc, int w, int top, int bot, void *stream);
+SBMC_API int sbmc_upsample2x_cat_nhwc_slab_bwd_f16(const void *gout, void *gcoarse, void *gleft, int b,
+                                          int cu, int cl, int hc, int w, int top, int bot, void *stream);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,8 @@ SYMBOLS = (
     "sbmc_upsample2x_cat_nhwc_bwd_f32",
     "sbmc_upsample2x_cat_nhwc_slab_fwd_f32",
     "sbmc_upsample2x_cat_nhwc_slab_bwd_f32",
+    "sbmc_upsample2x_cat_nhwc_slab_fwd_f16",
+    "sbmc_upsample2x_cat_nhwc_slab_bwd_f16",
 )
 ABI_VERSION = 2
 MAX_CHANNELS = 8
@@ -172,6 +174,8 @@ def lib():
     handle.sbmc_upsample2x_cat_nhwc_bwd_f32.argtypes = [p, p, p, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_nhwc_slab_fwd_f32.argtypes = [p, p, p, i, i, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_nhwc_slab_bwd_f32.argtypes = [p, p, p, i, i, i, i, i, i, i, p]
+    handle.sbmc_upsample2x_cat_nhwc_slab_fwd_f16.argtypes = handle.sbmc_upsample2x_cat_nhwc_slab_fwd_f32.argtypes
+    handle.sbmc_upsample2x_cat_nhwc_slab_bwd_f16.argtypes = handle.sbmc_upsample2x_cat_nhwc_slab_bwd_f32.argtypes
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t

@@ -17,6 +17,26 @@ namespace sbmc {
 
 __device__ __forceinline__ float nact(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// four consecutive channels of one pixel: 16 bytes of float or 8 bytes of _Float16 (fp16 activations under
+// torch.autocast: half storage, fp32 interpolation arithmetic)
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    static __device__ __forceinline__ float4 load(const float* p, size_t i) { return reinterpret_cast<const float4*>(p)[i]; }
+    static __device__ __forceinline__ void store(float* p, size_t i, float4 v) { reinterpret_cast<float4*>(p)[i] = v; }
+};
+template <> struct Quad<_Float16> {
+    using h4 = __attribute__((ext_vector_type(4))) _Float16;
+    static __device__ __forceinline__ float4 load(const _Float16* p, size_t i) {
+        const h4 h = reinterpret_cast<const h4*>(p)[i];
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+    static __device__ __forceinline__ void store(_Float16* p, size_t i, float4 v) {
+        h4 h;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        reinterpret_cast<h4*>(p)[i] = h;
+    }
+};
+
 // y [pixels, C] in place; one thread = one float4 of channels of one pixel
 __global__ __launch_bounds__(256) void bias_act_nhwc_fwd_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                                size_t total4, int c4n, float slope, int linear) {
@@ -68,8 +88,9 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __r
 // out[b, y, x, :cu] = bilinear x2 of coarse[b, :, :, :cu] (align_corners = False), out[b, y, x, cu:] = left
 // Row-slab form (sbmc_amd/dist.py): coarse holds hc = top + h + bot rows, the first `top` / last `bot` (0 or 1)
 // being the neighbouring slabs' edge rows; out / left are the 2h fine rows of this slab (see resample.hip).
-__global__ __launch_bounds__(256) void upcat_nhwc_fwd_kernel(const float* __restrict__ coarse, const float* __restrict__ left,
-                                                            float* __restrict__ out, int cu4, int cl4, int hc, int w,
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_nhwc_fwd_kernel(const T* __restrict__ coarse, const T* __restrict__ left,
+                                                            T* __restrict__ out, int cu4, int cl4, int hc, int w,
                                                             int top, int bot, size_t total4) {
     const int h = hc - top - bot;
     const int W = 2 * w, H = 2 * h, ct4 = cu4 + cl4;
@@ -82,7 +103,7 @@ __global__ __launch_bounds__(256) void upcat_nhwc_fwd_kernel(const float* __rest
         const size_t b = rest / H;
         float4 v;
         if (q >= cu4) {
-            v = reinterpret_cast<const float4*>(left)[((b * H + y) * W + x) * (size_t)cl4 + (q - cu4)];
+            v = Quad<T>::load(left, ((b * H + y) * W + x) * (size_t)cl4 + (q - cu4));
         } else {
             // source coordinate 0.5 * dst - 0.25 clamped at 0: even dst -> (i-1: .25, i: .75), odd -> (i: .75, i+1: .25)
             int r0, r1, c0, c1;
@@ -91,23 +112,26 @@ __global__ __launch_bounds__(256) void upcat_nhwc_fwd_kernel(const float* __rest
             const int i = yf >> 1, j = x >> 1;
             if (yf == 0) { r0 = r1 = 0; ly = 0.f; } else if (yf & 1) { r0 = i; r1 = i + 1 < hc ? i + 1 : i; ly = 0.25f; } else { r0 = i - 1; r1 = i; ly = 0.75f; }
             if (x == 0) { c0 = c1 = 0; lx = 0.f; } else if (x & 1) { c0 = j; c1 = j + 1 < w ? j + 1 : j; lx = 0.25f; } else { c0 = j - 1; c1 = j; lx = 0.75f; }
-            const float4* cz = reinterpret_cast<const float4*>(coarse) + (b * hc) * (size_t)w * cu4 + q;
-            const float4 a = cz[((size_t)r0 * w + c0) * cu4], bq = cz[((size_t)r0 * w + c1) * cu4];
-            const float4 c = cz[((size_t)r1 * w + c0) * cu4], d = cz[((size_t)r1 * w + c1) * cu4];
+            const size_t cz = (b * hc) * (size_t)w * cu4 + q;
+            const float4 a = Quad<T>::load(coarse, cz + ((size_t)r0 * w + c0) * cu4);
+            const float4 bq = Quad<T>::load(coarse, cz + ((size_t)r0 * w + c1) * cu4);
+            const float4 c = Quad<T>::load(coarse, cz + ((size_t)r1 * w + c0) * cu4);
+            const float4 d = Quad<T>::load(coarse, cz + ((size_t)r1 * w + c1) * cu4);
             const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
             v.x = w00 * a.x + w01 * bq.x + w10 * c.x + w11 * d.x;
             v.y = w00 * a.y + w01 * bq.y + w10 * c.y + w11 * d.y;
             v.z = w00 * a.z + w01 * bq.z + w10 * c.z + w11 * d.z;
             v.w = w00 * a.w + w01 * bq.w + w10 * c.w + w11 * d.w;
         }
-        reinterpret_cast<float4*>(out)[idx] = v;
+        Quad<T>::store(out, idx, v);
     }
 }
 
 // gcoarse[b, i, j, :] = sum over the <= 4x4 fine neighbours, separable weights {.25, .75, .75, .25}, a partner
 // that fell off the image was clamped onto the border row / column in the forward: its weight comes back there.
 // gleft (may be null) = gout[..., cu:] as a contiguous tensor.
-__global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gcoarse,
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const T* __restrict__ gout, T* __restrict__ gcoarse,
                                                             int cu4, int cl4, int hc, int w, int top, int bot,
                                                             size_t total4) {
     const int h = hc - top - bot;
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const float* __rest
         if (j == 0) { wx[0] = 0.f; wx[1] = 1.f; }
         if (j == w - 1) { wx[3] = 0.f; wx[2] = 1.f; }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4* g = reinterpret_cast<const float4*>(gout) + (b * H) * (size_t)W * ct4 + q;
+        const size_t g = (b * H) * (size_t)W * ct4 + q;
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy) {
             if (wy[dy] == 0.f) continue;
@@ -135,21 +159,22 @@ __global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const float* __rest
             for (int dx = 0; dx < 4; ++dx) {
                 if (wx[dx] == 0.f) continue;
                 const int xx = 2 * j - 1 + dx;
-                const float4 v = g[((size_t)yy * W + xx) * ct4];
+                const float4 v = Quad<T>::load(gout, g + ((size_t)yy * W + xx) * ct4);
                 const float wt = wy[dy] * wx[dx];
                 acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
             }
         }
-        reinterpret_cast<float4*>(gcoarse)[idx] = acc;
+        Quad<T>::store(gcoarse, idx, acc);
     }
 }
 
-__global__ __launch_bounds__(256) void slice_channels_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+template <typename T>
+__global__ __launch_bounds__(256) void slice_channels_nhwc_kernel(const T* __restrict__ src, T* __restrict__ dst,
                                                                  int ct4, int c0_4, int cn4, size_t total4) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
         const size_t px = idx / cn4;
         const int q = (int)(idx % cn4);
-        reinterpret_cast<float4*>(dst)[idx] = reinterpret_cast<const float4*>(src)[px * ct4 + c0_4 + q];
+        Quad<T>::store(dst, idx, Quad<T>::load(src, px * ct4 + c0_4 + q));
     }
 }
 
@@ -238,7 +263,8 @@ extern "C" int sbmc_upsample2x_cat_nhwc_supported(int cu, int cl, int h, int w) 
     return (cu >= 4 && cu % 4 == 0 && cl >= 0 && cl % 4 == 0 && h >= 1 && w >= 1) ? 1 : 0;
 }
 
-static int upcat_nhwc_fwd_impl(const float* coarse, const float* left, float* out, int b, int cu, int cl, int hc,
+template <typename T>
+static int upcat_nhwc_fwd_impl(const T* coarse, const T* left, T* out, int b, int cu, int cl, int hc,
                                int w, int top, int bot, void* stream) {
     const int h = hc - top - bot;
     if (b < 0 || top < 0 || top > 1 || bot < 0 || bot > 1 || !sbmc_upsample2x_cat_nhwc_supported(cu, cl, h, w))
@@ -247,12 +273,13 @@ static int upcat_nhwc_fwd_impl(const float* coarse, const float* left, float* ou
     if (!coarse || !out || (cl > 0 && !left) || (uintptr_t)coarse % 16 || (uintptr_t)out % 16 || (uintptr_t)left % 16)
         return SBMC_HIP_EINVAL;
     const size_t total4 = (size_t)b * (2 * (size_t)h) * (2 * (size_t)w) * ((cu + cl) / 4);
-    hipLaunchKernelGGL(upcat_nhwc_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, coarse, left,
-                       out, cu / 4, cl / 4, hc, w, top, bot, total4);
+    hipLaunchKernelGGL((upcat_nhwc_fwd_kernel<T>), dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, coarse,
+                       left, out, cu / 4, cl / 4, hc, w, top, bot, total4);
     return (int)hipGetLastError();
 }
 
-static int upcat_nhwc_bwd_impl(const float* gout, float* gcoarse, float* gleft, int b, int cu, int cl, int hc, int w,
+template <typename T>
+static int upcat_nhwc_bwd_impl(const T* gout, T* gcoarse, T* gleft, int b, int cu, int cl, int hc, int w,
                                int top, int bot, void* stream) {
     const int h = hc - top - bot;
     if (b < 0 || top < 0 || top > 1 || bot < 0 || bot > 1 || !sbmc_upsample2x_cat_nhwc_supported(cu, cl, h, w))
@@ -262,15 +289,15 @@ static int upcat_nhwc_bwd_impl(const float* gout, float* gcoarse, float* gleft, 
         return SBMC_HIP_EINVAL;
     if (gcoarse) {
         const size_t total4 = (size_t)b * hc * w * (cu / 4);
-        hipLaunchKernelGGL(upcat_nhwc_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, gout,
+        hipLaunchKernelGGL((upcat_nhwc_bwd_kernel<T>), dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, gout,
                            gcoarse, cu / 4, cl / 4, hc, w, top, bot, total4);
         const int err = (int)hipGetLastError();
         if (err) return err;
     }
     if (gleft && cl > 0) {
         const size_t total4 = (size_t)b * (2 * (size_t)h) * (2 * (size_t)w) * (cl / 4);
-        hipLaunchKernelGGL(slice_channels_nhwc_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, gout,
-                           gleft, (cu + cl) / 4, cu / 4, cl / 4, total4);
+        hipLaunchKernelGGL((slice_channels_nhwc_kernel<T>), dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                           gout, gleft, (cu + cl) / 4, cu / 4, cl / 4, total4);
     }
     return (int)hipGetLastError();
 }
@@ -290,6 +317,16 @@ extern "C" int sbmc_upsample2x_cat_nhwc_slab_fwd_f32(const float* coarse, const 
 extern "C" int sbmc_upsample2x_cat_nhwc_slab_bwd_f32(const float* gout, float* gcoarse, float* gleft, int b, int cu,
                                                      int cl, int hc, int w, int top, int bot, void* stream) {
     return upcat_nhwc_bwd_impl(gout, gcoarse, gleft, b, cu, cl, hc, w, top, bot, stream);
+}
+extern "C" int sbmc_upsample2x_cat_nhwc_slab_fwd_f16(const void* coarse, const void* left, void* out, int b, int cu,
+                                                     int cl, int hc, int w, int top, int bot, void* stream) {
+    return upcat_nhwc_fwd_impl(static_cast<const _Float16*>(coarse), static_cast<const _Float16*>(left),
+                               static_cast<_Float16*>(out), b, cu, cl, hc, w, top, bot, stream);
+}
+extern "C" int sbmc_upsample2x_cat_nhwc_slab_bwd_f16(const void* gout, void* gcoarse, void* gleft, int b, int cu,
+                                                     int cl, int hc, int w, int top, int bot, void* stream) {
+    return upcat_nhwc_bwd_impl(static_cast<const _Float16*>(gout), static_cast<_Float16*>(gcoarse),
+                               static_cast<_Float16*>(gleft), b, cu, cl, hc, w, top, bot, stream);
 }
 
 extern "C" int sbmc_transpose2d_f32(const float* src, float* dst, int b, int rows, int cols, void* stream) {

@@ -764,6 +764,270 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The backward for half activations on the f16 matrix pipe (training under torch.autocast(float16)): gy, y, x
+// and gx are _Float16 in HBM, gz = gy * act'(y) is formed in fp32 and rounded to half once (what autocast's
+// activation backward hands to its convolution backward), the weights are rounded to half, every product is
+// exact and accumulates in fp32 (v_mfma_f32_32x32x8_f16); gw / gbias partial sums and gt stay fp32.  The fp32-MFMA
+// kernel above is matrix-pipe bound on half tensors (4.2 ms per 128 -> 128 layer at 720p x 8 spp, for 7.5 GB of
+// traffic); at 8x the MFMA rate this one is HBM-bound.
+//
+// Operand layouts.  gw[co][k] = sum over pixels of gz[co][px] x[k][px] wants, per lane, 4 consecutive PIXELS of a
+// row of gz / x: the natural planar order (row pitch 68 halves = 34 words: the 8-byte operand reads of 16 lanes
+// cover the 32 banks exactly once).  gx[k][px] = sum over co of w[co][k] gz[co][px] wants 4 consecutive ROWS of gz
+// per pixel: a second, quad-transposed image of the gz tile ([Cout/4][64] entries of 4 halves, as in
+// pw_fwd_h_kernel), written by the same staging thread that holds a 4 x 4 block of gz in registers.
+constexpr int PBH_PITCH = 68;
+
+template <int KP, bool DX, bool TPIX, bool GM>
+__global__ __launch_bounds__(PW_THREADS) void pw_bwd_h_kernel(PwBwdParams p) {
+    using H = _Float16;
+    const H* gy_g = static_cast<const H*>(p.gy);
+    const H* y_g = static_cast<const H*>(p.y);
+    const H* gm_g = static_cast<const H*>(p.gm);
+    const H* x_g = static_cast<const H*>(p.x);
+    H* gx_g = static_cast<H*>(p.gx);
+    extern __shared__ float4 pw_lds[];
+    constexpr int GZN = 128 * PBH_PITCH;                // halves: gz tile, natural order
+    constexpr int XN = KP * PBH_PITCH;                  // halves: x tile, natural order
+    constexpr int GZT = 32 * PB_NT * 4;                 // halves: gz tile, quad-transposed
+    constexpr int STAGE = GZN + XN + GZT;               // halves per pipeline stage (a multiple of 4)
+    H* lds = reinterpret_cast<H*>(pw_lds);
+    constexpr int NB = KP / 32;
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int rb = wave & 3, ph = wave >> 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const unsigned hw = p.hw;
+    const unsigned g = blockIdx.x, G = gridDim.x;
+    const bool masked = p.slope != 1.f;
+
+    // staging role: pixels 4 pgp .. 4 pgp + 3 of the rows 4 q .. 4 q + 3 (of gy / y / gm, and of x)
+    const unsigned pgp = threadIdx.x & 15, q = threadIdx.x >> 4;
+
+    // w^T rows of this wave as f16 A-operands for gx: a2[kk][i] = w[8 kk + 4 (lane / 32) + i][32 rb + lane % 32]
+    h4 a2[DX ? 16 : 1];
+    if (DX) {
+        const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
+        const int k = rb * 32 + l31;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = 8 * kk + 4 * lhi + i;
+                a2[kk][i] = (H)buf_load(rw, (co < p.Cout && k < p.K) ? (unsigned)(co * p.K + k) * 4u : PW_OOB, 0);
+            }
+        }
+    }
+
+    struct Cursor { unsigned unit, s; };
+    auto coords = [&](Cursor c, unsigned& b, unsigned& bq, unsigned& p0) {
+        bq = c.unit / p.tiles_per_plane;
+        p0 = (c.unit % p.tiles_per_plane) * PB_NT;
+        b = bq * (unsigned)p.S + c.s;
+    };
+    auto advance = [&](Cursor c) {
+        Cursor n;
+        n.s = c.s + 1;
+        n.unit = c.unit;
+        if (n.s == (unsigned)p.S) {
+            n.s = 0;
+            n.unit = c.unit + G;
+        }
+        return n;
+    };
+
+    u32x2 pg[4], py[4], pm[GM ? 4 : 1], px[4];
+    const float inv_sm = GM ? 1.f / (float)p.Sm : 0.f;
+    auto issue = [&](Cursor c) {
+        unsigned b, bq, p0;
+        coords(c, b, bq, p0);
+        const rsrc_t rg = make_rsrc_n(gy_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 2u);
+        const rsrc_t rm = make_rsrc_n(GM ? gm_g + (size_t)(b / (unsigned)p.Sm) * p.Cout * hw : gy_g,
+                                      (unsigned)p.Cout * hw * 2u);
+        const rsrc_t ry = make_rsrc_n(y_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 2u);
+        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * 2u);
+        const bool colok = p0 + 4 * pgp < hw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned row = 4u * q + r;
+            const unsigned off = (colok && row < (unsigned)p.Cout) ? (row * hw + p0 + 4 * pgp) * 2u : PW_OOB;
+            pg[r] = __builtin_amdgcn_raw_buffer_load_b64(rg, off, 0, 0);
+            if (masked) py[r] = __builtin_amdgcn_raw_buffer_load_b64(ry, off, 0, 0);
+            if (GM) pm[r] = __builtin_amdgcn_raw_buffer_load_b64(rm, off, 0, 0);
+        }
+        if (q < (unsigned)(KP / 4)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned row = 4u * q + r;
+                const unsigned off = (colok && row < (unsigned)p.K) ? (row * hw + p0 + 4 * pgp) * 2u : PW_OOB;
+                px[r] = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
+            }
+        }
+    };
+
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // row sums of gz (rows 4 q + r)
+    float4 gts[TPIX ? 4 : 1];                           // sum over the samples of a pixel of gz
+    if (TPIX) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gts[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto flush_bias = [&](unsigned bq) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = bsum[r];
+            v += __shfl_xor(v, 8, 16);
+            v += __shfl_xor(v, 4, 16);
+            v += __shfl_xor(v, 2, 16);
+            v += __shfl_xor(v, 1, 16);
+            const unsigned row = 4u * q + r;
+            if (pgp == 0 && row < (unsigned)p.Cout)
+                p.gbp[((size_t)g * p.Bq + bq) * p.Cout + row] += v;     // this workgroup's own slice
+            bsum[r] = 0.f;
+        }
+    };
+    auto commit = [&](Cursor c, int buf) {
+        unsigned b, bq, p0;
+        coords(c, b, bq, p0);
+        H* gzn = lds + buf * STAGE;
+        H* xn = gzn + GZN;
+        u32x2* gzt = reinterpret_cast<u32x2*>(xn + XN);
+        h4 gh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 gv = unpack4<H>(pg[r]);
+            if (GM) {
+                const float4 m = unpack4<H>(pm[r]);
+                gv.x += m.x * inv_sm; gv.y += m.y * inv_sm; gv.z += m.z * inv_sm; gv.w += m.w * inv_sm;
+            }
+            if (masked) {
+                const float4 v = unpack4<H>(py[r]);
+                gv.x = v.x > 0.f ? gv.x : gv.x * p.slope;
+                gv.y = v.y > 0.f ? gv.y : gv.y * p.slope;
+                gv.z = v.z > 0.f ? gv.z : gv.z * p.slope;
+                gv.w = v.w > 0.f ? gv.w : gv.w * p.slope;
+            }
+            bsum[r] += (gv.x + gv.y) + (gv.z + gv.w);
+            if (TPIX) {
+                gts[r].x += gv.x; gts[r].y += gv.y; gts[r].z += gv.z; gts[r].w += gv.w;
+            }
+            gh[r][0] = (H)gv.x; gh[r][1] = (H)gv.y; gh[r][2] = (H)gv.z; gh[r][3] = (H)gv.w;
+            *reinterpret_cast<u32x2*>(gzn + (4 * q + r) * PBH_PITCH + 4 * pgp) = __builtin_bit_cast(u32x2, gh[r]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h4 o;
+            o[0] = gh[0][j]; o[1] = gh[1][j]; o[2] = gh[2][j]; o[3] = gh[3][j];
+            gzt[q * PB_NT + 4 * pgp + j] = __builtin_bit_cast(u32x2, o);
+        }
+        if (q < (unsigned)(KP / 4)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<u32x2*>(xn + (4 * q + r) * PBH_PITCH + 4 * pgp) = px[r];
+        }
+        if (c.s + 1 == (unsigned)p.S) {                 // last sample of this pixel tile
+            if (TPIX) {
+                const rsrc_t rt = make_rsrc_n(p.gt + (size_t)bq * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned row = 4u * q + r;
+                    const unsigned off = (p0 + 4 * pgp < hw && row < (unsigned)p.Cout) ? (row * hw + p0 + 4 * pgp) * 4u : PW_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gts[r]), rt, off, 0, 0);
+                    gts[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (p.t_mode == 1) flush_bias(bq);
+        }
+    };
+
+    Cursor cur;
+    cur.unit = g;
+    cur.s = 0;
+    bool valid = cur.unit < p.nunits;
+    if (valid) {
+        issue(cur);
+        commit(cur, 0);
+    }
+    __syncthreads();
+
+    f32x16 acc_w[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc_w[0][j] = acc_w[1][j] = 0.f;
+
+    const int kr0 = rb * 32;
+    const int nkrows = p.K - kr0 < 32 ? (p.K - kr0 > 0 ? p.K - kr0 : 0) : 32;
+
+    int buf = 0;
+    while (valid) {
+        const Cursor nxt = advance(cur);
+        const bool nvalid = nxt.unit < p.nunits;
+        if (nvalid) issue(nxt);
+
+        unsigned b, bq, p0;
+        coords(cur, b, bq, p0);
+        const H* gzn = lds + buf * STAGE;
+        const H* xn = gzn + GZN;
+        const u32x2* gzt = reinterpret_cast<const u32x2*>(xn + XN);
+
+        // ---- gx tile: rows 32 rb .. of K, pixels 32 ph ..; reduction over cout
+        if (DX) {
+            f32x16 acc_x;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc_x[j] = 0.f;
+            const u32x2* gb = gzt + lhi * PB_NT + ph * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                acc_x = __builtin_amdgcn_mfma_f32_32x32x8f16(a2[kk], __builtin_bit_cast(h4, gb[(2 * kk) * PB_NT]), acc_x, 0, 0, 0);
+            const unsigned col = p0 + ph * 32 + l31;
+            const unsigned o = (col < hw && nkrows > 0) ? (4u * lhi * hw + col) * 2u : PW_OOB;
+            const rsrc_t rgx = make_rsrc_n(gx_g + ((size_t)b * p.K + kr0) * hw, (unsigned)nkrows * hw * 2u);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 2u;
+                logit_store<H>(acc_x[j], rgx, o != PW_OOB ? o + ro : PW_OOB, 0);
+            }
+        }
+        // ---- gw: rows 32 rb .. of cout, column blocks 2 ph, 2 ph + 1 of K; reduction over the 64 pixels
+        if (2 * ph < NB) {
+            const H* ga = gzn + (rb * 32 + l31) * PBH_PITCH + 4 * lhi;
+            const H* xb0 = xn + ((2 * ph) * 32 + l31) * PBH_PITCH + 4 * lhi;
+            const H* xb1 = xn + ((2 * ph + 1 < NB ? 2 * ph + 1 : 2 * ph) * 32 + l31) * PBH_PITCH + 4 * lhi;
+            const bool two = 2 * ph + 1 < NB;
+#pragma unroll
+            for (int kk = 0; kk < PB_NT / 8; ++kk) {
+                const h4 av = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(ga + 8 * kk));
+                acc_w[0] = __builtin_amdgcn_mfma_f32_32x32x8f16(
+                    av, __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(xb0 + 8 * kk)), acc_w[0], 0, 0, 0);
+                if (two)
+                    acc_w[1] = __builtin_amdgcn_mfma_f32_32x32x8f16(
+                        av, __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(xb1 + 8 * kk)), acc_w[1], 0, 0, 0);
+            }
+        }
+
+        if (nvalid) commit(nxt, buf ^ 1);
+        __syncthreads();
+        cur = nxt;
+        valid = nvalid;
+        buf ^= 1;
+    }
+    if (p.t_mode != 1) flush_bias(0);
+
+    // ---- this workgroup's partial gw
+    {
+        const int r0 = rb * 32;
+        const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
+        const rsrc_t rgw = make_rsrc_n(p.gwp + ((size_t)g * p.Cout + r0) * p.K, (unsigned)(nrows * p.K) * 4u);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = (2 * ph + n) * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rl = (j & 3) + 8 * (j >> 2) + 4 * lhi;
+                buf_store(acc_w[n][j], rgw, (col < p.K && nrows > 0) ? (unsigned)(rl * p.K + col) * 4u : PW_OOB, 0);
+            }
+        }
+    }
+}
+
 static bool pw_dims_ok(int cin, int cout, long hw) {
     if (cin < 1 || cin > 128 || cout < 1 || hw < 4 || hw % 4) return false;
     const int kp = (cin + 31) / 32 * 32;
@@ -920,6 +1184,37 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
     hipError_t e = hipMemsetAsync(gb_partial, 0, (size_t)grid * p.Bq * cout * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     const int kp = (cin + 31) / 32 * 32;
+    if constexpr (sizeof(TA) == 2 && sizeof(TXT) == 2) {
+        // all-half layer: the f16 matrix pipe (SBMC_HIP_PW_F16MFMA=0 keeps the fp32-MFMA kernel: development knob)
+        const char* knob = getenv("SBMC_HIP_PW_F16MFMA");
+        if (!knob || atoi(knob) != 0) {
+            const size_t hlds = (size_t)2 * ((128 + kp) * PBH_PITCH + 32 * PB_NT * 4) * 2;
+#define SBMC_PWBH_LAUNCH2(KPV, DXV, TPV)                                                                 \
+    do {                                                                                                 \
+        auto kern = (gmean && !TPV) ? pw_bwd_h_kernel<KPV, DXV, false, true>                              \
+                                    : pw_bwd_h_kernel<KPV, DXV, TPV, false>;                              \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds);                  \
+        if (e == hipSuccess)                                                                             \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(PW_THREADS), hlds, (hipStream_t)stream, p);        \
+    } while (0)
+#define SBMC_PWBH_LAUNCH(KPV)                                                                            \
+    do {                                                                                                 \
+        if (gx) { if (t_mode == 2) SBMC_PWBH_LAUNCH2(KPV, true, true); else SBMC_PWBH_LAUNCH2(KPV, true, false); } \
+        else    { if (t_mode == 2) SBMC_PWBH_LAUNCH2(KPV, false, true); else SBMC_PWBH_LAUNCH2(KPV, false, false); } \
+    } while (0)
+            switch (kp) {
+                case 32: SBMC_PWBH_LAUNCH(32); break;
+                case 64: SBMC_PWBH_LAUNCH(64); break;
+                case 96: SBMC_PWBH_LAUNCH(96); break;
+                default: SBMC_PWBH_LAUNCH(128); break;
+            }
+#undef SBMC_PWBH_LAUNCH
+#undef SBMC_PWBH_LAUNCH2
+            if (e != hipSuccess) return (int)e;
+            return (int)hipGetLastError();
+        }
+    }
     const size_t lds = (size_t)2 * (128 + kp) * PB_PITCH * sizeof(float);
 #define SBMC_PWB_LAUNCH2(KPV, DXV, TPV)                                                                  \
     do {                                                                                                 \

@@ -770,11 +770,12 @@ class BiasActNHWC(th.autograd.Function):
 
 
 def upsample_cat_nhwc_supported(coarse, left, top=0, bot=0):
-    return (coarse.is_cuda and left.is_cuda and coarse.dtype == th.float32 and left.dtype == th.float32
+    """fp32, or fp16 (the U-nets under torch.autocast(float16)) channels-last tensors of one dtype."""
+    return (coarse.is_cuda and left.is_cuda and coarse.dtype in (th.float32, th.float16) and left.dtype == coarse.dtype
             and coarse.dim() == 4 and left.dim() == 4 and coarse.shape[0] == left.shape[0]
             and top in (0, 1) and bot in (0, 1)
             and left.shape[2] == 2 * (coarse.shape[2] - top - bot) and left.shape[3] == 2 * coarse.shape[3]
-            and coarse.numel() > 0 and not th.is_autocast_enabled()
+            and coarse.numel() > 0
             and _is_channels_last(coarse) and _is_channels_last(left)
             and coarse.data_ptr() % 16 == 0 and left.data_ptr() % 16 == 0
             and bool(_lib.lib().sbmc_upsample2x_cat_nhwc_supported(coarse.shape[1], left.shape[1],
@@ -782,23 +783,25 @@ def upsample_cat_nhwc_supported(coarse, left, top=0, bot=0):
 
 
 class UpsampleCatNHWC(th.autograd.Function):
-    """`UpsampleCat` on channels-last tensors (result channels-last too): one pass per direction, the
-    backward also delivers the skip connection's gradient as a contiguous tensor.  top, bot: row-slab form,
-    as for `UpsampleCat`."""
+    """`UpsampleCat` on channels-last tensors (result channels-last too), float32 or float16 storage: one pass
+    per direction, the backward also delivers the skip connection's gradient as a contiguous tensor.
+    top, bot: row-slab form, as for `UpsampleCat`."""
 
     @staticmethod
     def forward(ctx, coarse, left, top=0, bot=0):
-        _require_f32("UpsampleCatNHWC", coarse=coarse, left=left)
+        if not (coarse.is_cuda and coarse.dtype in (th.float32, th.float16) and left.dtype == coarse.dtype):
+            raise TypeError("UpsampleCatNHWC: float32 or float16 GPU tensors of one dtype expected")
         b, cu, hc, w = coarse.shape
         cl = left.shape[1]
         h = hc - top - bot
         out = th.empty(b, cu + cl, 2 * h, 2 * w, dtype=coarse.dtype, device=coarse.device,
                        memory_format=th.channels_last)
         dev = coarse.device
+        L = _lib.lib()
+        fwd = L.sbmc_upsample2x_cat_nhwc_slab_fwd_f16 if coarse.dtype == th.float16 else L.sbmc_upsample2x_cat_nhwc_slab_fwd_f32
         with th.cuda.device(dev):
-            rc = _lib.lib().sbmc_upsample2x_cat_nhwc_slab_fwd_f32(_lib.ptr(coarse), _lib.ptr(left), _lib.ptr(out),
-                                                                  b, cu, cl, hc, w, top, bot,
-                                                                  _lib.current_stream(dev))
+            rc = fwd(_lib.ptr(coarse), _lib.ptr(left), _lib.ptr(out), b, cu, cl, hc, w, top, bot,
+                     _lib.current_stream(dev))
         _lib.check(rc, "upsample2x_cat_nhwc_fwd")
         ctx.dims = (b, cu, cl, hc, w, top, bot)
         return out
@@ -815,10 +818,11 @@ class UpsampleCatNHWC(th.autograd.Function):
             gleft = th.empty(b, cl, 2 * h, 2 * w, dtype=g.dtype, device=g.device, memory_format=th.channels_last)
         if gcoarse is not None or gleft is not None:
             dev = g.device
+            L = _lib.lib()
+            bwd = L.sbmc_upsample2x_cat_nhwc_slab_bwd_f16 if g.dtype == th.float16 else L.sbmc_upsample2x_cat_nhwc_slab_bwd_f32
             with th.cuda.device(dev):
-                rc = _lib.lib().sbmc_upsample2x_cat_nhwc_slab_bwd_f32(_lib.ptr(g), _lib.ptr(gcoarse), _lib.ptr(gleft),
-                                                                      b, cu, cl, hc, w, top, bot,
-                                                                      _lib.current_stream(dev))
+                rc = bwd(_lib.ptr(g), _lib.ptr(gcoarse), _lib.ptr(gleft), b, cu, cl, hc, w, top, bot,
+                         _lib.current_stream(dev))
             _lib.check(rc, "upsample2x_cat_nhwc_bwd")
         return gcoarse, gleft, None, None
 
