@@ -36,12 +36,34 @@ _INC = os.path.join(_HERE, "sbmc_oracle_ops.inc")
 _LIB = None
 
 
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for path in (_SRC, _INC, os.path.join(_HERE, "Makefile")):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False):
-    """Compile ``sbmc_oracle.c`` into ``libsbmc_oracle.so`` (gcc + OpenMP)."""
-    stale = (not os.path.exists(_SO)
-             or os.path.getmtime(_SO) < max(os.path.getmtime(_SRC), os.path.getmtime(_INC)))
+    """Compile ``sbmc_oracle.c`` into ``libsbmc_oracle.so`` (gcc + OpenMP).  Staleness is decided by
+    content (a hash of the sources recorded beside the library), not by file times, which need not
+    survive the copy to a GPU box."""
+    stamp = _SO + ".srchash"
+    digest = _source_hash()
+    stale = not os.path.exists(_SO)
+    if not stale:
+        try:
+            with open(stamp) as f:
+                stale = f.read().strip() != digest
+        except OSError:
+            stale = True
     if force or stale:
         subprocess.check_call(["make", "-s", "-B", "-C", _HERE])
+        tmp = "%s.%d.tmp" % (stamp, os.getpid())
+        with open(tmp, "w") as f:
+            f.write(digest + "\n")
+        os.replace(tmp, stamp)
     return _SO
 
 

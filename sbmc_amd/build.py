@@ -26,27 +26,53 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def is_stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
+STAMP = LIB + ".srchash"
+
+
+def _source_hash():
+    """Hash of everything the library is built from (sources, headers, flags)."""
+    import hashlib
+    h = hashlib.sha256((ARCH + " -O3 -std=c++17").encode())
     for d in DEPS:
         path = d if os.path.isabs(d) else os.path.join(CSRC, d)
-        if os.path.getmtime(path) > t:
-            return True
-    return False
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def is_stale():
+    """Is the library missing or built from other sources than the ones present?  By CONTENT (a hash of
+    the sources recorded next to the library at build time), not by modification time: the library travels
+    to GPU boxes inside source snapshots whose file times need not survive the copy, and a spurious rebuild
+    there would run once per rank."""
+    if not os.path.exists(LIB):
+        return True
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() != _source_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+    tmp = "%s.%d.tmp" % (LIB, os.getpid())              # several ranks may build at once: private temporaries,
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",   # atomic renames
            "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-           "-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    digest = _source_hash()
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    with open(tmp + ".stamp", "w") as f:
+        f.write(digest + "\n")
+    os.replace(tmp + ".stamp", STAMP)
     return LIB
 
 
