@@ -24,8 +24,12 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     model = Multisteps(93, 3, ksize=K).to(dev).train()
     opt = th.optim.Adam(model.parameters(), lr=1e-4, fused=True)   # as bench.py
     loss_fn = losses.TonemappedRelativeMSE()
-    rank = world // 2 if world > 1 else 0          # an interior rank (halos on both sides)
-    part = sdist.SlabPartition(H, world, rank)
+    # the rank that bounds the step: most rows, and among those an interior one (halos on both sides)
+    parts = [sdist.SlabPartition(H, world, r) for r in range(world)]
+    rank = max(range(world), key=lambda r: (parts[r].rows, parts[r].has_up and parts[r].has_down))
+    if "SBMC_RANK" in os.environ:
+        rank = int(os.environ["SBMC_RANK"])
+    part = parts[rank]
     batch = {k: (v if k == "global_features" else v[..., part.y0:part.y1, :].contiguous()) for k, v in full.items()}
     runner = sdist.ShardedDenoiser(model, part)
     if world == 1:
