@@ -354,27 +354,38 @@ class ShardedDenoiser(object):
         return target[..., top:target.shape[-2] - bot, p:-p]
 
     def _flat_grads(self):
-        """One flat fp32 buffer holding every parameter gradient (each `.grad` is a view of it) plus
-        one slot for the loss: the cross-rank sum is ONE all-reduce of this buffer, no packing."""
-        params = [q for q in self.model.parameters() if q.requires_grad]
-        if self._flat is None or any(q.grad is None or q.grad.data_ptr() != v.data_ptr()
-                                     for q, v in zip(params, self._views)):
-            n = sum(q.numel() for q in params)
-            self._flat = th.zeros(n + 1, dtype=th.float32, device=params[0].device)
+        """One flat fp32 buffer with a slot per parameter gradient plus one for the loss: the cross-rank sum
+        is ONE all-reduce of this buffer."""
+        if self._flat is None:
+            self._params = [q for q in self.model.parameters() if q.requires_grad]
+            n = sum(q.numel() for q in self._params)
+            self._flat = th.zeros(n + 1, dtype=th.float32, device=self._params[0].device)
             self._views, off = [], 0
-            for q in params:
-                v = self._flat[off:off + q.numel()].view_as(q)
-                q.grad = v
-                self._views.append(v)
+            for q in self._params:
+                self._views.append(self._flat[off:off + q.numel()].view_as(q))
                 off += q.numel()
         return self._flat
+
+    def _gather_grads(self):
+        """The step's gradients into the flat buffer, and every `.grad` re-pointed at its slot (the optimizer
+        then reads the all-reduced values in place).  The backward itself runs with `.grad = None`, so autograd
+        hands each gradient over without an accumulation pass (one add kernel per parameter otherwise: 246
+        launches per step here); packing them is one multi-tensor copy."""
+        have = [(v, q.grad) for q, v in zip(self._params, self._views) if q.grad is not None]
+        if have:
+            th._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for q, v in zip(self._params, self._views):
+            if q.grad is None:
+                v.zero_()
+            q.grad = v
 
     def train_step(self, optimizer, loss_fn, batch, clip=1000):
         """The reference training step (sbmc/interfaces.py:78-105) on the sharded frame.
         `loss_fn` must be a mean over pixels (all of sbmc_amd.losses are)."""
         part = self.part
         flat = self._flat_grads()
-        flat.zero_()                                   # == optimizer.zero_grad(), keeping the views
+        for q in self._params:
+            q.grad = None                              # == optimizer.zero_grad(set_to_none=True)
         out = self.forward(batch)["radiance"]
         tgt = self.target_rows(batch["target_image"])
         # this rank's share of the global mean: the frame's output size is known from the partition (the
@@ -382,7 +393,8 @@ class ShardedDenoiser(object):
         p = (self.model.ksize - 1) // 2
         total = out.shape[0] * out.shape[1] * (part.height - 2 * p) * out.shape[-1]
         loss = loss_fn(out, tgt) * (out.numel() / float(total))
-        loss.backward()                                # accumulates into the views, in place
+        loss.backward()
+        self._gather_grads()
         flat[-1] = loss.detach()
         if part.world > 1:
             summed = _all_reduce_sum(flat, part)       # in place over RCCL; a new tensor when staged
