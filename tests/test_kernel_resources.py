@@ -36,3 +36,26 @@ def test_strip_kernels_do_not_spill(splat_kernels, name, min_occupancy):
     r = splat_kernels[name]
     assert r["scratch"] == 0 and r["spill"] == 0, r
     assert r["occupancy"] >= min_occupancy, r
+
+
+@pytest.fixture(scope="module")
+def pointwise_kernels():
+    import kernel_resources
+    return kernel_resources.resources(os.path.join(ROOT, "sbmc_amd", "csrc", "pointwise.hip"))
+
+
+@pytest.mark.parametrize("pattern", [
+    "sbmc::pw_fwd_kernel<128, 0, 2, float, float>",          # the 1x1 layers of the fp32 step
+    "sbmc::pw_fwd_kernel<128, 2, 2, float, float>",
+    "sbmc::pw_bwd_kernel<128, true, false, false, float, float>",
+    "pw_fwd_h_kernel",                                       # the f16 matrix pipe (every instantiation)
+    "pw_bwd_h_kernel",
+])
+def test_pointwise_kernels_do_not_spill(pointwise_kernels, pattern):
+    """(The TPIX / GM variants of the fp32 backward do spill 8-12 VGPRs at their 256-register budget: known,
+    priced in DESIGN.md section 8 -- they are not listed here.)"""
+    rows = [r for r in pointwise_kernels if pattern in r["name"]]
+    assert rows, pattern
+    for r in rows:
+        assert r["scratch"] == 0 and r["spill"] == 0, r
+        assert r["occupancy"] >= 2, r
