@@ -72,33 +72,66 @@ class SlabPartition(object):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
 
-def _exchange(part, to_up, to_down):
-    """Sends `to_up` to rank-1 and `to_down` to rank+1; returns (from_up, from_down).
+def _exchange_into(part, to_up, to_down, into_up, into_down, between=None):
+    """Sends `to_up` to rank-1 and `to_down` to rank+1, receives their counterparts into `into_up` /
+    `into_down` (written in place; may be views of a larger buffer).  All four are contiguous tensors; a pair
+    (what one rank sends down, what the next receives from above) has the same shape on both sides.
+    `between`: called after the transfers have been started and before they are waited for -- work that needs
+    neither (the copy of the slab's own rows) overlaps the transfer.
 
-    RCCL ("nccl") moves device tensors directly over xGMI.  A backend without device support
-    (gloo: the CPU tests, and the single-GPU two-process test of the device kernels) gets the
-    halo rows staged through host memory.
-    """
+    RCCL ("nccl") moves device tensors directly over xGMI.  A backend without device support (gloo: the CPU
+    tests, and the single-GPU two-process tests of the device kernels) gets the rows staged through host
+    memory."""
     staged = to_up.is_cuda and dist.get_backend(part.group) != "nccl"
-    dev = to_up.device
-    ops, from_up, from_down = [], None, None
-    if part.has_up:
-        to_up = to_up.contiguous().cpu() if staged else to_up.contiguous()
-        from_up = th.empty_like(to_up)
-        ops += [dist.P2POp(dist.isend, to_up, part.peer(-1), group=part.group),
-                dist.P2POp(dist.irecv, from_up, part.peer(-1), group=part.group)]
-    if part.has_down:
-        to_down = to_down.contiguous().cpu() if staged else to_down.contiguous()
-        from_down = th.empty_like(to_down)
-        ops += [dist.P2POp(dist.isend, to_down, part.peer(+1), group=part.group),
-                dist.P2POp(dist.irecv, from_down, part.peer(+1), group=part.group)]
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    if staged:
-        from_up = None if from_up is None else from_up.to(dev)
-        from_down = None if from_down is None else from_down.to(dev)
+    ops, landed = [], []
+    for has, src, dst, delta in ((part.has_up, to_up, into_up, -1), (part.has_down, to_down, into_down, +1)):
+        if not has:
+            continue
+        if staged:
+            src = src.cpu()
+            tmp = th.empty_like(src)
+            landed.append((dst, tmp))
+        else:
+            tmp = dst
+        ops += [dist.P2POp(dist.isend, src, part.peer(delta), group=part.group),
+                dist.P2POp(dist.irecv, tmp, part.peer(delta), group=part.group)]
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if between is not None:
+        between()
+    for req in reqs:
+        req.wait()
+    for dst, tmp in landed:
+        dst.copy_(tmp)
+
+
+def _exchange(part, to_up, to_down):
+    """Sends `to_up` to rank-1 and `to_down` to rank+1; returns (from_up, from_down) as new tensors in the
+    default (planar) memory order, whatever the order of the arguments -- layout-agnostic."""
+    to_up, to_down = to_up.contiguous(), to_down.contiguous()
+    from_up = th.empty_like(to_up) if part.has_up else None
+    from_down = th.empty_like(to_down) if part.has_down else None
+    _exchange_into(part, to_up, to_down, from_up, from_down)
     return from_up, from_down
+
+
+_AGREED = {}
+
+
+def _all_agree(flag, part, key):
+    """Logical AND of `flag` over the ranks of the partition (cached per key: one tiny collective per new shape).
+    Used for decisions every rank takes by *measurement* but that both ends of an exchange must share."""
+    key = (id(part.group),) + tuple(key)
+    if key not in _AGREED:
+        t = th.tensor([1.0 if flag else 0.0])
+        _AGREED[key] = bool(_all_reduce_min(t, part).item() > 0.5)
+    return _AGREED[key]
+
+
+def _all_reduce_min(t, part):
+    if dist.get_backend(part.group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=part.group)
+    return t.cpu()
 
 
 def _all_reduce_sum(t, part):
@@ -114,20 +147,37 @@ def _all_reduce_sum(t, part):
     return h.to(dev)
 
 
+def _rows_nhwc(t, r0, r1):
+    """Rows [r0, r1) of a channels-last map of ONE image as a contiguous [1, rows, w, c] view (one block of
+    memory: nothing is copied, and writes through the view land in `t`)."""
+    return t[..., r0:r1, :].permute(0, 2, 3, 1)
+
+
 class _HaloPad(th.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, part):
+    def forward(ctx, x, r, part, nhwc_wire=False):
         ctx.r, ctx.part, ctx.rows = r, part, x.shape[-2]
-        if x.shape[-2] < r:
-            raise RuntimeError("slab of %d rows is thinner than the halo (%d)" % (x.shape[-2], r))
+        h = x.shape[-2]
+        if h < r:
+            raise RuntimeError("slab of %d rows is thinner than the halo (%d)" % (h, r))
+        ctx.nhwc_wire = bool(nhwc_wire and x.dim() == 4 and x.shape[0] == 1 and funcs._is_channels_last(x))
+        if ctx.nhwc_wire:
+            # every rank runs this U-net channels-last (agreed, see sharded_autoencoder) on one image: a run of
+            # rows is one block of [row, column, channel] memory.  The halo rows travel in that order and land
+            # directly in the padded map; the slab's own rows are copied while they travel.
+            top = r if part.has_up else 0
+            bot = r if part.has_down else 0
+            out = th.empty(x.shape[:-2] + (top + h + bot, x.shape[-1]), dtype=x.dtype, device=x.device,
+                           memory_format=th.channels_last)
+            _exchange_into(part, _rows_nhwc(x, 0, r), _rows_nhwc(x, h - r, h),
+                           _rows_nhwc(out, 0, top), _rows_nhwc(out, top + h, top + h + bot),
+                           between=lambda: out[..., top:top + h, :].copy_(x))
+            return out
         from_up, from_down = _exchange(part, x[..., :r, :], x[..., -r:, :])
         if funcs._is_channels_last(x):
-            # keep the U-net's channels-last order: with one image per rank a run of rows is one contiguous
-            # block of [row, column, channel] memory, so the body is a plain copy and the halo rows (which
-            # travel in planar order) are the only elements that get re-ordered
+            # keep the U-net's channels-last order (the halo rows travelled in planar order: layout-agnostic)
             top = r if from_up is not None else 0
             bot = r if from_down is not None else 0
-            h = x.shape[-2]
             out = th.empty(x.shape[:-2] + (top + h + bot, x.shape[-1]), dtype=x.dtype, device=x.device,
                            memory_format=th.channels_last)
             out[..., top:top + h, :].copy_(x)
@@ -144,20 +194,39 @@ class _HaloPad(th.autograd.Function):
         r, part, h = ctx.r, ctx.part, ctx.rows
         top = r if part.has_up else 0
         # gradient of my halo rows goes back to their owners; theirs for my edge rows comes here
+        if ctx.nhwc_wire:
+            g = g.contiguous(memory_format=th.channels_last)     # the wire order both ends agreed on
+            hp = g.shape[-2]
+            box = {}
+            back_up = th.empty_like(_rows_nhwc(g, 0, r)) if part.has_up else None
+            back_down = th.empty_like(_rows_nhwc(g, 0, r)) if part.has_down else None
+
+            def own_rows():
+                box["gx"] = g[..., top:top + h, :].clone(memory_format=th.channels_last)
+            _exchange_into(part, _rows_nhwc(g, 0, r), _rows_nhwc(g, hp - r, hp), back_up, back_down,
+                           between=own_rows)
+            gx = box["gx"]
+            if back_up is not None:
+                _rows_nhwc(gx, 0, r).add_(back_up)
+            if back_down is not None:
+                _rows_nhwc(gx, h - r, h).add_(back_down)
+            return gx, None, None, None
         from_up, from_down = _exchange(part, g[..., :r, :], g[..., g.shape[-2] - r:, :])
         gx = g[..., top:top + h, :].clone()
         if from_up is not None:
             gx[..., :r, :] += from_up
         if from_down is not None:
             gx[..., h - r:, :] += from_down
-        return gx, None, None
+        return gx, None, None, None
 
 
-def halo_pad(x, r, part):
-    """[..., h, w] -> [..., (r if up) + h + (r if down), w] with the neighbours' edge rows."""
+def halo_pad(x, r, part, nhwc_wire=False):
+    """[..., h, w] -> [..., (r if up) + h + (r if down), w] with the neighbours' edge rows.
+    nhwc_wire: ALL ranks hold this tensor channels-last (an agreed fact, not a local guess): the rows then
+    travel in memory order and land in place."""
     if r == 0 or part.world == 1:
         return x
-    return _HaloPad.apply(x, r, part)
+    return _HaloPad.apply(x, r, part, nhwc_wire)
 
 
 class _CropRows(th.autograd.Function):
@@ -194,29 +263,29 @@ def _reach(chain):
     return r
 
 
-def _chain(chain, x, part):
+def _chain(chain, x, part, nhwc=False):
     r = _reach(chain)
-    return _crop_halo(chain(halo_pad(x, r, part)), r, part)
+    return _crop_halo(chain(halo_pad(x, r, part, nhwc)), r, part)
 
 
-def _level(level, x, part):
-    left = _chain(level.left, x, part)
+def _level(level, x, part, nhwc=False):
+    left = _chain(level.left, x, part, nhwc)
     if level.is_last:
         return left
     if left.shape[-2] % 2:
         raise RuntimeError("sharded path needs an even number of rows at every U-net level")
-    coarse = _level(level.next_level, level.downsample(left), part)
-    padded = halo_pad(coarse, 1, part)
+    coarse = _level(level.next_level, level.downsample(left), part, nhwc)
+    padded = halo_pad(coarse, 1, part, nhwc)
     top, bot = int(part.has_up), int(part.has_down)
     if funcs.upsample_cat_nhwc_supported(padded, left, top, bot):
-        return _chain(level.right, funcs.UpsampleCatNHWC.apply(padded, left, top, bot), part)
+        return _chain(level.right, funcs.UpsampleCatNHWC.apply(padded, left, top, bot), part, nhwc)
     if funcs.upsample_cat_supported(padded, left, top, bot):
         # one pass, the upsampled tensor never exists (functions.UpsampleCat in its row-slab form)
-        return _chain(level.right, funcs.UpsampleCat.apply(padded, left, top, bot), part)
+        return _chain(level.right, funcs.UpsampleCat.apply(padded, left, top, bot), part, nhwc)
     up = F.interpolate(padded, size=(2 * padded.shape[-2], left.shape[-1]), mode="bilinear",
                        align_corners=False)
     up = _crop_halo(up, 2, part)
-    return _chain(level.right, th.cat([up, left], 1), part)
+    return _chain(level.right, th.cat([up, left], 1), part, nhwc)
 
 
 def sharded_autoencoder(autoencoder, x, part):
@@ -226,14 +295,19 @@ def sharded_autoencoder(autoencoder, x, part):
     if part.world == 1:
         return autoencoder(x)
     from . import modules as ops
-    # (ranks may decide differently -- an edge rank convolves a different height: the exchange is
-    # layout-agnostic, correctness does not depend on the ranks agreeing)
+    # every rank measures for itself (an edge rank convolves a different height) and the ranks then settle on
+    # channels-last only if all of them would pick it: halo rows can then travel in [row, column, channel]
+    # memory order and land in place (_HaloPad), and no rank is left with the layout that is slow for it
     reach = _reach(autoencoder.net.left)
     rows = x.shape[-2] + reach * (int(part.has_up) + int(part.has_down))     # what the first chain convolves
-    if ops.unet_channels_last(autoencoder, x, rows=rows):
+    mine = ops.unet_channels_last(autoencoder, x, rows=rows)
+    grad = th.is_grad_enabled() and any(q.requires_grad for q in autoencoder.parameters())
+    # (the key holds nothing rank-specific: every rank meets a new key at the same call)
+    if _all_agree(mine, part, (part.world, part.height, x.shape[0], x.shape[1], x.shape[-1], x.dtype, grad,
+                               th.is_autocast_enabled())):
         xin = funcs.ToChannelsLast.apply(x) if funcs.ToChannelsLast.supported(x) \
             else x.contiguous(memory_format=th.channels_last)
-        y = _level(autoencoder.net, xin, part)
+        y = _level(autoencoder.net, xin, part, nhwc=True)
         if autoencoder.keep_channels_last:
             return y
         return funcs.FromChannelsLast.apply(y) if funcs.FromChannelsLast.supported(y) else y.contiguous()

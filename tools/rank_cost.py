@@ -10,8 +10,31 @@ from sbmc_amd import dist as sdist
 
 def fake_exchange(part, to_up, to_down):
     return (th.zeros_like(to_up) if part.has_up else None, th.zeros_like(to_down) if part.has_down else None)
-sdist._exchange = fake_exchange
-sdist._all_reduce_sum = lambda t, part: t.cuda() if not t.is_cuda else t
+
+RCCL_SELF = "--rccl-self" in sys.argv
+if RCCL_SELF:
+    # the exchanges for real, over RCCL, with this very rank as both neighbours (a single-rank `nccl` group:
+    # send/recv to self, one-rank all-reduce): every launch, copy and stream dependency of the multi-GPU step is
+    # there, only the xGMI transfer itself (<= 6 rows per message, 139 MB once) is not
+    sys.argv.remove("--rccl-self")
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    th.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=th.device("cuda", 0))
+    sdist.SlabPartition.peer = lambda self, delta: 0
+else:
+    def fake_exchange_into(part, to_up, to_down, into_up, into_down, between=None):
+        if part.has_up:
+            into_up.zero_()
+        if part.has_down:
+            into_down.zero_()
+        if between is not None:
+            between()
+    sdist._exchange = fake_exchange
+    sdist._exchange_into = fake_exchange_into
+    sdist._all_reduce_sum = lambda t, part: t.cuda() if not t.is_cuda else t
+    sdist._all_reduce_min = lambda t, part: t
 
 dev = th.device("cuda")
 H, W, S, K = 720, 1280, 8, 21
@@ -43,6 +66,7 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         step()
     th.cuda.synchronize()
     ms = (time.time() - t0) / 3 * 1e3
-    print("world %d rank %d rows %d: %.1f ms/step" % (world, rank, part.rows, ms), flush=True)
+    print("world %d rank %d rows %d%s: %.1f ms/step" % (world, rank, part.rows,
+                                                         " (exchanges over RCCL to self)" if RCCL_SELF else "", ms), flush=True)
     del model, opt, runner, batch
     th.cuda.empty_cache()
