@@ -21,12 +21,14 @@ tiling of scripts/denoise.py:54-93, which recomputes a 256-px halo per tile).  D
   frame and direction, nothing recomputed.  (Slabs thinner than p rows, or gather kernels: the
   regressor's inputs are halo-padded by p instead and the halo's destination rows dropped.)
 * training: the loss is the global mean (each rank contributes its rows); parameter
-  gradients live in one flat buffer (every `.grad` is a view of it) summed by ONE all-reduce.
+  gradients are packed into one persistent flat buffer and summed by ONE all-reduce.
 
 `halo_pad` is a `torch.autograd.Function`: its backward sends the gradient of the halo
 rows back to the rank that owns them, so autograd over the sharded graph equals autograd
 over the full frame.  Neighbour traffic is batched `isend/irecv` pairs (the direct xGMI
-link between adjacent GPUs); works unchanged on gloo (CPU tests) and nccl (= RCCL).
+link between adjacent GPUs); works unchanged on gloo (CPU tests) and nccl (= RCCL).  When
+all ranks run a U-net channels-last, its halo rows travel in memory order and are received
+in place, overlapped with the copy of the slab's own rows (`_HaloPad`).
 """
 import torch as th
 import torch.distributed as dist
