@@ -265,7 +265,26 @@ def _reach(chain):
     return r
 
 
+#: Slabs thinner than this many rows (at the frame's resolution) exchange ONE halo row before every convolution
+#: instead of three before every chain of three: a chain then convolves rows + 2 three times instead of rows + 6.
+#: Measured at 8 ranks of a 720p frame (23 rows per rank at the U-net's coarsest level; find records for the
+#: new heights are shipped): -4.4 ms of convolution work per step (80.8 -> 76.4 ms with the exchanges stubbed
+#: out) against +5.5 ms for the 62 extra exchanges issued through torch.distributed (84.5 vs 83.4 ms with the
+#: exchanges running over RCCL to the rank itself, tools/rank_cost.py --rccl-self): a loss until neighbour
+#: exchanges get cheaper than ~50 us apiece, so it is OFF (0) by default.
+PER_CONV_HALO_BELOW = 0
+
+
+def _per_conv(chain, part):
+    return (hasattr(chain, "_run") and part.min_rows < PER_CONV_HALO_BELOW
+            and all(m.padding[0] == m.kernel_size[0] // 2 and m.stride[0] == 1
+                    for m in chain.modules() if isinstance(m, th.nn.Conv2d)))
+
+
 def _chain(chain, x, part, nhwc=False):
+    if _per_conv(chain, part):          # (a property of the partition and the module: the same on every rank)
+        return chain._run(list(chain.children()), x,
+                          halo=(lambda t, r: halo_pad(t, r, part, nhwc), lambda t, r: _crop_halo(t, r, part)))
     r = _reach(chain)
     return _crop_halo(chain(halo_pad(x, r, part, nhwc)), r, part)
 

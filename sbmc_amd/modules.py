@@ -324,12 +324,25 @@ class ConvChain(nn.Module):
             return y + conv.bias.view(1, -1, 1, 1), False
         return funcs.BiasAct.apply(y, conv.bias, act, slope), act != 0
 
-    def _run(self, mods, x, mean_s=0, mean_out=None):
+    def _run(self, mods, x, mean_s=0, mean_out=None, halo=None):
+        """halo: the chain runs on a row slab of a frame sharded over several GPUs (sbmc_amd.dist) -- a pair
+        (pad, crop): before every padded k x k convolution `pad(x, k // 2)` attaches the neighbouring slabs'
+        k // 2 edge rows, and `crop(y, k // 2)` drops the rows of its result that saw the artificial zero padding
+        beyond them (lazily: just before the next exchange, or at the end, so that in-place activations never meet
+        a view)."""
         gemm = self.pointwise_as_gemm and x.is_cuda
+        pending = 0                                                # halo rows still to be dropped
         i = 0
         while i < len(mods):
             m = mods[i]
             i += 1
+            if halo is not None:
+                conv = m.layer[0] if isinstance(m, ConvChain._ConvBNRelu) else m
+                if isinstance(conv, nn.Conv2d) and conv.kernel_size[0] > 1:
+                    if pending:
+                        x = halo[1](x, pending)
+                    pending = conv.kernel_size[0] // 2
+                    x = halo[0](x, pending)
             if gemm and isinstance(m, ConvChain._ConvBNRelu) and _is_pointwise(m.layer[0]):
                 rest = list(m.layer.children())[1:]
                 x, fused = _pointwise_gemm(m.layer[0], x, rest[0] if len(rest) == 1 else None)
@@ -359,6 +372,8 @@ class ConvChain(nn.Module):
                         i += 1
             else:
                 x = m(x)
+        if halo is not None and pending:
+            x = halo[1](x, pending)
         return x
 
     class _ConvBNRelu(nn.Module):

@@ -29,7 +29,7 @@ def _close(a, b, rtol, what):
     assert err <= rtol * max(scale, 1e-30) + 1e-12, "%s: err %.3e scale %.3e" % (what, err, scale)
 
 
-def _worker(rank, world, port, height, train, merge_state):
+def _worker(rank, world, port, height, train, merge_state, per_conv=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -41,6 +41,8 @@ def _worker(rank, world, port, height, train, merge_state):
         from sbmc_amd import dist as sdist
         from sbmc_amd.utils import crop_like
         halide_ops.register_cpu_ops_for_testing(sbmc_oracle)
+        # the U-nets' halo exchange: one row before every convolution (thin slabs) or three before every chain
+        sdist.PER_CONV_HALO_BELOW = 10 ** 9 if per_conv else 0
 
         nf, ks, spp, w = 6, 5, 2, 20
         th.manual_seed(3)
@@ -88,11 +90,11 @@ def _worker(rank, world, port, height, train, merge_state):
 
 # merge_state=True: every rank splats its own samples and the overhang rows of the running state are
 # exchanged and merged; False: the halo-recompute form (inputs padded by the kernel radius)
-@pytest.mark.parametrize("world,height,train,merge_state", [
-    (2, 32, False, True), (2, 32, True, True), (3, 48, True, True), (3, 36, False, True),
-    (2, 32, True, False), (3, 48, False, False)])
-def test_sharded_denoiser_equals_full_frame(world, height, train, merge_state):
-    mp.spawn(_worker, args=(world, _free_port(), height, train, merge_state), nprocs=world, join=True)
+@pytest.mark.parametrize("world,height,train,merge_state,per_conv", [
+    (2, 32, False, True, True), (2, 32, True, True, True), (3, 48, True, True, False), (3, 36, False, True, False),
+    (2, 32, True, False, False), (3, 48, False, False, True), (3, 48, True, True, True)])
+def test_sharded_denoiser_equals_full_frame(world, height, train, merge_state, per_conv):
+    mp.spawn(_worker, args=(world, _free_port(), height, train, merge_state, per_conv), nprocs=world, join=True)
 
 
 def test_slab_partition():

@@ -28,7 +28,7 @@ def _close(a, b, rtol, what):
     assert err <= rtol * max(scale, 1e-30) + 1e-12, "%s: err %.3e scale %.3e" % (what, err, scale)
 
 
-def _worker(rank, world, port, height, layout="auto"):
+def _worker(rank, world, port, height, layout="auto", per_conv=True):
     sys.path.insert(0, ROOT)
     os.environ["SBMC_UNET_LAYOUT"] = layout
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -38,6 +38,7 @@ def _worker(rank, world, port, height, layout="auto"):
         from sbmc_amd import Multisteps, losses
         from sbmc_amd import dist as sdist
         from sbmc_amd.utils import crop_like
+        sdist.PER_CONV_HALO_BELOW = 10 ** 9 if per_conv else 0
         dev = th.device("cuda", 0)
         nf, ks, spp, w = 6, 21, 2, 72
         th.manual_seed(3)
@@ -76,9 +77,10 @@ def _worker(rank, world, port, height, layout="auto"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
-def test_sharded_denoiser_on_device_kernels(layout):
+@pytest.mark.parametrize("layout,per_conv", [("nchw", False), ("nhwc", False), ("nhwc", True), ("nchw", True)])
+def test_sharded_denoiser_on_device_kernels(layout, per_conv):
     """layout: the U-nets planar, or channels-last (MIOpen NHWC solvers, NHWC glue kernels in their
-    row-slab forms, layout-preserving halo padding) -- forced, so that both run whatever the measurement
-    would pick on this box."""
-    mp.spawn(_worker, args=(2, _free_port(), 64, layout), nprocs=2, join=True)
+    row-slab forms, halo rows sent and received in place) -- forced, so that both run whatever the
+    measurement would pick on this box.  per_conv: halo exchange before every convolution (thin slabs) or
+    before every chain of three."""
+    mp.spawn(_worker, args=(2, _free_port(), 64, layout, per_conv), nprocs=2, join=True)

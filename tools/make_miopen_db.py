@@ -32,7 +32,17 @@ if ranks == 1:
     bench.train_step(model, opt, loss_fn, batch, fp16=fp16)
 else:
     sdist._exchange = lambda part, a, b: (th.zeros_like(a) if part.has_up else None, th.zeros_like(b) if part.has_down else None)
+
+    def _into(part, to_up, to_down, into_up, into_down, between=None):
+        if part.has_up:
+            into_up.zero_()
+        if part.has_down:
+            into_down.zero_()
+        if between is not None:
+            between()
+    sdist._exchange_into = _into
     sdist._all_reduce_sum = lambda t, part: t.cuda() if not t.is_cuda else t
+    sdist._all_reduce_min = lambda t, part: t
     part = sdist.SlabPartition(H, ranks, rank)
     batch = bench.make_model_inputs(H, W, 8, dev, seed=1, rows=(part.y0, part.y1))
     sdist.ShardedDenoiser(model, part).train_step(opt, loss_fn, batch)
