@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    t0, n, fused_bwd, halves = time.time(), 0, 0, 0
+    t0, n, fused_bwd, halves, half_trains = time.time(), 0, 0, 0, 0
     while time.time() - t0 < args.seconds:
         S = int(rng.choice([1, 1, 2, 3, 8]))
         B = S * int(rng.choice([1, 1, 2, 3]))
@@ -88,13 +88,55 @@ def main():
                 errh = (yh.float() - refh).abs().max().item()
                 assert errh <= 1e-3 * refh.abs().max().item() + 1e-3, "half forward: %.3e" % errh
                 halves += 1
+            if n % 3 == 1 and cout <= 128:      # half-storage training (autocast): forward + backward on half tensors
+                half_training_case(x0, w0, b0, t0_, S, tm, act, slope, x_half=bool(n % 2))
+                half_trains += 1
         except Exception:
             print("FAILED case:", tag, flush=True)
             raise
         n += 1
         fused_bwd += int(cout <= 128)
-    print("fuzz ok: %d random layers (%d with the fused backward, %d half-storage forwards) in %.0f s" % (
-        n, fused_bwd, halves, time.time() - t0))
+    print("fuzz ok: %d random layers (%d with the fused backward, %d half-storage forwards, %d half-storage "
+          "forward+backward) in %.0f s" % (n, fused_bwd, halves, half_trains, time.time() - t0))
+
+
+def half_training_case(x0, w0, b0, t0, S, tm, act, slope, x_half):
+    """PointwiseLayer(..., half=True) forward + backward vs fp32 torch on exactly the values the kernels see
+    (tests/test_gpu_ops.py::test_pointwise_half_training): an all-half layer runs on the f16 matrix pipe in both
+    directions (weights and gz rounded to half, exact products, fp32 sums)."""
+    x0, w0, b0 = x0.detach(), w0.detach(), b0.detach()       # (main's fp32 leaves are these very tensors)
+    t0 = None if t0 is None else t0.detach()
+    B, cin, hw = x0.shape
+    cout = w0.shape[0]
+    x = x0.half() if x_half else x0
+    w, b = w0.clone().requires_grad_(), b0.clone().requires_grad_()
+    t = None if t0 is None else t0.clone().requires_grad_()
+    xg = x.clone().requires_grad_()
+    y = F.PointwiseLayer.apply(xg, w, b, t, S, act, slope, True)
+    gy = th.randn(B, cout, hw, device="cuda").half()
+    y.backward(gy)
+    xr = x.float()
+    wq = w0.half().float() if x_half else w0
+    pre = th.einsum("oc,bcp->bop", wq, xr) + b0.view(1, -1, 1)
+    if tm == 1:
+        pre = pre + t0.repeat_interleave(S, 0).unsqueeze(-1)
+    elif tm == 2:
+        pre = pre + t0.repeat_interleave(S, 0)
+    yr = pre if act == 0 else th.where(pre > 0, pre, pre * slope)
+    assert (y.float() - yr).abs().max().item() <= 2.0 ** -10 * yr.abs().max().item() + 1e-3, "half y"
+    g = gy.float()
+    gz = g if act == 0 else th.where(y > 0, g, g * slope)
+    gzq = gz.half().float() if x_half else gz
+    red = (B * hw) ** 0.5
+    close_sum(w.grad, th.einsum("bop,bcp->oc", gzq, xr).double(), 3e-5, 1e-6 * red)
+    close_sum(b.grad, gz.sum((0, 2)).double(), 3e-5, 1e-6 * red)
+    gxr = th.einsum("oc,bop->bcp", wq, gzq)
+    tol = 2.0 ** -10 if x_half else 1e-5
+    assert (xg.grad.float() - gxr).abs().max().item() <= tol * gxr.abs().max().item() + 1e-6, "half gx"
+    if tm == 1:
+        close_sum(t.grad, gz.view(B // S, S, cout, hw).sum((1, 3)).double(), 3e-5, 1e-6 * (S * hw) ** 0.5)
+    elif tm == 2:
+        close(t.grad, gz.view(B // S, S, cout, hw).sum(1), rtol=1e-5)
 
 
 if __name__ == "__main__":
