@@ -162,8 +162,11 @@ class _HaloPad(th.autograd.Function):
         h = x.shape[-2]
         if h < r:
             raise RuntimeError("slab of %d rows is thinner than the halo (%d)" % (h, r))
-        ctx.nhwc_wire = bool(nhwc_wire and x.dim() == 4 and x.shape[0] == 1 and funcs._is_channels_last(x))
+        # (decided from what every rank shares -- the agreed flag and the batch size -- never from this rank's
+        # strides: both ends of an exchange must interpret the bytes alike)
+        ctx.nhwc_wire = bool(nhwc_wire and x.dim() == 4 and x.shape[0] == 1)
         if ctx.nhwc_wire:
+            x = x.contiguous(memory_format=th.channels_last)     # a no-op in the channels-last U-net
             # every rank runs this U-net channels-last (agreed, see sharded_autoencoder) on one image: a run of
             # rows is one block of [row, column, channel] memory.  The halo rows travel in that order and land
             # directly in the padded map; the slab's own rows are copied while they travel.
