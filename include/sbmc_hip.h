@@ -41,7 +41,7 @@ extern "C" {
 #define SBMC_API
 #endif
 
-#define SBMC_HIP_ABI_VERSION 2
+#define SBMC_HIP_ABI_VERSION 3
 #define SBMC_HIP_EINVAL (-1)
 /* largest channel count the fused/plain kernels take in one call */
 #define SBMC_HIP_MAX_CHANNELS 8
@@ -467,6 +467,64 @@ SBMC_API int sbmc_upsample2x_cat_nhwc_slab_fwd_f16(const void *coarse, const voi
                                           int cu, int cl, int hc, int w, int top, int bot, void *stream);
 SBMC_API int sbmc_upsample2x_cat_nhwc_slab_bwd_f16(const void *gout, void *gcoarse, void *gleft, int b,
                                           int cu, int cl, int hc, int w, int top, int bot, void *stream);
+
+/* ---- neighbour halo transport for one frame sharded over the GPUs of a node (csrc/halo.hip) ----------
+ * New functionality (the reference is single-process; closest analogue: the overlapped tiles of
+ * scripts/denoise.py:54-93).  Every rank owns a MAILBOX in uncached device memory that its two neighbours map
+ * through HIP IPC; `put` packs rows of a tensor straight into the neighbour's mailbox (peer stores over xGMI)
+ * and raises a flag there, `get` waits for the flag on the device, unpacks into the consumer's tensor and hands
+ * the slot back: two launches per exchange, no communication library and no host round trip on the data path.
+ * These are the ONLY entry points of the library that allocate: the caller owns a mailbox from
+ * sbmc_halo_alloc to sbmc_halo_free and a mapping from sbmc_halo_open to sbmc_halo_close.
+ *
+ * Directions: 0 = up (rank - 1), 1 = down (rank + 1).  A mailbox has two rings of `nslots` slots of
+ * `slot_bytes` (a multiple of 16); message number `seq` of a direction (0, 1, 2, ... counted by the caller,
+ * the same on both ends of a link) uses slot seq % nslots, and its sender first waits until message
+ * seq - nslots was consumed.  A message is `chunks` runs of `chunk_bytes`, `pitch` bytes apart in the tensor
+ * and dense in the slot.  Waits are bounded by `timeout_ticks` of the 100 MHz wall clock; after a time-out
+ * the kernels run on and sbmc_halo_status reports a non-zero word (1/2: put waited for a free slot up/down,
+ * 3/4: get waited for data from above/below).
+ */
+#define SBMC_HALO_HANDLE_BYTES 64
+/* bytes of a mailbox with the given ring geometry (0: bad arguments) */
+SBMC_API size_t sbmc_halo_bytes(long long slot_bytes, int nslots);
+/* allocates and zeroes a mailbox on the current device, returns its address and its IPC handle */
+SBMC_API int sbmc_halo_alloc(size_t bytes, void **base, unsigned char *handle);
+SBMC_API int sbmc_halo_free(void *base);
+/* maps the mailbox another process exported (any GPU of the node) into this one / unmaps it */
+SBMC_API int sbmc_halo_open(const unsigned char *handle, void **base);
+SBMC_API int sbmc_halo_close(void *peer_base);
+/* reads the time-out word of a mailbox (synchronous 4-byte copy: call at a synchronisation point) */
+SBMC_API int sbmc_halo_status(void *box, unsigned *err);
+/* sends src_up to the mailbox up_box and src_down to down_box (a NULL box: no such neighbour) */
+SBMC_API int sbmc_halo_put(void *box, void *up_box, void *down_box, const void *src_up, const void *src_down,
+                  long long chunks, long long chunk_bytes, long long pitch, unsigned seq_up, unsigned seq_down,
+                  int nslots, long long slot_bytes, long long timeout_ticks, void *stream);
+/* receives into dst_up / dst_down (NULL: nothing expected from there): dst = received, or
+ * dst = add + received with add_elem = 4 (float) or 2 (_Float16) -- the adjoint of halo padding.  In the
+ * same launch, optionally, a plain 2-d copy body_src -> body_dst (the slab's own rows). */
+SBMC_API int sbmc_halo_get(void *box, void *up_box, void *down_box, void *dst_up, void *dst_down,
+                  const void *add_up, const void *add_down, int add_elem,
+                  long long chunks, long long chunk_bytes, long long dst_pitch, long long add_pitch,
+                  void *body_dst, const void *body_src, long long body_chunks, long long body_chunk_bytes,
+                  long long body_dst_pitch, long long body_src_pitch,
+                  unsigned seq_up, unsigned seq_down, int nslots, long long slot_bytes, long long timeout_ticks,
+                  void *stream);
+/* Cross-rank merge of the splat's running state (reference sbmc/modules.py:450-471: M = max(m1, m2),
+ * sums rescaled by exp(m - M)).  ext [bs, c + 2, top + rows + bot, w] is this rank's partial state on its slab
+ * extended by p rows towards each neighbour (channels: c of sum_r, sum_w, max_w; top, bot = p or 0); its
+ * overhang rows were sent with sbmc_halo_put (chunks = bs * (c + 2), chunk = p * w floats).  fwd waits for the
+ * neighbours' overhangs, merges them into the first / last p of the slab's own rows -> out [bs, c + 2, rows, w]
+ * and keeps what arrived in recv_up / recv_down [bs, c + 2, p, w]; bwd (local) returns the gradient of the own
+ * rows into gext[:, :, top : top + rows] and the gradient of what was received (to be sent back and stored
+ * into the sender's gext overhang rows with sbmc_halo_put / sbmc_halo_get). */
+SBMC_API int sbmc_halo_merge_state_fwd_f32(void *box, void *up_box, void *down_box, const float *ext, float *out,
+                                  float *recv_up, float *recv_down, int bs, int c, int rows, int w, int p,
+                                  int top, int bot, unsigned seq_up, unsigned seq_down, int nslots,
+                                  long long slot_bytes, long long timeout_ticks, void *stream);
+SBMC_API int sbmc_halo_merge_state_bwd_f32(const float *ext, const float *recv_up, const float *recv_down,
+                                  const float *gout, float *gext, float *grecv_up, float *grecv_down,
+                                  int bs, int c, int rows, int w, int p, int top, int bot, void *stream);
 
 #ifdef __cplusplus
 }

@@ -73,8 +73,18 @@ SYMBOLS = (
     "sbmc_upsample2x_cat_nhwc_slab_bwd_f32",
     "sbmc_upsample2x_cat_nhwc_slab_fwd_f16",
     "sbmc_upsample2x_cat_nhwc_slab_bwd_f16",
+    "sbmc_halo_bytes",
+    "sbmc_halo_alloc",
+    "sbmc_halo_free",
+    "sbmc_halo_open",
+    "sbmc_halo_close",
+    "sbmc_halo_status",
+    "sbmc_halo_put",
+    "sbmc_halo_get",
+    "sbmc_halo_merge_state_fwd_f32",
+    "sbmc_halo_merge_state_bwd_f32",
 )
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_CHANNELS = 8
 
 _LIB = None
@@ -176,8 +186,20 @@ def lib():
     handle.sbmc_upsample2x_cat_nhwc_slab_bwd_f32.argtypes = [p, p, p, i, i, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_nhwc_slab_fwd_f16.argtypes = handle.sbmc_upsample2x_cat_nhwc_slab_fwd_f32.argtypes
     handle.sbmc_upsample2x_cat_nhwc_slab_bwd_f16.argtypes = handle.sbmc_upsample2x_cat_nhwc_slab_bwd_f32.argtypes
+    ll, u = ctypes.c_longlong, ctypes.c_uint
+    handle.sbmc_halo_bytes.argtypes = [ll, i]
+    handle.sbmc_halo_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(p), ctypes.c_char_p]
+    handle.sbmc_halo_free.argtypes = [p]
+    handle.sbmc_halo_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(p)]
+    handle.sbmc_halo_close.argtypes = [p]
+    handle.sbmc_halo_status.argtypes = [p, ctypes.POINTER(u)]
+    handle.sbmc_halo_put.argtypes = [p] * 5 + [ll, ll, ll, u, u, i, ll, ll, p]
+    handle.sbmc_halo_get.argtypes = [p] * 7 + [i, ll, ll, ll, ll, p, p, ll, ll, ll, ll, u, u, i, ll, ll, p]
+    handle.sbmc_halo_merge_state_fwd_f32.argtypes = [p] * 7 + [i] * 7 + [u, u, i, ll, ll, p]
+    handle.sbmc_halo_merge_state_bwd_f32.argtypes = [p] * 7 + [i] * 7 + [p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
+    handle.sbmc_halo_bytes.restype = ctypes.c_size_t
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t
     if handle.sbmc_hip_abi_version() != ABI_VERSION:
         raise HipExtensionMissing("ABI version mismatch: rebuild with `python -m sbmc_amd.build --force`")

@@ -57,6 +57,10 @@ class SlabPartition(object):
         self.y0, self.y1 = u0 * unit, u1 * unit
         self.has_up = rank > 0
         self.has_down = rank < world - 1
+        #: halo.HaloChannel once ShardedDenoiser (or a test) has connected the ranks of one node through
+        #: IPC mailboxes; None: neighbour rows travel through torch.distributed P2P
+        self.channel = None
+        self._agreed = {}
 
     @property
     def rows(self):
@@ -116,17 +120,15 @@ def _exchange(part, to_up, to_down):
     return from_up, from_down
 
 
-_AGREED = {}
-
-
 def _all_agree(flag, part, key):
-    """Logical AND of `flag` over the ranks of the partition (cached per key: one tiny collective per new shape).
-    Used for decisions every rank takes by *measurement* but that both ends of an exchange must share."""
-    key = (id(part.group),) + tuple(key)
-    if key not in _AGREED:
+    """Logical AND of `flag` over the ranks of the partition (cached per key ON the partition object, whose
+    lifetime is the process group's: one tiny collective per new shape).  Used for decisions every rank takes
+    by *measurement* but that both ends of an exchange must share."""
+    key = tuple(key)
+    if key not in part._agreed:
         t = th.tensor([1.0 if flag else 0.0])
-        _AGREED[key] = bool(_all_reduce_min(t, part).item() > 0.5)
-    return _AGREED[key]
+        part._agreed[key] = bool(_all_reduce_min(t, part).item() > 0.5)
+    return part._agreed[key]
 
 
 def _all_reduce_min(t, part):
@@ -165,6 +167,9 @@ class _HaloPad(th.autograd.Function):
         # (decided from what every rank shares -- the agreed flag and the batch size -- never from this rank's
         # strides: both ends of an exchange must interpret the bytes alike)
         ctx.nhwc_wire = bool(nhwc_wire and x.dim() == 4 and x.shape[0] == 1)
+        ctx.via_channel = part.channel is not None and x.is_cuda
+        if ctx.via_channel:
+            return _halo_pad_channel(ctx, x, r, part, bool(nhwc_wire and x.dim() == 4))
         if ctx.nhwc_wire:
             x = x.contiguous(memory_format=th.channels_last)     # a no-op in the channels-last U-net
             # every rank runs this U-net channels-last (agreed, see sharded_autoencoder) on one image: a run of
@@ -199,6 +204,8 @@ class _HaloPad(th.autograd.Function):
         r, part, h = ctx.r, ctx.part, ctx.rows
         top = r if part.has_up else 0
         # gradient of my halo rows goes back to their owners; theirs for my edge rows comes here
+        if ctx.via_channel:
+            return _halo_pad_channel_bwd(ctx, g, r, part, h), None, None, None
         if ctx.nhwc_wire:
             g = g.contiguous(memory_format=th.channels_last)     # the wire order both ends agreed on
             hp = g.shape[-2]
@@ -223,6 +230,54 @@ class _HaloPad(th.autograd.Function):
         if from_down is not None:
             gx[..., h - r:, :] += from_down
         return gx, None, None, None
+
+
+def _halo_pad_channel(ctx, x, r, part, nhwc):
+    """`_HaloPad.forward` through the IPC mailboxes (halo.HaloChannel): one `put` (my edge rows into the
+    neighbours' mailboxes) and one `get` (their rows into the padded map + the copy of my own rows) -- two
+    launches, nothing on the host.  nhwc: every rank holds this tensor channels-last (agreed)."""
+    from .halo import rows_run
+    ch, h = part.channel, x.shape[-2]
+    ctx.nhwc = nhwc
+    fmt = th.channels_last if nhwc else th.contiguous_format
+    x = x.contiguous(memory_format=fmt)
+    top = r if part.has_up else 0
+    bot = r if part.has_down else 0
+    out = th.empty(x.shape[:-2] + (top + h + bot, x.shape[-1]), dtype=x.dtype, device=x.device, memory_format=fmt)
+    ch.put(rows_run(x, 0, r, nhwc) if top else None, rows_run(x, h - r, h, nhwc) if bot else None)
+    ch.get(rows_run(out, 0, top, nhwc) if top else None, rows_run(out, top + h, top + h + bot, nhwc) if bot else None,
+           body=(rows_run(out, top, top + h, nhwc), rows_run(x, 0, h, nhwc)))
+    return out
+
+
+def _halo_pad_channel_bwd(ctx, g, r, part, h):
+    """The adjoint: the gradient of my halo rows goes back to their owners, theirs for my edge rows is added
+    to my own rows' gradient inside the `get`."""
+    from .halo import rows_run
+    ch, nhwc = part.channel, ctx.nhwc
+    fmt = th.channels_last if nhwc else th.contiguous_format
+    g = g.contiguous(memory_format=fmt)
+    hp = g.shape[-2]
+    top = r if part.has_up else 0
+    bot = r if part.has_down else 0
+    gx = th.empty(g.shape[:-2] + (h, g.shape[-1]), dtype=g.dtype, device=g.device, memory_format=fmt)
+    es = g.element_size()
+    if es not in (2, 4):
+        raise RuntimeError("halo transport: float32 / float16 gradients only")
+    ch.put(rows_run(g, 0, r, nhwc) if top else None, rows_run(g, hp - r, hp, nhwc) if bot else None)
+    if top and bot and h < 2 * r:
+        # both neighbours reach the same rows: first the rows from above plus everything else, then the rows
+        # from below are added in place
+        ch.get(up=rows_run(gx, 0, r, nhwc), add_up=rows_run(g, top, top + r, nhwc), add_elem=es,
+               body=(rows_run(gx, r, h, nhwc), rows_run(g, top + r, top + h, nhwc)) if h > r else None)
+        ch.get(down=rows_run(gx, h - r, h, nhwc), add_down=rows_run(gx, h - r, h, nhwc), add_elem=es)
+        return gx
+    lo, hi = (r if top else 0), (h - r if bot else h)
+    ch.get(up=rows_run(gx, 0, r, nhwc) if top else None, add_up=rows_run(g, top, top + r, nhwc) if top else None,
+           down=rows_run(gx, h - r, h, nhwc) if bot else None,
+           add_down=rows_run(g, top + h - r, top + h, nhwc) if bot else None, add_elem=es,
+           body=(rows_run(gx, lo, hi, nhwc), rows_run(g, top + lo, top + hi, nhwc)) if hi > lo else None)
+    return gx
 
 
 def halo_pad(x, r, part, nhwc_wire=False):
@@ -273,13 +328,22 @@ def _reach(chain):
 #: Measured at 8 ranks of a 720p frame (23 rows per rank at the U-net's coarsest level; find records for the
 #: new heights are shipped): -4.4 ms of convolution work per step (80.8 -> 76.4 ms with the exchanges stubbed
 #: out) against +5.5 ms for the 62 extra exchanges issued through torch.distributed (84.5 vs 83.4 ms with the
-#: exchanges running over RCCL to the rank itself, tools/rank_cost.py --rccl-self): a loss until neighbour
-#: exchanges get cheaper than ~50 us apiece, so it is OFF (0) by default.
-PER_CONV_HALO_BELOW = 0
+#: exchanges running over RCCL to the rank itself, tools/rank_cost.py --rccl-self): a loss while a neighbour
+#: exchange costs ~50 us, so through torch.distributed P2P it stays OFF (0).  Through the IPC mailboxes
+#: (halo.HaloChannel, two launches per exchange) it is a gain: on below PER_CONV_HALO_BELOW_CHANNEL rows.
+#: None = that automatic choice; a number forces the threshold for both transports (tests).
+PER_CONV_HALO_BELOW = None
+PER_CONV_HALO_BELOW_CHANNEL = 128
+
+
+def _per_conv_below(part):
+    if PER_CONV_HALO_BELOW is not None:
+        return PER_CONV_HALO_BELOW
+    return PER_CONV_HALO_BELOW_CHANNEL if part.channel is not None else 0
 
 
 def _per_conv(chain, part):
-    return (hasattr(chain, "_run") and part.min_rows < PER_CONV_HALO_BELOW
+    return (hasattr(chain, "_run") and part.min_rows < _per_conv_below(part)
             and all(m.padding[0] == m.kernel_size[0] // 2 and m.stride[0] == 1
                     for m in chain.modules() if isinstance(m, th.nn.Conv2d)))
 
@@ -367,6 +431,41 @@ class _OverhangExchange(th.autograd.Function):
         return (th.cat(pieces, -2) if len(pieces) > 1 else g_own), None, None
 
 
+class _MergeOverhangChannel(th.autograd.Function):
+    """`merge_overhang` through the IPC mailboxes: the overhang rows are `put` into the neighbours' mailboxes,
+    one kernel waits for theirs and merges them into this slab's edge rows (csrc/halo.hip, the reference's
+    rule sbmc/modules.py:450-471, first the rows from above, then those from below, like `_merge_rows`); the
+    backward runs the merge's adjoint locally and returns the gradient of what was received to its sender."""
+
+    @staticmethod
+    def forward(ctx, state, p, part):
+        from .halo import rows_run
+        ch = part.channel
+        state = state.contiguous()
+        top = p if part.has_up else 0
+        bot = p if part.has_down else 0
+        hd = state.shape[-2]
+        ch.put(rows_run(state, 0, top) if top else None, rows_run(state, hd - bot, hd) if bot else None)
+        out, recv_up, recv_down = ch.merge_state_fwd(state, p, top, bot)
+        ctx.part, ctx.p = part, p
+        ctx.save_for_backward(state, recv_up, recv_down)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .halo import rows_run
+        part, p = ctx.part, ctx.p
+        ch = part.channel
+        state, recv_up, recv_down = ctx.saved_tensors
+        top = p if part.has_up else 0
+        bot = p if part.has_down else 0
+        hd = state.shape[-2]
+        gext, g_up, g_down = ch.merge_state_bwd(state, recv_up, recv_down, gout.contiguous(), p, top, bot)
+        ch.put(rows_run(g_up, 0, p) if top else None, rows_run(g_down, 0, p) if bot else None)
+        ch.get(rows_run(gext, 0, top) if top else None, rows_run(gext, hd - bot, hd) if bot else None)
+        return gext, None, None
+
+
 def _merge_rows(state, other, r0, r1, c):
     """Rows [r0, r1) of `state` (+)= `other`, the merge of two running-softmax states (reference
     sbmc/modules.py:450-471): M = max(m1, m2), sum = sum1 * exp(m1 - M) + sum2 * exp(m2 - M).
@@ -382,6 +481,10 @@ def merge_overhang(sum_r, sum_w, max_w, p, part):
     """The cross-rank step of the sharded splat.  In: this rank's partial state on
     its slab extended by p rows towards every neighbour; out: the complete state of its own rows."""
     c = sum_r.shape[1]
+    if part.channel is not None and sum_r.is_cuda and sum_r.dtype == th.float32 and c <= 8:
+        # put + ONE merge kernel (csrc/halo.hip) instead of an exchange and 9 torch kernels per edge
+        own = _MergeOverhangChannel.apply(th.cat([sum_r, sum_w, max_w], 1), p, part)
+        return own[:, :c], own[:, c:c + 1], own[:, c + 1:]
     own, from_up, from_down = _OverhangExchange.apply(th.cat([sum_r, sum_w, max_w], 1), p, part)
     rows = own.shape[-2]
     if part.has_up:
@@ -406,6 +509,30 @@ class ShardedDenoiser(object):
         # merge_state=False forces the halo-recompute form of the splat (kept for the comparison)
         self.merge_state = possible if merge_state is None else (bool(merge_state) and possible)
         self._flat = None
+        self._channel_tried = False
+
+    def _connect(self, device, bs, w):
+        """Once, at the first frame (a collective: every rank gets here): the IPC mailboxes between
+        neighbouring ranks (halo.HaloChannel) when all ranks sit on one node; SBMC_HALO_TRANSPORT=p2p keeps
+        torch.distributed P2P (RCCL over xGMI; gloo: staged through the host)."""
+        import os
+        self._channel_tried = True
+        part = self.part
+        if part.world == 1 or part.channel is not None or device.type != "cuda":
+            return
+        if os.environ.get("SBMC_HALO_TRANSPORT", "ipc").lower() != "ipc":
+            return
+        from .halo import HaloChannel
+        # the largest U-net message: 3 rows of a right branch's input (3 * width channels at full width; the
+        # same number of bytes at every level); larger runs (the halo-recompute form of the splat) are split
+        mb = 1 << 20
+        slot = min(64 * mb, max(mb, -(-9 * self.model.width * w * 4 * bs // mb) * mb))
+        part.channel = HaloChannel.connect(part, device, slot)
+
+    def check(self):
+        """Raises if the halo transport has reported a time-out (synchronises the device)."""
+        if self.part.channel is not None:
+            self.part.channel.check()
 
     def forward(self, batch):
         m, part = self.model, self.part
@@ -416,6 +543,8 @@ class ShardedDenoiser(object):
             radiance = radiance.mean(1, keepdim=True)
             features = features.mean(1, keepdim=True)
         bs, spp, nf, h, w = features.shape
+        if not self._channel_tried:
+            self._connect(radiance.device, bs, w)
         context = gfeatures
         for step in range(m.nsteps):
             features, reduced = m._embed(getattr(m, "embedding_{:02d}".format(step)), features, context,
@@ -499,7 +628,9 @@ class ShardedDenoiser(object):
             if summed.data_ptr() != flat.data_ptr():
                 flat.copy_(summed)
         total = flat[-1]
-        if not th.isfinite(total).item():              # the step's one host synchronisation (reference guard)
+        finite = th.isfinite(total).item()             # the step's one host synchronisation (reference guard)
+        self.check()                                   # (a 4-byte read right after it: did a halo wait time out?)
+        if not finite:
             raise RuntimeError("non-finite loss")
         th.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
         optimizer.step()

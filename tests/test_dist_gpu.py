@@ -28,9 +28,10 @@ def _close(a, b, rtol, what):
     assert err <= rtol * max(scale, 1e-30) + 1e-12, "%s: err %.3e scale %.3e" % (what, err, scale)
 
 
-def _worker(rank, world, port, height, layout="auto", per_conv=True):
+def _worker(rank, world, port, height, layout="auto", per_conv=True, transport="ipc"):
     sys.path.insert(0, ROOT)
     os.environ["SBMC_UNET_LAYOUT"] = layout
+    os.environ["SBMC_HALO_TRANSPORT"] = transport
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -73,14 +74,17 @@ def _worker(rank, world, port, height, layout="auto", per_conv=True):
         _close(loss, ref_loss.detach(), 2e-5, "loss")
         for k, q in model.named_parameters():
             _close(q.grad, ref_grads[k], 5e-4, "grad " + k)
+        assert (part.channel is not None) == (transport == "ipc")
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("transport", ["ipc", "p2p"])
 @pytest.mark.parametrize("layout,per_conv", [("nchw", False), ("nhwc", False), ("nhwc", True), ("nchw", True)])
-def test_sharded_denoiser_on_device_kernels(layout, per_conv):
+def test_sharded_denoiser_on_device_kernels(layout, per_conv, transport):
     """layout: the U-nets planar, or channels-last (MIOpen NHWC solvers, NHWC glue kernels in their
     row-slab forms, halo rows sent and received in place) -- forced, so that both run whatever the
     measurement would pick on this box.  per_conv: halo exchange before every convolution (thin slabs) or
-    before every chain of three."""
-    mp.spawn(_worker, args=(2, _free_port(), 64, layout, per_conv), nprocs=2, join=True)
+    before every chain of three.  transport: neighbour rows through the IPC mailboxes (csrc/halo.hip; the splat
+    state then merges in ONE kernel) or through torch.distributed P2P (gloo here: staged through the host)."""
+    mp.spawn(_worker, args=(2, _free_port(), 64, layout, per_conv, transport), nprocs=2, join=True)
