@@ -502,7 +502,8 @@ SBMC_API int sbmc_halo_put(void *box, void *up_box, void *down_box, const void *
                   int nslots, long long slot_bytes, long long timeout_ticks, void *stream);
 /* receives into dst_up / dst_down (NULL: nothing expected from there): dst = received, or
  * dst = add + received with add_elem = 4 (float) or 2 (_Float16) -- the adjoint of halo padding.  In the
- * same launch, optionally, a plain 2-d copy body_src -> body_dst (the slab's own rows). */
+ * same launch, optionally, a plain 2-d copy body_src -> body_dst (the slab's own rows; body_src NULL: the
+ * run body_dst is filled with zeros). */
 SBMC_API int sbmc_halo_get(void *box, void *up_box, void *down_box, void *dst_up, void *dst_down,
                   const void *add_up, const void *add_down, int add_elem,
                   long long chunks, long long chunk_bytes, long long dst_pitch, long long add_pitch,

@@ -111,8 +111,8 @@ struct GetArgs {
     unsigned nslots;
     long long slot_bytes;
     long long timeout_ticks;
-    char* body_dst;            // optional plain 2-d copy in the same launch (the slab's own rows)
-    const char* body_src;
+    char* body_dst;            // optional plain 2-d copy in the same launch (the slab's own rows);
+    const char* body_src;      // body_src == NULL: the run is filled with zeros instead
     long long body_dst_pitch, body_src_pitch;
     unsigned body_chunk_units, body_total_units;
     unsigned halo_blocks;      // blocks (of gridDim.x) that work on a halo part; the body uses all of them
@@ -140,8 +140,9 @@ __global__ void __launch_bounds__(THREADS) get_kernel(GetArgs a) {
         if (a.body_dst == nullptr) return;
         for (unsigned i = blockIdx.x * THREADS + threadIdx.x; i < a.body_total_units; i += gridDim.x * THREADS) {
             const unsigned chunk = i / a.body_chunk_units, off = i - chunk * a.body_chunk_units;
-            reinterpret_cast<U*>(a.body_dst + chunk * a.body_dst_pitch)[off] =
-                reinterpret_cast<const U*>(a.body_src + chunk * a.body_src_pitch)[off];
+            U v{};
+            if (a.body_src != nullptr) v = reinterpret_cast<const U*>(a.body_src + chunk * a.body_src_pitch)[off];
+            reinterpret_cast<U*>(a.body_dst + chunk * a.body_dst_pitch)[off] = v;
         }
         return;
     }
@@ -430,7 +431,7 @@ int sbmc_halo_get(void* box, void* up_box, void* down_box, void* dst_up, void* d
     if ((dst_up && !up_box) || (dst_down && !down_box)) return SBMC_HIP_EINVAL;
     if (add_elem != 0 && add_elem != 2 && add_elem != 4) return SBMC_HIP_EINVAL;
     if (add_elem != 0 && ((dst_up && !add_up) || (dst_down && !add_down))) return SBMC_HIP_EINVAL;
-    if (body_dst != nullptr && (body_src == nullptr || body_chunks <= 0 || body_chunk_bytes <= 0 ||
+    if (body_dst != nullptr && (body_chunks <= 0 || body_chunk_bytes <= 0 ||
                                 body_chunks * body_chunk_bytes >= (1ll << 32))) return SBMC_HIP_EINVAL;
     if (!any && body_dst == nullptr) return 0;
     GetArgs a;
@@ -459,6 +460,7 @@ int sbmc_halo_get(void* box, void* up_box, void* down_box, void* dst_up, void* d
               (!dst_down || aligned16(dst_down));
         if (add_elem) v16 = v16 && add_pitch % 16 == 0 && (!dst_up || aligned16(add_up)) && (!dst_down || aligned16(add_down));
     }
+    if (body_src == nullptr) body_src_pitch = 0;
     if (body_dst) v16 = v16 && body_chunk_bytes % 16 == 0 && body_dst_pitch % 16 == 0 && body_src_pitch % 16 == 0 &&
                         aligned16(body_dst) && aligned16(body_src);
     int unit = 16;

@@ -151,6 +151,21 @@ def _all_reduce_sum(t, part):
     return h.to(dev)
 
 
+def _all_reduce_sum_start(t, part):
+    """Starts the in-place sum of `t` over the ranks and returns what `wait()` must be called on before `t` is
+    read (None: already done).  RCCL: asynchronous on its own stream, ordered after what the current stream
+    has enqueued so far -- the rest of the backward overlaps it.  Other backends: done on return."""
+    if part.world == 1:
+        return None
+    if t.is_cuda and dist.get_backend(part.group) == "nccl":
+        with funcs._timed("grad_all_reduce", t.device):
+            return dist.all_reduce(t, group=part.group, async_op=True)
+    summed = _all_reduce_sum(t, part)
+    if summed.data_ptr() != t.data_ptr():
+        t.copy_(summed)
+    return None
+
+
 def _rows_nhwc(t, r0, r1):
     """Rows [r0, r1) of a channels-last map of ONE image as a contiguous [1, rows, w, c] view (one block of
     memory: nothing is copied, and writes through the view land in `t`)."""
@@ -289,6 +304,86 @@ def halo_pad(x, r, part, nhwc_wire=False):
     return _HaloPad.apply(x, r, part, nhwc_wire)
 
 
+class _HaloRefresh(th.autograd.Function):
+    """A padded map (top + h + bot rows whose outer rows hold stale values: the result of a padded convolution
+    on a halo-padded slab) gets FRESH halo rows from the neighbours, in place: the rows of a slab that a chain
+    of convolutions keeps halo-padded are never copied between its convolutions -- `_crop_halo` + `halo_pad`
+    would copy the whole slab to renew a row or two.  IPC mailboxes only (the kernels write through raw
+    pointers; torch sees a view of the same tensor).
+
+    Backward, in place on the incoming gradient as well: the halo rows' gradient goes back to the rows' owners,
+    theirs for this slab's edge rows is added to them, and the halo rows' own gradient becomes zero -- the
+    producer of the padded map computes nothing from it (its stale rows are not part of the function)."""
+
+    @staticmethod
+    def forward(ctx, x, r, part, nhwc):
+        from .halo import rows_run
+        ch = part.channel
+        top = r if part.has_up else 0
+        bot = r if part.has_down else 0
+        hp = x.shape[-2]
+        h = hp - top - bot
+        ctx.r, ctx.part, ctx.nhwc, ctx.h = r, part, nhwc, h
+        ch.put(rows_run(x, top, top + r, nhwc) if top else None, rows_run(x, top + h - r, top + h, nhwc) if bot else None)
+        ch.get(rows_run(x, 0, top, nhwc) if top else None, rows_run(x, top + h, hp, nhwc) if bot else None)
+        # a second handle on the same memory with the same strides: returning `x` itself would make autograd
+        # re-view it (`x.view_as(x)`), which loses the channels-last strides of a one-image batch -- MIOpen then
+        # transposes every input -- and marking it dirty would invalidate what its in-place producer saved
+        return x.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        from .halo import rows_run
+        r, part, nhwc, h = ctx.r, ctx.part, ctx.nhwc, ctx.h
+        ch = part.channel
+        fmt = th.channels_last if nhwc else th.contiguous_format
+        g = g.contiguous(memory_format=fmt)
+        top = r if part.has_up else 0
+        bot = r if part.has_down else 0
+        hp = top + h + bot
+        es = g.element_size()
+        ch.put(rows_run(g, 0, top, nhwc) if top else None, rows_run(g, top + h, hp, nhwc) if bot else None)
+        up = rows_run(g, top, top + r, nhwc) if top else None
+        down = rows_run(g, top + h - r, top + h, nhwc) if bot else None
+        # the halo rows' gradient has been sent: zero it in the same launch where the two halo runs are ONE
+        # 2-d run (a single channels-last image with both neighbours), else with torch
+        zero = None
+        if nhwc and g.shape[0] == 1 and top and bot:
+            a = rows_run(g, 0, top, nhwc)
+            zero = ((a[0], 2, a[2], (top + h) * g.shape[-1] * g.shape[1] * es), None)
+        if top and bot and h < 2 * r:                  # both neighbours reach the same rows: one after the other
+            ch.get(up=up, add_up=up, add_elem=es, body=zero)
+            ch.get(down=down, add_down=down, add_elem=es)
+        else:
+            ch.get(up=up, down=down, add_up=up, add_down=down, add_elem=es, body=zero)
+        if zero is None:
+            if top:
+                g[..., :top, :].zero_()
+            if bot:
+                g[..., top + h:, :].zero_()
+        return g, None, None, None
+
+
+def halo_refresh(x, r, part, nhwc=False):
+    """`x`: top + h + bot rows (top / bot = r where there is a neighbour), outer rows stale -> the same tensor
+    with the neighbours' current edge rows there; None where this in-place form does not apply (no IPC
+    channel, memory not dense in the agreed layout, half-precision planar...): the caller then crops and pads.
+    Either form puts the same messages on the wire, so neighbouring ranks need not choose alike."""
+    if part.channel is None or not x.is_cuda or x.dim() != 4 or x.element_size() not in (2, 4):
+        return None
+    top = r if part.has_up else 0
+    bot = r if part.has_down else 0
+    if x.shape[-2] - top - bot < r:
+        return None
+    if nhwc:
+        b, c, h, w = x.shape
+        if x.stride() != (h * w * c, 1, w * c, c):
+            return None
+    elif not x.is_contiguous():
+        return None
+    return _HaloRefresh.apply(x, r, part, bool(nhwc))
+
+
 class _CropRows(th.autograd.Function):
     """y[..., top : h - bot, :] whose backward is ONE zero-padding pass (torch's slice backward fills a
     zero tensor and then copies the gradient into it: two passes over every U-net activation)."""
@@ -339,6 +434,9 @@ PER_CONV_HALO_BELOW_CHANNEL = 128
 def _per_conv_below(part):
     if PER_CONV_HALO_BELOW is not None:
         return PER_CONV_HALO_BELOW
+    import os
+    if os.environ.get("SBMC_PER_CONV_HALO_BELOW"):        # measurements (the same value on every rank)
+        return int(os.environ["SBMC_PER_CONV_HALO_BELOW"])
     return PER_CONV_HALO_BELOW_CHANNEL if part.channel is not None else 0
 
 
@@ -351,7 +449,8 @@ def _per_conv(chain, part):
 def _chain(chain, x, part, nhwc=False):
     if _per_conv(chain, part):          # (a property of the partition and the module: the same on every rank)
         return chain._run(list(chain.children()), x,
-                          halo=(lambda t, r: halo_pad(t, r, part, nhwc), lambda t, r: _crop_halo(t, r, part)))
+                          halo=(lambda t, r: halo_pad(t, r, part, nhwc), lambda t, r: _crop_halo(t, r, part),
+                                lambda t, r: halo_refresh(t, r, part, nhwc)))
     r = _reach(chain)
     return _crop_halo(chain(halo_pad(x, r, part, nhwc)), r, part)
 
@@ -580,31 +679,63 @@ class ShardedDenoiser(object):
         bot = 0 if self.part.has_down else p
         return target[..., top:target.shape[-2] - bot, p:-p]
 
+    #: bytes of gradients per all-reduce: the flat gradient buffer (139 MB for Multisteps(93, 3)) is summed in
+    #: buckets of about this size, each as soon as the backward has produced its gradients
+    BUCKET_BYTES = 48 << 20
+
     def _flat_grads(self):
-        """One flat fp32 buffer with a slot per parameter gradient plus one for the loss: the cross-rank sum
-        is ONE all-reduce of this buffer."""
+        """One flat fp32 buffer with a slot per parameter gradient plus one for the loss.  It is cut into
+        contiguous buckets at parameter boundaries (registration order: the backward fills the buffer from its
+        end); a bucket's cross-rank sum starts when its last gradient arrives (post-accumulate hooks), so only
+        the last bucket's all-reduce is not hidden behind the rest of the backward."""
         if self._flat is None:
             self._params = [q for q in self.model.parameters() if q.requires_grad]
             n = sum(q.numel() for q in self._params)
             self._flat = th.zeros(n + 1, dtype=th.float32, device=self._params[0].device)
             self._views, off = [], 0
-            for q in self._params:
+            self._buckets = []                       # [first param, last param + 1, first element, last element + 1]
+            for i, q in enumerate(self._params):
                 self._views.append(self._flat[off:off + q.numel()].view_as(q))
+                if not self._buckets or (off - self._buckets[-1][2]) * 4 >= self.BUCKET_BYTES:
+                    self._buckets.append([i, i, off, off])
                 off += q.numel()
+                self._buckets[-1][1], self._buckets[-1][3] = i + 1, off
+            self._buckets[-1][3] = n + 1             # the loss rides with the bucket the backward completes first
+            self._bucket_of = {}
+            for b, (i0, i1, _, _) in enumerate(self._buckets):
+                for i in range(i0, i1):
+                    self._bucket_of[i] = b
+            self._in_step = False
+            for i, q in enumerate(self._params):
+                q.register_post_accumulate_grad_hook(lambda _q, i=i: self._grad_arrived(i))
         return self._flat
 
-    def _gather_grads(self):
-        """The step's gradients into the flat buffer, and every `.grad` re-pointed at its slot (the optimizer
-        then reads the all-reduced values in place).  The backward itself runs with `.grad = None`, so autograd
-        hands each gradient over without an accumulation pass (one add kernel per parameter otherwise: 246
-        launches per step here); packing them is one multi-tensor copy."""
-        have = [(v, q.grad) for q, v in zip(self._params, self._views) if q.grad is not None]
+    def _grad_arrived(self, i):
+        if not self._in_step:
+            return
+        b = self._bucket_of[i]
+        self._missing[b] -= 1
+        if self._missing[b] == 0:
+            self._reduce_bucket(b)
+
+    def _reduce_bucket(self, b):
+        """The bucket's gradients into the flat buffer (ONE multi-tensor copy; the backward runs with
+        `.grad = None`, so autograd hands every gradient over without an accumulation pass), every `.grad`
+        re-pointed at its slot (clipping and the optimizer then read the summed values in place), and the
+        cross-rank sum of the bucket's slice started."""
+        i0, i1, e0, e1 = self._buckets[b]
+        params, views = self._params[i0:i1], self._views[i0:i1]
+        have = [(v, q.grad) for q, v in zip(params, views) if q.grad is not None]
         if have:
             th._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        for q, v in zip(self._params, self._views):
+        for q, v in zip(params, views):
             if q.grad is None:
                 v.zero_()
             q.grad = v
+        self._missing[b] = -1
+        work = _all_reduce_sum_start(self._flat[e0:e1], self.part)
+        if work is not None:
+            self._works.append(work)
 
     def train_step(self, optimizer, loss_fn, batch, clip=1000):
         """The reference training step (sbmc/interfaces.py:78-105) on the sharded frame.
@@ -613,6 +744,8 @@ class ShardedDenoiser(object):
         flat = self._flat_grads()
         for q in self._params:
             q.grad = None                              # == optimizer.zero_grad(set_to_none=True)
+        self._missing = [i1 - i0 for i0, i1, _, _ in self._buckets]
+        self._works = []
         out = self.forward(batch)["radiance"]
         tgt = self.target_rows(batch["target_image"])
         # this rank's share of the global mean: the frame's output size is known from the partition (the
@@ -620,13 +753,17 @@ class ShardedDenoiser(object):
         p = (self.model.ksize - 1) // 2
         total = out.shape[0] * out.shape[1] * (part.height - 2 * p) * out.shape[-1]
         loss = loss_fn(out, tgt) * (out.numel() / float(total))
-        loss.backward()
-        self._gather_grads()
         flat[-1] = loss.detach()
-        if part.world > 1:
-            summed = _all_reduce_sum(flat, part)       # in place over RCCL; a new tensor when staged
-            if summed.data_ptr() != flat.data_ptr():
-                flat.copy_(summed)
+        self._in_step = True
+        try:
+            loss.backward()                            # (buckets are summed across ranks as they complete)
+        finally:
+            self._in_step = False
+        for b in range(len(self._buckets) - 1, -1, -1):
+            if self._missing[b] >= 0:                  # holds a parameter the loss does not depend on
+                self._reduce_bucket(b)
+        for work in self._works:
+            work.wait()
         total = flat[-1]
         finite = th.isfinite(total).item()             # the step's one host synchronisation (reference guard)
         self.check()                                   # (a 4-byte read right after it: did a halo wait time out?)

@@ -175,7 +175,8 @@ class HaloChannel(object):
 
     def get(self, up=None, down=None, add_up=None, add_down=None, add_elem=0, body=None):
         """Receives into the runs `up` / `down`; with add_elem (4: float, 2: half) the result is
-        add_* + received.  body = (dst_run, src_run): a plain copy in the same launch."""
+        add_* + received.  body = (dst_run, src_run): a plain copy in the same launch (src_run None: dst_run is
+        filled with zeros)."""
         if self.peer[0] is None:
             up = None
         if self.peer[1] is None:
@@ -195,7 +196,7 @@ class HaloChannel(object):
         add_pitch = (add_up or add_down or (0, 0, 0, 0))[3]
         off, aoff = c0 * pitch + b0, c0 * add_pitch + b0
         bd = body[0] if body else (None, 0, 0, 0)
-        bs = body[1] if body else (None, 0, 0, 0)
+        bs = (body[1] if body else None) or (None, 0, 0, 0)
         rc = self.lib.sbmc_halo_get(
             self.box, self.peer[0] if up else None, self.peer[1] if down else None,
             up[0] + off if up else None, down[0] + off if down else None,

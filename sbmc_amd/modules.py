@@ -325,11 +325,12 @@ class ConvChain(nn.Module):
         return funcs.BiasAct.apply(y, conv.bias, act, slope), act != 0
 
     def _run(self, mods, x, mean_s=0, mean_out=None, halo=None):
-        """halo: the chain runs on a row slab of a frame sharded over several GPUs (sbmc_amd.dist) -- a pair
-        (pad, crop): before every padded k x k convolution `pad(x, k // 2)` attaches the neighbouring slabs'
-        k // 2 edge rows, and `crop(y, k // 2)` drops the rows of its result that saw the artificial zero padding
-        beyond them (lazily: just before the next exchange, or at the end, so that in-place activations never meet
-        a view)."""
+        """halo: the chain runs on a row slab of a frame sharded over several GPUs (sbmc_amd.dist) -- a tuple
+        (pad, crop[, refresh]): before every padded k x k convolution `pad(x, k // 2)` attaches the neighbouring
+        slabs' k // 2 edge rows, and `crop(y, k // 2)` drops the rows of its result that saw the artificial zero
+        padding beyond them (lazily: just before the next exchange, or at the end, so that in-place activations
+        never meet a view).  `refresh(y, k // 2)`, where given and applicable (it returns None otherwise), does
+        crop + pad without copying the slab: the stale outer rows of `y` are overwritten by the neighbours'."""
         gemm = self.pointwise_as_gemm and x.is_cuda
         pending = 0                                                # halo rows still to be dropped
         i = 0
@@ -339,10 +340,15 @@ class ConvChain(nn.Module):
             if halo is not None:
                 conv = m.layer[0] if isinstance(m, ConvChain._ConvBNRelu) else m
                 if isinstance(conv, nn.Conv2d) and conv.kernel_size[0] > 1:
-                    if pending:
-                        x = halo[1](x, pending)
-                    pending = conv.kernel_size[0] // 2
-                    x = halo[0](x, pending)
+                    need = conv.kernel_size[0] // 2
+                    fresh = halo[2](x, need) if (len(halo) > 2 and pending == need) else None
+                    if fresh is not None:
+                        x = fresh                                 # the stale halo rows renewed in place
+                    else:
+                        if pending:
+                            x = halo[1](x, pending)
+                        x = halo[0](x, need)
+                    pending = need
             if gemm and isinstance(m, ConvChain._ConvBNRelu) and _is_pointwise(m.layer[0]):
                 rest = list(m.layer.children())[1:]
                 x, fused = _pointwise_gemm(m.layer[0], x, rest[0] if len(rest) == 1 else None)

@@ -118,7 +118,53 @@ def progressive_fp64_torch(datas, kerns, grads=None, splat=True):
     return (sr, sw, mw), [d.grad for d in datas], [k.grad for k in kerns]
 
 
-def no_worse_than(a, ref32, truth, rtol=1e-5, slack=2.0, what=""):
+class ProgressiveFP64(th.nn.Module):
+    """ProgressiveKernelApply(splat=True) (reference sbmc/modules.py:422-471) in torch ops of any dtype."""
+
+    def forward(self, data, kernels, sum_r, sum_w, max_w):
+        bs, k2, h, w = kernels.shape
+        k = int(round(k2 ** 0.5))
+        p = (k - 1) // 2
+        g = gather_logits_fp64(kernels)
+        kmax = g.max(1, keepdim=True)[0]
+        new_max = kmax if sum_r is None else th.max(kmax, max_w)
+        wts = th.exp(g - new_max)
+        dpad = th.nn.functional.pad(data, (p, p, p, p))
+        new_r = th.zeros_like(data)
+        for dy in range(k):
+            for dx in range(k):
+                new_r = new_r + wts[:, dy * k + dx:dy * k + dx + 1] * dpad[:, :, dy:dy + h, dx:dx + w]
+        new_w = wts.sum(1, keepdim=True)
+        if sum_r is None:
+            return new_r, new_w, new_max
+        sc = th.exp(max_w - new_max)
+        return sum_r * sc + new_r, sum_w * sc + new_w, new_max
+
+
+def multisteps_fp64(model, ctor_args, ctor_kwargs):
+    """A float64 twin of `model` (a Multisteps with splat kernels) on the CPU: same weights, torch ops only
+    (the per-sample reference structure: no fused 1x1 kernels, no batched samples, the progressive update in
+    torch float64).  The yardstick two fp32 evaluations are measured against; never "the reference"."""
+    from sbmc_amd import Multisteps
+    m64 = Multisteps(*ctor_args, pointwise_gemm=False, batch_samples=False, **ctor_kwargs)
+    m64.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    m64.double()
+    m64.kernel_update = ProgressiveFP64()
+    return m64
+
+
+def module_scales(named_grads):
+    """max |gradient| per MODULE ({parameter name: scale}): `weight_g` and `weight_v` of a weight-normalised
+    convolution are two projections of one quantity, dL/dw, and weight_g's gradient is a cancellation
+    residual of it -- its rounding error has the size of dL/dw's, not of its own value."""
+    per = {}
+    for k, g in named_grads.items():
+        mod = k.rsplit(".", 1)[0]
+        per[mod] = max(per.get(mod, 0.0), g.detach().abs().max().item())
+    return {k: per[k.rsplit(".", 1)[0]] for k in named_grads}
+
+
+def no_worse_than(a, ref32, truth, rtol=1e-5, slack=2.0, what="", scale=None):
     """|a - truth| <= rtol-bound, OR no worse than `slack` x the error the reference-order fp32
     computation (`ref32`, the oracle) itself makes against the float64 truth, element by element max.
     For quantities whose fp32 value is a difference of two long sums: both implementations round, so
@@ -126,7 +172,7 @@ def no_worse_than(a, ref32, truth, rtol=1e-5, slack=2.0, what=""):
     a = a.detach().cpu().double()
     ref32 = ref32.detach().cpu().double()
     truth = truth.detach().cpu().double()
-    scale = truth.abs().max().item()
+    scale = truth.abs().max().item() if scale is None else scale
     err = (a - truth).abs().max().item()
     ref_err = (ref32 - truth).abs().max().item()
     bound = max(rtol * scale, slack * ref_err)

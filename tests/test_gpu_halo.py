@@ -57,6 +57,40 @@ def test_halo_pad_loopback(shape, nhwc, r, dtype):
     part.channel.check()
 
 
+@pytest.mark.parametrize("shape,nhwc,r", [((1, 8, 12, 20), True, 1), ((1, 8, 12, 20), False, 1), ((2, 4, 9, 16), True, 2),
+                                          ((1, 4, 7, 16), True, 2)])
+def test_halo_refresh_in_place_loopback(shape, nhwc, r):
+    """`halo_refresh`: the stale outer rows of a halo-padded map renewed in place (no copy of the slab), and its
+    adjoint in place on the gradient; vs the closed form of the loop-back wiring.  (1, 4, 7, 16) with r = 2: three
+    interior rows, both neighbours' gradients land on the middle one."""
+    from sbmc_amd import dist as sdist
+    part = _loop()
+    g = th.Generator().manual_seed(3)
+    b, c, hp, w = shape
+    h = hp - 2 * r
+    fmt = th.channels_last if nhwc else th.contiguous_format
+    for it in range(5):
+        base = th.randn(shape, generator=g).cuda().contiguous(memory_format=fmt)
+        x = base.clone(memory_format=fmt).requires_grad_()
+        xin = x * 1.0                                  # a non-leaf the refresh may write into
+        y = sdist.halo_refresh(xin, r, part, nhwc)
+        assert y is not None and y.data_ptr() == xin.data_ptr()
+        want = base.clone()
+        want[..., :r, :] = base[..., h:h + r, :]       # what went down (my last interior rows) comes from above
+        want[..., r + h:, :] = base[..., r:2 * r, :]
+        assert th.equal(y.detach(), want), it
+        gy = th.randn(shape, generator=g).cuda().contiguous(memory_format=fmt)
+        keep = gy.clone()
+        y.backward(gy)
+        gx = keep.clone()
+        gx[..., r:2 * r, :] += keep[..., r + h:, :]
+        gx[..., h:h + r, :] += keep[..., :r, :]
+        gx[..., :r, :] = 0
+        gx[..., r + h:, :] = 0
+        assert th.allclose(x.grad, gx, rtol=0, atol=1e-6), it
+    part.channel.check()
+
+
 def test_halo_pad_loopback_thin_slab_and_split_messages():
     """h < 2r: both neighbours' gradients land on the same rows; a slot smaller than the message: the run is
     split into several messages on both sides."""

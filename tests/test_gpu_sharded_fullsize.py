@@ -105,18 +105,7 @@ def _rank_worker(rank, world, port, h, w, spp, seed, ref_path):
         batch = bench.make_model_inputs(h, w, spp, dev, seed=seed, rows=(part.y0, part.y1))
         runner = sdist.ShardedDenoiser(model, part)
         opt = th.optim.SGD(model.parameters(), lr=0.0)
-        # the size of what the all-reduce adds: the largest per-rank share of every gradient
-        shares = {}
-        reduce_sum = sdist._all_reduce_sum
-
-        def spying_all_reduce(flat, prt):
-            mine = th.stack([v.abs().max() for v in runner._views]).cpu()
-            dist.all_reduce(mine, op=dist.ReduceOp.MAX)
-            shares.update(zip([k for k, q in model.named_parameters() if q.requires_grad], mine.tolist()))
-            return reduce_sum(flat, prt)
-        sdist._all_reduce_sum = spying_all_reduce
         loss = runner.train_step(opt, losses.TonemappedRelativeMSE(), batch)
-        sdist._all_reduce_sum = reduce_sum
         t_step = time.time() - t0
         assert part.channel is not None, "neighbour rows must travel through the IPC mailboxes here"
         assert runner.merge_state, "the splat's state is merged across ranks, not recomputed"
@@ -138,7 +127,7 @@ def _rank_worker(rank, world, port, h, w, spp, seed, ref_path):
         module_scale = {}
         for k, g in a["grads"].items():
             mod = k.rsplit(".", 1)[0]
-            module_scale[mod] = max(module_scale.get(mod, 0.0), g.abs().max().item(), shares[k])
+            module_scale[mod] = max(module_scale.get(mod, 0.0), g.abs().max().item())
         checks = [judge(q.grad, "grad " + k, lambda r, k=k: r["grads"][k], module_scale[k.rsplit(".", 1)[0]])
                   for k, q in model.named_parameters()]
         # the fp32 noise floor of a module: the largest over its parameters

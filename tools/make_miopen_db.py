@@ -42,6 +42,7 @@ else:
             between()
     sdist._exchange_into = _into
     sdist._all_reduce_sum = lambda t, part: t.cuda() if not t.is_cuda else t
+    sdist._all_reduce_sum_start = lambda t, part: None
     sdist._all_reduce_min = lambda t, part: t
     part = sdist.SlabPartition(H, ranks, rank)
     batch = bench.make_model_inputs(H, W, 8, dev, seed=1, rows=(part.y0, part.y1))

@@ -13,6 +13,6 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
 print("kernel time per step (5 steps): %.2f ms" % (tot / 5e6))
 for r in rows:
-    if "ccl" in r["Name"].lower() or "SendRecv" in r["Name"] or "AllReduce" in r["Name"]:
+    if "ccl" in r["Name"].lower() or "SendRecv" in r["Name"] or "AllReduce" in r["Name"] or "halo::" in r["Name"]:
         print("  %8.3f ms/step %5d calls  %s" % (int(r["TotalDurationNs"]) / 5e6, int(r["Calls"]), r["Name"][:90]))
 PY

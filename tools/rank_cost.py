@@ -11,6 +11,13 @@ from sbmc_amd import dist as sdist
 def fake_exchange(part, to_up, to_down):
     return (th.zeros_like(to_up) if part.has_up else None, th.zeros_like(to_down) if part.has_down else None)
 
+IPC_SELF = "--ipc-self" in sys.argv
+if IPC_SELF:
+    # neighbour rows through the IPC mailboxes with this very rank as both neighbours (halo.HaloChannel in
+    # loop-back: every put / get / merge kernel, flag and slot of the multi-GPU step runs, only the xGMI
+    # transfer itself is local); the gradient all-reduce over a single-rank RCCL group as with --rccl-self
+    sys.argv.remove("--ipc-self")
+    sys.argv.append("--rccl-self")
 RCCL_SELF = "--rccl-self" in sys.argv
 if RCCL_SELF:
     # the exchanges for real, over RCCL, with this very rank as both neighbours (a single-rank `nccl` group:
@@ -34,6 +41,7 @@ else:
     sdist._exchange = fake_exchange
     sdist._exchange_into = fake_exchange_into
     sdist._all_reduce_sum = lambda t, part: t.cuda() if not t.is_cuda else t
+    sdist._all_reduce_sum_start = lambda t, part: None
     sdist._all_reduce_min = lambda t, part: t
 
 dev = th.device("cuda")
@@ -55,6 +63,12 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     part = parts[rank]
     batch = {k: (v if k == "global_features" else v[..., part.y0:part.y1, :].contiguous()) for k, v in full.items()}
     runner = sdist.ShardedDenoiser(model, part)
+    runner._channel_tried = True                 # (no other ranks to connect to: the transport is chosen here)
+    if IPC_SELF and world > 1:
+        if not (part.has_up and part.has_down):
+            raise SystemExit("--ipc-self pairs what goes up with what comes from below: interior ranks only")
+        from sbmc_amd.halo import HaloChannel
+        part.channel = HaloChannel(dev, 64 << 20, 4).loopback()
     if world == 1:
         step = lambda: bench.train_step(model, opt, loss_fn, batch)
     else:
@@ -67,6 +81,6 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     th.cuda.synchronize()
     ms = (time.time() - t0) / 3 * 1e3
     print("world %d rank %d rows %d%s: %.1f ms/step" % (world, rank, part.rows,
-                                                         " (exchanges over RCCL to self)" if RCCL_SELF else "", ms), flush=True)
+                                                         " (exchanges through IPC mailboxes to self)" if IPC_SELF else " (exchanges over RCCL to self)" if RCCL_SELF else "", ms), flush=True)
     del model, opt, runner, batch
     th.cuda.empty_cache()
