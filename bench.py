@@ -76,6 +76,37 @@ def measured_traffic(kernel_substr):
     return (tot or None), os.path.basename(files[-1])
 
 
+def model_flops(model, h, w, spp, train):
+    """Algorithmic flop of one Multisteps pass as the reference computes it: every per-sample
+    1x1 convolution at full resolution over its whole (per-sample + context) input, every U-net convolution at
+    its level's resolution; a training step = forward + data gradient + weight gradient of every convolution
+    (no data gradient for the network's input)."""
+    import torch.nn as nn
+    fwd = first = 0.0
+    for name, m in model.named_modules():
+        if not isinstance(m, nn.Conv2d):
+            continue
+        lvl = name.count("next_level")
+        per = 2.0 * m.in_channels * m.out_channels * m.kernel_size[0] * m.kernel_size[1]
+        px = (h >> lvl) * (w >> lvl) * (1 if name.startswith("propagation") else spp)
+        fwd += per * px
+        if name == "embedding_00.layer_0.layer.0":
+            first = per * px
+    return 3.0 * fwd - first if train else fwd
+
+
+def unet_layout():
+    """What modules.unet_channels_last decided for the U-nets of this run."""
+    from sbmc_amd import modules
+    mode = os.environ.get("SBMC_UNET_LAYOUT", "auto").lower()
+    picks = set(modules._LAYOUT_DECISIONS.values())
+    if mode in ("nchw", "nhwc"):
+        return {"nchw": "planar (forced)", "nhwc": "channels_last (forced)"}[mode]
+    if not picks:
+        return None
+    return "channels_last (measured)" if picks == {True} else "planar (measured)" if picks == {False} else "mixed"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -413,10 +444,11 @@ def main():
 
             def step():
                 runner.train_step(opt, loss_fn, batch)
-        dt = timed(step, warmup, steps, timings, events_inside=False)
+        dt = timed(step, warmup, steps, timings if world == 1 else None, events_inside=False)
         med_s, spread = timed.median, timed.spread
         model_timings = timings
-        del batch
+        if world > 1:
+            runner.check()
         # source pixels whose logits this rank's splat kernels stream (its own rows: the overhang of the
         # running state is exchanged, nothing is recomputed)
         local_px = part.rows * W
@@ -449,8 +481,73 @@ def main():
         med_s, spread = timed.median, timed.spread
         local_px = part.rows * W
 
+    # ---------------------------------------------------------------- per-rank split of the sharded step
+    per_rank = None
+    if is_model and world > 1:
+        # two more, untimed, steps with events around every neighbour exchange (launches on this rank's stream:
+        # they include the wait for the neighbour's rows) and around the wait for the gradient all-reduces the
+        # backward did not hide; "compute" is the rest of the step
+        store = []
+        marks = [th.cuda.Event(enable_timing=True) for _ in range(3)]
+        functions.enable_kernel_timing(store)
+        for i in range(2):
+            marks[i].record()
+            step()
+        marks[2].record()
+        sync()
+        functions.enable_kernel_timing(None)
+        tot = {}
+        for name, a, b in store:
+            tot[name] = tot.get(name, 0.0) + a.elapsed_time(b) / 2
+        step_ms = marks[0].elapsed_time(marks[2]) / 2
+        mine = {"rank": rank, "rows": part.rows, "step_ms": round(step_ms, 3),
+                "exchange_ms": round(tot.get("halo_exchange", 0.0), 3),
+                "exchanges": sum(1 for n, _, _ in store if n == "halo_exchange") // 2,
+                "all_reduce_exposed_ms": round(tot.get("grad_all_reduce_exposed", 0.0), 3)}
+        mine["compute_ms"] = round(step_ms - mine["exchange_ms"] - mine["all_reduce_exposed_ms"], 3)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        model_timings = [t for t in store if t[0].startswith("pointwise")]
+
+    # ---------------------------------------------------------------- north_star's matrix: forward only
+    infer_stages = None
+    if is_model and not infer and not args.no_stages and not args.fp16_activations:
+        # 1280x720 (this run's frame) at 4 / 8 / 32 spp, eval mode, no_grad, 5 warm-up + 10 timed frames each
+        # (the timing protocol of the reference's scripts/denoise.py:152-165), on this run's ranks
+        infer_stages = {}
+        del batch
+        opt.zero_grad(set_to_none=True)
+        th.cuda.empty_cache()
+        model.train(False)
+        for spp_i in (4, 8, 32):
+            if world > 1:
+                b_i = make_model_inputs(H, W, spp_i, device, seed=1234, rows=(part.y0, part.y1))
+                fwd = runner
+            else:
+                b_i = make_model_inputs(H, W, spp_i, device, seed=1234)
+                fwd = model
+            b_i.pop("target_image")
+
+            def frame():
+                with th.no_grad():
+                    fwd(b_i)
+            idt = timed(frame, 5, 10, None)
+            infer_stages["infer_%dspp" % spp_i] = {
+                "workload": "Multisteps(93,3,ksize=%d) forward only (eval, no_grad), %dx%d, %d spp" % (K, W, H, spp_i),
+                "value": round(spp_i * H * W / (idt / 10) / 1e6, 2), "unit": "Msamples/s",
+                "ms_per_frame": round(idt / 10 * 1e3, 3), "ms_per_frame_median": round(timed.median * 1e3, 3),
+                "TFLOPs": round(model_flops(model, H, W, spp_i, False) / (idt / 10) / 1e12, 1),
+                "steps": 10, "warmup": 5}
+            del b_i
+            th.cuda.empty_cache()
+        if world > 1:
+            runner.check()
+        model.train(True)
+
     # ---------------------------------------------------------------- splat stages (N=1, model)
     stage = stage_all = stage_f16 = None
+    step_flops = model_flops(model, H, W, S, not infer) if is_model else None
+    layout = unet_layout() if is_model else None
     if is_model and not infer and world == 1 and not args.no_stages:
         del model, opt
         th.cuda.empty_cache()
@@ -561,8 +658,18 @@ def main():
                                 "state exchanged and merged" % (world, pad)),
             },
         }
-        if stage is not None:
-            res["stages"] = {"splat": stage}
+        if step_flops is not None:
+            res["whole_step_tflops"] = round(step_flops / (dt / steps) / 1e12, 1)
+            res["frac_of_fp32_mfma_peak"] = round(step_flops / (dt / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)
+            res["unet_layout"] = layout
+        if per_rank is not None:
+            res["per_rank"] = per_rank
+        if stage is not None or infer_stages:
+            res["stages"] = {}
+            if infer_stages:
+                res["stages"].update(infer_stages)
+            if stage is not None:
+                res["stages"]["splat"] = stage
             if stage_all is not None:
                 res["stages"]["splat_all_samples"] = stage_all
             if stage_f16 is not None:
@@ -593,6 +700,27 @@ def main():
                             "1-sample launch x samples per launch; not measured in this run"},
                 "alg_bytes_per_launch": kb["alg_bytes"],
                 "avg_launch_ms": kb["avg_ms"],
+            }
+        fk = "splat_update_fwd_all" if "splat_update_fwd_all" in kern else "splat_update_fwd"
+        if fk in kern and "roofline" in res:
+            kf = kern[fk]
+            ftraffic, fsrc = (None, None)
+            if (H, W, K) == (720, 1280, 21) and world == 1:
+                ftraffic, fsrc = measured_traffic(("splat_fwd_strip_kernel",))
+                if ftraffic is not None:
+                    ftraffic *= kf["samples_per_launch"]
+            res["roofline_fwd"] = {
+                "kernel": "sbmc::splat_fwd_strip_kernel<21,3> (%d sample(s) per launch; the timed call also holds "
+                          "the per-pixel fold of the samples' partial states)" % kf["samples_per_launch"],
+                "bound": "hbm", "achieved": kf["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(kf["GBps"] / HBM_PEAK_GBPS, 4), "traffic": None,
+                "traffic_profiled": None if ftraffic is None else {
+                    "hbm_bytes_per_launch": ftraffic, "ratio_to_algorithmic": round(ftraffic / kf["alg_bytes"], 3),
+                    "source": "profiles/" + fsrc,
+                    "note": "separate rocprofv3 --pmc passes (tools/prof.sh), per 1-sample launch x samples per "
+                            "launch: the misaligned 1 KB spans of the destination-centred forward fetch 9 lines "
+                            "for 8; not measured in this run"},
+                "alg_bytes_per_launch": kf["alg_bytes"], "avg_launch_ms": kf["avg_ms"],
             }
         if world == 1 and not args.no_cpu_baseline and not infer:
             try:

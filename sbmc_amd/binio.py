@@ -18,9 +18,10 @@ and parsed by `sbmc/datasets.py` (`_read_globals_and_meta` :501-550, `_read_comp
                                      (bit0 reflection, 1 transmission, 2 diffuse, 3 glossy, 4 specular)
     where block = int32 nbytes + an LZ4 *frame* of that many bytes.
 
-`read_tile` returns what the reference's `TilesDataset.__getitem__` returns in "sbmc" mode
-with every feature group enabled (93 features, datasets.py:309-354 and `_preprocess_standard`
-:741-778); `read_scene` assembles a frame like `FullImagesDataset.__getitem__` (:930-964).
+`read_tile` returns what the reference's `TilesDataset.__getitem__` returns (93 features in "sbmc"
+mode with every feature group enabled, datasets.py:309-354 and `_preprocess_standard` :741-778; fewer
+with the reference's `load_coords / load_gbuffer / load_p / load_ld / load_bt` flags off, :194-215,
+:706-717); `read_scene` assembles a frame like `FullImagesDataset.__getitem__` (:930-964).
 LZ4 framing goes through the system `liblz4.so.1` via ctypes (no Python lz4 in this image).
 """
 import ctypes
@@ -40,6 +41,53 @@ I_DIFFUSE, I_SPECULAR = 5, 8                                   # datasets.py:319
 I_NORMAL, I_DEPTH, I_ALBEDO = 14, 18, 24                       # g-buffer labels, datasets.py:326-335
 C_DIFFUSE, C_SPECULAR, C_ALBEDO = 0, 3, 6                      # pixel-data channels, datasets.py:300-306
 MODES = ("sbmc", "kpcn", "raw")
+FEATURE_FLAGS = ("load_coords", "load_gbuffer", "load_p", "load_ld", "load_bt")
+
+
+def feature_flags(mode="sbmc", load_coords=True, load_gbuffer=True, load_p=True, load_ld=True, load_bt=True):
+    """The five feature-group switches as the reference resolves them (datasets.py:194-215): the "raw" and
+    "kpcn" modes always read radiance + g-buffer only."""
+    if mode != "sbmc":
+        return dict(load_coords=False, load_gbuffer=True, load_p=False, load_ld=False, load_bt=False)
+    return dict(load_coords=bool(load_coords), load_gbuffer=bool(load_gbuffer), load_p=bool(load_p),
+                load_ld=bool(load_ld), load_bt=bool(load_bt))
+
+
+def feature_labels(load_coords=True, load_gbuffer=True, load_p=True, load_ld=True, load_bt=True):
+    """Names of the per-sample feature channels for a choice of feature groups (datasets.py:309-354)."""
+    labels = []
+    if load_coords:
+        labels += ["dx", "dy", "lens_u", "lens_v", "t"]
+    labels += ["diffuse_r", "diffuse_g", "diffuse_b", "specular_r", "specular_g", "specular_b"]
+    if load_gbuffer:
+        labels += ["normal_first_x", "normal_first_y", "normal_first_z", "normal_x", "normal_y", "normal_z",
+                   "depth_first", "depth", "visibility", "hasHit",
+                   "albedo_first_r", "albedo_first_g", "albedo_first_b", "albedo_r", "albedo_g", "albedo_b"]
+    if load_p:
+        labels += ["p"] * (PATH_DEPTH * 4)
+    if load_ld:
+        for i in range(PATH_DEPTH):
+            labels += ["ld_theta_%d" % i, "ld_phi_%d" % i]
+    if load_bt:
+        for txt in ("reflection", "transmisson", "diffuse", "glossy", "specular"):
+            labels += ["bt_%s_%d" % (txt, i) for i in range(PATH_DEPTH)]
+    return labels
+
+
+def _kept_channels(flags):
+    """Indices, in the file's 93-channel order, of the groups that are switched on (datasets.py:706-717; the
+    probabilities, light directions and bounce types the reference does not even copy, :646-701)."""
+    keep = list(range(0, 5)) if flags["load_coords"] else []
+    keep += list(range(5, 11))                                 # radiance: always
+    if flags["load_gbuffer"]:
+        keep += list(range(11, SAMPLE_FEATURES))
+    o = SAMPLE_FEATURES
+    for on, n in ((flags["load_p"], 4 * PATH_DEPTH), (flags["load_ld"], 2 * PATH_DEPTH),
+                  (flags["load_bt"], N_BT * PATH_DEPTH)):
+        if on:
+            keep += list(range(o, o + n))
+        o += n
+    return keep
 
 _LZ4 = None
 
@@ -191,6 +239,9 @@ def preprocess_kpcn(tile):
     means / variances of the samples, albedo-demodulated diffuse, log specular and their gradients
     (the reference's TilesDataset._preprocess_kpcn, datasets.py:780-856).  27 input channels per branch."""
     f, tgt = tile["features"], tile["image_data"]
+    labels = tile["labels"]
+    I_DEPTH, I_ALBEDO, I_NORMAL = labels.index("depth"), labels.index("albedo_r"), labels.index("normal_x")
+    I_DIFFUSE, I_SPECULAR = labels.index("diffuse_r"), labels.index("specular_r")
     spp = f.shape[0]
     depth = f[:, I_DEPTH:I_DEPTH + 1].mean(0)
     depth_v = f[:, I_DEPTH:I_DEPTH + 1].var(0)
@@ -228,19 +279,24 @@ def preprocess_kpcn(tile):
     return out
 
 
-def read_tile(path, spp=None, preprocess=True, mode="sbmc"):
+def read_tile(path, spp=None, preprocess=True, mode="sbmc", **flags):
     """One tile as the reference's TilesDataset yields it (datasets.py:395-411).
 
-    mode "sbmc" (all feature groups): a dict with block_x, block_y, global_features [3,1,1],
-    image_data [15,ts,ts], image_data_var, target_image [3,ts,ts], features [spp,93,ts,ts], radiance
-    [spp,3,ts,ts], low_spp [3,ts,ts], spp, scene_radius, header; the radiance features log-compressed
-    (`_preprocess_standard`) unless preprocess=False or mode "raw".  mode "kpcn": `preprocess_kpcn`.
+    mode "sbmc": a dict with block_x, block_y, global_features [3,1,1], image_data [15,ts,ts],
+    image_data_var, target_image [3,ts,ts], features [spp,nf,ts,ts] (nf = 93 with every feature group on;
+    flags: load_coords, load_gbuffer, load_p, load_ld, load_bt as in the reference, datasets.py:194-215),
+    labels (the nf channel names), radiance [spp,3,ts,ts], low_spp [3,ts,ts], spp, scene_radius, header; the
+    radiance features log-compressed (`_preprocess_standard`) unless preprocess=False.  mode "raw": radiance +
+    g-buffer (22 channels), not preprocessed; mode "kpcn": `preprocess_kpcn` of that.
     """
     if mode not in MODES:
         raise RuntimeError("Unknown dataset loading mode %s" % mode)
+    unknown = set(flags) - set(FEATURE_FLAGS)
+    if unknown:
+        raise TypeError("read_tile: unknown arguments %s" % sorted(unknown))
+    flags = feature_flags(mode, **flags)
     if mode != "sbmc":
-        raw = read_tile(path, spp, preprocess=False)
-        return preprocess_kpcn(raw) if mode == "kpcn" else raw
+        preprocess = False
     with open(path, "rb") as fid:
         hdr = read_header(fid)
         ts = hdr["tile_size"]
@@ -263,30 +319,37 @@ def read_tile(path, spp=None, preprocess=True, mode="sbmc"):
             buf = _read_block(fid, fsz + PATH_DEPTH * px * 2)
             nfl = SAMPLE_FEATURES + 6 * PATH_DEPTH
             feats[s, :nfl] = np.frombuffer(buf[:fsz], np.float32).reshape(nfl, ts, ts)
-            flags = np.frombuffer(buf[fsz:], np.int16).reshape(PATH_DEPTH, ts, ts)
+            bits = np.frombuffer(buf[fsz:], np.int16).reshape(PATH_DEPTH, ts, ts)
             for b in range(N_BT):                             # datasets.py:682-703
-                feats[s, nfl + b * PATH_DEPTH: nfl + (b + 1) * PATH_DEPTH] = (flags & (1 << b)) != 0
+                feats[s, nfl + b * PATH_DEPTH: nfl + (b + 1) * PATH_DEPTH] = (bits & (1 << b)) != 0
+    labels = feature_labels(**flags)
+    keep = _kept_channels(flags)
+    if len(keep) != NUM_FEATURES:
+        feats = np.ascontiguousarray(feats[:, keep])
+    i_d, i_s = labels.index("diffuse_r"), labels.index("specular_r")
     if n > 0:
-        out["radiance"] = feats[:, I_DIFFUSE:I_DIFFUSE + 3] + feats[:, I_SPECULAR:I_SPECULAR + 3]
+        out["radiance"] = feats[:, i_d:i_d + 3] + feats[:, i_s:i_s + 3]
         out["low_spp"] = out["radiance"].mean(0)
     else:
         out["low_spp"] = np.zeros_like(out["target_image"])
     if preprocess and n > 0:                                  # _preprocess_standard, :741-778
-        diffuse = np.maximum(feats[:, I_DIFFUSE:I_DIFFUSE + 3], 0)
-        specular = np.maximum(feats[:, I_SPECULAR:I_SPECULAR + 3], 0)
-        feats[:, I_DIFFUSE:I_DIFFUSE + 3] = np.log(1 + diffuse + specular) / 10.0
-        feats[:, I_SPECULAR:I_SPECULAR + 3] = np.log(1 + specular) / 10.0
+        diffuse = np.maximum(feats[:, i_d:i_d + 3], 0)
+        specular = np.maximum(feats[:, i_s:i_s + 3], 0)
+        feats[:, i_d:i_d + 3] = np.log(1 + diffuse + specular) / 10.0
+        feats[:, i_s:i_s + 3] = np.log(1 + specular) / 10.0
     out["features"] = feats
-    return out
+    out["labels"] = labels
+    return preprocess_kpcn(out) if mode == "kpcn" else out
 
 
-def read_scene(folder, spp=None, mode="sbmc"):
+def read_scene(folder, spp=None, mode="sbmc", **flags):
     """All tiles of one scene folder assembled into full-frame arrays (FullImagesDataset,
-    datasets.py:930-964: every tile is preprocessed on its own, then pasted)."""
+    datasets.py:930-964: every tile is preprocessed on its own, then pasted).  flags: the feature-group
+    switches of `read_tile`."""
     files = sorted(f for f in os.listdir(folder) if f.endswith(".bin"))
     if not files:
         raise RuntimeError("Empty dataset")
-    first = read_tile(os.path.join(folder, files[0]), spp, mode=mode)
+    first = read_tile(os.path.join(folder, files[0]), spp, mode=mode, **flags)
     hdr = first["header"]
     ts, w, h = hdr["tile_size"], hdr["image_width"], hdr["image_height"]
     keys = [k for k, v in first.items() if isinstance(v, np.ndarray) and v.ndim >= 3
@@ -295,8 +358,10 @@ def read_scene(folder, spp=None, mode="sbmc"):
     frame["global_features"] = first["global_features"]
     frame["scene_radius"] = first["scene_radius"]
     frame["header"] = hdr
+    if "labels" in first:
+        frame["labels"] = first["labels"]
     for f in files:
-        tile = first if f == files[0] else read_tile(os.path.join(folder, f), spp, mode=mode)
+        tile = first if f == files[0] else read_tile(os.path.join(folder, f), spp, mode=mode, **flags)
         th_ = tile["header"]
         for k in ("version", "tile_size", "image_width", "image_height", "sample_count"):
             if th_[k] != hdr[k]:

@@ -71,21 +71,29 @@ def denoise_frame(model, batch, tile_size=1024, tile_pad=256, kpcn_mode=False):
     return out_radiance
 
 
-def denoise_frame_sharded(model, batch, part, gather=True):
+def denoise_frame_sharded(model, batch, part, gather=True, slab_only=False, height=None):
     """One frame on several GPUs: this rank denoises the rows [part.y0, part.y1) of the frame with
     `dist.ShardedDenoiser` (U-net halo exchange + cross-rank merge of the splat state) and -- with
     gather=True -- every rank returns the whole [bs, 3, H, W] frame (zero border of (ksize-1)/2 pixels,
-    as `denoise_frame`).  `batch` holds the WHOLE frame on every rank; only the slab is moved through the
-    network.  The multi-GPU counterpart of the tile loop of scripts/denoise.py:142-165 (tiles -> ranks,
-    nothing recomputed in the overlap)."""
+    as `denoise_frame`).  `batch` holds the WHOLE frame (only the slab is moved through the network), or --
+    slab_only=True, `height` = rows of the frame -- just this rank's rows.  The multi-GPU counterpart of the
+    tile loop of scripts/denoise.py:142-165 (tiles -> ranks, nothing recomputed in the overlap)."""
     import torch.distributed as dist
     from . import dist as sdist
     p = (model.ksize - 1) // 2
-    slab = {k: (v if k in UNCHANGED_KEYS else v[..., part.y0:part.y1, :].contiguous())
-            for k, v in batch.items() if k in ("radiance", "features") + UNCHANGED_KEYS}
+    if slab_only:
+        slab = {k: v for k, v in batch.items() if k in ("radiance", "features") + UNCHANGED_KEYS}
+        h, w = int(height), batch["radiance"].shape[-1]
+        if slab["radiance"].shape[-2] != part.rows:
+            raise ValueError("slab_only: the batch must hold exactly this rank's %d rows" % part.rows)
+    else:
+        slab = {k: (v if k in UNCHANGED_KEYS else v[..., part.y0:part.y1, :].contiguous())
+                for k, v in batch.items() if k in ("radiance", "features") + UNCHANGED_KEYS}
+        h, w = batch["radiance"].shape[-2:]
+    runner = sdist.ShardedDenoiser(model, part)
     with th.no_grad():
-        out = sdist.ShardedDenoiser(model, part)(slab)["radiance"]
-    h, w = batch["radiance"].shape[-2:]
+        out = runner(slab)["radiance"]
+    runner.check()
     lo, hi = max(part.y0, p), min(part.y1, h - p)          # frame rows this rank's output covers
     assert out.shape[-2] == hi - lo
     if not gather:

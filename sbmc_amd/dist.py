@@ -78,6 +78,17 @@ class SlabPartition(object):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
 
+class _Nothing(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOTHING = _Nothing()
+
+
 def _exchange_into(part, to_up, to_down, into_up, into_down, between=None):
     """Sends `to_up` to rank-1 and `to_down` to rank+1, receives their counterparts into `into_up` /
     `into_down` (written in place; may be views of a larger buffer).  All four are contiguous tensors; a pair
@@ -101,13 +112,16 @@ def _exchange_into(part, to_up, to_down, into_up, into_down, between=None):
             tmp = dst
         ops += [dist.P2POp(dist.isend, src, part.peer(delta), group=part.group),
                 dist.P2POp(dist.irecv, tmp, part.peer(delta), group=part.group)]
-    reqs = dist.batch_isend_irecv(ops) if ops else []
+    dev = to_up.device
+    with funcs._timed("halo_exchange", dev) if to_up.is_cuda else _NOTHING:
+        reqs = dist.batch_isend_irecv(ops) if ops else []
     if between is not None:
         between()
-    for req in reqs:
-        req.wait()
-    for dst, tmp in landed:
-        dst.copy_(tmp)
+    with funcs._timed("halo_exchange", dev) if to_up.is_cuda else _NOTHING:
+        for req in reqs:
+            req.wait()
+        for dst, tmp in landed:
+            dst.copy_(tmp)
 
 
 def _exchange(part, to_up, to_down):
@@ -158,8 +172,7 @@ def _all_reduce_sum_start(t, part):
     if part.world == 1:
         return None
     if t.is_cuda and dist.get_backend(part.group) == "nccl":
-        with funcs._timed("grad_all_reduce", t.device):
-            return dist.all_reduce(t, group=part.group, async_op=True)
+        return dist.all_reduce(t, group=part.group, async_op=True)
     summed = _all_reduce_sum(t, part)
     if summed.data_ptr() != t.data_ptr():
         t.copy_(summed)
@@ -762,8 +775,10 @@ class ShardedDenoiser(object):
         for b in range(len(self._buckets) - 1, -1, -1):
             if self._missing[b] >= 0:                  # holds a parameter the loss does not depend on
                 self._reduce_bucket(b)
-        for work in self._works:
-            work.wait()
+        # (what of the all-reduces the backward did not hide: the stream waits here)
+        with funcs._timed("grad_all_reduce_exposed", flat.device) if flat.is_cuda else _NOTHING:
+            for work in self._works:
+                work.wait()
         total = flat[-1]
         finite = th.isfinite(total).item()             # the step's one host synchronisation (reference guard)
         self.check()                                   # (a 4-byte read right after it: did a halo wait time out?)

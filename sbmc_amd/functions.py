@@ -604,7 +604,9 @@ def upsample_cat_supported(coarse, left, top=0, bot=0):
             and top in (0, 1) and bot in (0, 1)
             and left.shape[2] == 2 * (coarse.shape[2] - top - bot) and left.shape[3] == 2 * coarse.shape[3]
             and coarse.numel() > 0 and not th.is_autocast_enabled()
-            and coarse.is_contiguous() and left.is_contiguous()       # planar [b, c, h, w]; NHWC: UpsampleCatNHWC
+            # planar tensors (NHWC: UpsampleCatNHWC).  Row-cropped views of planar maps -- what every rank of
+            # the planar sharded U-net holds -- qualify: the forward makes its operands contiguous itself
+            and not _is_channels_last(coarse) and not _is_channels_last(left)
             and bool(_lib.lib().sbmc_upsample2x_cat_supported(coarse.shape[2] - top - bot, coarse.shape[3])))
 
 

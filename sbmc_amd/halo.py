@@ -19,6 +19,7 @@ import torch as th
 import torch.distributed as dist
 
 from . import _lib
+from .functions import _timed
 
 LOG = logging.getLogger(__name__)
 
@@ -164,11 +165,12 @@ class HaloChannel(object):
         _, chunks, chunk_bytes, pitch = ref
         for c0, n, b0, nb in _pieces(chunks, chunk_bytes, self.slot_bytes):
             off = c0 * pitch + b0
-            rc = self.lib.sbmc_halo_put(
-                self.box, self.peer[0] if up else None, self.peer[1] if down else None,
-                up[0] + off if up else None, down[0] + off if down else None,
-                n, nb, pitch, self.send_seq[0], self.send_seq[1], self.nslots, self.slot_bytes,
-                self.timeout_ticks, self._stream())
+            with _timed("halo_exchange", self.device):
+                rc = self.lib.sbmc_halo_put(
+                    self.box, self.peer[0] if up else None, self.peer[1] if down else None,
+                    up[0] + off if up else None, down[0] + off if down else None,
+                    n, nb, pitch, self.send_seq[0], self.send_seq[1], self.nslots, self.slot_bytes,
+                    self.timeout_ticks, self._stream())
             _lib.check(rc, "sbmc_halo_put")
             self.send_seq[0] += 1 if up else 0
             self.send_seq[1] += 1 if down else 0
@@ -197,13 +199,14 @@ class HaloChannel(object):
         off, aoff = c0 * pitch + b0, c0 * add_pitch + b0
         bd = body[0] if body else (None, 0, 0, 0)
         bs = (body[1] if body else None) or (None, 0, 0, 0)
-        rc = self.lib.sbmc_halo_get(
-            self.box, self.peer[0] if up else None, self.peer[1] if down else None,
-            up[0] + off if up else None, down[0] + off if down else None,
-            add_up[0] + aoff if (add_elem and up) else None, add_down[0] + aoff if (add_elem and down) else None,
-            add_elem, n, nb, pitch, add_pitch,
-            bd[0], bs[0], bd[1], bd[2], bd[3], bs[3],
-            self.recv_seq[0], self.recv_seq[1], self.nslots, self.slot_bytes, self.timeout_ticks, self._stream())
+        with _timed("halo_exchange", self.device):
+            rc = self.lib.sbmc_halo_get(
+                self.box, self.peer[0] if up else None, self.peer[1] if down else None,
+                up[0] + off if up else None, down[0] + off if down else None,
+                add_up[0] + aoff if (add_elem and up) else None, add_down[0] + aoff if (add_elem and down) else None,
+                add_elem, n, nb, pitch, add_pitch,
+                bd[0], bs[0], bd[1], bd[2], bd[3], bs[3],
+                self.recv_seq[0], self.recv_seq[1], self.nslots, self.slot_bytes, self.timeout_ticks, self._stream())
         _lib.check(rc, "sbmc_halo_get")
         self.recv_seq[0] += 1 if up else 0
         self.recv_seq[1] += 1 if down else 0
@@ -216,10 +219,11 @@ class HaloChannel(object):
         out = ext.new_empty(bs, c2, rows, w)
         recv_up = ext.new_empty(bs, c2, p, w) if top else None
         recv_down = ext.new_empty(bs, c2, p, w) if bot else None
-        rc = self.lib.sbmc_halo_merge_state_fwd_f32(
-            self.box, self.peer[0] if top else None, self.peer[1] if bot else None, _lib.ptr(ext), _lib.ptr(out),
-            _lib.ptr(recv_up), _lib.ptr(recv_down), bs, c2 - 2, rows, w, p, top, bot,
-            self.recv_seq[0], self.recv_seq[1], self.nslots, self.slot_bytes, self.timeout_ticks, self._stream())
+        with _timed("halo_exchange", self.device):
+            rc = self.lib.sbmc_halo_merge_state_fwd_f32(
+                self.box, self.peer[0] if top else None, self.peer[1] if bot else None, _lib.ptr(ext), _lib.ptr(out),
+                _lib.ptr(recv_up), _lib.ptr(recv_down), bs, c2 - 2, rows, w, p, top, bot,
+                self.recv_seq[0], self.recv_seq[1], self.nslots, self.slot_bytes, self.timeout_ticks, self._stream())
         _lib.check(rc, "sbmc_halo_merge_state_fwd_f32")
         self.recv_seq[0] += 1 if top else 0
         self.recv_seq[1] += 1 if bot else 0

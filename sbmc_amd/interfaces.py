@@ -84,13 +84,15 @@ class SampleBasedDenoiserInterface(object):
 
 class TilesDataset(th.utils.data.Dataset):
     """`.bin` tiles under root/<scene>/*.bin (folder mode of the reference's TilesDataset,
-    sbmc/datasets.py:243-300) in "sbmc" mode with every feature group."""
+    sbmc/datasets.py:243-300).  load_coords / load_gbuffer / load_p / load_ld / load_bt select the per-sample
+    feature groups as in the reference (:194-215; "kpcn" mode ignores them)."""
 
     KEYS = {"sbmc": ("radiance", "features", "global_features", "target_image", "low_spp"),
             "kpcn": ("kpcn_diffuse_in", "kpcn_specular_in", "kpcn_diffuse_buffer", "kpcn_specular_buffer",
                      "kpcn_albedo", "target_image", "low_spp")}
 
-    def __init__(self, path, spp=None, mode="sbmc"):
+    def __init__(self, path, spp=None, mode="sbmc", load_coords=True, load_gbuffer=True, load_p=True,
+                 load_ld=True, load_bt=True):
         if mode not in self.KEYS:
             LOG.error("Unknown dataset loading mode %s", mode)
             raise RuntimeError("Unknown dataset loading mode %s" % mode)
@@ -99,14 +101,16 @@ class TilesDataset(th.utils.data.Dataset):
             LOG.error("Dataset is empty, please check the file format / folder structure.")
             raise RuntimeError("Empty dataset")
         self.spp, self.mode = spp, mode
-        self.num_features = 27 if mode == "kpcn" else binio.NUM_FEATURES     # datasets.py:413-419
+        self.flags = binio.feature_flags(mode, load_coords, load_gbuffer, load_p, load_ld, load_bt)
+        self.labels = binio.feature_labels(**self.flags)
+        self.num_features = 27 if mode == "kpcn" else len(self.labels)       # datasets.py:413-419
         self.num_global_features = len(binio.GLOBAL_LABELS)
 
     def __len__(self):
         return len(self.files)
 
     def __getitem__(self, idx):
-        tile = binio.read_tile(self.files[idx], self.spp, mode=self.mode)
+        tile = binio.read_tile(self.files[idx], self.spp, mode=self.mode, **self.flags)
         return {k: th.from_numpy(np.ascontiguousarray(tile[k])) for k in self.KEYS[self.mode]}
 
 
@@ -114,14 +118,14 @@ class MultiSampleCountDataset(th.utils.data.ConcatDataset):
     """Every tile at every sample count 2..spp (reference sbmc/datasets.py:1015-1043); the
     sample dimension varies between items, so use batch_size = 1."""
 
-    def __init__(self, path, spp=None, mode="sbmc"):
+    def __init__(self, path, spp=None, mode="sbmc", **flags):
         if spp is None:
             LOG.error("MultiSampleCountDataset requires a number of spps")
             raise RuntimeError("spp not provided.")
         if spp < 2:
             LOG.error("MultiSampleCountDataset needs at least 2spp")
             raise RuntimeError("spp too low to randomize sample count, should be at least 2.")
-        parts = [TilesDataset(path, spp=s, mode=mode) for s in range(2, spp + 1)]
+        parts = [TilesDataset(path, spp=s, mode=mode, **flags) for s in range(2, spp + 1)]
         super(MultiSampleCountDataset, self).__init__(parts)
         self.num_features = parts[0].num_features
         self.num_global_features = parts[0].num_global_features

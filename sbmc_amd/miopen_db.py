@@ -23,14 +23,26 @@ _INSTALLED = None
 
 
 def install():
-    """Points MIOpen's user find-db at a private scratch copy of the shipped records (unless the user chose a
-    db directory already: then the records are merged into it when it is writable) and defaults the find
-    mode to FAST.  Must run before the first convolution; called at package import.  Returns the directory."""
+    """Points MIOpen's user find-db at a private scratch copy of the shipped records and defaults the find mode
+    to FAST.  Must run before the first convolution; called at package import.  Returns the directory ("":
+    nothing installed).  SBMC_MIOPEN_DB=0 switches this off altogether; if the user has set
+    MIOPEN_USER_DB_PATH the records are merged into that directory only with SBMC_MIOPEN_DB=merge."""
     global _INSTALLED
     if _INSTALLED is not None:
         return _INSTALLED
+    choice = os.environ.get("SBMC_MIOPEN_DB", "1").lower()
+    if choice in ("0", "off", "no", "false"):
+        # opt-out: MIOpen's environment is left exactly as the user set it up (the U-nets then stay planar
+        # unless MIOpen's own find-db knows the channels-last shapes: modules.unet_channels_last measures)
+        _INSTALLED = ""
+        return _INSTALLED
     os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
     target = os.environ.get("MIOPEN_USER_DB_PATH")
+    if target and choice != "merge":
+        # the user chose a find-db directory: it is theirs -- nothing is written into it unless they ask for
+        # it with SBMC_MIOPEN_DB=merge
+        _INSTALLED = ""
+        return _INSTALLED
     if not target:
         # a private scratch copy per process (MIOpen appends what it learns to its user db; the shipped
         # records stay read-only), removed at exit

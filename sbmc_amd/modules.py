@@ -193,19 +193,25 @@ def unet_channels_last(net, x, rows=None):
     grad = th.is_grad_enabled() and any(q.requires_grad for q in net.parameters())
     shape = (x.shape[0], x.shape[1], int(rows) if rows else x.shape[2], x.shape[3])
     dtype = th.float16 if (half or x.dtype == th.float16) else th.float32     # what MIOpen will convolve in
-    key = (x.device.index,) + shape + (grad, dtype)
+    first = next((m for m in net.modules() if isinstance(m, nn.Conv2d) and m.kernel_size[0] > 1), None)
+    cout = first.out_channels if first is not None and first.in_channels == x.shape[1] else x.shape[1]
+    key = (x.device.index,) + shape + (cout, grad, dtype)
     if key not in _LAYOUT_DECISIONS:
-        _LAYOUT_DECISIONS[key] = _measure_layouts(shape, x.device, grad, dtype)
+        _LAYOUT_DECISIONS[key] = _measure_layouts(shape, x.device, grad, dtype, cout)
     return _LAYOUT_DECISIONS[key]
 
 
-def _measure_layouts(shape, device, grad, dtype=th.float32):
+def _measure_layouts(shape, device, grad, dtype=th.float32, cout=None):
+    """One 3x3 convolution of the net's first layer's shape (c -> cout channels), forward and -- with `grad`
+    -- backward, in both layouts: the median of five runs each; channels-last must win by 5 % (the decision
+    must not flip on timing noise: the two layouts differ in fp32 rounding).  Logged at INFO."""
     b, c, h, w = shape
+    cout = cout or c
     times = {}
     with th.enable_grad(), th.autocast("cuda", enabled=False):
         for cl in (False, True):
             xin = th.zeros(b, c, h, w, device=device, dtype=dtype)
-            wt = th.zeros(c, c, 3, 3, device=device, dtype=dtype)
+            wt = th.zeros(cout, c, 3, 3, device=device, dtype=dtype)
             if cl:
                 xin = xin.contiguous(memory_format=th.channels_last)
                 wt = wt.contiguous(memory_format=th.channels_last)
@@ -219,16 +225,19 @@ def _measure_layouts(shape, device, grad, dtype=th.float32):
                     xin.grad = wt.grad = None
             run()                                   # solver selection / kernel load
             th.cuda.synchronize(device)
-            t0, t1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
-            t0.record()
-            run()
-            run()
-            t1.record()
+            marks = [th.cuda.Event(enable_timing=True) for _ in range(6)]
+            for i in range(5):
+                marks[i].record()
+                run()
+            marks[5].record()
             th.cuda.synchronize(device)
-            times[cl] = t0.elapsed_time(t1)
+            times[cl] = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(5))[2]
             del xin, wt
-    LOG.debug("U-net layout at %s: planar %.2f ms, channels-last %.2f ms", tuple(shape), times[False], times[True])
-    return times[True] < 0.97 * times[False]
+    pick = times[True] < 0.95 * times[False]
+    LOG.info("U-net layout at %s (%d -> %d channels, %s%s): planar %.2f ms, channels-last %.2f ms -> %s",
+             tuple(shape), c, cout, str(dtype).replace("torch.", ""), ", with backward" if grad else "",
+             times[False], times[True], "channels-last" if pick else "planar")
+    return pick
 
 
 class ConvChain(nn.Module):

@@ -31,6 +31,13 @@ from sbmc_amd import KPCN, Multisteps, binio, denoise, imageio  # noqa: E402
 LOG = logging.getLogger("denoise")
 
 
+def data_flags(meta, kpcn_mode):
+    """The feature groups the checkpoint was trained on: `data_params` of its meta (reference
+    scripts/denoise.py:109-112 passes them to the dataset, train.py:139-148 sets them)."""
+    dp = meta.get("data_params") or {}
+    return binio.feature_flags("kpcn" if kpcn_mode else "sbmc", **{k: dp[k] for k in binio.FEATURE_FLAGS if k in dp})
+
+
 def build_model(meta, args):
     """The network the checkpoint was trained as (reference scripts/denoise.py:116-123 + train.py:56-70)."""
     params = dict(meta.get("model_params") or {})
@@ -45,7 +52,8 @@ def build_model(meta, args):
     for k in ("gather", "pixel"):
         if getattr(args, k) is not None and k in params and bool(params[k]) != getattr(args, k):
             LOG.warning("--%s overrides the checkpoint's model_params[%r] = %r", k, k, params[k])
-    return Multisteps(binio.NUM_FEATURES, len(binio.GLOBAL_LABELS), ksize=ksize, splat=not gather,
+    nf = len(binio.feature_labels(**data_flags(meta, False)))      # data.num_features (datasets.py:413-419)
+    return Multisteps(nf, len(binio.GLOBAL_LABELS), ksize=ksize, splat=not gather,
                       pixel=pixel, width=width, embedding_width=width), False
 
 
@@ -87,18 +95,25 @@ def main(args):
     model.train(False)
     model.to(device)
 
-    frame = binio.read_scene(args.input, spp=spp, mode="kpcn" if kpcn_mode else "sbmc")
+    frame = binio.read_scene(args.input, spp=spp, mode="kpcn" if kpcn_mode else "sbmc", **data_flags(meta, kpcn_mode))
     hdr = frame["header"]
     LOG.info("Denoising input %dx%d with %s spp", hdr["image_width"], hdr["image_height"], spp or hdr["sample_count"])
     keys = denoise.TILED_KEYS + denoise.UNCHANGED_KEYS + ("low_spp",)
-    batch = {k: th.from_numpy(np.ascontiguousarray(frame[k])).unsqueeze(0).to(device) for k in keys if k in frame}
+    sharded = world > 1 and not kpcn_mode
+    if sharded:
+        # only this rank's rows go to its GPU (the whole frame is 2.7 GB of features at 720p x 8 spp)
+        from sbmc_amd import dist as sdist
+        part = sdist.SlabPartition(hdr["image_height"], world, rank)
+        batch = {k: th.from_numpy(np.ascontiguousarray(
+            frame[k] if k in denoise.UNCHANGED_KEYS else frame[k][..., part.y0:part.y1, :])).unsqueeze(0).to(device)
+            for k in keys if k in frame}
+    else:
+        batch = {k: th.from_numpy(np.ascontiguousarray(frame[k])).unsqueeze(0).to(device) for k in keys if k in frame}
     LOG.info("setup time %.1f ms", (time.time() - start) * 1000)
     th.cuda.synchronize()
     start = time.time()
-    if world > 1 and not kpcn_mode:
-        from sbmc_amd import dist as sdist
-        part = sdist.SlabPartition(hdr["image_height"], world, rank)
-        out = denoise.denoise_frame_sharded(model, batch, part)
+    if sharded:
+        out = denoise.denoise_frame_sharded(model, batch, part, slab_only=True, height=hdr["image_height"])
     else:
         out = denoise.denoise_frame(model, batch, args.tile_size, args.tile_pad, kpcn_mode=kpcn_mode)
     th.cuda.synchronize()
@@ -121,9 +136,9 @@ def parser():
     # overrides of the checkpoint's meta (None = take the meta / the reference's defaults)
     p.add_argument("--ksize", type=int, default=None)
     p.add_argument("--width", type=int, default=None)
-    p.add_argument("--gather", action="store_true", default=None)
-    p.add_argument("--pixel", action="store_true", default=None)
-    p.add_argument("--kpcn_mode", action="store_true", default=None)
+    p.add_argument("--gather", action=argparse.BooleanOptionalAction, default=None)       # --gather / --no-gather
+    p.add_argument("--pixel", action=argparse.BooleanOptionalAction, default=None)
+    p.add_argument("--kpcn_mode", action=argparse.BooleanOptionalAction, default=None)
     return p
 
 

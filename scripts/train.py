@@ -23,13 +23,15 @@ def main(args):
     th.manual_seed(0)
     if not th.cuda.is_available():
         raise SystemExit("sbmc_amd runs its operators on MI355X only; no GPU is visible")
-    mode = "kpcn" if args.kpcn_mode else "sbmc"          # reference scripts/train.py:39-41
+    mode = "kpcn" if args.kpcn_mode else "sbmc"          # reference scripts/train.py:39-43
+    data_args = dict(spp=args.spp, mode=mode, load_coords=args.load_coords, load_gbuffer=args.load_gbuffer,
+                     load_p=args.load_p, load_ld=args.load_ld, load_bt=args.load_bt)
     if args.randomize_spp:
         if args.bs != 1:
             raise RuntimeError("Training with randomized spp is only valid for batch_size=1")
-        data = interfaces.MultiSampleCountDataset(args.data, spp=args.spp, mode=mode)
+        data = interfaces.MultiSampleCountDataset(args.data, **data_args)
     else:
-        data = interfaces.TilesDataset(args.data, spp=args.spp, mode=mode)
+        data = interfaces.TilesDataset(args.data, **data_args)
     if args.kpcn_mode:                                    # reference scripts/train.py:58-60
         model = KPCN(data.num_features, ksize=args.ksize)
     else:
@@ -38,10 +40,10 @@ def main(args):
     loader = DataLoader(data, batch_size=args.bs, num_workers=args.num_worker_threads, shuffle=True)
     val_loader = None
     if args.val_data:
-        val_loader = DataLoader(interfaces.TilesDataset(args.val_data, spp=args.spp, mode=mode),
+        val_loader = DataLoader(interfaces.TilesDataset(args.val_data, **data_args),
                                 batch_size=args.bs, num_workers=1, shuffle=False)
     meta = dict(model_params=dict(ksize=args.ksize, gather=args.gather, pixel=args.pixel),
-                kpcn_mode=args.kpcn_mode, data_params=dict(spp=args.spp))
+                kpcn_mode=args.kpcn_mode, data_params=data_args)   # (the reference stores them all: train.py:85-87)
     interface = interfaces.SampleBasedDenoiserInterface(model, lr=args.lr, cuda=True)
     ckpt = interfaces.Checkpointer(args.checkpoint_dir, model, interface.optimizer, meta=meta)
     extras, _ = ckpt.load_latest()
@@ -61,6 +63,12 @@ if __name__ == "__main__":
     p.add_argument("--pixel", action="store_true")
     p.add_argument("--kpcn_mode", action="store_true", help="train [Bako2017]'s KPCN baseline instead")
     p.add_argument("--constant_spp", dest="randomize_spp", action="store_false", default=True)
+    # feature groups (reference scripts/train.py:139-148)
+    p.add_argument("--dont_use_coords", dest="load_coords", action="store_false", default=True)
+    p.add_argument("--dont_use_gbuffer", dest="load_gbuffer", action="store_false", default=True)
+    p.add_argument("--dont_use_p", dest="load_p", action="store_false", default=True)
+    p.add_argument("--dont_use_ld", dest="load_ld", action="store_false", default=True)
+    p.add_argument("--dont_use_bt", dest="load_bt", action="store_false", default=True)
     p.add_argument("--lr", type=float, default=1e-4)
     p.add_argument("--bs", type=int, default=1)
     p.add_argument("--num_epochs", type=int, default=1)

@@ -333,7 +333,41 @@ def gen_bin_kpcn(ref_root):
     save("bin_scene_kpcn_expected.npz", out)
 
 
+def gen_bin_groups(ref_root):
+    """The committed scene read by the REFERENCE's sbmc/datasets.py with feature groups switched off
+    (load_* flags, datasets.py:194-215, :309-354, :706-717), as a checkpoint trained with
+    `--dont_use_p --dont_use_bt` (or without coordinates and g-buffer) asks for at denoising time."""
+    import importlib.util
+    import types
+    from sbmc_amd import binio
+    scene_root = os.path.join(HERE, "bin_scene")
+    lz4 = types.ModuleType("lz4")
+    frame = types.ModuleType("lz4.frame")
+    frame.decompress = lambda buf: binio.lz4f_decompress(buf, None)
+    lz4.frame = frame
+    sys.modules["lz4"], sys.modules["lz4.frame"] = lz4, frame
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    spec = importlib.util.spec_from_file_location("ref_datasets", os.path.join(ref_root, "sbmc", "datasets.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for tag, flags in (("no_p_bt", dict(load_p=False, load_bt=False)),
+                       ("no_coords_gbuffer_ld", dict(load_coords=False, load_gbuffer=False, load_ld=False))):
+        ds = mod.FullImagesDataset(scene_root, spp=3, **flags)
+        item = ds[0]
+        out[tag + ".num_features"] = np.asarray(ds.num_features)
+        out[tag + ".labels"] = np.asarray(ds.labels)
+        for k in ("features", "radiance", "low_spp", "target_image"):
+            out["%s.%s" % (tag, k)] = np.asarray(item[k])
+    save("bin_scene_groups_expected.npz", out)
+
+
 def main():
+    if "--round3" in sys.argv:        # the fixture added in round 3 only
+        refload.load_reference()      # (installs the stand-in for the absent `ttools` logger)
+        gen_bin_groups(refload.REFERENCE_ROOT)
+        return
     if "--round2" in sys.argv:        # the fixtures added in round 2 only (leaves the others untouched)
         ref = refload.load_reference()
         gen_interface(ref)
@@ -353,6 +387,7 @@ def main():
     gen_bin(refload.REFERENCE_ROOT)
     gen_interface(ref)
     gen_bin_kpcn(refload.REFERENCE_ROOT)
+    gen_bin_groups(refload.REFERENCE_ROOT)
 
 
 if __name__ == "__main__":

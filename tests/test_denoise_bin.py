@@ -25,6 +25,24 @@ def test_reader_matches_what_the_reference_reads():
             np.testing.assert_array_equal(frame[k], g["spp%d.%s" % (spp, k)], err_msg=k)
 
 
+@pytest.mark.parametrize("tag,flags", [("no_p_bt", dict(load_p=False, load_bt=False)),
+                                       ("no_coords_gbuffer_ld", dict(load_coords=False, load_gbuffer=False, load_ld=False))])
+def test_feature_groups_match_what_the_reference_reads(tag, flags):
+    """Feature-group selection (reference sbmc/datasets.py:194-215, :309-354, :706-717; set by
+    scripts/train.py:139-148 and handed to denoise.py through the checkpoint's data_params):
+    bin_scene_groups_expected.npz is what the REFERENCE's FullImagesDataset read with these groups off."""
+    from sbmc_amd import binio
+    g = golden("bin_scene_groups_expected.npz")
+    frame = binio.read_scene(os.path.join(GOLDEN, "bin_scene", "scene0"), spp=3, **flags)
+    assert frame["features"].shape[1] == int(g[tag + ".num_features"])
+    assert frame["labels"] == [str(x) for x in g[tag + ".labels"]]
+    assert len(binio.feature_labels(**binio.feature_flags("sbmc", **flags))) == int(g[tag + ".num_features"])
+    for k in ("features", "radiance", "low_spp", "target_image"):
+        np.testing.assert_array_equal(frame[k], g["%s.%s" % (tag, k)], err_msg=k)
+    with pytest.raises(TypeError):
+        binio.read_tile(os.path.join(GOLDEN, "bin_scene", "scene0", "tile_000.bin"), load_everything=True)
+
+
 def test_roundtrip_and_errors(tmp_path):
     from sbmc_amd import binio
     from make_golden import synthetic_scene
