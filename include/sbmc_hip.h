@@ -399,6 +399,19 @@ SBMC_API int sbmc_pointwise_bwd_f32(const float *gy, const float *y, const float
                            const float *gmean, int s_mean, int b, int s, int cin, int cout, long hw,
                            int t_mode, int act, float slope, void *stream);
 
+/* Forward and backward with SIGN BITS instead of the saved output.  The forward also writes, when signs is not
+ * NULL, one bit per output element -- pre-activation > 0 -- as [b, cout, ceil(hw / 32)] 32-bit words (bit i of
+ * word j of a row = pixel 32 j + i); the backward's activation adjoint reads those instead of y: 1/32 of the
+ * bytes.  (The fp32 forward runs on the bf16 matrix pipe at fp32 accuracy: every fp32 operand is the exact sum
+ * of three bf16 values and six of the nine partial products are accumulated -- csrc/pointwise.hip.) */
+SBMC_API int sbmc_pointwise_fwd_signs_f32(const float *x, const float *w, const float *bias, const float *t,
+                                 float *y, unsigned *signs, int b, int s, int cin, int cout, long hw,
+                                 int t_mode, int act, float slope, void *stream);
+SBMC_API int sbmc_pointwise_bwd_signs_f32(const float *gy, const unsigned *signs, const float *x, const float *w,
+                                 float *gx, float *gw_partial, float *gb_partial, float *gt,
+                                 const float *gmean, int s_mean, int b, int s, int cin, int cout, long hw,
+                                 int t_mode, int act, float slope, void *stream);
+
 /* The same backward with half-precision STORAGE (training under torch.autocast(float16), SURVEY.md row
  * N4): gy, y, gmean are _Float16; x and gx are _Float16 (x_is_half = 1) or float (a chain's first
  * layer, whose input is the network's fp32 features); w, gw_partial, gb_partial and gt stay float, every

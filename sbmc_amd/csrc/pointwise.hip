@@ -52,6 +52,7 @@ struct PwFwdParams {
     int nrt;             // row tiles of 128 output channels
     int t_mode;
     float slope;         // 1: linear, 0: relu, else leaky relu
+    unsigned* signs;     // [B, Cout, ceil(hw / 32)] one bit per output: pre-activation > 0 (nullptr: not wanted)
 };
 
 // KP: Cin rounded up to a multiple of 32 (<= 128); TMODE: the context term (0 none, 1 per image, 2 per pixel).
@@ -246,6 +247,288 @@ __global__ __launch_bounds__(256 * PH) void pw_fwd_kernel(PwFwdParams p) {
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) store_prev(j);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fp32 forward on the bf16 matrix pipe, at fp32 accuracy ("split precision").
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate, and at 128 -> 128 channels the layer needs the
+// fp32 matrix pipe and ~5 TB/s of HBM at once (the kernel above: 0.6 of the fp32 MFMA peak, clocks down under
+// the load).  An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 mantissa bits, fp32's exponent
+// range):  x = xh + xm + xl,  xh = bf16(x), xm = bf16(x - xh), xl = bf16(x - xh - xm)  -- so
+//     w x = wh xh + (wh xm + wm xh) + (wm xm + wh xl + wl xh) + [wm xl + wl xm + wl xl: <= 2^-23 |w x|, dropped]
+// is six bf16 products with exact fp32 partial products, accumulated in fp32 by v_mfma_f32_32x32x16_bf16:
+// 6 / 16 of the fp32 MFMA time.  Error per product term <= ~2^-23 relative, the size of one fp32 rounding (the
+// fp32-MFMA kernel rounds once per term as well); measured against float64 both kernels sit at ~1e-7 of the
+// output scale.  The layer becomes HBM-bound (the split costs ~6 VALU operations per input value, hidden behind
+// the other wave of the SIMD).
+//
+// Tile: 64 pixels; 8 waves = 4 blocks of 32 output channels x 2 pixel halves of 32 (one 32 x 32 accumulator
+// pair per wave: large and small terms apart, so that no MFMA waits for the previous one's result).  The B
+// operand of the bf16 MFMA wants 8 CONSECUTIVE input channels of one pixel per lane: a staging thread owns one
+// pixel (lane) and one channel octet (wave), loads its 8 values with 8 coalesced row reads (256 B per wave and
+// row), splits them in registers and writes three 16-byte entries; the LDS image of a tile is
+// [plane][K / 8][64 pixels] entries, an operand fetch one conflict-free ds_read_b128.  The A operand (weights)
+// lives in registers in its three planes.  Double-buffered LDS stage, next tile's loads in flight during the
+// MFMAs.  Optionally writes one SIGN BIT per output (pre-activation > 0): the backward then needs no y.
+using bf8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf2 = __attribute__((ext_vector_type(2))) __bf16;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);                 // v_cvt_pk_bf16_f32 (round to nearest even)
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// 8 floats -> their three bf16 planes (each 8 bf16 = 16 bytes, element i in bits 16 (i & 1) of word i / 2)
+__device__ __forceinline__ void split3(const float (&v)[8], u32x4& h, u32x4& m, u32x4& l) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned hp = pack_bf16(v[2 * i], v[2 * i + 1]);
+        const float r0 = v[2 * i] - bf16_lo(hp), r1 = v[2 * i + 1] - bf16_hi(hp);       // exact
+        const unsigned mp = pack_bf16(r0, r1);
+        const float s0 = r0 - bf16_lo(mp), s1 = r1 - bf16_hi(mp);                       // exact
+        h[i] = hp;
+        m[i] = mp;
+        l[i] = pack_bf16(s0, s1);
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL
+// access (s_waitcnt vmcnt(0)): loads issued for later tiles would have to land before each barrier, i.e.
+// within one tile's time -- exactly what a prefetch across tiles must avoid.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+
+constexpr int PS_NT = 64;           // pixels per tile of the split-precision kernels
+
+// WAVES: 8 (two waves per SIMD, 256 registers each; a wave owns 32 channels x 32 pixels) or 4 (one wave per
+// SIMD with the whole 512-entry register file -- accumulators in AccVGPRs --; a wave owns 32 channels x 64
+// pixels): the second form leaves the compiler room to keep LDS reads and the split of the next tile in
+// flight between the MFMAs instead of waiting for each operand.
+template <int KP, int TMODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
+    constexpr int KO = KP / 8;                         // channel octets
+    constexpr int KS = KP / 16;                        // MFMA k-steps
+    constexpr int NOCT = (KO + WAVES - 1) / WAVES;     // octets a staging thread owns
+    constexpr int NPH = 8 / WAVES;                     // 32-pixel blocks a wave owns
+    const float* xg = static_cast<const float*>(p.x);
+    float* yg = static_cast<float*>(p.y);
+    extern __shared__ float4 pw_lds[];
+    u32x4* xs = reinterpret_cast<u32x4*>(pw_lds);      // [2][3][KO][PS_NT]
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int rb = wave & 3, ph0 = (wave >> 2) * NPH;  // (WAVES = 4: ph0 = 0, both pixel blocks)
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const unsigned hw = p.hw;
+
+    const unsigned g = blockIdx.x, slot = g / NUM_XCD;
+    const int rt = (int)(slot % (unsigned)p.nrt);
+    const unsigned first = (slot / (unsigned)p.nrt) * NUM_XCD + g % NUM_XCD;
+    const unsigned stride = gridDim.x / (unsigned)p.nrt;
+    const int r0 = rt * 128 + rb * 32;
+    const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
+
+    auto tile_coords = [&](unsigned tile, unsigned& b, unsigned& bq, unsigned& p0) {
+        const unsigned s = tile % (unsigned)p.S, rest = tile / (unsigned)p.S;
+        const unsigned pt = rest % p.tiles_per_plane;
+        bq = rest / p.tiles_per_plane;
+        b = bq * (unsigned)p.S + s;
+        p0 = pt * PS_NT;
+    };
+    // staging role: pixel `lane` of the tile, channel octets wave + WAVES i.  One lane offset per tile, the row
+    // offsets are scalar (the octet is the wave's); rows beyond K (padding up to KP) are zeros.
+    auto issue_loads = [&](unsigned tile, float (&regs)[NOCT][8]) {
+        unsigned b, bq, p0;
+        tile_coords(tile, b, bq, p0);
+        const rsrc_t rx = make_rsrc_n(xg + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
+        const unsigned voff = p0 + lane < hw ? (p0 + lane) * 4u : PW_OOB;
+#pragma unroll
+        for (int i = 0; i < NOCT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const unsigned k = 8u * (unsigned)(wave + WAVES * i) + r;      // wave-uniform
+                const bool krow = k < (unsigned)p.K;                           // (no branch around the load)
+                regs[i][r] = buf_load(rx, krow ? voff : PW_OOB, krow ? k * hw * 4u : 0u);
+            }
+        }
+    };
+    auto commit = [&](int buf, const float (&regs)[NOCT][8]) {
+#pragma unroll
+        for (int i = 0; i < NOCT; ++i) {
+            const int o = wave + WAVES * i;
+            if (o < KO) {
+                u32x4 h, m, l;
+                split3(regs[i], h, m, l);
+                u32x4* d = xs + ((buf * 3) * KO + o) * PS_NT + lane;
+                d[0] = h;
+                d[KO * PS_NT] = m;
+                d[2 * KO * PS_NT] = l;
+            }
+        }
+    };
+
+    // weight rows of this wave as A operands, three planes: a*[s] = W[r0 + lane % 32][16 s + 8 (lane / 32) + 0..7]
+    u32x4 ah[KS], am[KS], al[KS];
+    {
+        const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
+        const int row = r0 + l31;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 16 * s + 8 * lhi + i;
+                v[i] = buf_load(rw, (row < p.Cout && k < p.K) ? (unsigned)(row * p.K + k) * 4u : PW_OOB, 0);
+            }
+            split3(v, ah[s], am[s], al[s]);
+        }
+    }
+    // (accumulator row of register j: r0 + (j & 3) + 8 (j >> 2) + 4 (lane / 32))
+    const unsigned wpr = (hw + 31) / 32;               // sign words per row
+
+    // Two tiles in flight per workgroup (64 KB per CU): at ~2 us of work per tile one tile's bytes do not cover
+    // the memory latency at full bandwidth.  The two register sets swap roles from tile to tile (an in-flight
+    // load is never copied: a copy would wait for it), and the barrier orders LDS traffic only.  The split of
+    // the next tile (registers -> LDS) is dealt out between the MFMAs of the k-steps.
+    float preA[NOCT][8], preB[NOCT][8];
+    unsigned tile = first;
+    if (tile < p.ntiles) {
+        issue_loads(tile, preA);
+        commit(0, preA);
+        if (tile + stride < p.ntiles) issue_loads(tile + stride, preA);
+    }
+    __syncthreads();
+
+    // one pair of values of the next tile -> its three bf16 words; a finished octet goes to LDS
+    u32x4 ch[NOCT], cm[NOCT], cl[NOCT];
+    auto commit_unit = [&](const float (&src)[NOCT][8], int u, int buf) {     // u = 4 (octet slot) + pair
+        const int i = u >> 2, q = u & 3;
+        const unsigned hp = pack_bf16(src[i][2 * q], src[i][2 * q + 1]);
+        const float r0 = src[i][2 * q] - bf16_lo(hp), r1 = src[i][2 * q + 1] - bf16_hi(hp);
+        const unsigned mp = pack_bf16(r0, r1);
+        ch[i][q] = hp;
+        cm[i][q] = mp;
+        cl[i][q] = pack_bf16(r0 - bf16_lo(mp), r1 - bf16_hi(mp));
+        if (q == 3) {
+            const int o = wave + WAVES * i;
+            if (o < KO) {
+                u32x4* d = xs + ((buf * 3) * KO + o) * PS_NT + lane;
+                d[0] = ch[i];
+                d[KO * PS_NT] = cm[i];
+                d[2 * KO * PS_NT] = cl[i];
+            }
+        }
+    };
+
+    // one tile; `cur` holds the NEXT tile's values (split and written to LDS stage buf ^ 1 during this one),
+    // `fill` receives the loads of the tile after that
+    auto step = [&](const float (&cur)[NOCT][8], float (&fill)[NOCT][8], const int buf) {
+        const unsigned next = tile + stride, next2 = next + stride;
+        if (next2 < p.ntiles && next2 > next) issue_loads(next2, fill);
+        const bool more = next < p.ntiles;
+
+        unsigned b, bq, p0;
+        tile_coords(tile, b, bq, p0);
+        unsigned o0[NPH];
+#pragma unroll
+        for (int h = 0; h < NPH; ++h) {
+            const unsigned col = p0 + (ph0 + h) * 32 + l31;
+            o0[h] = (col < hw && nrows > 0) ? (4u * lhi * hw + col) * 4u : PW_OOB;
+        }
+
+        f32x16 acc[NPH], small[NPH], t0[NPH];
+        float add[16];                                 // bias (+ the per-image context term) of the 16 accumulator rows
+#pragma unroll
+        for (int h = 0; h < NPH; ++h) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[h][j] = small[h][j] = 0.f;
+        }
+        if (TMODE == 2) {
+            const rsrc_t rt2 = make_rsrc_n(p.t + ((size_t)bq * p.Cout + r0) * hw, (unsigned)nrows * hw * 4u);
+#pragma unroll
+            for (int h = 0; h < NPH; ++h) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
+                    t0[h][j] = buf_load(rt2, o0[h] != PW_OOB ? o0[h] + ro : PW_OOB, 0);
+                }
+            }
+        }
+
+        const u32x4* xb = xs + ((buf * 3) * KO + lhi) * PS_NT + ph0 * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int h = 0; h < NPH; ++h) {
+                const u32x4 bh = xb[(2 * s) * PS_NT + 32 * h];
+                const u32x4 bm = xb[(KO + 2 * s) * PS_NT + 32 * h];
+                const u32x4 bl = xb[(2 * KO + 2 * s) * PS_NT + 32 * h];
+                acc[h] = mfma_bf16(ah[s], bh, acc[h]);
+                small[h] = mfma_bf16(ah[s], bl, small[h]);
+                acc[h] = mfma_bf16(ah[s], bm, acc[h]);
+                small[h] = mfma_bf16(al[s], bh, small[h]);
+                acc[h] = mfma_bf16(am[s], bh, acc[h]);
+                small[h] = mfma_bf16(am[s], bm, small[h]);
+            }
+            // fillers of this k-step
+            if (s == ((TMODE == 2 && WAVES == 8 && KS > 2) ? KS - 2 : 0)) {
+                // bias and per-image context term (cache hits), behind the first MFMAs; at 256 registers with a
+                // per-pixel term as well (16 more live registers) late in the loop, just in time for the epilogue
+                const rsrc_t rbias = make_rsrc_n(p.bias, (unsigned)p.Cout * 4u);
+                const rsrc_t rt1 = make_rsrc_n(TMODE == 1 ? p.t + (size_t)bq * p.Cout : p.bias, (unsigned)p.Cout * 4u);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const unsigned ro = (unsigned)(r0 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * 4u;
+                    add[j] = buf_load(rbias, ro, 0);
+                    if (TMODE == 1) add[j] += buf_load(rt1, ro, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 4 * NOCT * s / KS; u < 4 * NOCT * (s + 1) / KS; ++u) commit_unit(cur, u, buf ^ 1);   // in order
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // bias, context term, sign bits, activation, store
+        const rsrc_t ry = make_rsrc_n(yg + ((size_t)b * p.Cout + r0) * hw, (unsigned)nrows * hw * 4u);
+#pragma unroll
+        for (int h = 0; h < NPH; ++h) {
+            unsigned myword = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float v = acc[h][j] + (small[h][j] + add[j]);
+                if (TMODE == 2) v += t0[h][j];
+                const unsigned long long pos = __ballot(v > 0.f);
+                const unsigned word = lhi ? (unsigned)(pos >> 32) : (unsigned)pos;
+                myword = l31 == j ? word : myword;     // lane j (j + 32) keeps the word of register j's row (+ 4)
+                v = v > 0.f ? v : v * p.slope;
+                const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
+                buf_store(v, ry, o0[h] != PW_OOB ? o0[h] + ro : PW_OOB, 0);
+            }
+            if (p.signs != nullptr && l31 < 16) {
+                const int row = r0 + (l31 & 3) + 8 * (l31 >> 2) + 4 * lhi;
+                const unsigned c0 = p0 + (ph0 + h) * 32;
+                if (row < p.Cout && c0 < hw) p.signs[((size_t)b * p.Cout + row) * wpr + c0 / 32] = myword;
+            }
+        }
+        lds_barrier();
+    };
+    while (tile < p.ntiles) {
+        step(preA, preB, 0);
+        tile += stride;
+        if (!(tile < p.ntiles)) break;
+        step(preB, preA, 1);
+        tile += stride;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -494,10 +777,14 @@ struct PwBwdParams {
     float slope;
 };
 
-template <int KP, bool DX, bool TPIX, bool GM, typename TA = float, typename TXT = float>
+// SG: p.y holds the forward's SIGN BITS ([B, Cout, ceil(hw / 32)] words, written by pw_fwd_s_kernel) instead of
+// its output: the activation adjoint then reads 1 bit per element instead of 32 (-12 staging registers too).
+template <int KP, bool DX, bool TPIX, bool GM, typename TA = float, typename TXT = float, bool SG = false>
 __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     const TA* gy_g = static_cast<const TA*>(p.gy);
     const TA* y_g = static_cast<const TA*>(p.y);
+    const unsigned* sg_g = static_cast<const unsigned*>(p.y);
+    const unsigned wpr = (p.hw + 31) / 32;
     const TA* gm_g = static_cast<const TA*>(p.gm);
     const TXT* x_g = static_cast<const TXT*>(p.x);
     TXT* gx_g = static_cast<TXT*>(p.gx);
@@ -549,7 +836,8 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         return n;
     };
 
-    typename Pack4<TA>::type pg[4], py[4], pm[GM ? 4 : 1];
+    typename Pack4<TA>::type pg[4], py[SG ? 1 : 4], pm[GM ? 4 : 1];
+    unsigned psg[SG ? 4 : 1];
     typename Pack4<TXT>::type px[NX];
     const float inv_sm = GM ? 1.f / (float)p.Sm : 0.f;
     auto issue = [&](Cursor c) {
@@ -560,13 +848,20 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                                       (unsigned)p.Cout * hw * SA);
         const rsrc_t ry = make_rsrc_n(y_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * SA);
         const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * SX);
+        const rsrc_t rs = make_rsrc_n(SG ? sg_g + (size_t)b * p.Cout * wpr : sg_g, (unsigned)p.Cout * wpr * 4u);
         const bool colok = p0 + c4 < hw;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned r = srow + 32u * i;
             const unsigned off = (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * SA : PW_OOB;
             pg[i] = load4<TA>(rg, off);
-            if (masked) py[i] = load4<TA>(ry, off);
+            if constexpr (SG) {
+                // (rows / columns beyond the tensor read 0: their gradient is 0 as well)
+                psg[i] = __builtin_amdgcn_raw_buffer_load_b32(
+                    rs, (colok && r < (unsigned)p.Cout) ? (r * wpr + (p0 + c4) / 32) * 4u : PW_OOB, 0, 0);
+            } else {
+                if (masked) py[i] = load4<TA>(ry, off);
+            }
             if (GM) pm[i] = load4<TA>(rm, off);
         }
 #pragma unroll
@@ -610,7 +905,15 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                 const float4 m = unpack4<TA>(pm[i]);
                 gv.x += m.x * inv_sm; gv.y += m.y * inv_sm; gv.z += m.z * inv_sm; gv.w += m.w * inv_sm;
             }
-            if (masked) {
+            if constexpr (SG) {
+                if (masked) {
+                    const unsigned bits = psg[i] >> ((p0 + c4) & 31u);
+                    gv.x = (bits & 1u) ? gv.x : gv.x * p.slope;
+                    gv.y = (bits & 2u) ? gv.y : gv.y * p.slope;
+                    gv.z = (bits & 4u) ? gv.z : gv.z * p.slope;
+                    gv.w = (bits & 8u) ? gv.w : gv.w * p.slope;
+                }
+            } else if (masked) {
                 const float4 v = unpack4<TA>(py[i]);
                 gv.x = v.x > 0.f ? gv.x : gv.x * p.slope;
                 gv.y = v.y > 0.f ? gv.y : gv.y * p.slope;
@@ -1042,15 +1345,68 @@ extern "C" int sbmc_pointwise_supported(int cin, int cout, long hw) { return pw_
 
 template <typename TI, typename TO>
 static int pw_fwd_launch(const void* x, const float* w, const float* bias, const float* t, void* y, int b, int s,
-                         int cin, int cout, long hw, int t_mode, int act, float slope, void* stream) {
+                         int cin, int cout, long hw, int t_mode, int act, float slope, void* stream,
+                         unsigned* signs = nullptr) {
     if (b < 0 || s < 1 || act < 0 || act > 2 || t_mode < 0 || t_mode > 2) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!pw_dims_ok(cin, cout, hw) || b % s || !x || !w || !bias || !y || (t_mode && !t)) return SBMC_HIP_EINVAL;
     if ((uintptr_t)x % 16) return SBMC_HIP_EINVAL;
     PwFwdParams p;
     p.x = x; p.w = w; p.bias = bias; p.t = t; p.y = y;
+    p.signs = signs;
     p.B = b; p.S = t_mode ? s : 1; p.K = cin; p.Cout = cout;
     p.hw = (unsigned)hw;
+    if constexpr (sizeof(TI) == 4 && sizeof(TO) == 4) {
+        // fp32 in, fp32 out: the split-precision kernel on the bf16 matrix pipe (SBMC_HIP_PW_SPLIT=0 keeps the
+        // fp32-MFMA kernel: development knob, not part of the ABI)
+        const char* knob = getenv("SBMC_HIP_PW_SPLIT");
+        if (!knob || atoi(knob) != 0) {
+            p.tiles_per_plane = (unsigned)((hw + PS_NT - 1) / PS_NT);
+            const unsigned long long nts = (unsigned long long)p.tiles_per_plane * (unsigned)b;
+            if (nts > 0xFFFFFFFFull - 4096) return SBMC_HIP_EINVAL;
+            p.ntiles = (unsigned)nts;
+            p.t_mode = t_mode;
+            p.slope = act == 0 ? 1.f : (act == 1 ? 0.f : slope);
+            p.nrt = (cout + 127) / 128;
+            int sdev = 0, scus = 256;
+            if (hipGetDevice(&sdev) != hipSuccess ||
+                hipDeviceGetAttribute(&scus, hipDeviceAttributeMultiprocessorCount, sdev) != hipSuccess)
+                scus = 256;
+            const int skp = (cin + 31) / 32 * 32;
+            const size_t slds = (size_t)2 * 3 * (skp / 8) * PS_NT * 16;
+            const unsigned sunit = (unsigned)(NUM_XCD * p.nrt);
+            unsigned sgrid = (unsigned)scus / sunit * sunit;
+            const unsigned long long sneed = ((unsigned long long)p.ntiles + NUM_XCD - 1) / NUM_XCD * sunit;
+            if (sgrid > sneed) sgrid = (unsigned)sneed;
+            if (sgrid < sunit) sgrid = sunit;
+            hipError_t se = hipSuccess;
+#define SBMC_PWS_LAUNCH2(KPV, WV)                                                                        \
+    do {                                                                                                 \
+        auto kern = t_mode == 2 ? pw_fwd_s_kernel<KPV, 2, WV>                                             \
+                                : (t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV> : pw_fwd_s_kernel<KPV, 0, WV>); \
+        se = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);                 \
+        if (se == hipSuccess)                                                                            \
+            hipLaunchKernelGGL(kern, dim3(sgrid), dim3(64 * WV), slds, (hipStream_t)stream, p);          \
+    } while (0)
+#define SBMC_PWS_LAUNCH(KPV)                                                                             \
+    do { if (swaves == 4) SBMC_PWS_LAUNCH2(KPV, 4); else SBMC_PWS_LAUNCH2(KPV, 8); } while (0)
+            // 8 waves (two per SIMD) measured 7-10 % faster than 4 (one per SIMD, 512 registers); development knob
+            const char* wknob = getenv("SBMC_HIP_PW_SPLIT_WAVES");
+            const int swaves = (wknob && atoi(wknob) == 4) ? 4 : 8;
+            switch (skp) {
+                case 32: SBMC_PWS_LAUNCH(32); break;
+                case 64: SBMC_PWS_LAUNCH(64); break;
+                case 96: SBMC_PWS_LAUNCH(96); break;
+                default: SBMC_PWS_LAUNCH(128); break;
+            }
+#undef SBMC_PWS_LAUNCH
+#undef SBMC_PWS_LAUNCH2
+            if (se != hipSuccess) return (int)se;
+            return (int)hipGetLastError();
+        }
+        if (signs != nullptr) return SBMC_HIP_EINVAL;      // (the fp32-MFMA kernel writes no sign bits)
+    }
     const int ph = PW_FWD_PH;
     const int ntile = 64 * ph;
     p.tiles_per_plane = (unsigned)((hw + ntile - 1) / ntile);
@@ -1128,6 +1484,12 @@ extern "C" int sbmc_pointwise_fwd_f32(const float* x, const float* w, const floa
     return pw_fwd_launch<float, float>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream);
 }
 
+extern "C" int sbmc_pointwise_fwd_signs_f32(const float* x, const float* w, const float* bias, const float* t, float* y,
+                                            unsigned* signs, int b, int s, int cin, int cout, long hw, int t_mode,
+                                            int act, float slope, void* stream) {
+    return pw_fwd_launch<float, float>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream, signs);
+}
+
 extern "C" int sbmc_pointwise_fwd_f16(const void* x, int x_is_half, const float* w, const float* bias, const float* t,
                                       void* y, int b, int s, int cin, int cout, long hw, int t_mode, int act,
                                       float slope, void* stream) {
@@ -1160,13 +1522,13 @@ template <typename TA, typename TXT>
 static int pw_bwd_launch(const void* gy, const void* y, const void* x, const float* w, void* gx,
                          float* gw_partial, float* gb_partial, float* gt, const void* gmean,
                          int s_mean, int b, int s, int cin, int cout, long hw, int t_mode, int act,
-                         float slope, void* stream) {
+                         float slope, void* stream, bool y_is_signs = false) {
     if (b < 0 || s < 1 || act < 0 || act > 2 || t_mode < 0 || t_mode > 2) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!sbmc_pointwise_bwd_supported(cin, cout, hw) || b % s || !gy || !x || !w || !gw_partial || !gb_partial ||
         (act != 0 && !y) || (t_mode == 2 && !gt) || (gmean && (s_mean < 1 || b % s_mean || t_mode == 2)))
         return SBMC_HIP_EINVAL;
-    if ((uintptr_t)gy % 16 || (uintptr_t)x % 16 || (act != 0 && (uintptr_t)y % 16) ||
+    if ((uintptr_t)gy % 16 || (uintptr_t)x % 16 || (act != 0 && (uintptr_t)y % (y_is_signs ? 4 : 16)) ||
         (t_mode == 2 && (uintptr_t)gt % 16) || (uintptr_t)gmean % 16 || (uintptr_t)gx % 16)
         return SBMC_HIP_EINVAL;
     PwBwdParams p;
@@ -1220,6 +1582,11 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
     do {                                                                                                 \
         auto kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, TA, TXT>                       \
                                     : pw_bwd_kernel<KPV, DXV, TPV, false, TA, TXT>;                       \
+        if constexpr (sizeof(TA) == 4 && sizeof(TXT) == 4) {                                             \
+            if (y_is_signs)                                                                              \
+                kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, float, float, true>         \
+                                       : pw_bwd_kernel<KPV, DXV, TPV, false, float, float, true>;         \
+        }                                                                                                \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
         if (e == hipSuccess)                                                                             \
@@ -1248,6 +1615,14 @@ extern "C" int sbmc_pointwise_bwd_f32(const float* gy, const float* y, const flo
                                       float slope, void* stream) {
     return pw_bwd_launch<float, float>(gy, y, x, w, gx, gw_partial, gb_partial, gt, gmean, s_mean, b, s, cin, cout,
                                        hw, t_mode, act, slope, stream);
+}
+
+extern "C" int sbmc_pointwise_bwd_signs_f32(const float* gy, const unsigned* signs, const float* x, const float* w,
+                                            float* gx, float* gw_partial, float* gb_partial, float* gt,
+                                            const float* gmean, int s_mean, int b, int s, int cin, int cout, long hw,
+                                            int t_mode, int act, float slope, void* stream) {
+    return pw_bwd_launch<float, float>(gy, signs, x, w, gx, gw_partial, gb_partial, gt, gmean, s_mean, b, s, cin, cout,
+                                       hw, t_mode, act, slope, stream, true);
 }
 
 extern "C" int sbmc_pointwise_bwd_f16(const void* gy, const void* y, const void* x, int x_is_half, const float* w,

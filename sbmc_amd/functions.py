@@ -490,11 +490,21 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False):
     y = th.empty(B, cout, hw, dtype=th.float16 if half else th.float32, device=x.device)
     dev = x.device
     L = _lib.lib()
+    # an activated fp32 layer whose backward is the fused kernel keeps one SIGN BIT per output for it instead
+    # of the output itself (written by the forward kernel: 1/32 of the bytes the adjoint has to read back)
+    signs = None
+    if (not half and act != 0 and any(ctx.needs_input_grad[:4]) and _pw_split_enabled()
+            and L.sbmc_pointwise_bwd_supported(cin, cout, hw)):
+        signs = th.empty(B, cout, (hw + 31) // 32, dtype=th.int32, device=dev)
     with th.cuda.device(dev), _timed("pointwise_fwd%s %dx%d" % ("_f16" if half else "", cout, cin), dev):
         if half:
             rc = L.sbmc_pointwise_fwd_f16(_lib.ptr(x), int(x.dtype == th.float16), _lib.ptr(w), _lib.ptr(bias),
                                           _lib.ptr(t) if t is not None else None, _lib.ptr(y),
                                           B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
+        elif signs is not None:
+            rc = L.sbmc_pointwise_fwd_signs_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
+                                                _lib.ptr(t) if t is not None else None, _lib.ptr(y), _lib.ptr(signs),
+                                                B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
         else:
             rc = L.sbmc_pointwise_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
                                           _lib.ptr(t) if t is not None else None, _lib.ptr(y),
@@ -502,8 +512,16 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False):
     _lib.check(rc, "pointwise_fwd")
     ctx.cfg = (s, act, slope, t_mode, None if t is None else tuple(t.shape))
     ctx.half = half
-    ctx.save_for_backward(x, w, y if act != 0 else None)
+    ctx.has_signs = signs is not None
+    ctx.save_for_backward(x, w, signs if signs is not None else (y if act != 0 else None))
     return y
+
+
+def _pw_split_enabled():
+    """SBMC_HIP_PW_SPLIT=0 (development knob, read by the library as well) keeps the fp32-MFMA forward kernel,
+    which writes no sign bits."""
+    import os
+    return os.environ.get("SBMC_HIP_PW_SPLIT", "1") != "0"
 
 
 def _pointwise_backward(ctx, gy, gmean, mean_s):
@@ -544,6 +562,8 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
                     B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
             if half:
                 rc = L.sbmc_pointwise_bwd_f16(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), int(x.dtype == th.float16), *tail)
+            elif getattr(ctx, "has_signs", False):
+                rc = L.sbmc_pointwise_bwd_signs_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), *tail)    # y: the sign bits
             else:
                 rc = L.sbmc_pointwise_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), *tail)
         _lib.check(rc, "pointwise_bwd")

@@ -45,9 +45,11 @@ def pointwise_kernels():
 
 
 @pytest.mark.parametrize("pattern", [
-    "sbmc::pw_fwd_kernel<128, 0, 2, float, float>",          # the 1x1 layers of the fp32 step
+    "pw_fwd_s_kernel",                                       # the fp32 layers' forward (bf16 matrix pipe, split precision)
+    "sbmc::pw_fwd_kernel<128, 0, 2, float, float>",          # the fp32-MFMA forward (kept behind a knob)
     "sbmc::pw_fwd_kernel<128, 2, 2, float, float>",
-    "sbmc::pw_bwd_kernel<128, true, false, false, float, float>",
+    "sbmc::pw_bwd_kernel<128, true, false, false, float, float, false>",
+    "sbmc::pw_bwd_kernel<128, true, false, false, float, float, true>",     # with sign bits instead of y
     "pw_fwd_h_kernel",                                       # the f16 matrix pipe (every instantiation)
     "pw_bwd_h_kernel",
 ])
