@@ -465,6 +465,13 @@ SBMC_API int sbmc_bias_act_nhwc_fwd_f32(float *y, const float *bias, long pixels
                                void *stream);
 SBMC_API int sbmc_bias_act_nhwc_bwd_f32(const float *gy, const float *y, float *gx, float *partial, long pixels,
                                int c, int act, float slope, void *stream);
+/* bias_act_nhwc with SIGN BITS (act = 1 or 2): the forward also writes one bit per element, pre-activation > 0
+ * -- float4 number i of y (i = pixel * c / 4 + channel quad) owns nibble i % 8 of word i / 8,
+ * ceil(pixels * c / 32) words --, and the backward's activation adjoint reads those instead of y. */
+SBMC_API int sbmc_bias_act_nhwc_fwd_signs_f32(float *y, const float *bias, unsigned *signs, long pixels, int c,
+                                     int act, float slope, void *stream);
+SBMC_API int sbmc_bias_act_nhwc_bwd_signs_f32(const float *gy, const unsigned *signs, float *gx, float *partial,
+                                     long pixels, int c, int act, float slope, void *stream);
 SBMC_API int sbmc_upsample2x_cat_nhwc_supported(int cu, int cl, int h, int w);
 SBMC_API int sbmc_upsample2x_cat_nhwc_fwd_f32(const float *coarse, const float *left, float *out, int b, int cu,
                                      int cl, int h, int w, void *stream);

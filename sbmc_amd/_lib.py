@@ -68,6 +68,8 @@ SYMBOLS = (
     "sbmc_bias_act_nhwc_chunks",
     "sbmc_bias_act_nhwc_fwd_f32",
     "sbmc_bias_act_nhwc_bwd_f32",
+    "sbmc_bias_act_nhwc_fwd_signs_f32",
+    "sbmc_bias_act_nhwc_bwd_signs_f32",
     "sbmc_upsample2x_cat_nhwc_supported",
     "sbmc_upsample2x_cat_nhwc_fwd_f32",
     "sbmc_upsample2x_cat_nhwc_bwd_f32",
@@ -183,6 +185,8 @@ def lib():
     handle.sbmc_bias_act_nhwc_chunks.argtypes = [ctypes.c_long, i]
     handle.sbmc_bias_act_nhwc_fwd_f32.argtypes = [p, p, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_bias_act_nhwc_bwd_f32.argtypes = [p, p, p, p, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_bias_act_nhwc_fwd_signs_f32.argtypes = [p, p, p, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_bias_act_nhwc_bwd_signs_f32.argtypes = [p, p, p, p, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_upsample2x_cat_nhwc_supported.argtypes = [i, i, i, i]
     handle.sbmc_upsample2x_cat_nhwc_fwd_f32.argtypes = [p, p, p, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_nhwc_bwd_f32.argtypes = [p, p, p, i, i, i, i, i, p]

@@ -51,8 +51,38 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_fwd_kernel(float* __restric
     }
 }
 
+// The same forward that also records one SIGN BIT per element (pre-activation > 0): thread i owns float4 number i,
+// its 4 bits are nibble i % 8 of word i / 8 (eight neighbouring lanes combine theirs).  The backward then reads
+// 1 bit instead of 32 per element for the activation adjoint: two streams instead of three.
+__global__ __launch_bounds__(256) void bias_act_nhwc_fwd_signs_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                                     unsigned* __restrict__ signs, size_t total4,
+                                                                     int c4n, float slope) {
+    float4* y4 = reinterpret_cast<float4*>(y);
+    const float4* b4 = reinterpret_cast<const float4*>(bias);
+    const size_t n8 = (total4 + 7) & ~(size_t)7;      // (the 8 lanes of a word run the same iterations)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bool ok = i < total4;
+        unsigned bits = 0;
+        if (ok) {
+            const float4 bv = b4[i % (size_t)c4n];
+            float4 v = y4[i];
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            bits = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            v.x = nact(v.x, slope); v.y = nact(v.y, slope); v.z = nact(v.z, slope); v.w = nact(v.w, slope);
+            y4[i] = v;
+        }
+        unsigned word = bits << (4 * (threadIdx.x & 7));
+        word |= __shfl_xor(word, 1);
+        word |= __shfl_xor(word, 2);
+        word |= __shfl_xor(word, 4);
+        if ((threadIdx.x & 7) == 0) signs[i >> 3] = word;
+    }
+}
+
 // gx = gy * act'(y); partial[chunk, C] = this workgroup's sums of gx per channel.
 // 256 threads = (256 / c4n) pixel lanes x c4n channel quads; c4n must divide 256.
+// SG: `y` holds the forward's sign bits (bias_act_nhwc_fwd_signs_kernel) instead of its output.
+template <bool SG>
 __global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                float* __restrict__ gx, float* __restrict__ partial,
                                                                size_t pixels, int c4n, float slope, int linear) {
@@ -67,9 +97,15 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __r
         const size_t i = px * c4n + cq;
         float4 g = reinterpret_cast<const float4*>(gy)[i];
         if (!linear) {
-            const float4 v = reinterpret_cast<const float4*>(y)[i];
-            g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
-            g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
+            if constexpr (SG) {
+                const unsigned bits = reinterpret_cast<const unsigned*>(y)[i >> 3] >> (4 * (unsigned)(i & 7));
+                g.x = (bits & 1u) ? g.x : g.x * slope; g.y = (bits & 2u) ? g.y : g.y * slope;
+                g.z = (bits & 4u) ? g.z : g.z * slope; g.w = (bits & 8u) ? g.w : g.w * slope;
+            } else {
+                const float4 v = reinterpret_cast<const float4*>(y)[i];
+                g.x = v.x > 0.f ? g.x : g.x * slope; g.y = v.y > 0.f ? g.y : g.y * slope;
+                g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
+            }
         }
         if (store) reinterpret_cast<float4*>(gx)[i] = g;
         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
@@ -254,8 +290,32 @@ extern "C" int sbmc_bias_act_nhwc_bwd_f32(const float* gy, const float* y, float
     if (pixels == 0 || c == 0) return 0;
     if (!gy || !y || !gx || !partial || !sbmc_bias_act_nhwc_supported(c)) return SBMC_HIP_EINVAL;
     if ((uintptr_t)gy % 16 || (uintptr_t)y % 16 || (uintptr_t)gx % 16 || (uintptr_t)partial % 16) return SBMC_HIP_EINVAL;
-    hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel, dim3((unsigned)sbmc_bias_act_nhwc_chunks(pixels, c)), dim3(256), 0,
+    hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel<false>, dim3((unsigned)sbmc_bias_act_nhwc_chunks(pixels, c)), dim3(256), 0,
                        (hipStream_t)stream, gy, y, gx, partial, (size_t)pixels, c / 4, act == 1 ? 0.f : slope, act == 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_bias_act_nhwc_fwd_signs_f32(float* y, const float* bias, unsigned* signs, long pixels, int c, int act,
+                                                float slope, void* stream) {
+    if (pixels < 0 || c < 0 || act < 1 || act > 2) return SBMC_HIP_EINVAL;
+    if (pixels == 0 || c == 0) return 0;
+    if (!y || !bias || !signs || !sbmc_bias_act_nhwc_supported(c) || (uintptr_t)y % 16 || (uintptr_t)bias % 16 ||
+        (uintptr_t)signs % 4) return SBMC_HIP_EINVAL;
+    const size_t total4 = (size_t)pixels * (c / 4);
+    hipLaunchKernelGGL(bias_act_nhwc_fwd_signs_kernel, dim3(grid_for(total4 / 4 + 1)), dim3(256), 0, (hipStream_t)stream,
+                       y, bias, signs, total4, c / 4, act == 1 ? 0.f : slope);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_bias_act_nhwc_bwd_signs_f32(const float* gy, const unsigned* signs, float* gx, float* partial,
+                                                long pixels, int c, int act, float slope, void* stream) {
+    if (pixels < 0 || c < 0 || act < 1 || act > 2) return SBMC_HIP_EINVAL;
+    if (pixels == 0 || c == 0) return 0;
+    if (!gy || !signs || !gx || !partial || !sbmc_bias_act_nhwc_supported(c)) return SBMC_HIP_EINVAL;
+    if ((uintptr_t)gy % 16 || (uintptr_t)signs % 4 || (uintptr_t)gx % 16 || (uintptr_t)partial % 16) return SBMC_HIP_EINVAL;
+    hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel<true>, dim3((unsigned)sbmc_bias_act_nhwc_chunks(pixels, c)), dim3(256), 0,
+                       (hipStream_t)stream, gy, reinterpret_cast<const float*>(signs), gx, partial, (size_t)pixels, c / 4,
+                       act == 1 ? 0.f : slope, 0);
     return (int)hipGetLastError();
 }
 

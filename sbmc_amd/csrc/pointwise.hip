@@ -320,6 +320,9 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     constexpr int KS = KP / 16;                        // MFMA k-steps
     constexpr int NOCT = (KO + WAVES - 1) / WAVES;     // octets a staging thread owns
     constexpr int NPH = 8 / WAVES;                     // 32-pixel blocks a wave owns
+    // large and small terms in accumulators of their own (no MFMA waits for the previous one's result) -- except
+    // where a per-pixel context term needs the 16 registers at 128 channels
+    constexpr bool TWO = !(TMODE == 2 && KP == 128 && WAVES == 8);
     const float* xg = static_cast<const float*>(p.x);
     float* yg = static_cast<float*>(p.y);
     extern __shared__ float4 pw_lds[];
@@ -471,12 +474,21 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
                 const u32x4 bh = xb[(2 * s) * PS_NT + 32 * h];
                 const u32x4 bm = xb[(KO + 2 * s) * PS_NT + 32 * h];
                 const u32x4 bl = xb[(2 * KO + 2 * s) * PS_NT + 32 * h];
-                acc[h] = mfma_bf16(ah[s], bh, acc[h]);
-                small[h] = mfma_bf16(ah[s], bl, small[h]);
-                acc[h] = mfma_bf16(ah[s], bm, acc[h]);
-                small[h] = mfma_bf16(al[s], bh, small[h]);
-                acc[h] = mfma_bf16(am[s], bh, acc[h]);
-                small[h] = mfma_bf16(am[s], bm, small[h]);
+                if constexpr (TWO) {
+                    acc[h] = mfma_bf16(ah[s], bh, acc[h]);
+                    small[h] = mfma_bf16(ah[s], bl, small[h]);
+                    acc[h] = mfma_bf16(ah[s], bm, acc[h]);
+                    small[h] = mfma_bf16(al[s], bh, small[h]);
+                    acc[h] = mfma_bf16(am[s], bh, acc[h]);
+                    small[h] = mfma_bf16(am[s], bm, small[h]);
+                } else {
+                    acc[h] = mfma_bf16(ah[s], bl, acc[h]);
+                    acc[h] = mfma_bf16(al[s], bh, acc[h]);
+                    acc[h] = mfma_bf16(am[s], bm, acc[h]);
+                    acc[h] = mfma_bf16(ah[s], bm, acc[h]);
+                    acc[h] = mfma_bf16(am[s], bh, acc[h]);
+                    acc[h] = mfma_bf16(ah[s], bh, acc[h]);
+                }
             }
             // fillers of this k-step
             if (s == ((TMODE == 2 && WAVES == 8 && KS > 2) ? KS - 2 : 0)) {
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
             unsigned myword = 0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                float v = acc[h][j] + (small[h][j] + add[j]);
+                float v = TWO ? acc[h][j] + (small[h][j] + add[j]) : acc[h][j] + add[j];
                 if (TMODE == 2) v += t0[h][j];
                 const unsigned long long pos = __ballot(v > 0.f);
                 const unsigned word = lhi ? (unsigned)(pos >> 32) : (unsigned)pos;
@@ -1389,11 +1401,9 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
         if (se == hipSuccess)                                                                            \
             hipLaunchKernelGGL(kern, dim3(sgrid), dim3(64 * WV), slds, (hipStream_t)stream, p);          \
     } while (0)
-#define SBMC_PWS_LAUNCH(KPV)                                                                             \
-    do { if (swaves == 4) SBMC_PWS_LAUNCH2(KPV, 4); else SBMC_PWS_LAUNCH2(KPV, 8); } while (0)
-            // 8 waves (two per SIMD) measured 7-10 % faster than 4 (one per SIMD, 512 registers); development knob
-            const char* wknob = getenv("SBMC_HIP_PW_SPLIT_WAVES");
-            const int swaves = (wknob && atoi(wknob) == 4) ? 4 : 8;
+            // (WAVES = 4 -- one wave per SIMD with 512 registers -- measured 7-10 % slower than two waves per SIMD
+            // and is not instantiated)
+#define SBMC_PWS_LAUNCH(KPV) SBMC_PWS_LAUNCH2(KPV, 8)
             switch (skp) {
                 case 32: SBMC_PWS_LAUNCH(32); break;
                 case 64: SBMC_PWS_LAUNCH(64); break;

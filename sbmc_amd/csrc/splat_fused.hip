@@ -403,30 +403,32 @@ __global__ __launch_bounds__(256) void splat_bwd_state_kernel(SplatBwdParams p) 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const size_t n = i / hw, pix = i % hw;
+        // (the two dot products and their difference in double: they cancel wherever the loss does not depend on
+        // the running max, and this kernel is per pixel, not per tap -- see splat_chain_bwd_kernel)
         const float dW = p.d_sum_w_out[i];
         float dR[C];
-        float dot_out = dW * p.sum_w_out[i];
+        double dot_out = (double)dW * (double)p.sum_w_out[i];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             dR[c] = p.d_sum_r_out[(n * C + c) * hw + pix];
-            dot_out = fmaf(dR[c], p.sum_r_out[(n * C + c) * hw + pix], dot_out);
+            dot_out += (double)dR[c] * (double)p.sum_r_out[(n * C + c) * hw + pix];
         }
-        const float dMtot = p.d_max_w_out[i] - dot_out;
+        const double dMtot = (double)p.d_max_w_out[i] - dot_out;
         const float M = p.max_w_out[i];
-        float dkmax = dMtot;
+        float dkmax = (float)dMtot;
         if (!first) {
             const float Mp = p.max_w_in[i], km = p.kmax[i];
             const float sigma = expf(Mp - M);
-            float dot_in = dW * p.sum_w_in[i];
+            double dot_in = (double)dW * (double)p.sum_w_in[i];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                dot_in = fmaf(dR[c], p.sum_r_in[(n * C + c) * hw + pix], dot_in);
+                dot_in += (double)dR[c] * (double)p.sum_r_in[(n * C + c) * hw + pix];
                 p.d_sum_r_in[(n * C + c) * hw + pix] = dR[c] * sigma;
             }
             p.d_sum_w_in[i] = dW * sigma;
-            const float sel_prev = Mp > km ? 1.f : (Mp == km ? 0.5f : 0.f);
-            p.d_max_w_in[i] = sigma * dot_in + dMtot * sel_prev;
-            dkmax = dMtot * (1.f - sel_prev);
+            const double sel_prev = Mp > km ? 1. : (Mp == km ? 0.5 : 0.);
+            p.d_max_w_in[i] = (float)((double)sigma * dot_in + dMtot * sel_prev);
+            dkmax = (float)(dMtot * (1. - sel_prev));
         }
         if constexpr (RECORDS) {
             static_assert(C <= 4, "records hold up to 4 channels");
@@ -860,31 +862,37 @@ __global__ __launch_bounds__(256) void splat_chain_bwd_kernel(SplatChainParams p
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const size_t n = i / hw, pix = i % hw;
-        float dW = p.d_sum_w[i], dM = p.d_max_w[i], dR[4] = {0.f, 0.f, 0.f, 0.f};
+        // The chain is carried in DOUBLE from sample to sample (this kernel is per pixel, not per tap: free):
+        // dM - (dW sum_w + dR . sum_r) is a difference of equal sums wherever the loss does not depend on the
+        // running max (out = sum_r / sum_w: always), so what reaches d_kernels through the arg-max tap is pure
+        // rounding residue; in fp32 it grew with every step of the chain (tools/fuzz_slab.py: up to 4e-5 of the
+        // tensor's scale after 5 samples, 7x the oracle's in unlucky cases).  Now the only roundings are those of
+        // the fp32 inputs and of the records written below.
+        double dW = p.d_sum_w[i], dM = p.d_max_w[i], dR[4] = {0., 0., 0., 0.};
 #pragma unroll
         for (int c = 0; c < C; ++c) dR[c] = p.d_sum_r[(n * C + c) * hw + pix];
         for (int s = p.s - 1; s >= 0; --s) {
             const size_t o = (n * p.s + s) * hw + pix;
             const float M = p.run_m[o];
-            float dot_out = dW * p.run_w[o];
+            double dot_out = dW * (double)p.run_w[o];
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                dot_out = fmaf(dR[c], p.run_r[((n * p.s + s) * C + c) * hw + pix], dot_out);
-            const float dMtot = dM - dot_out;
-            float sel_prev = 0.f, sigma = 0.f, dot_in = 0.f;
+                dot_out += dR[c] * (double)p.run_r[((n * p.s + s) * C + c) * hw + pix];
+            const double dMtot = dM - dot_out;
+            double sel_prev = 0., sigma = 0., dot_in = 0.;
             if (s > 0) {
                 const size_t op = o - hw;
                 const float Mp = p.run_m[op], km = p.part_m[o];
-                sel_prev = Mp > km ? 1.f : (Mp == km ? 0.5f : 0.f);
-                sigma = expf(Mp - M);
-                dot_in = dW * p.run_w[op];
+                sel_prev = Mp > km ? 1. : (Mp == km ? 0.5 : 0.);
+                sigma = exp((double)Mp - (double)M);
+                dot_in = dW * (double)p.run_w[op];
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    dot_in = fmaf(dR[c], p.run_r[((n * p.s + s - 1) * C + c) * hw + pix], dot_in);
+                    dot_in += dR[c] * (double)p.run_r[((n * p.s + s - 1) * C + c) * hw + pix];
             }
             float4 r0, r1;
-            r0.x = M; r0.y = dW; r0.z = dMtot * (1.f - sel_prev); r0.w = __int_as_float(p.atap[o]);
-            r1.x = dR[0]; r1.y = dR[1]; r1.z = dR[2]; r1.w = dR[3];
+            r0.x = M; r0.y = (float)dW; r0.z = (float)(dMtot * (1. - sel_prev)); r0.w = __int_as_float(p.atap[o]);
+            r1.x = (float)dR[0]; r1.y = (float)dR[1]; r1.z = (float)dR[2]; r1.w = (float)dR[3];
             float4* rec = reinterpret_cast<float4*>(p.records) + o * 2;
             rec[0] = r0;
             rec[1] = r1;

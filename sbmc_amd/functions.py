@@ -765,28 +765,41 @@ class BiasActNHWC(th.autograd.Function):
         b, c, h, w = y.shape
         bias = bias.contiguous()
         dev = y.device
+        # with an activation and a backward to come: one sign bit per element for the adjoint (1/32 of the bytes
+        # it would otherwise read back from y -- and y, which later passes overwrite in place, is not kept)
+        signs = None
+        if act != 0 and any(ctx.needs_input_grad[:2]):
+            signs = th.empty((y.numel() + 31) // 32, dtype=th.int32, device=dev)
         with th.cuda.device(dev):
-            rc = _lib.lib().sbmc_bias_act_nhwc_fwd_f32(_lib.ptr(y), _lib.ptr(bias), b * h * w, c, act, slope,
-                                                       _lib.current_stream(dev))
+            if signs is not None:
+                rc = _lib.lib().sbmc_bias_act_nhwc_fwd_signs_f32(_lib.ptr(y), _lib.ptr(bias), _lib.ptr(signs), b * h * w, c,
+                                                                 act, slope, _lib.current_stream(dev))
+            else:
+                rc = _lib.lib().sbmc_bias_act_nhwc_fwd_f32(_lib.ptr(y), _lib.ptr(bias), b * h * w, c, act, slope,
+                                                           _lib.current_stream(dev))
         _lib.check(rc, "bias_act_nhwc_fwd")
         ctx.mark_dirty(y)
         ctx.act, ctx.slope = act, slope
-        if act != 0:
-            ctx.save_for_backward(y)
+        if signs is not None:
+            ctx.save_for_backward(signs)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         gy = gy.contiguous(memory_format=th.channels_last)
-        y = ctx.saved_tensors[0] if ctx.act != 0 else gy
         b, c, h, w = gy.shape
         gx = th.empty_like(gy, memory_format=th.channels_last)
         L = _lib.lib()
         partial = gy.new_empty(L.sbmc_bias_act_nhwc_chunks(b * h * w, c), c)
         dev = gy.device
         with th.cuda.device(dev):
-            rc = L.sbmc_bias_act_nhwc_bwd_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(gx), _lib.ptr(partial),
-                                              b * h * w, c, ctx.act, ctx.slope, _lib.current_stream(dev))
+            if ctx.act != 0:
+                rc = L.sbmc_bias_act_nhwc_bwd_signs_f32(_lib.ptr(gy), _lib.ptr(ctx.saved_tensors[0]), _lib.ptr(gx),
+                                                        _lib.ptr(partial), b * h * w, c, ctx.act, ctx.slope,
+                                                        _lib.current_stream(dev))
+            else:
+                rc = L.sbmc_bias_act_nhwc_bwd_f32(_lib.ptr(gy), _lib.ptr(gy), _lib.ptr(gx), _lib.ptr(partial),
+                                                  b * h * w, c, ctx.act, ctx.slope, _lib.current_stream(dev))
         _lib.check(rc, "bias_act_nhwc_bwd")
         return gx, partial.sum(0), None, None
 

@@ -5,7 +5,8 @@ import os
 import pytest
 import torch as th
 
-from helpers import close, golden, multisteps_from_golden, run_progressive, t
+from helpers import (close, golden, module_scales, multisteps_fp64, multisteps_from_golden, no_worse_than,
+                     run_progressive, t)
 
 pytestmark = pytest.mark.gpu
 
@@ -126,8 +127,17 @@ def test_multisteps_on_gpu_matches_reference_fixture():
     loss = losses.TonemappedRelativeMSE()(res, crop_like(target, res))
     close(loss, g["train.loss"], rtol=2e-5, what="loss")
     loss.backward()
+    # parameter gradients: sums over every pixel and sample whose fp32 value depends on the order of addition
+    # (MIOpen's weight-gradient kernels, the 1x1 kernels' per-workgroup partial sums): within 1e-5 of a float64
+    # evaluation of the model, or no further from it than twice the reference fixture is (scales per module)
+    nf, ngf, width, ew, ks, nsteps = [int(v) for v in g["meta"]]
+    m64 = multisteps_fp64(model, (nf, ngf), dict(width=width, embedding_width=ew, ksize=ks, nsteps=nsteps)).train(True)
+    o64 = m64({k: v.cpu().double() for k, v in batch.items()})["radiance"]
+    losses.TonemappedRelativeMSE()(o64, crop_like(target.cpu().double(), o64)).backward()
+    g64 = {k: q.grad for k, q in m64.named_parameters()}
+    scales = module_scales(g64)
     for k, p in model.named_parameters():
-        close(p.grad, g["grad." + k], rtol=1e-4, what="grad " + k)
+        no_worse_than(p.grad, t(g["grad." + k]), g64[k], what="grad " + k, scale=scales[k])
 
 
 def test_native_library_is_loaded():

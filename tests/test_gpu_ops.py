@@ -237,6 +237,7 @@ def test_multisteps_batched_samples_equals_sequential():
     from sbmc_amd import Multisteps
     th.manual_seed(10)
     kw = dict(width=8, embedding_width=8, ksize=21, nsteps=1)
+    from helpers import module_scales, multisteps_fp64
     a = Multisteps(6, 3, batch_samples=True, **kw).cuda()
     b = Multisteps(6, 3, batch_samples=False, **kw).cuda()
     b.load_state_dict(a.state_dict())
@@ -250,8 +251,16 @@ def test_multisteps_batched_samples_equals_sequential():
     go = th.randn(oa.shape, generator=g).cuda()
     oa.backward(go)
     ob.backward(go)
+    # parameter gradients: both within 1e-5 of a float64 evaluation of the model or no further from it than
+    # twice the other path (helpers.no_worse_than, scales per module)
+    m64 = multisteps_fp64(a, (6, 3), kw)
+    o64 = m64({k: v.cpu().double() for k, v in batch.items()})["radiance"]
+    o64.backward(go.cpu().double())
+    g64 = {k: q.grad for k, q in m64.named_parameters()}
+    scales = module_scales(g64)
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        close(pa.grad, pb.grad, rtol=5e-5, what=n)
+        no_worse_than(pa.grad, pb.grad, g64[n], what=n + " (batched)", scale=scales[n])
+        no_worse_than(pb.grad, pa.grad, g64[n], what=n + " (sequential)", scale=scales[n])
 
 
 def test_32spp_fused_vs_scatter2gather_dual_path():

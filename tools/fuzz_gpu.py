@@ -14,7 +14,7 @@ import torch as th
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from helpers import close, run_progressive  # noqa: E402
+from helpers import close, close_or_yardstick, progressive_fp64, run_progressive  # noqa: E402
 from oracle import sbmc_oracle as orc  # noqa: E402
 from sbmc_amd import functions as F, modules  # noqa: E402
 
@@ -22,8 +22,19 @@ from sbmc_amd import functions as F, modules  # noqa: E402
 # d_kernels gets, at each destination's arg-max tap, the routed gradient of the running max
 # dM - (dR.sum_r + dW*sum_w): a difference of 441-term fp32 sums, so that one element inherits
 # their rounding (1.5e-5 of max|d_kernels| was observed on a 1x4 frame with k=21, where nearly
-# every tap is the zero-filled border).  Everything else is held to 1e-5.
-DK_RTOL = 5e-5
+# every tap is the zero-filled border).  Everything is held to 1e-5 of the oracle; where a d_kernels
+# tensor misses that, it must be no further from the float64 evaluation of the chain than twice the
+# oracle's own fp32 result is (helpers.close_or_yardstick).
+DK_RTOL = 1e-5
+YARDSTICK = [0]
+
+
+def dk_close(got, ref32, s, datas, kerns, grads, splat):
+    def truth():
+        _, _, dk64 = progressive_fp64(datas, kerns, grads, splat=splat)
+        return dk64[s]
+    if close_or_yardstick(got, ref32, truth, rtol=DK_RTOL, slack=2.0, what="d_kernels[%d]" % s) is not None:
+        YARDSTICK[0] += 1
 
 
 def main():
@@ -55,7 +66,7 @@ def main():
             for a, b in zip(out, ref_out):
                 close(a, b)
             for s in range(spp):
-                close(dd[s], ref_dd[s]); close(dk[s], ref_dk[s], rtol=DK_RTOL)
+                close(dd[s], ref_dd[s]); dk_close(dk[s], ref_dk[s], s, datas, kerns, grads, True)
             # gather-kernel (splat=False) update, fused where the strip kernels apply
             g_ref, g_dd, g_dk = run_progressive(
                 lambda d, kk, a, b, m: orc.progressive_kernel_apply(d, kk, a, b, m, splat=False),
@@ -64,7 +75,7 @@ def main():
             for a, b in zip(g_out, g_ref):
                 close(a, b)
             for s in range(spp):
-                close(gdd[s], g_dd[s]); close(gdk[s], g_dk[s], rtol=DK_RTOL)
+                close(gdd[s], g_dd[s]); dk_close(gdk[s], g_dk[s], s, datas, kerns, grads, False)
             dg = th.stack(datas, 1).cuda().requires_grad_()
             kg = th.stack(kerns, 1).cuda().requires_grad_()
             if F.splat_all_supported(dg, kg):
@@ -73,7 +84,7 @@ def main():
                 for a, b in zip(res, ref_out):
                     close(a, b)
                 for s in range(spp):
-                    close(dg.grad[:, s], ref_dd[s]); close(kg.grad[:, s], ref_dk[s], rtol=DK_RTOL)
+                    close(dg.grad[:, s], ref_dd[s]); dk_close(kg.grad[:, s], ref_dk[s], s, datas, kerns, grads, True)
                 tag += " all"
             # boundary ops on the first sample
             x5 = kerns[0].view(bs, k, k, h, w)
@@ -92,7 +103,8 @@ def main():
             raise
         stats[tag] = stats.get(tag, 0) + 1
         n += 1
-    print("fuzz ok: %d random cases in %.0f s" % (n, time.time() - t0))
+    print("fuzz ok: %d random cases in %.0f s (everything within 1e-5 of the oracle, except %d d_kernels tensors held to "
+          "the float64 yardstick instead: no worse than 2x the oracle's own error)" % (n, time.time() - t0, YARDSTICK[0]))
     print(" ".join("%s:%d" % kv for kv in sorted(stats.items())))
 
 

@@ -23,7 +23,7 @@ from oracle import sbmc_oracle as orc  # noqa: E402
 from sbmc_amd import functions as F  # noqa: E402
 
 
-DK_RTOL = 5e-5
+DK_RTOL = 1e-5
 
 
 def main():
@@ -33,7 +33,10 @@ def main():
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
     t0, n, vs_oracle, halves = time.time(), 0, 0, 0
-    worst = [0.0, 0.0]     # largest d_kernels error vs float64 in units of the oracle's own: whole-frame GPU, sharded GPU
+    # largest d_kernels error vs float64 in units of the bound max(1e-5 of scale, 2 x the oracle's own fp32 error,
+    # 1e-5 of the cancelling terms -- see below): whole-frame GPU, sharded GPU; and how many cases needed more than 1e-5
+    worst = [0.0, 0.0]
+    beyond = 0
     while time.time() - t0 < args.seconds:
         k = int(rng.choice([3, 5, 7, 9, 13, 21, 21, 21]))
         p = (k - 1) // 2
@@ -68,7 +71,7 @@ def main():
             # gradient of the running max is a cancellation residual in fp32 whose value depends on the order of the
             # merges (up to 2.5e-4 between two correct fp32 codes) -- the small cases below hold
             # it to the float64 evaluation instead; half logit gradients: one half rounding each
-            rt = 2e-3 if half else 2e-4
+            rt = 2e-3 if half else 2e-4       # (GPU vs GPU, any size; the small cases go to the float64 evaluation)
             close(o2, o1, what="normalised output")
             close(r2.grad, r1.grad, what="d_radiance")
             close(k2.grad.float(), k1.grad.float(), rtol=rt, what="d_kernels")
@@ -88,23 +91,52 @@ def main():
                 for s in range(S):
                     st = orc.progressive_kernel_apply(r64[:, s], k64[:, s], *st, splat=True)
                 (st[0] / (st[1] + 1e-8)).backward(d_out.double())
-                # (DK_RTOL, as tools/fuzz_gpu.py: with this objective the routed element is analytically zero --
-                # d(out)/d(max) = 0 -- so its fp32 value is pure rounding noise of 441-term sums in every
-                # implementation.  The summary line reports the largest error seen for the whole-frame and the
-                # sharded GPU path in units of the oracle's own: the two turn out equal, sharding adds none.)
-                no_worse_than(k2.grad, ko.grad, k64.grad, rtol=DK_RTOL, slack=4.0, what="d_kernels vs float64")
-                eo = (ko.grad.double() - k64.grad).abs().max().item() + 1e-30
-                worst[0] = max(worst[0], (k1.grad.detach().cpu().double() - k64.grad).abs().max().item() / eo)
-                worst[1] = max(worst[1], (k2.grad.detach().cpu().double() - k64.grad).abs().max().item() / eo)
+                # d_kernels[s, tap, source] = e (dW[q] + sum_c dR[q, c] D[c]) at its destination q (+ the routed
+                # gradient of the running max, analytically zero with this objective).  With out = sum_r / sum_w,
+                # dR = g / sum_w and dW = -g . out / sum_w: the bracket is g . (D - out) / sum_w, the difference of two
+                # terms of size |g| |D| / sum_w that nearly cancel wherever one tap dominates the softmax (out ~ D).
+                # An fp32 evaluation is off by rounding relative to the TERMS, not to their difference: what the
+                # forward's sum_r / sum_w carry (each within 1e-5, typically 1e-6) is multiplied by |dW| + |dR| |D|.
+                # (The failing case of an earlier version of this tool: a 2-pixel-wide frame, D = 8, g = 2.5: value
+                # 0.517, oracle off by 1.1e-5, GPU by 5.3e-5 = 2.6e-6 of the two terms.)  So: 1e-5 of the tensor's
+                # scale, or twice the oracle's own error, or 1e-5 of the largest |dW| + |dR| . |D| of the frame.
+                sr64, sw64 = st[0].detach(), st[1].detach()
+                g64 = d_out.double()
+                d_r = g64.abs() / (sw64 + 1e-8)
+                d_w = ((g64 * sr64).sum(1, keepdim=True) / (sw64 + 1e-8) ** 2).abs()
+                terms = (d_w + d_r.sum(1, keepdim=True) * rad.double().abs().max()).max().item()
+                floor = DK_RTOL * terms
+                scale = k64.grad.abs().max().item()
+                eo = (ko.grad.double() - k64.grad).abs().max().item()
+                bound = max(DK_RTOL * scale, 2.0 * eo, floor)
+                e1 = (k1.grad.detach().cpu().double() - k64.grad).abs().max().item()
+                e2 = (k2.grad.detach().cpu().double() - k64.grad).abs().max().item()
+                if not (e1 <= bound and e2 <= bound):
+                    d = (k1.grad.detach().cpu().double() - k64.grad).abs()
+                    at = [int(v) for v in th.unravel_index(d.argmax(), d.shape)]
+                    _, sidx, tap, yy, xx = at
+                    dy, dx = tap // k, tap % k
+                    Y, X = yy + dy - p, xx + dx - p                      # the destination this splat tap lands on
+                    print("worst element: sample %d tap (%d, %d) source (%d, %d) -> destination (%d, %d); gpu %.9g oracle "
+                          "%.9g float64 %.9g" % (sidx, dy, dx, yy, xx, Y, X, k1.grad[tuple(at)].item(),
+                                                 ko.grad[tuple(at)].item(), k64.grad[tuple(at)].item()), flush=True)
+                    srt = d.flatten().sort(descending=True)[0][:8]
+                    print("largest errors:", ["%.2e" % v for v in srt.tolist()], "median", "%.2e" % d.median().item(), flush=True)
+                assert e1 <= bound and e2 <= bound, "d_kernels vs float64: whole-frame %.3e, sharded %.3e > max(1e-5 * scale " \
+                    "= %.3e, 2 x oracle %.3e, 1e-5 of the cancelling terms %.3e)" % (e1, e2, DK_RTOL * scale, 2.0 * eo, floor)
+                worst[0] = max(worst[0], e1 / bound)
+                worst[1] = max(worst[1], e2 / bound)
+                beyond += int(max(e1, e2) > DK_RTOL * scale)
                 vs_oracle += 1
             halves += int(half)
         except Exception:
             print("FAILED case:", tag, flush=True)
             raise
         n += 1
-    print("fuzz ok: %d random sharded frames (%d also against the CPU oracle, %d with half logits) in %.0f s; largest "
-          "d_kernels error vs float64 in units of the oracle's own fp32 error: whole-frame GPU %.2f, sharded GPU %.2f" % (
-              n, vs_oracle, halves, time.time() - t0, worst[0], worst[1]))
+    print("fuzz ok: %d random sharded frames (%d also against the CPU oracle and float64, %d with half logits) in %.0f s; "
+          "d_kernels vs float64: %d of those cases beyond 1e-5 of the tensor's scale, all within max(2 x the oracle's own "
+          "fp32 error, 1e-5 of the terms that cancel in g . (D - out) / sum_w); largest error in units of the bound: "
+          "whole-frame GPU %.2f, sharded GPU %.2f" % (n, vs_oracle, halves, time.time() - t0, beyond, worst[0], worst[1]))
 
 
 if __name__ == "__main__":
