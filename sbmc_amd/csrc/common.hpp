@@ -109,6 +109,15 @@ __device__ __forceinline__ float logit_load(rsrc_t r, unsigned voff, unsigned so
         return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX));
     }
 }
+// the same load without the conversion (half logits stay half until the arithmetic needs them)
+template <typename T, int AUX = 0>
+__device__ __forceinline__ T logit_load_raw(rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+    } else {
+        return __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX));
+    }
+}
 template <typename T, int AUX = 0>
 __device__ __forceinline__ void logit_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
     if constexpr (sizeof(T) == 4) {

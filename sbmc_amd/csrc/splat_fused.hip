@@ -186,18 +186,25 @@ __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_tile_kernel(SplatFwdPar
 // ------------------------------------------------------------------ strip forward
 // One kernel row (K taps) of the online softmax for one destination pixel.
 //   v[dx] : the K gather logits of this row;  srow : LDS, staged radiance positions
-template <int K, int C>
-__device__ __forceinline__ void fwd_row_update(const float (&v)[K], const float* srow, int dy,
+//   VT: float, or _Float16 for half logits.  The half kernel is VALU-bound (98 % busy, profiles/r02_half_splat_pmc.txt),
+//   so its logits stay half through the row maximum (exact in half: v_max_f16, no conversion) and enter fp32
+//   only inside the exponent's multiply-add (v_fma_mix_f32 converts its half operand on the fly).
+template <int K, int C, typename VT>
+__device__ __forceinline__ void fwd_row_update(const VT (&v)[K], const float* srow, int dy,
                                                float& m, float& kmax, int& atap,
                                                float (&acc)[C], float& accw) {
-    float rmax = v[0];
+    VT rmaxv = v[0];
 #pragma unroll
-    for (int dx = 1; dx < K; ++dx) rmax = fmaxf(rmax, v[dx]);
+    for (int dx = 1; dx < K; ++dx) {
+        if constexpr (sizeof(VT) == 2) rmaxv = __builtin_fmaxf16(rmaxv, v[dx]);
+        else rmaxv = fmaxf(rmaxv, v[dx]);
+    }
+    const float rmax = (float)rmaxv;
     if (rmax > kmax) {  // strict: the first row attaining the max wins
         kmax = rmax;
         int idx = K - 1;
 #pragma unroll
-        for (int dx = K - 2; dx >= 0; --dx) idx = (v[dx] == rmax) ? dx : idx;  // first tap in the row
+        for (int dx = K - 2; dx >= 0; --dx) idx = (v[dx] == rmaxv) ? dx : idx;  // first tap in the row
         atap = dy * K + idx;
     }
     const float mn = fmaxf(m, rmax);
@@ -206,6 +213,7 @@ __device__ __forceinline__ void fwd_row_update(const float (&v)[K], const float*
     accw *= sc;
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] *= sc;
+    const float nmn = -mn * LOG2E;
     // taps in groups of G: the scheduling barrier keeps the compiler from hoisting all
     // K*C LDS reads of the row to the top (which costs >100 VGPRs and the occupancy)
     constexpr int G = FWD_TAP_GROUP;
@@ -213,7 +221,9 @@ __device__ __forceinline__ void fwd_row_update(const float (&v)[K], const float*
     for (int g = 0; g < K; g += G) {
 #pragma unroll
         for (int dx = g; dx < (g + G < K ? g + G : K); ++dx) {
-            const float e = fast_exp2((v[dx] - mn) * LOG2E);
+            float e;
+            if constexpr (sizeof(VT) == 2) e = fast_exp2(fmaf((float)v[dx], LOG2E, nmn));
+            else e = fast_exp2((v[dx] - mn) * LOG2E);
             accw += e;
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c] = fmaf(e, srow[c * V2_ROW + dx], acc[c]);
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     // border strips: lane's source column X+dx-P is inside the image for dx in [dx_lo, dx_hi)
     const int dx_lo = P - X, dx_hi = p.w + P - X;
 
-    auto load_row = [&](int dy, float (&v)[K], float (&s)[2 * C]) {
+    auto load_row = [&](int dy, LT (&v)[K], float (&s)[2 * C]) {
         const int ys = Y - p.top + dy - P;
         const bool yin = (ys >= 0) && (ys < p.h);  // wave-uniform
         if constexpr (GATHER) {
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
             const unsigned vo = xact ? voff : BUF_OOB;
 #pragma unroll
             for (int dx = 0; dx < K; ++dx)
-                v[dx] = logit_load<LT, AUX_FWD_LD>(rs, vo, (unsigned)dx * (unsigned)(hw * sizeof(LT)));
+                v[dx] = logit_load_raw<LT, AUX_FWD_LD>(rs, vo, (unsigned)dx * (unsigned)(hw * sizeof(LT)));
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const float* dr = data + c * hw + (size_t)(yin ? ys : 0) * p.w;
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
         }
         if (!yin) {   // beyond an IMAGE edge (rows beyond an inner slab edge are never visited, see below)
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) v[dx] = 0.f;
+            for (int dx = 0; dx < K; ++dx) v[dx] = (LT)0.f;
 #pragma unroll
             for (int j = 0; j < 2 * C; ++j) s[j] = 0.f;
             return;
@@ -300,12 +310,12 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
         const rsrc_t rs = make_rsrc(S + ((long)((2 * P - dy) * K) * (long)hw + (long)ys * p.w + (long)(X0 + P)));
         if (interior_x) {
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) v[dx] = logit_load<LT, AUX_FWD_LD>(rs, voff, (unsigned)(K - 1 - dx) * tap_stride);
+            for (int dx = 0; dx < K; ++dx) v[dx] = logit_load_raw<LT, AUX_FWD_LD>(rs, voff, (unsigned)(K - 1 - dx) * tap_stride);
         } else {
 #pragma unroll
             for (int dx = 0; dx < K; ++dx) {
                 const unsigned vo = (dx >= dx_lo && dx < dx_hi) ? voff : BUF_OOB;  // OOB lanes read 0
-                v[dx] = logit_load<LT, AUX_FWD_LD>(rs, vo, (unsigned)(K - 1 - dx) * tap_stride);
+                v[dx] = logit_load_raw<LT, AUX_FWD_LD>(rs, vo, (unsigned)(K - 1 - dx) * tap_stride);
             }
         }
 #pragma unroll
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
             s[2 * c + 1] = inB ? dr[colB] : 0.f;
         }
     };
-    auto step = [&](int dy, const float (&v)[K], const float (&s)[2 * C]) {
+    auto step = [&](int dy, const LT (&v)[K], const float (&s)[2 * C]) {
         wave_lds_sync();  // previous row's reads are done before its slots are overwritten
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -323,12 +333,13 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
             if (lane < K - 1) buf[c * V2_ROW + TX + lane] = s[2 * c + 1];
         }
         wave_lds_sync();
-        fwd_row_update<K, C>(v, buf + lane, dy, m, kmax, atap, acc, accw);
+        fwd_row_update<K, C, LT>(v, buf + lane, dy, m, kmax, atap, acc, accw);
     };
 
     // (A register double-buffer that prefetches row dy+1 while row dy is reduced was tried:
     // it costs ~40 VGPRs, i.e. 2-3 waves/SIMD of occupancy, and measured slower.)
-    float v[K], s[2 * C];
+    LT v[K];
+    float s[2 * C];
     // kernel rows whose source row lies beyond an INNER slab edge belong to the neighbouring slab and are
     // not visited at all (scalar loop bounds; whole frame: 0 .. K)
     const int dy_lo = p.zero_top ? 0 : max(0, P + p.top - Y);
@@ -706,8 +717,10 @@ __global__ __launch_bounds__(V2_WAVES * TX, 7) void gather_bwd_dg_kernel(SplatBw
     }
 }
 
+// (7 / 3 waves per SIMD instead of 8: at 64 registers this kernel spilled 2-4 VGPRs with up to 3 channels and 87
+// with 4 -- tools/kernel_resources.py; a read-only sweep, nowhere near needing the last wave of occupancy)
 template <int K, int C, typename LT>
-__global__ __launch_bounds__(V2_WAVES * TX, 8) void gather_bwd_ddata_kernel(SplatBwdParams p) {
+__global__ __launch_bounds__(V2_WAVES * TX, C > 3 ? 3 : 7) void gather_bwd_ddata_kernel(SplatBwdParams p) {
     static_assert(TX + K - 1 <= V2_ROW, "staged row too short");
     static_assert(C <= 4, "records hold up to 4 channels");
     constexpr int P = (K - 1) / 2;

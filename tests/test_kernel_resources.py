@@ -38,6 +38,15 @@ def test_strip_kernels_do_not_spill(splat_kernels, name, min_occupancy):
     assert r["occupancy"] >= min_occupancy, r
 
 
+def test_gather_kernels_do_not_spill(splat_kernels):
+    """The gather-kernel variant (ProgressiveKernelApply(splat=False)): round 2's gather_bwd_ddata_kernel<21, 4>
+    spilled 87 VGPRs at its 64-register budget."""
+    rows = [r for n, r in splat_kernels.items() if "gather_bwd" in n]
+    assert len(rows) >= 8
+    for r in rows:
+        assert r["scratch"] == 0 and r["spill"] == 0, r
+
+
 @pytest.fixture(scope="module")
 def pointwise_kernels():
     import kernel_resources

@@ -1,15 +1,36 @@
 #!/bin/bash
-# final round-2 measurements: bench lines, profiles, rank costs, the whole GPU suite, smoke
+# A round's measurements on one MI355X box:  gpurun -- bash tools/measure_round.sh r03
+# bench lines, rocprofv3 kernel statistics and PMC passes, per-rank cost of the sharded step in every transport,
+# the 8-rank partition as communicating processes on this one GPU, fuzz sweeps.  Everything lands in
+# gpurun_out/<tag>/ ; copy what is to be kept into profiles/.
+tag=${1:-r03}
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/p
-( time timeout 1500 python bench.py > gpurun_out/p/r02_bench.json 2> gpurun_out/p/r02_bench.err ); echo "bench rc=$?"
-head -c 420 gpurun_out/p/r02_bench.json; echo
-for spp in 4 8 32; do timeout 900 python bench.py --workload infer --spp $spp > gpurun_out/p/infer$spp.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/p/infer$spp.json'));print('infer',$spp, d['value'], d['ms_per_step'])"; done
-timeout 900 python bench.py --workload infer --spp 32 --fp16-activations > gpurun_out/p/infer32_fp16.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/p/infer32_fp16.json'));print('infer 32 fp16', d['value'], d['ms_per_step'])"
-timeout 900 python bench.py --fp16-activations --no-cpu-baseline --no-stages > gpurun_out/p/train_fp16.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/p/train_fp16.json'));print('train fp16', d['value'], d['ms_per_step'])"
-timeout 900 python scripts/bench_ops.py > gpurun_out/p/r02_bench_ops.jsonl 2>/dev/null
-bash tools/prof.sh r02 > gpurun_out/p/prof.log 2>&1; echo "prof rc=$?"
-timeout 900 python tools/rank_cost.py 1 2 4 8 > gpurun_out/p/rank_cost.txt 2>&1; grep world gpurun_out/p/rank_cost.txt
-timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/p/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 gpurun_out/p/gpu_tests.log
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-SBMC_BENCH_BACKEND=gloo SBMC_BENCH_SINGLE_DEVICE=1 timeout 900 python bench.py --gpus 2 --steps 4 --warmup 3 --no-cpu-baseline > gpurun_out/p/bench_2rank_gloo.json 2> gpurun_out/p/bench_2rank_gloo.err; echo "2-rank rc=$?"; head -c 300 gpurun_out/p/bench_2rank_gloo.json; echo
+o=gpurun_out/$tag
+mkdir -p $o
+( time timeout 1500 python bench.py > $o/${tag}_bench.json 2> $o/bench.err ); echo "bench rc=$?"
+head -c 300 $o/${tag}_bench.json; echo
+timeout 900 python bench.py --workload infer --spp 32 --fp16-activations > $o/infer32_fp16.json 2>/dev/null
+timeout 900 python bench.py --fp16-activations --no-cpu-baseline --no-stages > $o/train_fp16.json 2>/dev/null
+cat $o/infer32_fp16.json $o/train_fp16.json | grep '^{' > $o/${tag}_bench_fp16_activations.jsonl
+python - <<PY
+import json
+for l in open("$o/${tag}_bench_fp16_activations.jsonl"):
+    d = json.loads(l); print("fp16 activations:", d["config"]["workload"][:40], d["value"], d["ms_per_step"])
+PY
+timeout 900 python scripts/bench_ops.py > $o/${tag}_bench_ops.jsonl 2>/dev/null
+# per-rank cost of the sharded 720p step: exchanges stubbed, over RCCL to self, through the IPC mailboxes to self
+( for mode in "" "--rccl-self" "--ipc-self"; do timeout 400 python tools/rank_cost.py $mode 8 2>&1 | grep "^world"; done
+  SBMC_PER_CONV_HALO_BELOW=0 timeout 400 python tools/rank_cost.py --ipc-self 8 2>&1 | grep "^world" | sed "s/$/ [halo per chain instead of per convolution]/"
+  timeout 600 python tools/rank_cost.py --ipc-self --4k 8 2>&1 | grep "^world" | sed "s/$/ [3840x2160]/"
+  timeout 600 python tools/rank_cost.py 1 2 4 2>&1 | grep "^world" ) | tee $o/${tag}_rank_cost.txt
+# the real 8-rank partition as 8 communicating processes on this one GPU (gloo collectives, IPC mailboxes)
+SBMC_BENCH_BACKEND=gloo SBMC_BENCH_SINGLE_DEVICE=1 OMP_NUM_THREADS=8 timeout 1200 python bench.py --gpus 8 --steps 3 --warmup 2 --no-cpu-baseline --no-stages > $o/${tag}_bench_8ranks_one_gpu.json 2> $o/bench8.err; echo "8 ranks on one GPU rc=$?"
+head -c 400 $o/${tag}_bench_8ranks_one_gpu.json; echo
+bash tools/prof.sh $tag > $o/prof.log 2>&1; echo "prof rc=$?"
+cp gpurun_out/profiles_$tag/* $o/ 2>/dev/null
+bash tools/prof_pointwise.sh > $o/prof_pw.log 2>&1; cp gpurun_out/profiles_pw/r02_pointwise_pmc.txt $o/${tag}_pointwise_pmc.txt; tail -5 $o/${tag}_pointwise_pmc.txt
+bash tools/prof_half_splat.sh > $o/prof_half.log 2>&1; cp gpurun_out/half_splat/summary.txt $o/${tag}_half_splat_pmc.txt; tail -5 $o/${tag}_half_splat_pmc.txt
+bash tools/prof_conv_stack.sh > $o/prof_conv.log 2>&1; cp gpurun_out/conv_stack/r02_conv_stack_mfma.txt $o/${tag}_conv_stack_mfma.txt; tail -3 $o/${tag}_conv_stack_mfma.txt
+bash tools/prof_rank.sh 8 --ipc-self > $o/prof_rank.log 2>&1; cp gpurun_out/q/rank8_stats.csv $o/${tag}_rank8_kernel_stats.csv
+( timeout 300 python tools/fuzz_gpu.py --seconds 120 2>&1 | tail -2; timeout 300 python tools/fuzz_slab.py --seconds 120 2>&1 | tail -1; timeout 200 python tools/fuzz_pointwise.py --seconds 60 2>&1 | tail -1 ) > $o/${tag}_fuzz.txt; cat $o/${tag}_fuzz.txt | cut -c1-300
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
