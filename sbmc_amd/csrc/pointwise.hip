@@ -791,8 +791,29 @@ struct PwBwdParams {
 
 // SG: p.y holds the forward's SIGN BITS ([B, Cout, ceil(hw / 32)] words, written by pw_fwd_s_kernel) instead of
 // its output: the activation adjoint then reads 1 bit per element instead of 32 (-12 staging registers too).
-template <int KP, bool DX, bool TPIX, bool GM, typename TA = float, typename TXT = float, bool SG = false>
+// GWS (fp32 tensors only): the weight-gradient product gw += gz x^T runs on the bf16 matrix pipe at fp32 accuracy
+// (three-way split of both operands, six products, see pw_fwd_s_kernel) -- 1536 instead of 4096 matrix-pipe
+// cycles per wave and tile.  Its reduction runs over PIXELS, so both operands want 8 consecutive pixels of a
+// row per lane: the natural planar order (LDS images [plane][row][64 pixels] of bf16, row pitch 144 bytes: a
+// 16-lane group of a ds_read_b128 covers the 64 banks exactly once).  gx = w^T gz reduces over OUTPUT CHANNELS
+// and stays on the fp32 MFMA with the fp32 gz tile (a channel-contiguous bf16 image of gz would be a second,
+// transposed copy).  One LDS stage (fp32 gz 34 KB + two bf16 images 55 KB each), two barriers per tile.
+constexpr int PBS_PITCH = 72;       // halves per row of the bf16 images (64 pixels + 8)
+
+__device__ __forceinline__ void split3_4(float4 v, u32x2& h, u32x2& m, u32x2& l) {
+    const unsigned h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
+    const float r0 = v.x - bf16_lo(h0), r1 = v.y - bf16_hi(h0), r2 = v.z - bf16_lo(h1), r3 = v.w - bf16_hi(h1);
+    const unsigned m0 = pack_bf16(r0, r1), m1 = pack_bf16(r2, r3);
+    h[0] = h0; h[1] = h1;
+    m[0] = m0; m[1] = m1;
+    l[0] = pack_bf16(r0 - bf16_lo(m0), r1 - bf16_hi(m0));
+    l[1] = pack_bf16(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
+}
+
+template <int KP, bool DX, bool TPIX, bool GM, typename TA = float, typename TXT = float, bool SG = false,
+          bool GWS = false>
 __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
+    static_assert(!GWS || (sizeof(TA) == 4 && sizeof(TXT) == 4), "split gw: fp32 tensors");
     const TA* gy_g = static_cast<const TA*>(p.gy);
     const TA* y_g = static_cast<const TA*>(p.y);
     const unsigned* sg_g = static_cast<const unsigned*>(p.y);
@@ -807,6 +828,9 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     extern __shared__ float4 pw_lds[];
     float* lds = reinterpret_cast<float*>(pw_lds);
     constexpr int BUF = (128 + KP) * PB_PITCH;          // floats per pipeline stage: gz tile, then x tile
+    // GWS: one stage -- fp32 gz tile, then the bf16 images of gz and x ([3][128][PBS_PITCH], [3][KP][PBS_PITCH] halves)
+    _Float16* gzn = reinterpret_cast<_Float16*>(lds + 128 * PB_PITCH);
+    _Float16* xn = gzn + 3 * 128 * PBS_PITCH;
     constexpr int NB = KP / 32;                         // 32-column blocks of gw
     constexpr int NX = KP / 32;                         // staging passes of the x tile
     const int lane = threadIdx.x & 63, wave = wave_id();
@@ -876,6 +900,22 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             }
             if (GM) pm[i] = load4<TA>(rm, off);
         }
+        if constexpr (!GWS) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const unsigned r = srow + 32u * i;
+                const unsigned off = (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * SX : PW_OOB;
+                px[i] = load4<TXT>(rx, off);
+            }
+        }
+    };
+    // GWS: the x tile is wanted by the weight-gradient product only -- its loads are issued after the gx
+    // product (16 registers less in flight through it), with the gw product's time to land
+    auto issue_x = [&](Cursor c) {
+        unsigned b, bq, p0;
+        coords(c, b, bq, p0);
+        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * SX);
+        const bool colok = p0 + c4 < hw;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const unsigned r = srow + 32u * i;
@@ -908,7 +948,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     auto commit = [&](Cursor c, int buf) {
         unsigned b, bq, p0;
         coords(c, b, bq, p0);
-        float* gzs = lds + buf * BUF;
+        float* gzs = lds + (GWS ? 0 : buf) * BUF;
         float* xst = gzs + 128 * PB_PITCH;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -939,13 +979,30 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             float2* d = reinterpret_cast<float2*>(gzs + (srow + 32 * i) * PB_PITCH + c4);
             d[0] = make_float2(gv.x, gv.y);
             d[1] = make_float2(gv.z, gv.w);
+            if constexpr (GWS) {
+                u32x2 h, m, l;
+                split3_4(gv, h, m, l);
+                _Float16* e = gzn + (srow + 32 * i) * PBS_PITCH + c4;
+                *reinterpret_cast<u32x2*>(e) = h;
+                *reinterpret_cast<u32x2*>(e + 128 * PBS_PITCH) = m;
+                *reinterpret_cast<u32x2*>(e + 2 * 128 * PBS_PITCH) = l;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const float4 xv = unpack4<TXT>(px[i]);
-            float2* d = reinterpret_cast<float2*>(xst + (srow + 32 * i) * PB_PITCH + c4);
-            d[0] = make_float2(xv.x, xv.y);
-            d[1] = make_float2(xv.z, xv.w);
+            if constexpr (GWS) {
+                u32x2 h, m, l;
+                split3_4(xv, h, m, l);
+                _Float16* e = xn + (srow + 32 * i) * PBS_PITCH + c4;
+                *reinterpret_cast<u32x2*>(e) = h;
+                *reinterpret_cast<u32x2*>(e + KP * PBS_PITCH) = m;
+                *reinterpret_cast<u32x2*>(e + 2 * KP * PBS_PITCH) = l;
+            } else {
+                float2* d = reinterpret_cast<float2*>(xst + (srow + 32 * i) * PB_PITCH + c4);
+                d[0] = make_float2(xv.x, xv.y);
+                d[1] = make_float2(xv.z, xv.w);
+            }
         }
         if (c.s + 1 == (unsigned)p.S) {                 // last sample of this pixel tile
             if (TPIX) {
@@ -968,6 +1025,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     bool valid = cur.unit < p.nunits;
     if (valid) {
         issue(cur);
+        if constexpr (GWS) issue_x(cur);
         commit(cur, 0);
     }
     __syncthreads();
@@ -998,7 +1056,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 
         unsigned b, bq, p0;
         coords(cur, b, bq, p0);
-        const float* gzs = lds + buf * BUF;
+        const float* gzs = lds + (GWS ? 0 : buf) * BUF;
         const float* xst = gzs + 128 * PB_PITCH;
 
         // ---- gx tile: rows 32 rb .. of K, pixels 32 ph ..; reduction over cout
@@ -1012,6 +1070,9 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 #pragma unroll
                 for (int kk = grp * 8; kk < grp * 8 + 8; ++kk)
                     acc_x = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk], gb[(2 * kk) * PB_PITCH], acc_x, 0, 0, 0);
+                if constexpr (GWS) {
+                    if (grp == 3 && nvalid) issue_x(nxt);     // half of the gx product + the gw product to land
+                }
                 if (PIPE) {
                     store_prev(2 * grp);
                     store_prev(2 * grp + 1);
@@ -1019,8 +1080,59 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        auto store_gx = [&]() {
+            if (DX) {
+                const unsigned col = p0 + ph * 32 + l31;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) out[j] = acc_x[j];
+                b_prev = __builtin_amdgcn_readfirstlane(b);
+                o_prev = (col < hw && nkrows > 0) ? (4u * lhi * hw + col) * 4u : PW_OOB;
+                if (!PIPE) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) store_prev(j);
+                }
+            }
+        };
         // ---- gw: rows 32 rb .. of cout, column blocks 2 ph, 2 ph + 1 of K; reduction over the 64 pixels
-        {
+        if constexpr (GWS) {
+            if (!DX && nvalid) issue_x(nxt);
+            store_gx();                                // (its 16 accumulator registers are free for the gw product)
+            const bool two = 2 * ph + 1 < NB;
+            if (2 * ph < NB) {
+                const _Float16* ga = gzn + (rb * 32 + l31) * PBS_PITCH + 8 * lhi;
+                const _Float16* xb0 = xn + ((2 * ph) * 32 + l31) * PBS_PITCH + 8 * lhi;
+                const _Float16* xb1 = xn + ((2 * ph + 1) * 32 + l31) * PBS_PITCH + 8 * lhi;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {           // 16 pixels per step
+                    const u32x4 ah = *reinterpret_cast<const u32x4*>(ga + 16 * s);
+                    const u32x4 am = *reinterpret_cast<const u32x4*>(ga + 16 * s + 128 * PBS_PITCH);
+                    const u32x4 al = *reinterpret_cast<const u32x4*>(ga + 16 * s + 2 * 128 * PBS_PITCH);
+                    {
+                        const u32x4 bh = *reinterpret_cast<const u32x4*>(xb0 + 16 * s);
+                        const u32x4 bm = *reinterpret_cast<const u32x4*>(xb0 + 16 * s + KP * PBS_PITCH);
+                        const u32x4 bl = *reinterpret_cast<const u32x4*>(xb0 + 16 * s + 2 * KP * PBS_PITCH);
+                        acc_w[0] = mfma_bf16(ah, bl, acc_w[0]);
+                        acc_w[0] = mfma_bf16(al, bh, acc_w[0]);
+                        acc_w[0] = mfma_bf16(am, bm, acc_w[0]);
+                        acc_w[0] = mfma_bf16(ah, bm, acc_w[0]);
+                        acc_w[0] = mfma_bf16(am, bh, acc_w[0]);
+                        acc_w[0] = mfma_bf16(ah, bh, acc_w[0]);
+                    }
+                    if (two) {
+                        const u32x4 bh = *reinterpret_cast<const u32x4*>(xb1 + 16 * s);
+                        const u32x4 bm = *reinterpret_cast<const u32x4*>(xb1 + 16 * s + KP * PBS_PITCH);
+                        const u32x4 bl = *reinterpret_cast<const u32x4*>(xb1 + 16 * s + 2 * KP * PBS_PITCH);
+                        acc_w[1] = mfma_bf16(ah, bl, acc_w[1]);
+                        acc_w[1] = mfma_bf16(al, bh, acc_w[1]);
+                        acc_w[1] = mfma_bf16(am, bm, acc_w[1]);
+                        acc_w[1] = mfma_bf16(ah, bm, acc_w[1]);
+                        acc_w[1] = mfma_bf16(am, bh, acc_w[1]);
+                        acc_w[1] = mfma_bf16(ah, bh, acc_w[1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
             const float* ga = gzs + (rb * 32 + l31) * PB_PITCH + lhi;
             const float* xb0 = xst + ((2 * ph) * 32 + l31) * PB_PITCH + lhi;
             const float* xb1 = xst + ((2 * ph + 1) * 32 + l31) * PB_PITCH + lhi;
@@ -1038,18 +1150,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                 }
             }
         }
-        if (DX) {
-            const unsigned col = p0 + ph * 32 + l31;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) out[j] = acc_x[j];
-            b_prev = __builtin_amdgcn_readfirstlane(b);
-            o_prev = (col < hw && nkrows > 0) ? (4u * lhi * hw + col) * 4u : PW_OOB;
-            if (!PIPE) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) store_prev(j);
-            }
-        }
+        if constexpr (!GWS) store_gx();
 
+        if constexpr (GWS) lds_barrier();            // one stage: every wave is through with it before it is refilled
+                                                     // (LDS ordering only: the x loads stay in flight)
         if (nvalid) commit(nxt, buf ^ 1);
         __syncthreads();
         cur = nxt;
@@ -1587,15 +1691,29 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
             return (int)hipGetLastError();
         }
     }
-    const size_t lds = (size_t)2 * (128 + kp) * PB_PITCH * sizeof(float);
+    size_t lds = (size_t)2 * (128 + kp) * PB_PITCH * sizeof(float);
+    // fp32 tensors: the weight-gradient product on the bf16 matrix pipe (split precision); SBMC_HIP_PW_GWS=0 keeps
+    // the all-fp32-MFMA kernel (development knob)
+    // (not with a per-pixel context gradient or a mean gradient: 16 more live registers make that form spill
+    // 15-17 VGPRs and measure 8 % slower than the fp32-MFMA kernel; plain layers: 4.41 -> 3.96 ms at 720p x 8 spp)
+    bool gws = false;
+    if constexpr (sizeof(TA) == 4 && sizeof(TXT) == 4) {
+        const char* gknob = getenv("SBMC_HIP_PW_GWS");
+        gws = (!gknob || atoi(gknob) != 0) && t_mode != 2 && !gmean;
+        if (gws) lds = (size_t)128 * PB_PITCH * sizeof(float) + (size_t)3 * (128 + kp) * PBS_PITCH * 2;
+    }
 #define SBMC_PWB_LAUNCH2(KPV, DXV, TPV)                                                                  \
     do {                                                                                                 \
         auto kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, TA, TXT>                       \
                                     : pw_bwd_kernel<KPV, DXV, TPV, false, TA, TXT>;                       \
         if constexpr (sizeof(TA) == 4 && sizeof(TXT) == 4) {                                             \
-            if (y_is_signs)                                                                              \
+            if (y_is_signs && gws && !TPV && !gmean)                                                     \
+                kern = pw_bwd_kernel<KPV, DXV, false, false, float, float, true, true>;                  \
+            else if (y_is_signs)                                                                         \
                 kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, float, float, true>         \
                                        : pw_bwd_kernel<KPV, DXV, TPV, false, float, float, true>;         \
+            else if (gws && !TPV && !gmean)                                                              \
+                kern = pw_bwd_kernel<KPV, DXV, false, false, float, float, false, true>;                 \
         }                                                                                                \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \

@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void splat_chain_bwd_kernel(SplatChainParams p
         // dM - (dW sum_w + dR . sum_r) is a difference of equal sums wherever the loss does not depend on the
         // running max (out = sum_r / sum_w: always), so what reaches d_kernels through the arg-max tap is pure
         // rounding residue; in fp32 it grew with every step of the chain (tools/fuzz_slab.py: up to 4e-5 of the
-        // tensor's scale after 5 samples, 7x the oracle's in unlucky cases).  Now the only roundings are those of
+        // tensor's scale after 5 samples, several times the CPU restatement's in unlucky cases).  Now the only roundings are those of
         // the fp32 inputs and of the records written below.
         double dW = p.d_sum_w[i], dM = p.d_max_w[i], dR[4] = {0., 0., 0., 0.};
 #pragma unroll

@@ -111,3 +111,11 @@ def test_product_never_installs_a_host_implementation():
             assert len(re.findall(r"register_cpu_ops_for_testing\s*\(", src)) == 1, path
             continue
         assert not uses, "%s touches the test-only host-op seam" % path
+
+
+def test_halo_mailbox_geometry():
+    """sbmc_halo_bytes is host arithmetic (no GPU): header + two rings of nslots slots; bad geometry -> 0."""
+    from sbmc_amd import _lib
+    L = _lib.lib()
+    assert L.sbmc_halo_bytes(1 << 20, 4) == 4096 + 2 * 4 * (1 << 20)
+    assert L.sbmc_halo_bytes(0, 4) == 0 and L.sbmc_halo_bytes(1 << 20, 0) == 0 and L.sbmc_halo_bytes(100, 2) == 0

@@ -25,6 +25,17 @@ def _run(args, env=None):
     return json.loads(lines[0])
 
 
+def test_bench_line_carries_the_inference_matrix():
+    """north_star's matrix in the default line: forward-only stages at 4 / 8 / 32 spp, the forward kernel's
+    roofline entry, the whole step's TFLOP/s and the U-nets' layout (tiny frame here)."""
+    d = _run([a for a in SMALL if a != "--no-stages"])
+    for spp in (4, 8, 32):
+        st = d["stages"]["infer_%dspp" % spp]
+        assert st["value"] > 0 and st["unit"] == "Msamples/s" and st["steps"] == 10
+    assert d["whole_step_tflops"] > 0 and 0 < d["frac_of_fp32_mfma_peak"] < 2 and "unet_layout" in d
+    assert "roofline" in d and "stages" in d and "splat" in d["stages"]
+
+
 def test_bench_single_gpu_line():
     d = _run(SMALL)
     assert d["n_gpus"] == 1 and d["world_size"] == 1 and d["value"] > 0 and d["unit"] == "Msamples/s"
@@ -39,3 +50,10 @@ def test_bench_starts_its_own_ranks(workload):
     assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo"
     assert d["value"] > 0 and d["scaling"] == "strong"
     assert "H-slabs x2" in d["config"]["parallelism"]
+    if workload in ("model", "infer"):
+        # the per-rank split of the sharded step: neighbour exchanges, exposed all-reduce, the rest
+        assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+        for r in d["per_rank"]:
+            assert r["step_ms"] > 0 and r["exchanges"] > 0 and r["exchange_ms"] >= 0
+            assert abs(r["compute_ms"] + r["exchange_ms"] + r["all_reduce_exposed_ms"] - r["step_ms"]) < 1e-2
+        assert d["whole_step_tflops"] > 0 and "unet_layout" in d

@@ -57,8 +57,8 @@ def pointwise_kernels():
     "pw_fwd_s_kernel",                                       # the fp32 layers' forward (bf16 matrix pipe, split precision)
     "sbmc::pw_fwd_kernel<128, 0, 2, float, float>",          # the fp32-MFMA forward (kept behind a knob)
     "sbmc::pw_fwd_kernel<128, 2, 2, float, float>",
-    "sbmc::pw_bwd_kernel<128, true, false, false, float, float, false>",
-    "sbmc::pw_bwd_kernel<128, true, false, false, float, float, true>",     # with sign bits instead of y
+    "sbmc::pw_bwd_kernel<128, true, false, false, float, float, false, false>",
+    "sbmc::pw_bwd_kernel<128, true, false, false, float, float, true, false>",     # with sign bits instead of y
     "pw_fwd_h_kernel",                                       # the f16 matrix pipe (every instantiation)
     "pw_bwd_h_kernel",
 ])

@@ -28,9 +28,11 @@ SBMC_BENCH_BACKEND=gloo SBMC_BENCH_SINGLE_DEVICE=1 OMP_NUM_THREADS=8 timeout 120
 head -c 400 $o/${tag}_bench_8ranks_one_gpu.json; echo
 bash tools/prof.sh $tag > $o/prof.log 2>&1; echo "prof rc=$?"
 cp gpurun_out/profiles_$tag/* $o/ 2>/dev/null
-bash tools/prof_pointwise.sh > $o/prof_pw.log 2>&1; cp gpurun_out/profiles_pw/r02_pointwise_pmc.txt $o/${tag}_pointwise_pmc.txt; tail -5 $o/${tag}_pointwise_pmc.txt
-bash tools/prof_half_splat.sh > $o/prof_half.log 2>&1; cp gpurun_out/half_splat/summary.txt $o/${tag}_half_splat_pmc.txt; tail -5 $o/${tag}_half_splat_pmc.txt
-bash tools/prof_conv_stack.sh > $o/prof_conv.log 2>&1; cp gpurun_out/conv_stack/r02_conv_stack_mfma.txt $o/${tag}_conv_stack_mfma.txt; tail -3 $o/${tag}_conv_stack_mfma.txt
-bash tools/prof_rank.sh 8 --ipc-self > $o/prof_rank.log 2>&1; cp gpurun_out/q/rank8_stats.csv $o/${tag}_rank8_kernel_stats.csv
+rm -rf gpurun_out/prof_$tag gpurun_out/profiles_$tag        # (raw traces: gpurun brings back 64 MiB at most)
+bash tools/prof_pointwise.sh > $o/prof_pw.log 2>&1; cp gpurun_out/profiles_pw/r02_pointwise_pmc.txt $o/${tag}_pointwise_pmc.txt; tail -5 $o/${tag}_pointwise_pmc.txt; rm -rf gpurun_out/prof_pw gpurun_out/profiles_pw
+bash tools/prof_half_splat.sh > $o/prof_half.log 2>&1; cp gpurun_out/half_splat/summary.txt $o/${tag}_half_splat_pmc.txt; tail -5 $o/${tag}_half_splat_pmc.txt; rm -rf gpurun_out/half_splat
+bash tools/prof_conv_stack.sh > $o/prof_conv.log 2>&1; cp gpurun_out/conv_stack/r02_conv_stack_mfma.txt $o/${tag}_conv_stack_mfma.txt; tail -3 $o/${tag}_conv_stack_mfma.txt; rm -rf gpurun_out/conv_stack
+bash tools/prof_rank.sh 8 --ipc-self > $o/prof_rank.log 2>&1; cp gpurun_out/q/rank8_stats.csv $o/${tag}_rank8_kernel_stats.csv; rm -rf gpurun_out/q
 ( timeout 300 python tools/fuzz_gpu.py --seconds 120 2>&1 | tail -2; timeout 300 python tools/fuzz_slab.py --seconds 120 2>&1 | tail -1; timeout 200 python tools/fuzz_pointwise.py --seconds 60 2>&1 | tail -1 ) > $o/${tag}_fuzz.txt; cat $o/${tag}_fuzz.txt | cut -c1-300
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+rm -f $o/*.err $o/prof*.log; du -sh gpurun_out
