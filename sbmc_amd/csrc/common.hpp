@@ -109,15 +109,20 @@ __device__ __forceinline__ float logit_load(rsrc_t r, unsigned voff, unsigned so
         return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX));
     }
 }
-// the same load without the conversion (half logits stay half until the arithmetic needs them)
+// The same load without the conversion: half logits stay half until the arithmetic needs them -- each in the
+// low half of a 32-bit register of its own (RawLogit<_Float16> = unsigned: as `_Float16` values the compiler
+// packs two per VGPR and spends a v_perm + v_lshr per pair on it).
+template <typename T> struct RawLogit { using type = float; };
+template <> struct RawLogit<_Float16> { using type = unsigned; };
 template <typename T, int AUX = 0>
-__device__ __forceinline__ T logit_load_raw(rsrc_t r, unsigned voff, unsigned soff) {
+__device__ __forceinline__ typename RawLogit<T>::type logit_load_raw(rsrc_t r, unsigned voff, unsigned soff) {
     if constexpr (sizeof(T) == 4) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
     } else {
-        return __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX));
+        return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, AUX);
     }
 }
+__device__ __forceinline__ _Float16 raw_half(unsigned u) { return __builtin_bit_cast(_Float16, (unsigned short)u); }
 template <typename T, int AUX = 0>
 __device__ __forceinline__ void logit_store(float v, rsrc_t r, unsigned voff, unsigned soff) {
     if constexpr (sizeof(T) == 4) {

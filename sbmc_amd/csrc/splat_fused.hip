@@ -189,22 +189,33 @@ __global__ __launch_bounds__(FWD_TY * TX) void splat_fwd_tile_kernel(SplatFwdPar
 //   VT: float, or _Float16 for half logits.  The half kernel is VALU-bound (98 % busy, profiles/r02_half_splat_pmc.txt),
 //   so its logits stay half through the row maximum (exact in half: v_max_f16, no conversion) and enter fp32
 //   only inside the exponent's multiply-add (v_fma_mix_f32 converts its half operand on the fly).
+//   (v: float, or the raw half in the low 16 bits of an unsigned -- RawLogit)
 template <int K, int C, typename VT>
 __device__ __forceinline__ void fwd_row_update(const VT (&v)[K], const float* srow, int dy,
                                                float& m, float& kmax, int& atap,
                                                float (&acc)[C], float& accw) {
-    VT rmaxv = v[0];
+    constexpr bool HALF = !__is_same(VT, float);
+    float rmax;
+    if constexpr (HALF) {
+        _Float16 r = raw_half(v[0]);
 #pragma unroll
-    for (int dx = 1; dx < K; ++dx) {
-        if constexpr (sizeof(VT) == 2) rmaxv = __builtin_fmaxf16(rmaxv, v[dx]);
-        else rmaxv = fmaxf(rmaxv, v[dx]);
+        for (int dx = 1; dx < K; ++dx) r = __builtin_fmaxf16(r, raw_half(v[dx]));
+        rmax = (float)r;
+    } else {
+        rmax = v[0];
+#pragma unroll
+        for (int dx = 1; dx < K; ++dx) rmax = fmaxf(rmax, v[dx]);
     }
-    const float rmax = (float)rmaxv;
     if (rmax > kmax) {  // strict: the first row attaining the max wins
         kmax = rmax;
         int idx = K - 1;
 #pragma unroll
-        for (int dx = K - 2; dx >= 0; --dx) idx = (v[dx] == rmaxv) ? dx : idx;  // first tap in the row
+        for (int dx = K - 2; dx >= 0; --dx) {           // first tap in the row
+            bool eq;
+            if constexpr (HALF) eq = (float)raw_half(v[dx]) == rmax;
+            else eq = v[dx] == rmax;
+            idx = eq ? dx : idx;
+        }
         atap = dy * K + idx;
     }
     const float mn = fmaxf(m, rmax);
@@ -222,7 +233,7 @@ __device__ __forceinline__ void fwd_row_update(const VT (&v)[K], const float* sr
 #pragma unroll
         for (int dx = g; dx < (g + G < K ? g + G : K); ++dx) {
             float e;
-            if constexpr (sizeof(VT) == 2) e = fast_exp2(fmaf((float)v[dx], LOG2E, nmn));
+            if constexpr (HALF) e = fast_exp2(fmaf((float)raw_half(v[dx]), LOG2E, nmn));
             else e = fast_exp2((v[dx] - mn) * LOG2E);
             accw += e;
 #pragma unroll
@@ -281,7 +292,8 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
     // border strips: lane's source column X+dx-P is inside the image for dx in [dx_lo, dx_hi)
     const int dx_lo = P - X, dx_hi = p.w + P - X;
 
-    auto load_row = [&](int dy, LT (&v)[K], float (&s)[2 * C]) {
+    using RL = typename RawLogit<LT>::type;
+    auto load_row = [&](int dy, RL (&v)[K], float (&s)[2 * C]) {
         const int ys = Y - p.top + dy - P;
         const bool yin = (ys >= 0) && (ys < p.h);  // wave-uniform
         if constexpr (GATHER) {
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
         }
         if (!yin) {   // beyond an IMAGE edge (rows beyond an inner slab edge are never visited, see below)
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) v[dx] = (LT)0.f;
+            for (int dx = 0; dx < K; ++dx) v[dx] = (RL)0;      // (+0.0 in either representation)
 #pragma unroll
             for (int j = 0; j < 2 * C; ++j) s[j] = 0.f;
             return;
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
             s[2 * c + 1] = inB ? dr[colB] : 0.f;
         }
     };
-    auto step = [&](int dy, const LT (&v)[K], const float (&s)[2 * C]) {
+    auto step = [&](int dy, const RL (&v)[K], const float (&s)[2 * C]) {
         wave_lds_sync();  // previous row's reads are done before its slots are overwritten
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -333,12 +345,12 @@ __global__ __launch_bounds__(V2_WAVES * TX, FWD_MIN_WAVES) void splat_fwd_strip_
             if (lane < K - 1) buf[c * V2_ROW + TX + lane] = s[2 * c + 1];
         }
         wave_lds_sync();
-        fwd_row_update<K, C, LT>(v, buf + lane, dy, m, kmax, atap, acc, accw);
+        fwd_row_update<K, C, RL>(v, buf + lane, dy, m, kmax, atap, acc, accw);
     };
 
     // (A register double-buffer that prefetches row dy+1 while row dy is reduced was tried:
     // it costs ~40 VGPRs, i.e. 2-3 waves/SIMD of occupancy, and measured slower.)
-    LT v[K];
+    RL v[K];
     float s[2 * C];
     // kernel rows whose source row lies beyond an INNER slab edge belong to the neighbouring slab and are
     // not visited at all (scalar loop bounds; whole frame: 0 .. K)
