@@ -467,13 +467,32 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
         }
 
         const u32x4* xb = xs + ((buf * 3) * KO + lhi) * PS_NT + ph0 * 32 + l31;
+        // the B operands of the next k-step are fetched while this one's MFMAs run (where 12 registers are to
+        // spare: without a context term) -- else each group of MFMAs starts by waiting for its own LDS reads
+        constexpr bool AHEAD = (TMODE == 0 && NPH == 1);
+        u32x4 nbh, nbm, nbl;
+        if constexpr (AHEAD) {
+            nbh = xb[0];
+            nbm = xb[KO * PS_NT];
+            nbl = xb[2 * KO * PS_NT];
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
 #pragma unroll
             for (int h = 0; h < NPH; ++h) {
-                const u32x4 bh = xb[(2 * s) * PS_NT + 32 * h];
-                const u32x4 bm = xb[(KO + 2 * s) * PS_NT + 32 * h];
-                const u32x4 bl = xb[(2 * KO + 2 * s) * PS_NT + 32 * h];
+                u32x4 bh, bm, bl;
+                if constexpr (AHEAD) {
+                    bh = nbh; bm = nbm; bl = nbl;
+                    if (s + 1 < KS) {
+                        nbh = xb[(2 * s + 2) * PS_NT];
+                        nbm = xb[(KO + 2 * s + 2) * PS_NT];
+                        nbl = xb[(2 * KO + 2 * s + 2) * PS_NT];
+                    }
+                } else {
+                    bh = xb[(2 * s) * PS_NT + 32 * h];
+                    bm = xb[(KO + 2 * s) * PS_NT + 32 * h];
+                    bl = xb[(2 * KO + 2 * s) * PS_NT + 32 * h];
+                }
                 if constexpr (TWO) {
                     acc[h] = mfma_bf16(ah[s], bh, acc[h]);
                     small[h] = mfma_bf16(ah[s], bl, small[h]);
