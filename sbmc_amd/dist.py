@@ -293,6 +293,15 @@ def _halo_pad_channel_bwd(ctx, g, r, part, h):
     if es not in (2, 4):
         raise RuntimeError("halo transport: float32 / float16 gradients only")
     ch.put(rows_run(g, 0, r, nhwc) if top else None, rows_run(g, hp - r, hp, nhwc) if bot else None)
+    if nhwc and g.shape[0] == 1 and not (top and bot and h < 2 * r):
+        # one channels-last image: its own rows are one dense block of the incoming gradient -- the neighbours'
+        # contributions are added to its edge rows in place and that block is handed on as a view (no copy of the
+        # slab; the gradient of a padded map has no other consumer: it comes out of the first convolution's
+        # data-gradient kernel)
+        ch.get(up=rows_run(g, top, top + r, nhwc) if top else None, add_up=rows_run(g, top, top + r, nhwc) if top else None,
+               down=rows_run(g, top + h - r, top + h, nhwc) if bot else None,
+               add_down=rows_run(g, top + h - r, top + h, nhwc) if bot else None, add_elem=es)
+        return g[..., top:top + h, :]
     if top and bot and h < 2 * r:
         # both neighbours reach the same rows: first the rows from above plus everything else, then the rows
         # from below are added in place

@@ -138,6 +138,17 @@ class HaloChannel(object):
                         ch.open_peer(d, handle)
             except Exception as e:  # noqa: BLE001
                 ok, err = False, "%s: %s" % (type(e).__name__, e)
+        if ok:
+            # a handshake over every link before anything depends on it: a few bytes to each neighbour and back,
+            # with a short time-out.  Stores into a mapped mailbox that the other side never sees (a platform
+            # on which peer writes or the flags do not behave) show up here, as "no channel", not as a hang
+            # in the first training step.
+            try:
+                ok = ch._handshake(part)
+                if not ok:
+                    err = "handshake over the mailboxes failed"
+            except Exception as e:  # noqa: BLE001
+                ok, err = False, "%s: %s" % (type(e).__name__, e)
         flags = [None] * part.world
         dist.all_gather_object(flags, (ok, err), group=part.group)
         if all(f[0] for f in flags):
@@ -147,6 +158,26 @@ class HaloChannel(object):
         if ch is not None:
             ch._finalizer()
         return None
+
+    def _handshake(self, part, timeout_s=10.0):
+        """Every rank sends 256 bytes that name it to both neighbours and checks what arrives (all ranks call
+        this together: the sequence numbers advance alike on both ends of every link)."""
+        mine = th.full((1, 1, 1, 64), float(part.rank + 1), dtype=th.float32, device=self.device)
+        got = th.zeros(2, 1, 1, 64, dtype=th.float32, device=self.device)
+        keep, self.timeout_ticks = self.timeout_ticks, int(timeout_s * TICKS_PER_SECOND)
+        try:
+            run = rows_run(mine, 0, 1)
+            self.put(run if part.has_up else None, run if part.has_down else None)
+            self.get(rows_run(got[0:1], 0, 1) if part.has_up else None, rows_run(got[1:2], 0, 1) if part.has_down else None)
+            th.cuda.synchronize(self.device)
+            err = ctypes.c_uint(0)
+            with th.cuda.device(self.device):
+                _lib.check(self.lib.sbmc_halo_status(self.box, ctypes.byref(err)), "sbmc_halo_status")
+        finally:
+            self.timeout_ticks = keep
+        want_up = float(part.rank) if part.has_up else 0.0           # rank - 1 sends rank - 1 + 1
+        want_down = float(part.rank + 2) if part.has_down else 0.0
+        return (err.value == 0 and bool((got[0] == want_up).all().item()) and bool((got[1] == want_down).all().item()))
 
     # -- data path --------------------------------------------------------------------------------------
     def _stream(self):
