@@ -211,3 +211,46 @@ def _two_rank_worker(rank, world, port):
 
 def test_two_processes_exchange_through_ipc_mailboxes():
     mp.spawn(_two_rank_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _stress_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sbmc_amd import dist as sdist
+        from sbmc_amd.halo import HaloChannel, rows_run
+        dev = th.device("cuda", 0)
+        th.cuda.set_device(dev)
+        part = sdist.SlabPartition(4 * world, world, rank)
+        ch = HaloChannel.connect(part, dev, 1 << 16, nslots=2)       # two slots: every third message waits for an ack
+        assert ch is not None
+        rng = th.Generator().manual_seed(9)                            # the same sizes on every rank
+        bad = th.zeros((), device=dev)
+        for it in range(1500):
+            planes = int(th.randint(1, 9, (1,), generator=rng))
+            w = 4 * int(th.randint(1, 300, (1,), generator=rng))
+            # what rank r sends in exchange `it`: a ramp offset by 1000 r + it (fp32-exact)
+            src = (th.arange(planes * 2 * w, device=dev, dtype=th.float32).view(1, planes, 2, w) + (1000.0 * rank + it))
+            up = th.full((1, planes, 2, w), -1.0, device=dev)
+            down = th.full((1, planes, 2, w), -1.0, device=dev)
+            run = rows_run(src, 0, 2)
+            ch.put(run if part.has_up else None, run if part.has_down else None)
+            ch.get(rows_run(up, 0, 2) if part.has_up else None, rows_run(down, 0, 2) if part.has_down else None)
+            if part.has_up:
+                bad += (up != src - 1000.0).any()
+            if part.has_down:
+                bad += (down != src + 1000.0).any()
+        assert bad.item() == 0, "%d corrupted exchanges on rank %d" % (int(bad.item()), rank)
+        ch.check()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_processes_1500_exchanges_in_a_row():
+    """Three ranks (the middle one has both neighbours), 1500 back-to-back exchanges of random sizes through
+    two-slot rings, no host synchronisation in between: every flag, ack and slot-reuse rule under load; any
+    stale or torn row would show in the data."""
+    mp.spawn(_stress_worker, args=(3, _free_port()), nprocs=3, join=True)
