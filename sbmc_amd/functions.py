@@ -7,6 +7,8 @@ returned shapes and dispatch rule (``_is_cuda`` -> ``*_cuda_float32``, else
 body of ``ProgressiveKernelApply.forward`` (sbmc/modules.py:422-471) backed by the
 fused gfx950 kernels of ``csrc/splat_fused.hip``.
 """
+import os
+
 import torch as th
 
 from . import _lib
@@ -746,8 +748,36 @@ class ContextProductNHWC(th.autograd.Function):
             g_rows = th.bmm(gt.transpose(1, 2), w.unsqueeze(0).expand(bs, -1, -1))   # [bs, hw, cp]: channels-last
             g_context = g_rows.view(bs, h, wd, cp).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            g_w = th.bmm(gt, rows).sum(0)
+            g_w = _context_weight_grad(gt, rows, w, (bs, cp, h, wd))
         return g_context, g_w
+
+
+def _context_weight_grad(gt, rows, w, dims):
+    """g_w = sum over pixels of gt[:, px] rows[px, :]: a 128 x 128 result over a 921 600-long reduction.  The GEMM
+    library takes 1.46 ms for it at 720p (a 32 x 32 x 256 tile, profiles/r03_model_kernel_stats.csv); the fused
+    1x1 backward in its weight-gradient-only form streams the same operands at the HBM rate once the context is
+    planar: an LDS-tile transpose (0.25 ms) + 0.3 ms."""
+    bs, cp, h, wd = dims
+    cout, hw = w.shape[0], h * wd
+    L = _lib.lib()
+    if (gt.is_cuda and gt.dtype == th.float32 and rows.dtype == th.float32 and rows.is_contiguous() and cp % 4 == 0
+            and hw % 4 == 0 and L.sbmc_pointwise_bwd_supported(cp, cout, hw)
+            and os.environ.get("SBMC_CTX_WGRAD", "fused") == "fused"):
+        gt = gt.contiguous()
+        dev = gt.device
+        planar = th.empty(bs, cp, hw, dtype=rows.dtype, device=dev)
+        groups = L.sbmc_pointwise_bwd_groups(bs, 1, 0, hw)
+        gwp = w.new_empty(groups, cout, cp)
+        gbp = w.new_empty(groups, 1, cout)
+        with th.cuda.device(dev):
+            rc = L.sbmc_transpose2d_f32(_lib.ptr(rows), _lib.ptr(planar), bs, hw, cp, _lib.current_stream(dev))
+            _lib.check(rc, "transpose2d")
+            rc = L.sbmc_pointwise_bwd_f32(_lib.ptr(gt), _lib.ptr(gt), _lib.ptr(planar), _lib.ptr(w.contiguous()), None,
+                                          _lib.ptr(gwp), _lib.ptr(gbp), None, None, 1, bs, 1, cp, cout, hw, 0, 0, 0.0,
+                                          _lib.current_stream(dev))
+        _lib.check(rc, "pointwise_bwd (context weight gradient)")
+        return gwp.sum(0)
+    return th.bmm(gt, rows).sum(0)
 
 
 class BiasActNHWC(th.autograd.Function):
