@@ -407,6 +407,13 @@ SBMC_API int sbmc_pointwise_bwd_f32(const float *gy, const float *y, const float
 SBMC_API int sbmc_pointwise_fwd_signs_f32(const float *x, const float *w, const float *bias, const float *t,
                                  float *y, unsigned *signs, int b, int s, int cin, int cout, long hw,
                                  int t_mode, int act, float slope, void *stream);
+/* The same forward that also returns ymean [b / s_mean, cout, hw], the mean of y over groups of s_mean consecutive
+ * batch elements (the per-pixel mean over samples that feeds the U-net, reference sbmc/models.py:179): the kernel
+ * walks the samples of a pixel tile one after the other and accumulates in LDS, so y is not read back (cout <= 128;
+ * with t_mode != 0: s_mean == s).  signs may be NULL. */
+SBMC_API int sbmc_pointwise_fwd_mean_f32(const float *x, const float *w, const float *bias, const float *t, float *y,
+                                unsigned *signs, float *ymean, int s_mean, int b, int s, int cin, int cout,
+                                long hw, int t_mode, int act, float slope, void *stream);
 SBMC_API int sbmc_pointwise_bwd_signs_f32(const float *gy, const unsigned *signs, const float *x, const float *w,
                                  float *gx, float *gw_partial, float *gb_partial, float *gt,
                                  const float *gmean, int s_mean, int b, int s, int cin, int cout, long hw,

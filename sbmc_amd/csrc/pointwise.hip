@@ -53,6 +53,7 @@ struct PwFwdParams {
     int t_mode;
     float slope;         // 1: linear, 0: relu, else leaky relu
     unsigned* signs;     // [B, Cout, ceil(hw / 32)] one bit per output: pre-activation > 0 (nullptr: not wanted)
+    float* ymean;        // [B / S, Cout, hw] mean of y over the S samples of a pixel (pw_fwd_s_kernel; nullptr: not wanted)
 };
 
 // KP: Cin rounded up to a multiple of 32 (<= 128); TMODE: the context term (0 none, 1 per image, 2 per pixel).
@@ -332,10 +333,19 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     const int l31 = lane & 31, lhi = lane >> 5;
     const unsigned hw = p.hw;
 
+    // Walk: a workgroup takes UNITS (one 64-pixel tile of one pixel plane) first, first + stride, ... and within
+    // a unit the S samples one after the other -- step v is sample v % S of unit first + (v / S) stride.  The
+    // samples of a pixel share their per-pixel context tile (it comes from HBM once) and their mean over the
+    // samples (p.ymean) is accumulated by the workgroup itself, in LDS.  S = 1: plain tile order.
     const unsigned g = blockIdx.x, slot = g / NUM_XCD;
     const int rt = (int)(slot % (unsigned)p.nrt);
     const unsigned first = (slot / (unsigned)p.nrt) * NUM_XCD + g % NUM_XCD;
     const unsigned stride = gridDim.x / (unsigned)p.nrt;
+    const unsigned S = (unsigned)p.S, nunits = p.ntiles / S;
+    auto tile_at = [&](unsigned v) -> unsigned {
+        const unsigned unit = first + (v / S) * stride;
+        return unit < nunits ? unit * S + v % S : 0xFFFFFFFFu;
+    };
     const int r0 = rt * 128 + rb * 32;
     const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
 
@@ -402,13 +412,17 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     // load is never copied: a copy would wait for it), and the barrier orders LDS traffic only.  The split of
     // the next tile (registers -> LDS) is dealt out between the MFMAs of the k-steps.
     float preA[NOCT][8], preB[NOCT][8];
-    unsigned tile = first;
+    unsigned v = 0;
+    unsigned tile = tile_at(0);
     if (tile < p.ntiles) {
         issue_loads(tile, preA);
         commit(0, preA);
-        if (tile + stride < p.ntiles) issue_loads(tile + stride, preA);
+        if (tile_at(1) < p.ntiles) issue_loads(tile_at(1), preA);
     }
     __syncthreads();
+    // the mean over a pixel's samples: every wave accumulates its own 32 x 32 block of outputs in LDS
+    float* macc = reinterpret_cast<float*>(xs + 2 * 3 * KO * PS_NT);        // [128][PS_NT]
+    const float inv_s = 1.f / (float)S;
 
     // one pair of values of the next tile -> its three bf16 words; a finished octet goes to LDS
     u32x4 ch[NOCT], cm[NOCT], cl[NOCT];
@@ -434,8 +448,8 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     // one tile; `cur` holds the NEXT tile's values (split and written to LDS stage buf ^ 1 during this one),
     // `fill` receives the loads of the tile after that
     auto step = [&](const float (&cur)[NOCT][8], float (&fill)[NOCT][8], const int buf) {
-        const unsigned next = tile + stride, next2 = next + stride;
-        if (next2 < p.ntiles && next2 > next) issue_loads(next2, fill);
+        const unsigned next = tile_at(v + 1), next2 = tile_at(v + 2);
+        if (next2 < p.ntiles) issue_loads(next2, fill);
         const bool more = next < p.ntiles;
 
         unsigned b, bq, p0;
@@ -531,6 +545,9 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
 
         // bias, context term, sign bits, activation, store
         const rsrc_t ry = make_rsrc_n(yg + ((size_t)b * p.Cout + r0) * hw, (unsigned)nrows * hw * 4u);
+        const rsrc_t rm = make_rsrc_n(p.ymean != nullptr ? p.ymean + ((size_t)bq * p.Cout + r0) * hw : yg,
+                                      (unsigned)nrows * hw * 4u);
+        const unsigned s_in = tile % S;                // which of the pixel's samples this tile is
 #pragma unroll
         for (int h = 0; h < NPH; ++h) {
             unsigned myword = 0;
@@ -544,6 +561,12 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
                 v = v > 0.f ? v : v * p.slope;
                 const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
                 buf_store(v, ry, o0[h] != PW_OOB ? o0[h] + ro : PW_OOB, 0);
+                if (p.ymean != nullptr) {
+                    float* mp = macc + (rb * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * PS_NT + (ph0 + h) * 32 + l31;
+                    const float m = s_in == 0 ? v : *mp + v;
+                    if (s_in + 1 == S) buf_store(m * inv_s, rm, o0[h] != PW_OOB ? o0[h] + ro : PW_OOB, 0);
+                    else *mp = m;
+                }
             }
             if (p.signs != nullptr && l31 < 16) {
                 const int row = r0 + (l31 & 3) + 8 * (l31 >> 2) + 4 * lhi;
@@ -555,10 +578,10 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     };
     while (tile < p.ntiles) {
         step(preA, preB, 0);
-        tile += stride;
+        tile = tile_at(++v);
         if (!(tile < p.ntiles)) break;
         step(preB, preA, 1);
-        tile += stride;
+        tile = tile_at(++v);
     }
 }
 
@@ -1481,7 +1504,7 @@ extern "C" int sbmc_pointwise_supported(int cin, int cout, long hw) { return pw_
 template <typename TI, typename TO>
 static int pw_fwd_launch(const void* x, const float* w, const float* bias, const float* t, void* y, int b, int s,
                          int cin, int cout, long hw, int t_mode, int act, float slope, void* stream,
-                         unsigned* signs = nullptr) {
+                         unsigned* signs = nullptr, float* ymean = nullptr, int s_mean = 1) {
     if (b < 0 || s < 1 || act < 0 || act > 2 || t_mode < 0 || t_mode > 2) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!pw_dims_ok(cin, cout, hw) || b % s || !x || !w || !bias || !y || (t_mode && !t)) return SBMC_HIP_EINVAL;
@@ -1489,7 +1512,10 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
     PwFwdParams p;
     p.x = x; p.w = w; p.bias = bias; p.t = t; p.y = y;
     p.signs = signs;
-    p.B = b; p.S = t_mode ? s : 1; p.K = cin; p.Cout = cout;
+    p.ymean = ymean;
+    if (ymean != nullptr && (s_mean < 1 || b % s_mean || cout > 128 || (t_mode && s != s_mean) ||
+                             sizeof(TI) != 4 || sizeof(TO) != 4)) return SBMC_HIP_EINVAL;
+    p.B = b; p.S = t_mode ? s : (ymean != nullptr ? s_mean : 1); p.K = cin; p.Cout = cout;
     p.hw = (unsigned)hw;
     if constexpr (sizeof(TI) == 4 && sizeof(TO) == 4) {
         // fp32 in, fp32 out: the split-precision kernel on the bf16 matrix pipe (SBMC_HIP_PW_SPLIT=0 keeps the
@@ -1508,10 +1534,10 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
                 hipDeviceGetAttribute(&scus, hipDeviceAttributeMultiprocessorCount, sdev) != hipSuccess)
                 scus = 256;
             const int skp = (cin + 31) / 32 * 32;
-            const size_t slds = (size_t)2 * 3 * (skp / 8) * PS_NT * 16;
+            const size_t slds = (size_t)2 * 3 * (skp / 8) * PS_NT * 16 + (ymean != nullptr ? (size_t)128 * PS_NT * 4 : 0);
             const unsigned sunit = (unsigned)(NUM_XCD * p.nrt);
             unsigned sgrid = (unsigned)scus / sunit * sunit;
-            const unsigned long long sneed = ((unsigned long long)p.ntiles + NUM_XCD - 1) / NUM_XCD * sunit;
+            const unsigned long long sneed = ((unsigned long long)(p.ntiles / (unsigned)p.S) + NUM_XCD - 1) / NUM_XCD * sunit;
             if (sgrid > sneed) sgrid = (unsigned)sneed;
             if (sgrid < sunit) sgrid = sunit;
             hipError_t se = hipSuccess;
@@ -1538,7 +1564,7 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
             if (se != hipSuccess) return (int)se;
             return (int)hipGetLastError();
         }
-        if (signs != nullptr) return SBMC_HIP_EINVAL;      // (the fp32-MFMA kernel writes no sign bits)
+        if (signs != nullptr || ymean != nullptr) return SBMC_HIP_EINVAL;      // (the fp32-MFMA kernel writes neither)
     }
     const int ph = PW_FWD_PH;
     const int ntile = 64 * ph;
@@ -1621,6 +1647,14 @@ extern "C" int sbmc_pointwise_fwd_signs_f32(const float* x, const float* w, cons
                                             unsigned* signs, int b, int s, int cin, int cout, long hw, int t_mode,
                                             int act, float slope, void* stream) {
     return pw_fwd_launch<float, float>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream, signs);
+}
+
+extern "C" int sbmc_pointwise_fwd_mean_f32(const float* x, const float* w, const float* bias, const float* t, float* y,
+                                           unsigned* signs, float* ymean, int s_mean, int b, int s, int cin, int cout,
+                                           long hw, int t_mode, int act, float slope, void* stream) {
+    if (ymean == nullptr) return SBMC_HIP_EINVAL;
+    return pw_fwd_launch<float, float>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream, signs, ymean,
+                                       s_mean);
 }
 
 extern "C" int sbmc_pointwise_fwd_f16(const void* x, int x_is_half, const float* w, const float* bias, const float* t,

@@ -447,7 +447,7 @@ class PointwiseLayer(th.autograd.Function):
         """half=True ("fp16 activations", torch.autocast(float16)): y is float16, x float16 or float32 (a
         chain's first layer); w, bias, t stay float32 and so does all arithmetic; backward likewise
         (sbmc_pointwise_{fwd,bwd}_f16)."""
-        return _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half)
+        return _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half)[0]
 
     @staticmethod
     def backward(ctx, gy):
@@ -463,10 +463,12 @@ class PointwiseLayerMean(th.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, t, s, act, slope, mean_s, half=False):
-        y = _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half)
+        y, ymean = _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half, mean_s=mean_s)
         ctx.mean_s = mean_s
-        B, cout, hw = y.shape
-        return y, y.view(B // mean_s, mean_s, cout, hw).mean(1)
+        if ymean is None:                    # (half storage, wide layers, the fp32-MFMA kernel: one more pass over y)
+            B, cout, hw = y.shape
+            ymean = y.view(B // mean_s, mean_s, cout, hw).mean(1)
+        return y, ymean
 
     @staticmethod
     def backward(ctx, gy, gmean):
@@ -476,7 +478,9 @@ class PointwiseLayerMean(th.autograd.Function):
         return _pointwise_backward(ctx, gy, gmean, ctx.mean_s) + (None, None, None, None, None)
 
 
-def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False):
+def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False, mean_s=0):
+    """-> (y, ymean): ymean = the mean of y over groups of mean_s consecutive batch elements where the kernel
+    computes it on the way (fp32 split-precision forward, cout <= 128), else None."""
     _require_f32("PointwiseLayer", w=w, bias=bias, t=t, x=None if half else x)
     if half and not (x.is_cuda and x.dtype in (th.float32, th.float16)):
         raise TypeError("PointwiseLayer(half): x must be a float32 or float16 GPU tensor")
@@ -498,8 +502,17 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False):
     if (not half and act != 0 and any(ctx.needs_input_grad[:4]) and _pw_split_enabled()
             and L.sbmc_pointwise_bwd_supported(cin, cout, hw)):
         signs = th.empty(B, cout, (hw + 31) // 32, dtype=th.int32, device=dev)
+    ymean = None
+    if (mean_s and mean_s >= 1 and not half and _pw_split_enabled() and cout <= 128 and B % mean_s == 0
+            and (t_mode == 0 or s == mean_s) and os.environ.get("SBMC_PW_FUSED_MEAN", "1") != "0"):
+        ymean = th.empty(B // mean_s, cout, hw, dtype=th.float32, device=dev)
     with th.cuda.device(dev), _timed("pointwise_fwd%s %dx%d" % ("_f16" if half else "", cout, cin), dev):
-        if half:
+        if ymean is not None:
+            rc = L.sbmc_pointwise_fwd_mean_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
+                                               _lib.ptr(t) if t is not None else None, _lib.ptr(y),
+                                               _lib.ptr(signs) if signs is not None else None, _lib.ptr(ymean), mean_s,
+                                               B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
+        elif half:
             rc = L.sbmc_pointwise_fwd_f16(_lib.ptr(x), int(x.dtype == th.float16), _lib.ptr(w), _lib.ptr(bias),
                                           _lib.ptr(t) if t is not None else None, _lib.ptr(y),
                                           B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
@@ -516,7 +529,7 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False):
     ctx.half = half
     ctx.has_signs = signs is not None
     ctx.save_for_backward(x, w, signs if signs is not None else (y if act != 0 else None))
-    return y
+    return y, ymean
 
 
 def _pw_split_enabled():
