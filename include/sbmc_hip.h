@@ -41,7 +41,7 @@ extern "C" {
 #define SBMC_API
 #endif
 
-#define SBMC_HIP_ABI_VERSION 3
+#define SBMC_HIP_ABI_VERSION 4
 #define SBMC_HIP_EINVAL (-1)
 /* largest channel count the fused/plain kernels take in one call */
 #define SBMC_HIP_MAX_CHANNELS 8
@@ -553,6 +553,27 @@ SBMC_API int sbmc_halo_merge_state_fwd_f32(void *box, void *up_box, void *down_b
 SBMC_API int sbmc_halo_merge_state_bwd_f32(const float *ext, const float *recv_up, const float *recv_down,
                                   const float *gout, float *gext, float *grecv_up, float *grecv_down,
                                   int bs, int c, int rows, int w, int p, int top, int bot, void *stream);
+
+/*
+ * 3 x 3 convolution, stride 1, zero padding 1, of a channels-last fp32 image -- replaces the cuDNN convolution
+ * behind every `nn.Conv2d(..., 3, padding=1)` of the reference's U-nets (sbmc/modules.py:195-320 via
+ * ttools ConvChain) at fp32 accuracy on the f16 matrix pipe (csrc/conv3x3.hip: x = h + l in two f16 planes,
+ * three products per term, scales from the tensors' largest magnitudes taken on the device).
+ *   supported:        cin % 32 == 0, cout % 128 == 0 (and sizes whose tile offsets fit 31 bits)
+ *   weights_bytes:    size of the prepared weights of one layer (0: unsupported)
+ *   absmax:           *out = bit pattern of max |x| over n floats (x 16-byte aligned)
+ *   prepare_weights:  w[co][ci][ky][kx] with element strides s_* (storage_elems floats of dense storage) ->
+ *                     wp; flip != 0 prepares the adjoint's weights: call with cin / cout and s_co / s_ci
+ *                     exchanged, taps are mirrored (gx = conv(gy, flipped transposed w))
+ *   nhwc:             y[n][h][w][cout] = sum x[n][h + ky - 1][w + kx - 1][ci] w[co][ci][ky][kx]
+ */
+SBMC_API int sbmc_conv3x3_supported(int n, int h, int w, int cin, int cout);
+SBMC_API size_t sbmc_conv3x3_weights_bytes(int cin, int cout);
+SBMC_API int sbmc_conv3x3_absmax_f32(const float *x, long n, unsigned *out, void *stream);
+SBMC_API int sbmc_conv3x3_prepare_weights_f32(const float *w, long s_co, long s_ci, long s_ky, long s_kx,
+                                     long storage_elems, int cin, int cout, int flip, void *wp, void *stream);
+SBMC_API int sbmc_conv3x3_nhwc_f32(const float *x, const unsigned *xmax, const void *wp, float *y, int n, int h,
+                          int w, int cin, int cout, void *stream);
 
 #ifdef __cplusplus
 }

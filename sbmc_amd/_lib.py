@@ -88,8 +88,13 @@ SYMBOLS = (
     "sbmc_halo_get",
     "sbmc_halo_merge_state_fwd_f32",
     "sbmc_halo_merge_state_bwd_f32",
+    "sbmc_conv3x3_supported",
+    "sbmc_conv3x3_weights_bytes",
+    "sbmc_conv3x3_absmax_f32",
+    "sbmc_conv3x3_prepare_weights_f32",
+    "sbmc_conv3x3_nhwc_f32",
 )
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_CHANNELS = 8
 
 _LIB = None
@@ -207,9 +212,16 @@ def lib():
     handle.sbmc_halo_get.argtypes = [p] * 7 + [i, ll, ll, ll, ll, p, p, ll, ll, ll, ll, u, u, i, ll, ll, p]
     handle.sbmc_halo_merge_state_fwd_f32.argtypes = [p] * 7 + [i] * 7 + [u, u, i, ll, ll, p]
     handle.sbmc_halo_merge_state_bwd_f32.argtypes = [p] * 7 + [i] * 7 + [p]
+    lg = ctypes.c_long
+    handle.sbmc_conv3x3_supported.argtypes = [i] * 5
+    handle.sbmc_conv3x3_weights_bytes.argtypes = [i, i]
+    handle.sbmc_conv3x3_absmax_f32.argtypes = [p, lg, p, p]
+    handle.sbmc_conv3x3_prepare_weights_f32.argtypes = [p, lg, lg, lg, lg, lg, i, i, i, p, p]
+    handle.sbmc_conv3x3_nhwc_f32.argtypes = [p, p, p, p, i, i, i, i, i, p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_halo_bytes.restype = ctypes.c_size_t
+    handle.sbmc_conv3x3_weights_bytes.restype = ctypes.c_size_t
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t
     if handle.sbmc_hip_abi_version() != ABI_VERSION:
         raise HipExtensionMissing("ABI version mismatch: rebuild with `python -m sbmc_amd.build --force`")

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libsbmc_hip.so")
-SOURCES = ["plain_ops.hip", "splat_fused.hip", "bias_act.hip", "pointwise.hip", "resample.hip", "nhwc_ops.hip", "halo.hip"]
+SOURCES = ["plain_ops.hip", "splat_fused.hip", "bias_act.hip", "pointwise.hip", "resample.hip", "nhwc_ops.hip", "halo.hip", "conv3x3.hip"]
 DEPS = SOURCES + ["common.hpp", os.path.join(ROOT, "include", "sbmc_hip.h")]
 ARCH = "gfx950"
 

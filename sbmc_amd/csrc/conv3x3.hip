@@ -1,0 +1,430 @@
+// 3 x 3 convolution of a channels-last fp32 image (stride 1, zero padding 1: every convolution of the U-nets),
+// at fp32 accuracy on the f16 matrix pipe.
+//
+// v_mfma_f32_32x32x2_f32 -- what an fp32 implicit GEMM runs on -- has 1/16 of the f16 / bf16 MFMA rate.  An
+// fp32 value x, scaled by a power of two c so that the tensor's largest magnitude lands in [2^14, 2^15), is
+//     c x = h + l + e,    h = f16(c x),  l = f16(c x - h),   |e| <= max(2^-22 |c x|, 2^-25)
+// (c x - h is exact in fp32; l is a subnormal half below 2^-14, hence the absolute floor: 2^-39 of the tensor's
+// largest value), so
+//     x w = (hx hw + hx lw + lx hw) / (cx cw) + [lx lw: <= 2^-22 |x w|, dropped]
+// is THREE f16 products with exact fp32 partial products, accumulated in fp32 by v_mfma_f32_32x32x16_f16:
+// 3 / 16 of the fp32 MFMA time.  Every term carries >= 22 significant bits unless it is more than 2^17 below its
+// tensor's largest value (then: an absolute error of 2^-39 of that value) -- the sum over 9 Cin terms in fp32
+// loses more than that on either pipe.  The scales are powers of two (exact), taken from the tensors' largest
+// magnitudes ON THE DEVICE (no host synchronisation): sbmc_conv3x3_absmax_f32 for the image, the weight
+// preparation for the weights.
+//
+// Implicit GEMM, A = pixels x (tap, cin) from the image, B = (tap, cin) x cout from the weights:
+//   * a workgroup (4 waves, one per SIMD, the whole 512-entry register file each) owns 16 x 16 pixels x 128
+//     output channels; a wave 8 x 16 pixels x 64 channels = 4 x 2 accumulators of 32 x 32;
+//   * the 18 x 18 pixel patch of 32 input channels is fetched ONCE for all nine taps (fp32, 128 contiguous
+//     bytes per pixel), split in registers and kept in LDS as [plane][octet of channels][pixel] 16-byte entries:
+//     the A operand of tap (ky, kx) is the same image shifted by (ky, kx) entries, one conflict-free
+//     ds_read_b128 (16 lanes = 16 consecutive pixels of a patch row = 256 contiguous bytes);
+//   * the weights are prepared once per step (sbmc_conv3x3_prepare_weights_f32: split, and laid out so that one
+//     STAGE -- a kernel row of 3 taps x 16 input channels x 128 output channels x 2 planes, 24 KB -- is one
+//     contiguous block that goes to LDS as it is), double-buffered, one barrier per stage (72 MFMAs per wave);
+//   * persistent workgroups: the fetches of the next chunk / stage / tile are in flight during the MFMAs of the
+//     current one, across tile boundaries.
+// LDS traffic is what bounds this shape: a 32 x 32 x 16 MFMA eats 2 KB of operands in 32 cycles while LDS
+// delivers 128 B / cycle to the whole CU, so operands must be re-used from registers -- 12 operand reads per 24
+// MFMAs here (0.5 of the LDS bandwidth at full matrix rate).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sbmc_hip.h"
+#include "common.hpp"
+
+namespace sbmc {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+using h2 = __attribute__((ext_vector_type(2))) _Float16;
+using f2 = __attribute__((ext_vector_type(2))) float;
+
+constexpr int CV_TS = 16;                    // tile side (pixels)
+constexpr int CV_PS = CV_TS + 2;             // patch side
+constexpr int CV_PP = CV_PS * CV_PS;         // patch pixels (324)
+constexpr int CV_ABUF = 2 * 4 * CV_PP;       // 16-byte entries of one patch: [plane 2][octet 4][pixel]
+constexpr int CV_WSTAGE = 3 * 2 * 2 * 128;   // 16-byte entries of one weight stage: [kx 3][plane 2][k half 2][cout 128]
+constexpr unsigned CV_LDS_BYTES = (2 * CV_ABUF + 2 * CV_WSTAGE) * 16;   // 132096
+constexpr int CV_AROUNDS = (2 * CV_PP + 255) / 256;                     // staging rounds: (pixel, 16 channels) units
+constexpr unsigned CV_OOB = 0xFFFFFFF0u;
+
+__device__ __forceinline__ rsrc_t cv_rsrc(const void* base, unsigned bytes) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* u = reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+__device__ __forceinline__ void cv_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// power of two that brings a tensor whose largest magnitude has the bit pattern `maxbits` into [2^14, 2^15)
+__device__ __forceinline__ float cv_scale_of(unsigned maxbits) {
+    int e = 268 - (int)(maxbits >> 23);      // 127 + 14 - (exponent - 127)
+    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    return __builtin_bit_cast(float, (unsigned)e << 23);
+}
+
+__device__ __forceinline__ unsigned cv_pack(float a, float b) {
+    h2 v;
+    v[0] = (_Float16)a;
+    v[1] = (_Float16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// 8 floats (already scaled) -> their two f16 planes
+__device__ __forceinline__ void cv_split(const float (&v)[8], u32x4& h, u32x4& l) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h2 hp;
+        hp[0] = (_Float16)v[2 * i];
+        hp[1] = (_Float16)v[2 * i + 1];
+        h[i] = __builtin_bit_cast(unsigned, hp);
+        l[i] = cv_pack(v[2 * i] - (float)hp[0], v[2 * i + 1] - (float)hp[1]);      // differences exact
+    }
+}
+
+__device__ __forceinline__ f32x16 cv_mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
+struct Conv3Params {
+    const float* x;          // [N, H, W, Cin]
+    const u32x4* wp;         // prepared weights: [cout tile][Cin / 16][ky][kx][plane][k half][128] entries of 8 halves
+    float* y;                // [N, H, W, Cout]
+    const unsigned* xmax;    // bit pattern of max |x|
+    const float* wscale;     // the weights' scale
+    int N, H, W, Cin, Cout;
+    int tiles_x, tiles_y, ncot;
+    unsigned ntiles;         // N * tiles_y * tiles_x * ncot
+};
+
+__global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
+    extern __shared__ float4 cv_lds[];
+    u32x4* As = reinterpret_cast<u32x4*>(cv_lds);
+    u32x4* Ws = As + 2 * CV_ABUF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int mh = wave & 1, nh = wave >> 1;
+    const float cx = cv_scale_of(*p.xmax);
+    const float oscale = (1.f / cx) * (1.f / *p.wscale);
+    const unsigned nchunks = (unsigned)p.Cin / 32u;
+
+    // the chunks of this workgroup, in order: chunk h is channels 32 (h % nchunks) .. of tile first + (h / nchunks) stride
+    const unsigned first = blockIdx.x, stride = gridDim.x;
+    const unsigned my_tiles = first < p.ntiles ? (p.ntiles - first + stride - 1) / stride : 0;
+    const unsigned total = my_tiles * nchunks;
+    struct Tile { int n, y0, x0, ct; };
+    auto tile_of = [&](unsigned h) -> Tile {
+        // output-channel tiles of one pixel tile are neighbours in the walk (they read the same patch)
+        const unsigned t = first + (h / nchunks) * stride;
+        Tile r;
+        r.ct = (int)(t % (unsigned)p.ncot);
+        const unsigned pt = t / (unsigned)p.ncot;
+        r.x0 = (int)(pt % (unsigned)p.tiles_x) * CV_TS;
+        const unsigned rest = pt / (unsigned)p.tiles_x;
+        r.y0 = (int)(rest % (unsigned)p.tiles_y) * CV_TS;
+        r.n = (int)(rest / (unsigned)p.tiles_y);
+        return r;
+    };
+
+    // ---- staging of a patch: unit u = (pixel u / 2, channels 16 (u % 2) ..), 64 contiguous bytes ----
+    float areg[CV_AROUNDS][16];
+    auto issue_a = [&](unsigned h) {
+        const Tile t = tile_of(h);
+        const unsigned cc = h % nchunks;
+        const float* xb = p.x + (((long)t.n * p.H + (t.y0 - 1)) * (long)p.W + (t.x0 - 1)) * (long)p.Cin;
+        const rsrc_t rx = cv_rsrc(xb, 0x7FFFFFF0u);
+#pragma unroll
+        for (int j = 0; j < CV_AROUNDS; ++j) {
+            const int u = tid + 256 * j, q = u >> 1, half = u & 1;
+            const int qr = q / CV_PS, qc = q - qr * CV_PS;
+            const int gy = t.y0 - 1 + qr, gx = t.x0 - 1 + qc;
+            const bool in = u < 2 * CV_PP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const unsigned voff = in ? (unsigned)((qr * p.W + qc) * p.Cin + half * 16) * 4u : CV_OOB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, cc * 128u + 16u * i, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned word = v[c];      // (a copy: bit_cast of the element expression itself reads element 0)
+                    areg[j][4 * i + c] = __builtin_bit_cast(float, word);
+                }
+            }
+        }
+    };
+    auto commit_a = [&](int abuf) {
+#pragma unroll
+        for (int j = 0; j < CV_AROUNDS; ++j) {
+            const int u = tid + 256 * j, q = u >> 1, half = u & 1;
+            if (u < 2 * CV_PP) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    float v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = areg[j][8 * o + c] * cx;
+                    u32x4 hh, ll;
+                    cv_split(v, hh, ll);
+                    u32x4* d = As + abuf * CV_ABUF + (2 * half + o) * CV_PP + q;
+                    d[0] = hh;
+                    d[4 * CV_PP] = ll;
+                }
+            }
+        }
+    };
+    // ---- staging of a weight stage (h, st): 1536 entries, 6 per thread ----
+    u32x4 wreg[6];
+    const rsrc_t rw = cv_rsrc(p.wp, (unsigned)p.ncot * ((unsigned)p.Cin / 16u) * 3u * (unsigned)CV_WSTAGE * 16u);
+    auto issue_w = [&](unsigned h, int st) {
+        const Tile t = tile_of(h);
+        const unsigned cc = h % nchunks;
+        const unsigned k16 = cc * 2u + (unsigned)(st / 3), ky = (unsigned)(st % 3);
+        const unsigned block = ((unsigned)t.ct * ((unsigned)p.Cin / 16u) + k16) * 3u + ky;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(tid + 256 * i) * 16u,
+                                                            block * (unsigned)(CV_WSTAGE * 16), 0);
+    };
+    auto commit_w = [&](int wbuf) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Ws[wbuf * CV_WSTAGE + tid + 256 * i] = wreg[i];
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (total == 0) return;
+    issue_a(0);
+    issue_w(0, 0);
+    commit_a(0);
+    commit_w(0);
+    __syncthreads();
+
+    // operands of one tap: A 4 m-blocks x 2 planes, B 2 n-blocks x 2 planes
+    struct Ops { u32x4 ah[4], al[4], bh[2], bl[2]; };
+    auto load_ops = [&](Ops& o, const u32x4* Ab, const u32x4* Wb, int kx) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            o.ah[mi] = Ab[mi * 2 * CV_PS + kx];
+            o.al[mi] = Ab[4 * CV_PP + mi * 2 * CV_PS + kx];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            o.bh[ni] = Wb[kx * 512 + ni * 32];
+            o.bl[ni] = Wb[kx * 512 + 256 + ni * 32];
+        }
+    };
+    auto mfmas = [&](const Ops& o) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.ah[mi], o.bh[ni], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.ah[mi], o.bl[ni], acc[mi][ni]);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.al[mi], o.bh[ni], acc[mi][ni]);
+    };
+
+    for (unsigned h = 0; h < total; ++h) {
+        const int abuf = (int)(h & 1u);
+        const bool more = h + 1 < total;
+        if (more) issue_a(h + 1);
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            const int kk = st / 3, ky = st % 3, wbuf = st & 1;
+            const bool next_w = st < 5 || more;
+            if (next_w) {
+                if (st < 5) issue_w(h, st + 1);
+                else issue_w(h + 1, 0);
+            }
+            const u32x4* Ab = As + abuf * CV_ABUF + (2 * kk + lhi) * CV_PP + (mh * 8 + (l31 >> 4) + ky) * CV_PS + (l31 & 15);
+            const u32x4* Wb = Ws + wbuf * CV_WSTAGE + lhi * 128 + nh * 64 + l31;
+            Ops o0, o1;
+            load_ops(o0, Ab, Wb, 0);
+            load_ops(o1, Ab, Wb, 1);
+            mfmas(o0);
+            load_ops(o0, Ab, Wb, 2);
+            mfmas(o1);
+            mfmas(o0);
+            if (st == 3 && more) commit_a(abuf ^ 1);
+            if (next_w) commit_w(wbuf ^ 1);
+            cv_lds_barrier();
+        }
+        if (h % nchunks == nchunks - 1) {
+            // ---- the tile is complete: scale back, store, clear ----
+            const Tile t = tile_of(h);
+            float* yb = p.y + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)p.Cout + t.ct * 128;
+            const rsrc_t ry = cv_rsrc(yb, 0x7FFFFFF0u);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // accumulator register r of a 32 x 32 block: pixel (r & 3) + 8 (r >> 2) + 4 (lane / 32) of the
+                    // block's 2 rows x 16 columns; output channel lane % 32
+                    const int row = mh * 8 + mi * 2 + (r >> 3);
+                    const int col = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi;
+                    const bool ok = t.y0 + row < p.H && t.x0 + col < p.W;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const unsigned voff = ok ? (unsigned)((row * p.W + col) * p.Cout + nh * 64 + ni * 32 + l31) * 4u : CV_OOB;
+                        buf_store(acc[mi][ni][r] * oscale, ry, voff, 0);
+                        acc[mi][ni][r] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- largest magnitude of a tensor (bit pattern; 0 for an empty or all-zero tensor) ----
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    const long n4 = n / 4;
+    const uint4* x4 = reinterpret_cast<const uint4*>(x);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const uint4 v = x4[i];
+        const unsigned a = v.x & 0x7FFFFFFFu, b = v.y & 0x7FFFFFFFu, c = v.z & 0x7FFFFFFFu, d = v.w & 0x7FFFFFFFu;
+        const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+        const unsigned q = ab > cd ? ab : cd;
+        m = m > q ? m : q;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4 * 4)) {
+        const unsigned a = __builtin_bit_cast(unsigned, x[n4 * 4 + threadIdx.x]) & 0x7FFFFFFFu;
+        m = m > a ? m : a;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, s, 64);
+        m = m > o ? m : o;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// ---- weights [cout][cin][3][3] (any strides) -> the two f16 planes in stage order ----
+// entry e = ((((ct K16 + k16) 3 + ky) 3 + kx) 2 + plane) 2 + khalf) 128 + co holds input channels
+// 16 k16 + 8 khalf .. + 7 of output channel 128 ct + co at tap (ky, kx) [flip: tap (2 - ky, 2 - kx)]
+struct PrepParams {
+    const float* w;
+    long s_co, s_ci, s_ky, s_kx;
+    int cout, cin, flip;
+    const unsigned* wmax;
+    u32x4* wp;
+    float* wscale;
+};
+__global__ __launch_bounds__(256) void prep_weights_kernel(PrepParams p) {
+    const float c = cv_scale_of(*p.wmax);
+    const long K16 = p.cin / 16, units = (long)(p.cout / 128) * K16 * 9 * 2 * 128;
+    const long u = (long)blockIdx.x * 256 + threadIdx.x;
+    if (u == 0) *p.wscale = c;
+    if (u >= units) return;
+    const int co = (int)(u % 128);
+    long r = u / 128;
+    const int khalf = (int)(r % 2);
+    r /= 2;
+    const int kx = (int)(r % 3);
+    r /= 3;
+    const int ky = (int)(r % 3);
+    r /= 3;
+    const int k16 = (int)(r % K16), ct = (int)(r / K16);
+    const int sy = p.flip ? 2 - ky : ky, sx = p.flip ? 2 - kx : kx;
+    const float* src = p.w + (long)(ct * 128 + co) * p.s_co + (long)(k16 * 16 + khalf * 8) * p.s_ci + sy * p.s_ky + sx * p.s_kx;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = src[i * p.s_ci] * c;
+    u32x4 h, l;
+    cv_split(v, h, l);
+    const long base = ((((long)(ct * K16 + k16) * 3 + ky) * 3 + kx) * 2) * 256 + khalf * 128 + co;
+    p.wp[base] = h;
+    p.wp[base + 256] = l;
+}
+
+static bool conv3_dims_ok(int n, int h, int w, int cin, int cout) {
+    if (n < 1 || h < 1 || w < 1 || cin < 32 || cout < 128 || cin % 32 || cout % 128) return false;
+    // byte offsets inside one tile's rows stay below 2^31
+    if ((long long)(CV_PS + 1) * w * (cin > cout ? cin : cout) * 4 >= 0x7FFFFFF0ll) return false;
+    const long long tiles = (long long)n * ((h + CV_TS - 1) / CV_TS) * ((w + CV_TS - 1) / CV_TS) * (cout / 128);
+    return tiles < 0x7FFFFFFFll / 64 && (long long)cout * cin * 9 * 4 < 0x7FFFFFF0ll;
+}
+
+}  // namespace sbmc
+
+using namespace sbmc;
+
+extern "C" int sbmc_conv3x3_supported(int n, int h, int w, int cin, int cout) {
+    return conv3_dims_ok(n, h, w, cin, cout) ? 1 : 0;
+}
+
+extern "C" size_t sbmc_conv3x3_weights_bytes(int cin, int cout) {
+    if (cin < 32 || cout < 128 || cin % 32 || cout % 128) return 0;
+    // prepared planes + [scale, bit pattern of the largest magnitude]
+    return (size_t)(cout / 128) * (cin / 16) * 3 * CV_WSTAGE * 16 + 16;
+}
+
+extern "C" int sbmc_conv3x3_absmax_f32(const float* x, long n, unsigned* out, void* stream) {
+    if (n < 0 || (n && !x) || !out || (uintptr_t)x % 16) return SBMC_HIP_EINVAL;
+    hipError_t e = hipMemsetAsync(out, 0, 4, (hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    if (n == 0) return 0;
+    long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_conv3x3_prepare_weights_f32(const float* w, long s_co, long s_ci, long s_ky, long s_kx,
+                                                 long storage_elems, int cin, int cout, int flip, void* wp,
+                                                 void* stream) {
+    const size_t bytes = sbmc_conv3x3_weights_bytes(cin, cout);
+    if (!bytes || !w || !wp || (uintptr_t)wp % 16 || (uintptr_t)w % 16 || storage_elems < 1) return SBMC_HIP_EINVAL;
+    char* tail = static_cast<char*>(wp) + bytes - 16;
+    float* wscale = reinterpret_cast<float*>(tail);
+    unsigned* wmax = reinterpret_cast<unsigned*>(tail + 4);
+    int rc = sbmc_conv3x3_absmax_f32(w, storage_elems, wmax, stream);
+    if (rc != 0) return rc;
+    PrepParams p;
+    p.w = w; p.s_co = s_co; p.s_ci = s_ci; p.s_ky = s_ky; p.s_kx = s_kx;
+    p.cout = cout; p.cin = cin; p.flip = flip; p.wmax = wmax;
+    p.wp = static_cast<u32x4*>(wp); p.wscale = wscale;
+    const long units = (long)(cout / 128) * (cin / 16) * 9 * 2 * 128;
+    hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_conv3x3_nhwc_f32(const float* x, const unsigned* xmax, const void* wp, float* y, int n, int h,
+                                      int w, int cin, int cout, void* stream) {
+    if (!conv3_dims_ok(n, h, w, cin, cout) || !x || !xmax || !wp || !y) return SBMC_HIP_EINVAL;
+    if ((uintptr_t)x % 16 || (uintptr_t)wp % 16) return SBMC_HIP_EINVAL;
+    Conv3Params p;
+    p.x = x; p.wp = static_cast<const u32x4*>(wp); p.y = y; p.xmax = xmax;
+    p.wscale = reinterpret_cast<const float*>(static_cast<const char*>(wp) + sbmc_conv3x3_weights_bytes(cin, cout) - 16);
+    p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout;
+    p.tiles_x = (w + CV_TS - 1) / CV_TS; p.tiles_y = (h + CV_TS - 1) / CV_TS; p.ncot = cout / 128;
+    p.ntiles = (unsigned)((long long)n * p.tiles_y * p.tiles_x * p.ncot);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        hipError_t de = hipGetDevice(&dev);
+        if (de == hipSuccess) de = hipGetDeviceProperties(&prop, dev);
+        if (de != hipSuccess) { (void)hipGetLastError(); return (int)de; }
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    unsigned grid = p.ntiles < (unsigned)cus ? p.ntiles : (unsigned)cus;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    hipLaunchKernelGGL(conv3_kernel, dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,106 @@
+"""The split-precision 3 x 3 convolution against MIOpen's fp32 solver: values (vs float64) and time.
+
+    python tools/conv3x3_experiment.py [--shapes 720p|all] [--reps 10]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch as th
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sbmc_amd  # noqa: E402,F401  (installs the MIOpen find records)
+from sbmc_amd import _lib  # noqa: E402
+
+
+def prepare(w, flip=False):
+    lib = _lib.lib()
+    cout, cin = w.shape[:2]
+    if flip:
+        cout, cin = cin, cout
+    nbytes = lib.sbmc_conv3x3_weights_bytes(cin, cout)
+    assert nbytes, (cin, cout)
+    wp = th.empty(nbytes, dtype=th.uint8, device=w.device)
+    s = w.stride()
+    s_co, s_ci = (s[1], s[0]) if flip else (s[0], s[1])
+    _lib.check(lib.sbmc_conv3x3_prepare_weights_f32(_lib.ptr(w), s_co, s_ci, s[2], s[3], w.numel(), cin, cout,
+                                                     1 if flip else 0, _lib.ptr(wp), _lib.current_stream(th.device("cuda"))), "prepare")
+    return wp
+
+
+def conv(x_nhwc, wp, cout, xmax=None):
+    lib = _lib.lib()
+    n, h, w, cin = x_nhwc.shape
+    if xmax is None:
+        xmax = th.empty(1, dtype=th.int32, device=x_nhwc.device)
+        _lib.check(lib.sbmc_conv3x3_absmax_f32(_lib.ptr(x_nhwc), x_nhwc.numel(), _lib.ptr(xmax), _lib.current_stream(th.device("cuda"))), "absmax")
+    y = th.empty(n, h, w, cout, dtype=th.float32, device=x_nhwc.device)
+    _lib.check(lib.sbmc_conv3x3_nhwc_f32(_lib.ptr(x_nhwc), _lib.ptr(xmax), _lib.ptr(wp), _lib.ptr(y), n, h, w, cin, cout,
+                                         _lib.current_stream(th.device("cuda"))), "conv3x3")
+    return y, xmax
+
+
+def timed(fn, reps):
+    for _ in range(2):
+        fn()
+    th.cuda.synchronize()
+    a, b = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    th.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="720p")
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    dev = th.device("cuda")
+    th.manual_seed(1)
+    # small: values against float64 (odd sizes: edge tiles)
+    for (h, w, cin, cout) in [(37, 53, 32, 128), (16, 16, 64, 128), (40, 70, 128, 256)]:
+        x = th.randn(1, cin, h, w, device=dev) * 3.0
+        wt = th.randn(cout, cin, 3, 3, device=dev) * 0.05
+        ref = F.conv2d(x.double(), wt.double(), padding=1)
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        y, _ = conv(xn, prepare(wt), cout)
+        y = y.permute(0, 3, 1, 2)
+        mi = F.conv2d(x.contiguous(memory_format=th.channels_last), wt.contiguous(memory_format=th.channels_last), padding=1)
+        scale = ref.abs().max().item()
+        print("values %3dx%3d %3d->%3d: ours %.3e  MIOpen fp32 %.3e  (max abs error / max |ref|)" % (
+            h, w, cin, cout, (y.double() - ref).abs().max().item() / scale, (mi.double() - ref).abs().max().item() / scale))
+        # adjoint weights: gx = conv(gy, flipped transposed w)
+        gy = th.randn(1, cout, h, w, device=dev)
+        gref = th.nn.grad.conv2d_input(x.shape, wt.double(), gy.double(), padding=1)
+        if cin % 128 == 0 and cout % 32 == 0:
+            gx, _ = conv(gy.permute(0, 2, 3, 1).contiguous(), prepare(wt, flip=True), cin)
+            print("   adjoint: %.3e" % ((gx.permute(0, 3, 1, 2).double() - gref).abs().max().item() / gref.abs().max().item()))
+    shapes = [(720, 1280, 128, 128)]
+    if args.shapes == "all":
+        shapes += [(720, 1280, 384, 128), (360, 640, 128, 256), (360, 640, 256, 256), (360, 640, 768, 256),
+                   (180, 320, 256, 512), (180, 320, 512, 512)]
+    for (h, w, cin, cout) in shapes:
+        x = th.randn(1, cin, h, w, device=dev).contiguous(memory_format=th.channels_last)
+        wt = (th.randn(cout, cin, 3, 3, device=dev) * 0.05).contiguous(memory_format=th.channels_last)
+        xn = x.permute(0, 2, 3, 1)
+        assert xn.is_contiguous()
+        wp = prepare(wt)
+        y, xmax = conv(xn, wp, cout)
+        mi = F.conv2d(x, wt, padding=1)
+        err = (y.permute(0, 3, 1, 2) - mi).abs().max().item() / mi.abs().max().item()
+        t_mi = timed(lambda: F.conv2d(x, wt, padding=1), args.reps)
+        t_us = timed(lambda: conv(xn, wp, cout, xmax), args.reps)
+        t_all = timed(lambda: conv(xn, prepare(wt), cout), args.reps)
+        gf = 2.0 * h * w * cin * cout * 9 / 1e9
+        print("%4dx%4d %3d->%3d: MIOpen %.3f ms (%.0f TFLOP/s)  ours %.3f ms (%.0f TFLOP/s fp32-equivalent, %.0f f16)  "
+              "with absmax+prepare %.3f ms   diff %.2e" % (h, w, cin, cout, t_mi, gf / t_mi, t_us, gf / t_us,
+                                                          3 * gf / t_us, t_all, err))
+
+
+if __name__ == "__main__":
+    main()
