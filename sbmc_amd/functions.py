@@ -847,6 +847,85 @@ class BiasActNHWC(th.autograd.Function):
         return gx, partial.sum(0), None, None
 
 
+class Conv3x3NHWC(th.autograd.Function):
+    """3 x 3 convolution (stride 1, zero padding 1, no bias) of a channels-last fp32 activation: the U-nets'
+    convolutions (reference sbmc/modules.py:195-320 through ttools' ConvChain -> cuDNN) on csrc/conv3x3.hip --
+    fp32 accuracy from three f16 matrix products per term, ~2.8x MIOpen's fp32 solver.  The data gradient is the
+    same kernel on the mirrored, transposed weights; the weight gradient stays with MIOpen (for now).
+
+    SBMC_CONV3X3=0 keeps every convolution on MIOpen."""
+
+    @staticmethod
+    def supported(x, conv):
+        if os.environ.get("SBMC_CONV3X3", "1") in ("0", "off", "no"):
+            return False
+        if not (isinstance(conv, th.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+                and conv.padding_mode == "zeros"):
+            return False
+        if not (x.is_cuda and x.dtype == th.float32 and x.numel() > 0 and _is_channels_last(x)
+                and x.data_ptr() % 16 == 0 and x.shape[1] == conv.in_channels):
+            return False
+        b, c, h, w = x.shape
+        L = _lib.lib()
+        # (the adjoint runs the kernel with the channel counts exchanged)
+        return bool(L.sbmc_conv3x3_supported(b, h, w, c, conv.out_channels)
+                    and L.sbmc_conv3x3_supported(b, h, w, conv.out_channels, c))
+
+    @staticmethod
+    def _prepare(w, flip):
+        """The weights' two f16 planes in the kernel's stage order (and their scale), on the device."""
+        L = _lib.lib()
+        cout, cin = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
+        if w.data_ptr() % 16 or not (w.is_contiguous() or w.is_contiguous(memory_format=th.channels_last)):
+            w = w.contiguous()
+        s = w.stride()
+        wp = th.empty(L.sbmc_conv3x3_weights_bytes(cin, cout), dtype=th.uint8, device=w.device)
+        s_co, s_ci = (s[1], s[0]) if flip else (s[0], s[1])
+        _lib.check(L.sbmc_conv3x3_prepare_weights_f32(_lib.ptr(w), s_co, s_ci, s[2], s[3], w.numel(), cin, cout,
+                                                      1 if flip else 0, _lib.ptr(wp), _lib.current_stream(w.device)),
+                   "conv3x3_prepare_weights")
+        return wp
+
+    @staticmethod
+    def _conv(x, wp, cout):
+        """x [b, cin, h, w] in channels-last memory order -> [b, cout, h, w], the same order."""
+        L = _lib.lib()
+        b, cin, h, w = x.shape
+        dev = x.device
+        xmax = th.empty(1, dtype=th.int32, device=dev)
+        y = th.empty((b, cout, h, w), dtype=th.float32, device=dev, memory_format=th.channels_last)
+        _lib.check(L.sbmc_conv3x3_absmax_f32(_lib.ptr(x), x.numel(), _lib.ptr(xmax), _lib.current_stream(dev)),
+                   "conv3x3_absmax")
+        _lib.check(L.sbmc_conv3x3_nhwc_f32(_lib.ptr(x), _lib.ptr(xmax), _lib.ptr(wp), _lib.ptr(y), b, h, w, cin, cout,
+                                           _lib.current_stream(dev)), "conv3x3_nhwc")
+        return y
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _require_f32("Conv3x3NHWC", x=x, w=w)
+        with th.cuda.device(x.device), _timed("conv3x3_fwd", x.device):
+            y = Conv3x3NHWC._conv(x, Conv3x3NHWC._prepare(w, False), w.shape[0])
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=th.channels_last)
+        gx = gw = None
+        with th.cuda.device(gy.device):
+            if ctx.needs_input_grad[0]:
+                with _timed("conv3x3_bwd_data", gy.device):
+                    gx = Conv3x3NHWC._conv(gy, Conv3x3NHWC._prepare(w, True), w.shape[1])
+            if ctx.needs_input_grad[1]:
+                with _timed("conv3x3_bwd_weight", gy.device):
+                    wcl = w.contiguous(memory_format=th.channels_last)      # (MIOpen's NHWC solver, as before)
+                    gw = th.ops.aten.convolution_backward(gy, x, wcl, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                          [False, True, False])[1]
+        return gx, gw
+
+
 def upsample_cat_nhwc_supported(coarse, left, top=0, bot=0):
     """fp32, or fp16 (the U-nets under torch.autocast(float16)) channels-last tensors of one dtype."""
     return (coarse.is_cuda and left.is_cuda and coarse.dtype in (th.float32, th.float16) and left.dtype == coarse.dtype

@@ -321,8 +321,11 @@ class ConvChain(nn.Module):
         if funcs._is_channels_last(x):
             # the U-net runs channels-last (Autoencoder.forward): MIOpen's NHWC solvers without any layout
             # change around them, bias + activation by the NHWC pass
-            w = w.contiguous(memory_format=th.channels_last)
-            y = th.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if funcs.Conv3x3NHWC.supported(x, conv):
+                y = funcs.Conv3x3NHWC.apply(x, w)             # csrc/conv3x3.hip: fp32 values on the f16 matrix pipe
+            else:
+                w = w.contiguous(memory_format=th.channels_last)
+                y = th.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
             if funcs.BiasActNHWC.supported(y):
                 return funcs.BiasActNHWC.apply(y, conv.bias, act, slope), act != 0
             return y + conv.bias.view(1, -1, 1, 1), False
