@@ -574,6 +574,15 @@ SBMC_API int sbmc_conv3x3_prepare_weights_f32(const float *w, long s_co, long s_
                                      long storage_elems, int cin, int cout, int flip, void *wp, void *stream);
 SBMC_API int sbmc_conv3x3_nhwc_f32(const float *x, const unsigned *xmax, const void *wp, float *y, int n, int h,
                           int w, int cin, int cout, void *stream);
+/* Weight gradient of the same convolution: gw[co][ci][ky][kx] (element strides s_*) = sum over the pixels of
+ * gy[n][y][x][co] x[n][y + ky - 1][x + kx - 1][ci]; gmax / xmax: the tensors' largest magnitudes as written by
+ * sbmc_conv3x3_absmax_f32; scratch: wgrad_scratch_bytes of device memory (partial sums of the pixel ranges,
+ * added in a fixed order: the result does not depend on the run).  cin % 128 == 0, cout % 128 == 0. */
+SBMC_API int sbmc_conv3x3_wgrad_supported(int n, int h, int w, int cin, int cout);
+SBMC_API size_t sbmc_conv3x3_wgrad_scratch_bytes(int n, int h, int w, int cin, int cout);
+SBMC_API int sbmc_conv3x3_wgrad_f32(const float *gy, const unsigned *gmax, const float *x, const unsigned *xmax,
+                           float *gw, long s_co, long s_ci, long s_ky, long s_kx, void *scratch, int n, int h,
+                           int w, int cin, int cout, void *stream);
 
 #ifdef __cplusplus
 }

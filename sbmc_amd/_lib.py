@@ -93,6 +93,9 @@ SYMBOLS = (
     "sbmc_conv3x3_absmax_f32",
     "sbmc_conv3x3_prepare_weights_f32",
     "sbmc_conv3x3_nhwc_f32",
+    "sbmc_conv3x3_wgrad_supported",
+    "sbmc_conv3x3_wgrad_scratch_bytes",
+    "sbmc_conv3x3_wgrad_f32",
 )
 ABI_VERSION = 4
 MAX_CHANNELS = 8
@@ -218,10 +221,14 @@ def lib():
     handle.sbmc_conv3x3_absmax_f32.argtypes = [p, lg, p, p]
     handle.sbmc_conv3x3_prepare_weights_f32.argtypes = [p, lg, lg, lg, lg, lg, i, i, i, p, p]
     handle.sbmc_conv3x3_nhwc_f32.argtypes = [p, p, p, p, i, i, i, i, i, p]
+    handle.sbmc_conv3x3_wgrad_supported.argtypes = [i] * 5
+    handle.sbmc_conv3x3_wgrad_scratch_bytes.argtypes = [i] * 5
+    handle.sbmc_conv3x3_wgrad_f32.argtypes = [p, p, p, p, p, lg, lg, lg, lg, p, i, i, i, i, i, p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_halo_bytes.restype = ctypes.c_size_t
     handle.sbmc_conv3x3_weights_bytes.restype = ctypes.c_size_t
+    handle.sbmc_conv3x3_wgrad_scratch_bytes.restype = ctypes.c_size_t
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t
     if handle.sbmc_hip_abi_version() != ABI_VERSION:
         raise HipExtensionMissing("ABI version mismatch: rebuild with `python -m sbmc_amd.build --force`")

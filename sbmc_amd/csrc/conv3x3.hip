@@ -428,3 +428,279 @@ extern "C" int sbmc_conv3x3_nhwc_f32(const float* x, const unsigned* xmax, const
     hipLaunchKernelGGL(conv3_kernel, dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
+
+// =============================================================================================================
+// Weight gradient:  gw[co][ci][ky][kx] = sum over pixels  gy[n][y][x][co] * x[n][y + ky - 1][x + kx - 1][ci]
+//
+// A GEMM whose REDUCTION runs over the pixels: the matrix instruction wants 8 consecutive pixels of one channel
+// per lane, the channels-last image has them Cin floats apart.  The staging does the transposition: a thread owns
+// one channel (lane = channel: every global load of a wave is 256 contiguous bytes of one pixel) and 8 pixels of
+// a row, splits them and writes ONE 16-byte entry per plane, [plane][pixel octet][channel] in LDS -- conflict
+// free both ways.  The tap's column shift kx - 1 breaks the octets' alignment, so the x row is kept in three
+// copies, one per kx (same registers, three packings); the row shift ky - 1 is simply another image row.
+//   * a workgroup owns 128 output x 128 input channels x the 3 taps of ONE kernel row ky (a wave: 64 x 64 x 3 =
+//     12 accumulators of 32 x 32 -- 9 taps would be 288 registers, more than the 256 accumulation registers) and
+//     a contiguous range of ROW STAGES (32 pixels of one image row: 2 k-steps of 16); the three ky workgroups of
+//     a range are neighbours on one XCD and read the same rows through its L2;
+//   * per k-step a wave reads 4 gy operands + 12 x operands for 36 MFMAs (0.44 of the LDS bandwidth at full
+//     matrix rate); the next stage's rows are in flight meanwhile;
+//   * the ranges' partial sums go to a scratch buffer and a second kernel adds them in a FIXED order (no
+//     atomics: the result does not depend on the run) and scales back.
+namespace sbmc {
+
+constexpr int WG_TW = 32;                       // pixels of a row stage
+constexpr int WG_OCT = WG_TW / 8;
+constexpr int WG_G = 2 * WG_OCT * 128;          // entries of a gy row: [plane][octet][co 128]
+constexpr int WG_X = 3 * 2 * WG_OCT * 128;      // entries of an x row: [kx][plane][octet][ci 128]
+constexpr unsigned WG_LDS_BYTES = (2 * WG_G + 2 * WG_X) * 16;      // 131072
+constexpr int WG_TILE = 128 * 128 * 3;          // outputs of a workgroup
+
+struct WgradParams {
+    const float* gy;         // [N, H, W, Cout]
+    const float* x;          // [N, H, W, Cin]
+    float* partial;          // [combo][split][WG_TILE]
+    const unsigned* gmax;    // bit patterns of max |gy|, max |x|
+    const unsigned* xmax;
+    int N, H, W, Cin, Cout;
+    int nstrips, ncot, ncit, nsplit;
+    unsigned long long total;   // row stages: N * nstrips * H
+};
+
+__device__ __forceinline__ unsigned cv_pack_hh(_Float16 a, _Float16 b) {
+    h2 v;
+    v[0] = a;
+    v[1] = b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+__global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
+    extern __shared__ float4 cv_lds[];
+    u32x4* Gs = reinterpret_cast<u32x4*>(cv_lds);       // [2][WG_G]
+    u32x4* Xs = Gs + 2 * WG_G;                          // [2][WG_X]
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const float cg = cv_scale_of(*p.gmax), cx = cv_scale_of(*p.xmax);
+
+    const unsigned logical = logical_block_id();
+    const int ncombo = p.ncot * p.ncit * 3;
+    const int combo = (int)(logical % (unsigned)ncombo), split = (int)(logical / (unsigned)ncombo);
+    const int ky = combo % 3, cit = (combo / 3) % p.ncit, cot = combo / (3 * p.ncit);
+    const unsigned long long t0 = p.total * (unsigned)split / (unsigned)p.nsplit;
+    const unsigned long long t1 = p.total * (unsigned)(split + 1) / (unsigned)p.nsplit;
+
+    // ---- loaders: a wave owns pixel octet `wave` of the stage, a lane two channels (lane, lane + 64) ----
+    float gr[2][8], xr[2][10];
+    auto issue = [&](unsigned long long t) {
+        const int y = (int)(t % (unsigned)p.H);
+        const unsigned long long rest = t / (unsigned)p.H;
+        const int x0 = (int)(rest % (unsigned)p.nstrips) * WG_TW, n = (int)(rest / (unsigned)p.nstrips);
+        {
+            const float* row = p.gy + ((long)n * p.H + y) * (long)p.W * p.Cout + cot * 128;
+            const rsrc_t r = cv_rsrc(row, 0x7FFFFFF0u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int px = x0 + 8 * wave + j;                          // wave-uniform
+                const bool in = px < p.W;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    gr[q][j] = buf_load(r, in ? (unsigned)(lane + 64 * q) * 4u : CV_OOB, in ? (unsigned)(px * p.Cout) * 4u : 0u);
+            }
+        }
+        {
+            const int yy = y + ky - 1;                                     // (outside the image: zeros)
+            const bool rowin = yy >= 0 && yy < p.H;
+            const float* row = p.x + ((long)n * p.H + (rowin ? yy : 0)) * (long)p.W * p.Cin + cit * 128;
+            const rsrc_t r = cv_rsrc(row, 0x7FFFFFF0u);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int px = x0 + 8 * wave - 1 + j;
+                const bool in = rowin && px >= 0 && px < p.W;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    xr[q][j] = buf_load(r, in ? (unsigned)(lane + 64 * q) * 4u : CV_OOB, in ? (unsigned)(px * p.Cin) * 4u : 0u);
+            }
+        }
+    };
+    auto commit = [&](int par) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gr[q][j] * cg;
+            u32x4 hh, ll;
+            cv_split(v, hh, ll);
+            u32x4* d = Gs + par * WG_G + wave * 128 + lane + 64 * q;
+            d[0] = hh;
+            d[WG_OCT * 128] = ll;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            _Float16 h[10], l[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const float v = xr[q][j] * cx;
+                h[j] = (_Float16)v;
+                l[j] = (_Float16)(v - (float)h[j]);
+            }
+            u32x4* d = Xs + par * WG_X + wave * 128 + lane + 64 * q;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                u32x4 hh, ll;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hh[i] = cv_pack_hh(h[kx + 2 * i], h[kx + 2 * i + 1]);
+                    ll[i] = cv_pack_hh(l[kx + 2 * i], l[kx + 2 * i + 1]);
+                }
+                d[(kx * 2 + 0) * WG_OCT * 128] = hh;
+                d[(kx * 2 + 1) * WG_OCT * 128] = ll;
+            }
+        }
+    };
+
+    f32x16 acc[2][2][3];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][kx][r] = 0.f;
+
+    if (t0 < t1) {
+        issue(t0);
+        commit(0);
+    }
+    __syncthreads();
+    int par = 0;
+    for (unsigned long long t = t0; t < t1; ++t) {
+        const bool pre = t + 1 < t1;
+        if (pre) issue(t + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4* Gb = Gs + par * WG_G + (2 * ks + lhi) * 128 + wm * 64 + l31;
+            const u32x4* Xb = Xs + par * WG_X + (2 * ks + lhi) * 128 + wn * 64 + l31;
+            u32x4 ah[2], al[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                ah[mi] = Gb[mi * 32];
+                al[mi] = Gb[WG_OCT * 128 + mi * 32];
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                u32x4 bh[2], bl[2];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    bh[ni] = Xb[(kx * 2 + 0) * WG_OCT * 128 + ni * 32];
+                    bl[ni] = Xb[(kx * 2 + 1) * WG_OCT * 128 + ni * 32];
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(ah[mi], bh[ni], acc[mi][ni][kx]);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(ah[mi], bl[ni], acc[mi][ni][kx]);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(al[mi], bh[ni], acc[mi][ni][kx]);
+            }
+        }
+        if (pre) commit(par ^ 1);
+        par ^= 1;
+        cv_lds_barrier();
+    }
+
+    // ---- partial sums of this pixel range: [wave][mi][ni][kx][r][lane] ----
+    float* out = p.partial + ((size_t)combo * p.nsplit + split) * WG_TILE + (size_t)wave * (12 * 16 * 64) + lane;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) out[(((mi * 2 + ni) * 3 + kx) * 16 + r) * 64] = acc[mi][ni][kx][r];
+}
+
+struct WreduceParams {
+    const float* partial;
+    float* gw;
+    long s_co, s_ci, s_ky, s_kx;
+    const unsigned* gmax;
+    const unsigned* xmax;
+    int ncit, nsplit;
+};
+__global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(WreduceParams p) {
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;              // element of the workgroup tile
+    const int combo = blockIdx.y;
+    if (e >= (unsigned)WG_TILE) return;
+    const float* src = p.partial + (size_t)combo * p.nsplit * WG_TILE + e;
+    float s = 0.f;
+    for (int i = 0; i < p.nsplit; ++i) s += src[(size_t)i * WG_TILE];
+    const float oscale = (1.f / cv_scale_of(*p.gmax)) * (1.f / cv_scale_of(*p.xmax));
+    const int lane = e & 63, r = (e >> 6) & 15;
+    const int rest = e >> 10, kx = rest % 3, ni = (rest / 3) & 1, mi = (rest / 6) & 1, wave = rest / 12;
+    const int ky = combo % 3, cit = (combo / 3) % p.ncit, cot = combo / (3 * p.ncit);
+    const int co = cot * 128 + (wave & 1) * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int ci = cit * 128 + (wave >> 1) * 64 + ni * 32 + (lane & 31);
+    p.gw[co * p.s_co + ci * p.s_ci + ky * p.s_ky + kx * p.s_kx] = s * oscale;
+}
+
+static bool wgrad_dims_ok(int n, int h, int w, int cin, int cout) {
+    if (n < 1 || h < 1 || w < 1 || cin < 128 || cout < 128 || cin % 128 || cout % 128) return false;
+    if ((long long)w * (cin > cout ? cin : cout) * 4 >= 0x7FFFFFF0ll) return false;
+    return (cout / 128) * (cin / 128) * 3 <= 256 && (long long)n * h * ((w + WG_TW - 1) / WG_TW) < (1ll << 40);
+}
+static int wgrad_splits(int cin, int cout, long long total) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+        else { (void)hipGetLastError(); cus = 256; }
+    }
+    const int ncombo = (cout / 128) * (cin / 128) * 3;
+    long long s = cus / ncombo;
+    s = s < 1 ? 1 : s;
+    return (int)(s > total ? total : s);
+}
+
+}  // namespace sbmc
+
+extern "C" int sbmc_conv3x3_wgrad_supported(int n, int h, int w, int cin, int cout) {
+    return wgrad_dims_ok(n, h, w, cin, cout) ? 1 : 0;
+}
+extern "C" size_t sbmc_conv3x3_wgrad_scratch_bytes(int n, int h, int w, int cin, int cout) {
+    if (!wgrad_dims_ok(n, h, w, cin, cout)) return 0;
+    const long long total = (long long)n * h * ((w + WG_TW - 1) / WG_TW);
+    return (size_t)(cout / 128) * (cin / 128) * 3 * wgrad_splits(cin, cout, total) * WG_TILE * 4;
+}
+extern "C" int sbmc_conv3x3_wgrad_f32(const float* gy, const unsigned* gmax, const float* x, const unsigned* xmax,
+                                       float* gw, long s_co, long s_ci, long s_ky, long s_kx, void* scratch, int n,
+                                       int h, int w, int cin, int cout, void* stream) {
+    if (!wgrad_dims_ok(n, h, w, cin, cout) || !gy || !gmax || !x || !xmax || !gw || !scratch) return SBMC_HIP_EINVAL;
+    if ((uintptr_t)gy % 16 || (uintptr_t)x % 16 || (uintptr_t)scratch % 16) return SBMC_HIP_EINVAL;
+    WgradParams p;
+    p.gy = gy; p.x = x; p.partial = static_cast<float*>(scratch); p.gmax = gmax; p.xmax = xmax;
+    p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout;
+    p.nstrips = (w + WG_TW - 1) / WG_TW; p.ncot = cout / 128; p.ncit = cin / 128;
+    p.total = (unsigned long long)n * h * p.nstrips;
+    p.nsplit = wgrad_splits(cin, cout, (long long)p.total);
+    const int ncombo = p.ncot * p.ncit * 3;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    hipLaunchKernelGGL(conv3_wgrad_kernel, dim3((unsigned)(ncombo * p.nsplit)), dim3(256), WG_LDS_BYTES, (hipStream_t)stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    WreduceParams q;
+    q.partial = p.partial; q.gw = gw; q.s_co = s_co; q.s_ci = s_ci; q.s_ky = s_ky; q.s_kx = s_kx;
+    q.gmax = gmax; q.xmax = xmax; q.ncit = p.ncit; q.nsplit = p.nsplit;
+    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(WG_TILE / 256, (unsigned)ncombo), dim3(256), 0, (hipStream_t)stream, q);
+    return (int)hipGetLastError();
+}

@@ -851,7 +851,8 @@ class Conv3x3NHWC(th.autograd.Function):
     """3 x 3 convolution (stride 1, zero padding 1, no bias) of a channels-last fp32 activation: the U-nets'
     convolutions (reference sbmc/modules.py:195-320 through ttools' ConvChain -> cuDNN) on csrc/conv3x3.hip --
     fp32 accuracy from three f16 matrix products per term, ~2.8x MIOpen's fp32 solver.  The data gradient is the
-    same kernel on the mirrored, transposed weights; the weight gradient stays with MIOpen (for now).
+    same kernel on the mirrored, transposed weights; the weight gradient a kernel of its own (a GEMM that reduces
+    over the pixels).
 
     SBMC_CONV3X3=0 keeps every convolution on MIOpen."""
 
@@ -888,41 +889,60 @@ class Conv3x3NHWC(th.autograd.Function):
         return wp
 
     @staticmethod
-    def _conv(x, wp, cout):
-        """x [b, cin, h, w] in channels-last memory order -> [b, cout, h, w], the same order."""
-        L = _lib.lib()
-        b, cin, h, w = x.shape
-        dev = x.device
-        xmax = th.empty(1, dtype=th.int32, device=dev)
-        y = th.empty((b, cout, h, w), dtype=th.float32, device=dev, memory_format=th.channels_last)
-        _lib.check(L.sbmc_conv3x3_absmax_f32(_lib.ptr(x), x.numel(), _lib.ptr(xmax), _lib.current_stream(dev)),
+    def _absmax(x):
+        """Bit pattern of the largest magnitude of x, on the device (the kernels derive their power-of-two scale
+        from it: no host synchronisation)."""
+        out = th.empty(1, dtype=th.int32, device=x.device)
+        _lib.check(_lib.lib().sbmc_conv3x3_absmax_f32(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.current_stream(x.device)),
                    "conv3x3_absmax")
-        _lib.check(L.sbmc_conv3x3_nhwc_f32(_lib.ptr(x), _lib.ptr(xmax), _lib.ptr(wp), _lib.ptr(y), b, h, w, cin, cout,
-                                           _lib.current_stream(dev)), "conv3x3_nhwc")
+        return out
+
+    @staticmethod
+    def _conv(x, xmax, wp, cout):
+        """x [b, cin, h, w] in channels-last memory order -> [b, cout, h, w], the same order."""
+        b, cin, h, w = x.shape
+        y = th.empty((b, cout, h, w), dtype=th.float32, device=x.device, memory_format=th.channels_last)
+        _lib.check(_lib.lib().sbmc_conv3x3_nhwc_f32(_lib.ptr(x), _lib.ptr(xmax), _lib.ptr(wp), _lib.ptr(y), b, h, w, cin,
+                                                    cout, _lib.current_stream(x.device)), "conv3x3_nhwc")
         return y
 
     @staticmethod
     def forward(ctx, x, w):
         _require_f32("Conv3x3NHWC", x=x, w=w)
         with th.cuda.device(x.device), _timed("conv3x3_fwd", x.device):
-            y = Conv3x3NHWC._conv(x, Conv3x3NHWC._prepare(w, False), w.shape[0])
-        ctx.save_for_backward(x, w)
+            xmax = Conv3x3NHWC._absmax(x)
+            y = Conv3x3NHWC._conv(x, xmax, Conv3x3NHWC._prepare(w, False), w.shape[0])
+        ctx.save_for_backward(x, w, xmax)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, xmax = ctx.saved_tensors
         gy = gy.contiguous(memory_format=th.channels_last)
+        b, cin, h, wd = x.shape
+        cout = w.shape[0]
         gx = gw = None
-        with th.cuda.device(gy.device):
+        L = _lib.lib()
+        dev = gy.device
+        with th.cuda.device(dev):
+            gmax = Conv3x3NHWC._absmax(gy)
             if ctx.needs_input_grad[0]:
-                with _timed("conv3x3_bwd_data", gy.device):
-                    gx = Conv3x3NHWC._conv(gy, Conv3x3NHWC._prepare(w, True), w.shape[1])
+                with _timed("conv3x3_bwd_data", dev):
+                    gx = Conv3x3NHWC._conv(gy, gmax, Conv3x3NHWC._prepare(w, True), cin)
             if ctx.needs_input_grad[1]:
-                with _timed("conv3x3_bwd_weight", gy.device):
-                    wcl = w.contiguous(memory_format=th.channels_last)      # (MIOpen's NHWC solver, as before)
-                    gw = th.ops.aten.convolution_backward(gy, x, wcl, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                          [False, True, False])[1]
+                with _timed("conv3x3_bwd_weight", dev):
+                    if (os.environ.get("SBMC_CONV3X3_WGRAD", "1") not in ("0", "off", "no")
+                            and L.sbmc_conv3x3_wgrad_supported(b, h, wd, cin, cout)):
+                        gw = th.empty((cout, cin, 3, 3), dtype=th.float32, device=dev, memory_format=th.channels_last)
+                        scratch = th.empty(L.sbmc_conv3x3_wgrad_scratch_bytes(b, h, wd, cin, cout), dtype=th.uint8, device=dev)
+                        s = gw.stride()
+                        _lib.check(L.sbmc_conv3x3_wgrad_f32(_lib.ptr(gy), _lib.ptr(gmax), _lib.ptr(x), _lib.ptr(xmax),
+                                                            _lib.ptr(gw), s[0], s[1], s[2], s[3], _lib.ptr(scratch), b, h,
+                                                            wd, cin, cout, _lib.current_stream(dev)), "conv3x3_wgrad")
+                    else:
+                        wcl = w.contiguous(memory_format=th.channels_last)      # (MIOpen's NHWC solver)
+                        gw = th.ops.aten.convolution_backward(gy, x, wcl, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                              [False, True, False])[1]
         return gx, gw
 
 

@@ -1,0 +1,172 @@
+"""The split-precision 3 x 3 convolution (csrc/conv3x3.hip) against torch's float64 convolution: forward, data
+gradient (the same kernel on mirrored weights) and weight gradient, through the C ABI and through the autograd
+function the U-nets use.  The fp32 library convolution (MIOpen) is the yardstick: ours must be no further from
+float64 than twice its error."""
+import os
+
+import pytest
+import torch as th
+import torch.nn.functional as F
+
+from sbmc_amd import _lib
+from sbmc_amd import functions as funcs
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not th.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return th.device("cuda")
+
+
+def _cl(t):
+    return t.contiguous(memory_format=th.channels_last)
+
+
+def _err(a, ref):
+    return (a.double() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-300)
+
+
+def _yardstick(x, w, gy):
+    """float64 results and the fp32 library's distance from them (forward, data gradient, weight gradient)."""
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, padding=1)
+    gxd, gwd = th.autograd.grad(yd, (xd, wd), gy.double())
+    xf, wf = _cl(x).clone().requires_grad_(True), _cl(w).clone().requires_grad_(True)
+    yf = F.conv2d(xf, wf, padding=1)
+    gxf, gwf = th.autograd.grad(yf, (xf, wf), _cl(gy))
+    return (yd.detach(), gxd, gwd), (_err(yf, yd.detach()), _err(gxf, gxd), _err(gwf, gwd))
+
+
+SHAPES = [
+    # b, cin, cout, h, w
+    (1, 128, 128, 16, 16),        # exactly one tile
+    (1, 128, 128, 37, 53),        # ragged: edge tiles in both directions, strips that end inside a stage
+    (2, 128, 256, 24, 40),        # batch of two, two output-channel tiles
+    (1, 384, 128, 19, 70),        # the U-net's skip concatenation
+    (1, 256, 128, 5, 3),          # smaller than a tile
+    (1, 128, 128, 1, 1),
+]
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w", SHAPES)
+def test_function_matches_float64(b, cin, cout, h, w):
+    dev = _dev()
+    g = th.Generator(device="cpu").manual_seed(b * 1000 + cin + h * w)
+    x = (th.randn(b, cin, h, w, generator=g) * 2.0).to(dev)
+    wt = (th.randn(cout, cin, 3, 3, generator=g) * 0.03).to(dev)
+    gy = th.randn(b, cout, h, w, generator=g).to(dev)
+    (yd, gxd, gwd), lib_err = _yardstick(x, wt, gy)
+    conv = th.nn.Conv2d(cin, cout, 3, padding=1).to(dev)
+    xs = _cl(x).clone().requires_grad_(True)
+    ws = wt.clone().requires_grad_(True)
+    if h * w == 1:
+        # (a 1 x 1 image is contiguous in both orders: the module path keeps such tensors planar)
+        assert not funcs.Conv3x3NHWC.supported(xs, conv)
+        return
+    assert funcs.Conv3x3NHWC.supported(xs, conv)
+    y = funcs.Conv3x3NHWC.apply(xs, ws)
+    assert y.is_contiguous(memory_format=th.channels_last)
+    gx, gw = th.autograd.grad(y, (xs, ws), _cl(gy))
+    for name, got, ref, yard in (("y", y, yd, lib_err[0]), ("gx", gx, gxd, lib_err[1]), ("gw", gw, gwd, lib_err[2])):
+        e = _err(got, ref)
+        assert e <= max(2.0 * yard, 2e-7), "%s: %.3e of the largest value (fp32 library: %.3e)" % (name, e, yard)
+
+
+def test_weight_gradient_is_reproducible():
+    """The pixel ranges' partial sums are added in a fixed order: two runs agree to the bit."""
+    dev = _dev()
+    x = _cl(th.randn(1, 128, 45, 77, device=dev))
+    wt = th.randn(128, 128, 3, 3, device=dev, requires_grad=True)
+    gy = _cl(th.randn(1, 128, 45, 77, device=dev))
+    xs = x.clone().requires_grad_(True)
+    a = th.autograd.grad(funcs.Conv3x3NHWC.apply(xs, wt), (xs, wt), gy)
+    b = th.autograd.grad(funcs.Conv3x3NHWC.apply(xs, wt), (xs, wt), gy)
+    assert th.equal(a[0], b[0]) and th.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-9, 1.0), (3e4, 1e-6), (1.0, 1e3)])
+def test_scales_follow_the_tensors(xs, ws):
+    """Gradients are ~1e-9, activations can be large: the power-of-two scales come from the tensors themselves."""
+    dev = _dev()
+    g = th.Generator(device="cpu").manual_seed(5)
+    x = (th.randn(1, 128, 20, 33, generator=g) * xs).to(dev)
+    wt = (th.randn(128, 128, 3, 3, generator=g) * ws).to(dev)
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    y = funcs.Conv3x3NHWC.apply(_cl(x), wt)
+    lib = F.conv2d(_cl(x), _cl(wt), padding=1)
+    assert _err(y, ref) <= max(2.0 * _err(lib, ref), 2e-7)
+
+
+def test_wide_dynamic_range_inside_a_tensor():
+    """Values 2^-17 and more below the tensor's largest keep an ABSOLUTE accuracy of 2^-39 of that largest value
+    (csrc/conv3x3.hip): a region of tiny values next to large ones stays within 1e-5 of ITS OWN scale down to
+    ~1e-6 of the tensor's maximum."""
+    dev = _dev()
+    g = th.Generator(device="cpu").manual_seed(9)
+    x = th.randn(1, 128, 32, 64, generator=g)
+    x[..., 32:] *= 1e-5                       # the right half: five decades below
+    x = x.to(dev)
+    wt = (th.randn(128, 128, 3, 3, generator=g) * 0.05).to(dev)
+    ref = F.conv2d(x.double(), wt.double(), padding=1)
+    y = funcs.Conv3x3NHWC.apply(_cl(x), wt)
+    far = (slice(None), slice(None), slice(None), slice(40, None))        # pixels that see only the small half
+    assert _err(y[far], ref[far]) <= 1e-5
+    assert _err(y, ref) <= 2e-6
+
+
+def test_zero_input_gives_zeros():
+    dev = _dev()
+    x = _cl(th.zeros(1, 128, 16, 20, device=dev))
+    wt = th.randn(128, 128, 3, 3, device=dev)
+    assert funcs.Conv3x3NHWC.apply(x, wt).abs().max().item() == 0.0
+
+
+def test_abi_rejects_unsupported_shapes():
+    _dev()
+    L = _lib.lib()
+    assert L.sbmc_conv3x3_supported(1, 8, 8, 128, 128) == 1
+    assert L.sbmc_conv3x3_supported(1, 8, 8, 48, 128) == 0          # input channels: multiples of 32
+    assert L.sbmc_conv3x3_supported(1, 8, 8, 128, 64) == 0          # output channels: multiples of 128
+    assert L.sbmc_conv3x3_weights_bytes(48, 128) == 0
+    assert L.sbmc_conv3x3_wgrad_supported(1, 8, 8, 64, 128) == 0
+    assert L.sbmc_conv3x3_wgrad_supported(1, 8, 8, 256, 128) == 1
+    assert L.sbmc_conv3x3_nhwc_f32(None, None, None, None, 1, 8, 8, 128, 128, None) == -1
+
+
+def test_unet_is_the_same_function_with_and_without_the_kernel(monkeypatch):
+    """One U-net (the model's own module) forward + backward, every convolution on MIOpen vs on the kernel:
+    both against float64."""
+    from sbmc_amd import modules as ops
+    dev = _dev()
+    th.manual_seed(3)
+    net = ops.Autoencoder(128, 128, num_levels=3, increase_factor=2.0, num_convs=3, width=128, ksize=3,
+                          output_type="leaky_relu", pooling="max").to(dev)
+    for m in net.modules():
+        if isinstance(m, ops.ConvChain):
+            m.fuse_bias_act = True
+    x = th.randn(1, 128, 48, 80, device=dev)
+    gy = th.randn(1, 128, 48, 80, device=dev)
+
+    def run(flag, dtype=th.float32):
+        monkeypatch.setenv("SBMC_CONV3X3", flag)
+        n = net if dtype == th.float32 else net.double()
+        xi = x.to(dtype).requires_grad_(True)
+        ps = [p for p in n.parameters()]
+        y = n(xi)
+        gs = th.autograd.grad(y, [xi] + ps, gy.to(dtype))
+        out = [y.detach().double()] + [g_.double() for g_ in gs]
+        if dtype != th.float32:
+            n.float()
+        return out
+
+    ours = run("1")
+    lib = run("0")
+    ref = run("0", th.float64)
+    worst = 0.0
+    for a, b, r in zip(ours, lib, ref):
+        ea, eb = _err(a, r), _err(b, r)
+        worst = max(worst, ea)
+        assert ea <= max(2.0 * eb, 1e-6), (ea, eb)
+    assert worst < 2e-5

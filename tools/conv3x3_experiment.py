@@ -97,6 +97,28 @@ def main():
         t_us = timed(lambda: conv(xn, wp, cout, xmax), args.reps)
         t_all = timed(lambda: conv(xn, prepare(wt), cout), args.reps)
         gf = 2.0 * h * w * cin * cout * 9 / 1e9
+        # weight gradient: ours (C ABI) against MIOpen's
+        lib = _lib.lib()
+        gy = th.randn(1, cout, h, w, device=dev).contiguous(memory_format=th.channels_last)
+        if lib.sbmc_conv3x3_wgrad_supported(1, h, w, cin, cout):
+            gmax = th.empty(1, dtype=th.int32, device=dev)
+            st = _lib.current_stream(dev)
+            _lib.check(lib.sbmc_conv3x3_absmax_f32(_lib.ptr(gy), gy.numel(), _lib.ptr(gmax), st), "absmax")
+            gw = th.empty((cout, cin, 3, 3), device=dev).contiguous(memory_format=th.channels_last)
+            scratch = th.empty(lib.sbmc_conv3x3_wgrad_scratch_bytes(1, h, w, cin, cout), dtype=th.uint8, device=dev)
+            sw = gw.stride()
+
+            def ours_w():
+                _lib.check(lib.sbmc_conv3x3_wgrad_f32(_lib.ptr(gy), _lib.ptr(gmax), _lib.ptr(xn), _lib.ptr(xmax), _lib.ptr(gw),
+                                                      sw[0], sw[1], sw[2], sw[3], _lib.ptr(scratch), 1, h, w, cin, cout, st), "wgrad")
+
+            def lib_w():
+                return th.ops.aten.convolution_backward(gy, x, wt, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [False, True, False])[1]
+            ours_w()
+            ref_w = lib_w()
+            werr = (gw - ref_w).abs().max().item() / ref_w.abs().max().item()
+            print("      weight gradient: MIOpen %.3f ms  ours %.3f ms  diff %.2e" % (timed(lib_w, args.reps), timed(ours_w, args.reps), werr))
         print("%4dx%4d %3d->%3d: MIOpen %.3f ms (%.0f TFLOP/s)  ours %.3f ms (%.0f TFLOP/s fp32-equivalent, %.0f f16)  "
               "with absmax+prepare %.3f ms   diff %.2e" % (h, w, cin, cout, t_mi, gf / t_mi, t_us, gf / t_us,
                                                           3 * gf / t_us, t_all, err))
