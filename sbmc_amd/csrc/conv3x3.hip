@@ -31,6 +31,7 @@
 // MFMAs here (0.5 of the LDS bandwidth at full matrix rate).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/sbmc_hip.h"
 #include "common.hpp"
 
@@ -45,9 +46,11 @@ using f2 = __attribute__((ext_vector_type(2))) float;
 constexpr int CV_TS = 16;                    // tile side (pixels)
 constexpr int CV_PS = CV_TS + 2;             // patch side
 constexpr int CV_PP = CV_PS * CV_PS;         // patch pixels (324)
-constexpr int CV_ABUF = 2 * 4 * CV_PP;       // 16-byte entries of one patch: [plane 2][octet 4][pixel]
+constexpr int CV_PR = CV_PP + 2;             // entries of one (plane, octet) region: 2 CV_PR = 4 (mod 8), so that the two
+                                             // octets a pair of staging lanes writes fall into different halves of 128 B
+constexpr int CV_ABUF = 2 * 4 * CV_PR;       // 16-byte entries of one patch: [plane 2][octet 4][pixel]
 constexpr int CV_WSTAGE = 3 * 2 * 2 * 128;   // 16-byte entries of one weight stage: [kx 3][plane 2][k half 2][cout 128]
-constexpr unsigned CV_LDS_BYTES = (2 * CV_ABUF + 2 * CV_WSTAGE) * 16;   // 132096
+constexpr unsigned CV_LDS_BYTES = (2 * CV_ABUF + 3 * CV_WSTAGE) * 16;   // 156672 of the CU's 163840
 constexpr int CV_AROUNDS = (2 * CV_PP + 255) / 256;                     // staging rounds: (pixel, 16 channels) units
 constexpr unsigned CV_OOB = 0xFFFFFFF0u;
 
@@ -102,6 +105,7 @@ struct Conv3Params {
     unsigned ntiles;         // N * tiles_y * tiles_x * ncot
 };
 
+template <int DBG>
 __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     extern __shared__ float4 cv_lds[];
     u32x4* As = reinterpret_cast<u32x4*>(cv_lds);
@@ -109,6 +113,11 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int l31 = lane & 31, lhi = lane >> 5;
     const int mh = wave & 1, nh = wave >> 1;
+    // Row i of a 32 x 32 block is pixel (i / 16, column) of the block's 2 rows x 16 columns.  ds_read_b128 serves
+    // lanes {0-3, 12-15, 20-27} (and so on) together: with the patch rows 18 entries apart, the second row's
+    // lanes must be rotated by 18 mod 16 = 2 columns for every such group to cover 16 different 16-byte slots of
+    // the 256-byte bank row: lane 16 + j reads column (j + 14) mod 16.
+    const int pcol = (l31 + 14 * (l31 >> 4)) & 15;
     const float cx = cv_scale_of(*p.xmax);
     const float oscale = (1.f / cx) * (1.f / *p.wscale);
     const unsigned nchunks = (unsigned)p.Cin / 32u;
@@ -118,9 +127,9 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     const unsigned my_tiles = first < p.ntiles ? (p.ntiles - first + stride - 1) / stride : 0;
     const unsigned total = my_tiles * nchunks;
     struct Tile { int n, y0, x0, ct; };
-    auto tile_of = [&](unsigned h) -> Tile {
+    auto tile_at = [&](unsigned i) -> Tile {
         // output-channel tiles of one pixel tile are neighbours in the walk (they read the same patch)
-        const unsigned t = first + (h / nchunks) * stride;
+        const unsigned t = first + i * stride;
         Tile r;
         r.ct = (int)(t % (unsigned)p.ncot);
         const unsigned pt = t / (unsigned)p.ncot;
@@ -130,12 +139,13 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         r.n = (int)(rest / (unsigned)p.tiles_y);
         return r;
     };
+    // the tile of the current chunk and the one after it (the divisions above: once per tile, not per stage)
+    Tile tcur = tile_at(0), tnext = tile_at(1);
+    unsigned cc = 0;                                    // chunk of the current tile
 
     // ---- staging of a patch: unit u = (pixel u / 2, channels 16 (u % 2) ..), 64 contiguous bytes ----
     float areg[CV_AROUNDS][16];
-    auto issue_a = [&](unsigned h) {
-        const Tile t = tile_of(h);
-        const unsigned cc = h % nchunks;
+    auto issue_a = [&](const Tile& t, unsigned cc) {
         const float* xb = p.x + (((long)t.n * p.H + (t.y0 - 1)) * (long)p.W + (t.x0 - 1)) * (long)p.Cin;
         const rsrc_t rx = cv_rsrc(xb, 0x7FFFFFF0u);
 #pragma unroll
@@ -156,31 +166,31 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
             }
         }
     };
-    auto commit_a = [&](int abuf) {
+    auto commit_a_round = [&](int abuf, int j) {
+        const int u = tid + 256 * j, q = u >> 1, half = u & 1;
+        if (u < 2 * CV_PP) {
 #pragma unroll
-        for (int j = 0; j < CV_AROUNDS; ++j) {
-            const int u = tid + 256 * j, q = u >> 1, half = u & 1;
-            if (u < 2 * CV_PP) {
+            for (int o = 0; o < 2; ++o) {
+                float v[8];
 #pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    float v[8];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] = areg[j][8 * o + c] * cx;
-                    u32x4 hh, ll;
-                    cv_split(v, hh, ll);
-                    u32x4* d = As + abuf * CV_ABUF + (2 * half + o) * CV_PP + q;
-                    d[0] = hh;
-                    d[4 * CV_PP] = ll;
-                }
+                for (int c = 0; c < 8; ++c) v[c] = areg[j][8 * o + c] * cx;
+                u32x4 hh, ll;
+                cv_split(v, hh, ll);
+                u32x4* d = As + abuf * CV_ABUF + (2 * half + o) * CV_PR + q;
+                d[0] = hh;
+                d[4 * CV_PR] = ll;
             }
         }
     };
-    // ---- staging of a weight stage (h, st): 1536 entries, 6 per thread ----
-    u32x4 wreg[6];
+    auto commit_a = [&](int abuf) {
+#pragma unroll
+        for (int j = 0; j < CV_AROUNDS; ++j) commit_a_round(abuf, j);
+    };
+    // ---- staging of a weight stage (h, st): 1536 entries, 6 per thread; two register sets: a stage's loads are
+    // in flight for two stages ----
+    u32x4 wregA[6], wregB[6];
     const rsrc_t rw = cv_rsrc(p.wp, (unsigned)p.ncot * ((unsigned)p.Cin / 16u) * 3u * (unsigned)CV_WSTAGE * 16u);
-    auto issue_w = [&](unsigned h, int st) {
-        const Tile t = tile_of(h);
-        const unsigned cc = h % nchunks;
+    auto issue_w = [&](u32x4 (&wreg)[6], const Tile& t, unsigned cc, int st) {
         const unsigned k16 = cc * 2u + (unsigned)(st / 3), ky = (unsigned)(st % 3);
         const unsigned block = ((unsigned)t.ct * ((unsigned)p.Cin / 16u) + k16) * 3u + ky;
 #pragma unroll
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
             wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(tid + 256 * i) * 16u,
                                                             block * (unsigned)(CV_WSTAGE * 16), 0);
     };
-    auto commit_w = [&](int wbuf) {
+    auto commit_w = [&](const u32x4 (&wreg)[6], int wbuf) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) Ws[wbuf * CV_WSTAGE + tid + 256 * i] = wreg[i];
     };
@@ -202,11 +212,6 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     if (total == 0) return;
-    issue_a(0);
-    issue_w(0, 0);
-    commit_a(0);
-    commit_w(0);
-    __syncthreads();
 
     // operands of one tap: A 4 m-blocks x 2 planes, B 2 n-blocks x 2 planes
     struct Ops { u32x4 ah[4], al[4], bh[2], bl[2]; };
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             o.ah[mi] = Ab[mi * 2 * CV_PS + kx];
-            o.al[mi] = Ab[4 * CV_PP + mi * 2 * CV_PS + kx];
+            o.al[mi] = Ab[4 * CV_PR + mi * 2 * CV_PS + kx];
         }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -236,35 +241,81 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.al[mi], o.bh[ni], acc[mi][ni]);
     };
+    // The next tap's 12 operand fetches go BETWEEN the current tap's 24 MFMAs (2 MFMAs, 1 fetch, ...): left to
+    // itself the compiler sinks them to just before their first use and the matrix pipe waits for LDS every tap.
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
+        }
+    };
+    // LDS addresses of stage st of chunk h for this lane (tap kx adds kx / 512 kx entries)
+    auto a_ptr = [&](unsigned h, int st) -> const u32x4* {
+        return As + (int)(h & 1u) * CV_ABUF + (2 * (st / 3) + lhi) * CV_PR + (mh * 8 + (l31 >> 4) + st % 3) * CV_PS + pcol;
+    };
+    auto w_ptr = [&](int st) -> const u32x4* { return Ws + (st % 3) * CV_WSTAGE + lhi * 128 + nh * 64 + l31; };
+
+    // Pipeline.  Stage s = 6 h + st reads weight buffer s % 3 (= st % 3: a chunk has 6 stages).  The weights of
+    // stage s + 3 are REQUESTED at the start of stage s (register set (s + 1) % 2), those of stage s + 2 are
+    // WRITTEN to LDS at its end (set s % 2; buffer (s + 2) % 3, last read in stage s - 1, i.e. before the previous
+    // barrier), so every stage finds its weights -- and its patch: written in stage 3 of the previous chunk --
+    // in LDS one whole stage early, and the operands of its first tap are fetched during the last tap of the
+    // stage before: after a barrier the matrix pipe continues at once.
+    issue_a(tcur, 0);
+    issue_w(wregA, tcur, 0, 0);
+    issue_w(wregB, tcur, 0, 1);
+    commit_a(0);
+    commit_w(wregA, 0);
+    commit_w(wregB, 1);
+    __syncthreads();
+    issue_w(wregA, tcur, 0, 2);
+    Ops o0, o1;
+    load_ops(o0, a_ptr(0, 0), w_ptr(0), 0);
 
     for (unsigned h = 0; h < total; ++h) {
-        const int abuf = (int)(h & 1u);
         const bool more = h + 1 < total;
-        if (more) issue_a(h + 1);
-#pragma unroll
-        for (int st = 0; st < 6; ++st) {
-            const int kk = st / 3, ky = st % 3, wbuf = st & 1;
-            const bool next_w = st < 5 || more;
-            if (next_w) {
-                if (st < 5) issue_w(h, st + 1);
-                else issue_w(h + 1, 0);
+        const bool last = cc + 1 == nchunks;               // the next chunk opens the next tile
+        const Tile tn = last ? tnext : tcur;
+        const unsigned ccn = last ? 0u : cc + 1;
+        // (the patch of the next chunk: requested in stage 2 AFTER that stage's weight request -- loads return in
+        // order, and no weight stage may have to wait for the patch's HBM burst -- and written, round by round
+        // between the taps' MFMAs, in stage 4: visible when stage 5 fetches the next chunk's first operands)
+        auto stage = [&](Ops& cur, Ops& other, u32x4 (&wfill)[6], const u32x4 (&wdone)[6], const int st) {
+            if (!(DBG & 2)) {
+                if (st < 3) issue_w(wfill, tcur, cc, st + 3);
+                else if (more) issue_w(wfill, tn, ccn, st - 3);
             }
-            const u32x4* Ab = As + abuf * CV_ABUF + (2 * kk + lhi) * CV_PP + (mh * 8 + (l31 >> 4) + ky) * CV_PS + (l31 & 15);
-            const u32x4* Wb = Ws + wbuf * CV_WSTAGE + lhi * 128 + nh * 64 + l31;
-            Ops o0, o1;
-            load_ops(o0, Ab, Wb, 0);
-            load_ops(o1, Ab, Wb, 1);
-            mfmas(o0);
-            load_ops(o0, Ab, Wb, 2);
-            mfmas(o1);
-            mfmas(o0);
-            if (st == 3 && more) commit_a(abuf ^ 1);
-            if (next_w) commit_w(wbuf ^ 1);
-            cv_lds_barrier();
-        }
-        if (h % nchunks == nchunks - 1) {
+            if (!(DBG & 4) && !(DBG & 32) && st == 2 && more) issue_a(tn, ccn);
+            const bool ca = !(DBG & 4) && !(DBG & 16) && st == 4;
+            const int nbuf = (int)((h + 1) & 1u);
+            const u32x4* Ab = a_ptr(h, st);
+            const u32x4* Wb = w_ptr(st);
+            load_ops(other, Ab, Wb, 1);
+            mfmas(cur);
+            interleave();
+            if (ca) commit_a_round(nbuf, 0);
+            load_ops(cur, Ab, Wb, 2);
+            mfmas(other);
+            interleave();
+            if (ca) commit_a_round(nbuf, 1);
+            if (st < 5) load_ops(other, a_ptr(h, st + 1), w_ptr(st + 1), 0);
+            else if (more) load_ops(other, a_ptr(h + 1, 0), w_ptr(0), 0);
+            mfmas(cur);
+            interleave();
+            if (ca) commit_a_round(nbuf, 2);
+            if (!(DBG & 2)) commit_w(wdone, (st + 2) % 3);
+            if (!(DBG & 1)) cv_lds_barrier();
+        };
+        stage(o0, o1, wregB, wregA, 0);
+        stage(o1, o0, wregA, wregB, 1);
+        stage(o0, o1, wregB, wregA, 2);
+        stage(o1, o0, wregA, wregB, 3);
+        stage(o0, o1, wregB, wregA, 4);
+        stage(o1, o0, wregA, wregB, 5);
+        if (!(DBG & 8) && last) {
             // ---- the tile is complete: scale back, store, clear ----
-            const Tile t = tile_of(h);
+            const Tile t = tcur;
             float* yb = p.y + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)p.Cout + t.ct * 128;
             const rsrc_t ry = cv_rsrc(yb, 0x7FFFFFF0u);
 #pragma unroll
@@ -274,7 +325,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
                     // accumulator register r of a 32 x 32 block: pixel (r & 3) + 8 (r >> 2) + 4 (lane / 32) of the
                     // block's 2 rows x 16 columns; output channel lane % 32
                     const int row = mh * 8 + mi * 2 + (r >> 3);
-                    const int col = (r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi;
+                    const int col = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi + 14 * (r >> 3)) & 15;     // (the rotation above)
                     const bool ok = t.y0 + row < p.H && t.x0 + col < p.W;
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
@@ -284,6 +335,13 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
                     }
                 }
             }
+        }
+        if (last) {
+            tcur = tnext;
+            tnext = tile_at(h / nchunks + 2);
+            cc = 0;
+        } else {
+            ++cc;
         }
     }
 }
@@ -422,10 +480,25 @@ extern "C" int sbmc_conv3x3_nhwc_f32(const float* x, const unsigned* xmax, const
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     unsigned grid = p.ntiles < (unsigned)cus ? p.ntiles : (unsigned)cus;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel),
+    const char* dbg = getenv("SBMC_CONV3_DBG");
+    const int d = dbg ? atoi(dbg) : 0;
+    auto kern = conv3_kernel<0>;
+    switch (d) {
+        case 1: kern = conv3_kernel<1>; break;
+        case 2: kern = conv3_kernel<2>; break;
+        case 4: kern = conv3_kernel<4>; break;
+        case 6: kern = conv3_kernel<6>; break;
+        case 7: kern = conv3_kernel<7>; break;
+        case 8: kern = conv3_kernel<8>; break;
+        case 15: kern = conv3_kernel<15>; break;
+        case 16: kern = conv3_kernel<16>; break;
+        case 32: kern = conv3_kernel<32>; break;
+        default: break;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
-    hipLaunchKernelGGL(conv3_kernel, dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 
@@ -490,8 +563,8 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     const unsigned long long t1 = p.total * (unsigned)(split + 1) / (unsigned)p.nsplit;
 
     // ---- loaders: a wave owns pixel octet `wave` of the stage, a lane two channels (lane, lane + 64) ----
-    float gr[2][8], xr[2][10];
-    auto issue = [&](unsigned long long t) {
+    struct Rows { float g[2][8], x[2][10]; };
+    auto issue = [&](Rows& rr, unsigned long long t) {
         const int y = (int)(t % (unsigned)p.H);
         const unsigned long long rest = t / (unsigned)p.H;
         const int x0 = (int)(rest % (unsigned)p.nstrips) * WG_TW, n = (int)(rest / (unsigned)p.nstrips);
@@ -504,7 +577,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
                 const bool in = px < p.W;
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-                    gr[q][j] = buf_load(r, in ? (unsigned)(lane + 64 * q) * 4u : CV_OOB, in ? (unsigned)(px * p.Cout) * 4u : 0u);
+                    rr.g[q][j] = buf_load(r, in ? (unsigned)(lane + 64 * q) * 4u : CV_OOB, in ? (unsigned)(px * p.Cout) * 4u : 0u);
             }
         }
         {
@@ -518,16 +591,16 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
                 const bool in = rowin && px >= 0 && px < p.W;
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-                    xr[q][j] = buf_load(r, in ? (unsigned)(lane + 64 * q) * 4u : CV_OOB, in ? (unsigned)(px * p.Cin) * 4u : 0u);
+                    rr.x[q][j] = buf_load(r, in ? (unsigned)(lane + 64 * q) * 4u : CV_OOB, in ? (unsigned)(px * p.Cin) * 4u : 0u);
             }
         }
     };
-    auto commit = [&](int par) {
+    auto commit = [&](const Rows& rr, int par) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = gr[q][j] * cg;
+            for (int j = 0; j < 8; ++j) v[j] = rr.g[q][j] * cg;
             u32x4 hh, ll;
             cv_split(v, hh, ll);
             u32x4* d = Gs + par * WG_G + wave * 128 + lane + 64 * q;
@@ -539,7 +612,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
             _Float16 h[10], l[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
-                const float v = xr[q][j] * cx;
+                const float v = rr.x[q][j] * cx;
                 h[j] = (_Float16)v;
                 l[j] = (_Float16)(v - (float)h[j]);
             }
@@ -568,50 +641,83 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][kx][r] = 0.f;
 
+    // operands: gy (A) per k-step, x (B) per (k-step, kx) sub-step
+    struct OpA { u32x4 h[2], l[2]; };
+    struct OpB { u32x4 h[2], l[2]; };
+    auto load_a = [&](OpA& o, int par, int ks) {
+        const u32x4* Gb = Gs + par * WG_G + (2 * ks + lhi) * 128 + wm * 64 + l31;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            o.h[mi] = Gb[mi * 32];
+            o.l[mi] = Gb[WG_OCT * 128 + mi * 32];
+        }
+    };
+    auto load_b = [&](OpB& o, int par, int ks, int kx) {
+        const u32x4* Xb = Xs + par * WG_X + (2 * ks + lhi) * 128 + wn * 64 + l31;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            o.h[ni] = Xb[(kx * 2 + 0) * WG_OCT * 128 + ni * 32];
+            o.l[ni] = Xb[(kx * 2 + 1) * WG_OCT * 128 + ni * 32];
+        }
+    };
+    auto mfmas = [&](const OpA& a, const OpB& b, int kx) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(a.h[mi], b.h[ni], acc[mi][ni][kx]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(a.h[mi], b.l[ni], acc[mi][ni][kx]);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(a.l[mi], b.h[ni], acc[mi][ni][kx]);
+    };
+
+    // Pipeline.  Stage k (= t - t0) lives in LDS buffer k % 2.  Its rows are REQUESTED at the start of stage
+    // k - 2 (register set k % 2) and WRITTEN in the middle of stage k - 1, between two barriers: the first makes
+    // them visible, the second -- at the end of stage k - 1 -- frees the other buffer.  Operands are fetched one
+    // sub-step (12 MFMAs) ahead, across both barriers: the matrix pipe never waits for LDS after a barrier.
+    Rows r0, r1;
     if (t0 < t1) {
-        issue(t0);
-        commit(0);
+        issue(r0, t0);
+        if (t0 + 1 < t1) issue(r1, t0 + 1);
+        commit(r0, 0);
     }
     __syncthreads();
-    int par = 0;
-    for (unsigned long long t = t0; t < t1; ++t) {
-        const bool pre = t + 1 < t1;
-        if (pre) issue(t + 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const u32x4* Gb = Gs + par * WG_G + (2 * ks + lhi) * 128 + wm * 64 + l31;
-            const u32x4* Xb = Xs + par * WG_X + (2 * ks + lhi) * 128 + wn * 64 + l31;
-            u32x4 ah[2], al[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                ah[mi] = Gb[mi * 32];
-                al[mi] = Gb[WG_OCT * 128 + mi * 32];
-            }
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                u32x4 bh[2], bl[2];
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    bh[ni] = Xb[(kx * 2 + 0) * WG_OCT * 128 + ni * 32];
-                    bl[ni] = Xb[(kx * 2 + 1) * WG_OCT * 128 + ni * 32];
-                }
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(ah[mi], bh[ni], acc[mi][ni][kx]);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(ah[mi], bl[ni], acc[mi][ni][kx]);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(al[mi], bh[ni], acc[mi][ni][kx]);
-            }
-        }
-        if (pre) commit(par ^ 1);
-        par ^= 1;
+    OpA a0, a1;
+    OpB b0, b1;
+    if (t0 < t1) {
+        load_a(a0, 0, 0);
+        load_b(b0, 0, 0, 0);
+    }
+    auto stage = [&](unsigned long long t, Rows& fill, const Rows& done, const int par) {
+        const bool next = t + 1 < t1;
+        if (t + 2 < t1) issue(fill, t + 2);
+        load_b(b1, par, 0, 1);
+        mfmas(a0, b0, 0);
+        load_b(b0, par, 0, 2);
+        mfmas(a0, b1, 1);
+        load_a(a1, par, 1);
+        load_b(b1, par, 1, 0);
+        mfmas(a0, b0, 2);
+        if (next) commit(done, par ^ 1);
         cv_lds_barrier();
+        load_b(b0, par, 1, 1);
+        mfmas(a1, b1, 0);
+        load_b(b1, par, 1, 2);
+        mfmas(a1, b0, 1);
+        if (next) {
+            load_a(a0, par ^ 1, 0);
+            load_b(b0, par ^ 1, 0, 0);
+        }
+        mfmas(a1, b1, 2);
+        cv_lds_barrier();
+    };
+    for (unsigned long long t = t0; t < t1; t += 2) {
+        stage(t, r0, r1, 0);
+        if (t + 1 < t1) stage(t + 1, r1, r0, 1);
     }
 
     // ---- partial sums of this pixel range: [wave][mi][ni][kx][r][lane] ----
