@@ -479,6 +479,14 @@ SBMC_API int sbmc_bias_act_nhwc_fwd_signs_f32(float *y, const float *bias, unsig
                                      int act, float slope, void *stream);
 SBMC_API int sbmc_bias_act_nhwc_bwd_signs_f32(const float *gy, const unsigned *signs, float *gx, float *partial,
                                      long pixels, int c, int act, float slope, void *stream);
+/* The two passes above which also leave, in *amax, the bit pattern of the largest magnitude of what they wrote
+ * (y / gx): the 3 x 3 convolution that consumes it (sbmc_conv3x3_*) takes its scale from there instead of running
+ * sbmc_conv3x3_absmax_f32 over the tensor.  fwd: signs may be NULL (no sign bits; act 0 allowed);
+ * bwd: signs NULL <=> act 0. */
+SBMC_API int sbmc_bias_act_nhwc_fwd_amax_f32(float *y, const float *bias, unsigned *signs, unsigned *amax, long pixels,
+                                    int c, int act, float slope, void *stream);
+SBMC_API int sbmc_bias_act_nhwc_bwd_amax_f32(const float *gy, const unsigned *signs, float *gx, float *partial,
+                                    unsigned *amax, long pixels, int c, int act, float slope, void *stream);
 SBMC_API int sbmc_upsample2x_cat_nhwc_supported(int cu, int cl, int h, int w);
 SBMC_API int sbmc_upsample2x_cat_nhwc_fwd_f32(const float *coarse, const float *left, float *out, int b, int cu,
                                      int cl, int h, int w, void *stream);

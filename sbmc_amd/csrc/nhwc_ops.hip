@@ -37,18 +37,49 @@ template <> struct Quad<_Float16> {
     }
 };
 
+
+// Largest magnitude seen by a wave -> *amax (bit pattern; magnitudes order like unsigned integers).  The 3 x 3
+// convolution that consumes the tensor takes its power-of-two scale from it (csrc/conv3x3.hip): the producer's
+// pass finds it on the way instead of a pass of its own.
+__device__ __forceinline__ unsigned abits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu; }
+__device__ __forceinline__ unsigned amax4(unsigned m, const float4& v) {
+    const unsigned a = abits(v.x), b = abits(v.y), c = abits(v.z), d = abits(v.w);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+    return m > q ? m : q;
+}
+__device__ __forceinline__ void amax_publish(unsigned m, unsigned* amax) {
+    __shared__ unsigned wave_max[16];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, s, 64);
+        m = m > o ? m : o;
+    }
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup at most -- and none once the word already holds something at least as large (a
+    // stale read only costs a superfluous atomic): a hundred thousand waves on one address would take a millisecond
+    if (threadIdx.x == 0) {
+        for (unsigned w = 1; w < (blockDim.x + 63) / 64; ++w) m = m > wave_max[w] ? m : wave_max[w];
+        if (m > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, m);
+    }
+}
+
 // y [pixels, C] in place; one thread = one float4 of channels of one pixel
 __global__ __launch_bounds__(256) void bias_act_nhwc_fwd_kernel(float* __restrict__ y, const float* __restrict__ bias,
-                                                               size_t total4, int c4n, float slope, int linear) {
+                                                               size_t total4, int c4n, float slope, int linear,
+                                                               unsigned* __restrict__ amax) {
     float4* y4 = reinterpret_cast<float4*>(y);
     const float4* b4 = reinterpret_cast<const float4*>(bias);
+    unsigned m = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 bv = b4[i % (size_t)c4n];
         float4 v = y4[i];
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
         if (!linear) { v.x = nact(v.x, slope); v.y = nact(v.y, slope); v.z = nact(v.z, slope); v.w = nact(v.w, slope); }
         y4[i] = v;
+        m = amax4(m, v);
     }
+    if (amax) amax_publish(m, amax);
 }
 
 // The same forward that also records one SIGN BIT per element (pre-activation > 0): thread i owns float4 number i,
@@ -56,10 +87,11 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_fwd_kernel(float* __restric
 // 1 bit instead of 32 per element for the activation adjoint: two streams instead of three.
 __global__ __launch_bounds__(256) void bias_act_nhwc_fwd_signs_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                                      unsigned* __restrict__ signs, size_t total4,
-                                                                     int c4n, float slope) {
+                                                                     int c4n, float slope, unsigned* __restrict__ amax) {
     float4* y4 = reinterpret_cast<float4*>(y);
     const float4* b4 = reinterpret_cast<const float4*>(bias);
     const size_t n8 = (total4 + 7) & ~(size_t)7;      // (the 8 lanes of a word run the same iterations)
+    unsigned m = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
         const bool ok = i < total4;
         unsigned bits = 0;
@@ -70,6 +102,7 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_fwd_signs_kernel(float* __r
             bits = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
             v.x = nact(v.x, slope); v.y = nact(v.y, slope); v.z = nact(v.z, slope); v.w = nact(v.w, slope);
             y4[i] = v;
+            m = amax4(m, v);
         }
         unsigned word = bits << (4 * (threadIdx.x & 7));
         word |= __shfl_xor(word, 1);
@@ -77,6 +110,7 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_fwd_signs_kernel(float* __r
         word |= __shfl_xor(word, 4);
         if ((threadIdx.x & 7) == 0) signs[i >> 3] = word;
     }
+    if (amax) amax_publish(m, amax);
 }
 
 // gx = gy * act'(y); partial[chunk, C] = this workgroup's sums of gx per channel.
@@ -85,8 +119,10 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_fwd_signs_kernel(float* __r
 template <bool SG>
 __global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                float* __restrict__ gx, float* __restrict__ partial,
-                                                               size_t pixels, int c4n, float slope, int linear) {
+                                                               size_t pixels, int c4n, float slope, int linear,
+                                                               unsigned* __restrict__ amax) {
     __shared__ float4 red[256];
+    unsigned m = 0;
     const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n, npl = 256 / c4n;
     const size_t per = (pixels + gridDim.x - 1) / gridDim.x;
     const size_t p0 = (size_t)blockIdx.x * per;
@@ -109,7 +145,9 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __r
         }
         if (store) reinterpret_cast<float4*>(gx)[i] = g;
         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        m = amax4(m, g);
     }
+    if (amax) amax_publish(m, amax);
     red[threadIdx.x] = acc;
     __syncthreads();
     if (pl == 0) {
@@ -280,7 +318,7 @@ extern "C" int sbmc_bias_act_nhwc_fwd_f32(float* y, const float* bias, long pixe
     if (!y || !bias || !sbmc_bias_act_nhwc_supported(c) || (uintptr_t)y % 16 || (uintptr_t)bias % 16) return SBMC_HIP_EINVAL;
     const size_t total4 = (size_t)pixels * (c / 4);
     hipLaunchKernelGGL(bias_act_nhwc_fwd_kernel, dim3(grid_for(total4 / 4 + 1)), dim3(256), 0, (hipStream_t)stream, y,
-                       bias, total4, c / 4, act == 1 ? 0.f : slope, act == 0);
+                       bias, total4, c / 4, act == 1 ? 0.f : slope, act == 0, (unsigned*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -291,7 +329,8 @@ extern "C" int sbmc_bias_act_nhwc_bwd_f32(const float* gy, const float* y, float
     if (!gy || !y || !gx || !partial || !sbmc_bias_act_nhwc_supported(c)) return SBMC_HIP_EINVAL;
     if ((uintptr_t)gy % 16 || (uintptr_t)y % 16 || (uintptr_t)gx % 16 || (uintptr_t)partial % 16) return SBMC_HIP_EINVAL;
     hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel<false>, dim3((unsigned)sbmc_bias_act_nhwc_chunks(pixels, c)), dim3(256), 0,
-                       (hipStream_t)stream, gy, y, gx, partial, (size_t)pixels, c / 4, act == 1 ? 0.f : slope, act == 0);
+                       (hipStream_t)stream, gy, y, gx, partial, (size_t)pixels, c / 4, act == 1 ? 0.f : slope, act == 0,
+                       (unsigned*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -303,7 +342,7 @@ extern "C" int sbmc_bias_act_nhwc_fwd_signs_f32(float* y, const float* bias, uns
         (uintptr_t)signs % 4) return SBMC_HIP_EINVAL;
     const size_t total4 = (size_t)pixels * (c / 4);
     hipLaunchKernelGGL(bias_act_nhwc_fwd_signs_kernel, dim3(grid_for(total4 / 4 + 1)), dim3(256), 0, (hipStream_t)stream,
-                       y, bias, signs, total4, c / 4, act == 1 ? 0.f : slope);
+                       y, bias, signs, total4, c / 4, act == 1 ? 0.f : slope, (unsigned*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -315,7 +354,47 @@ extern "C" int sbmc_bias_act_nhwc_bwd_signs_f32(const float* gy, const unsigned*
     if ((uintptr_t)gy % 16 || (uintptr_t)signs % 4 || (uintptr_t)gx % 16 || (uintptr_t)partial % 16) return SBMC_HIP_EINVAL;
     hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel<true>, dim3((unsigned)sbmc_bias_act_nhwc_chunks(pixels, c)), dim3(256), 0,
                        (hipStream_t)stream, gy, reinterpret_cast<const float*>(signs), gx, partial, (size_t)pixels, c / 4,
-                       act == 1 ? 0.f : slope, 0);
+                       act == 1 ? 0.f : slope, 0, (unsigned*)nullptr);
+    return (int)hipGetLastError();
+}
+
+// The same two passes, also leaving the bit pattern of the result's largest magnitude in *amax (see amax_publish):
+// fwd with or without sign bits (signs == nullptr: act may be 0), bwd reading sign bits (act 1 / 2) or nothing
+// (act 0: signs == nullptr).
+extern "C" int sbmc_bias_act_nhwc_fwd_amax_f32(float* y, const float* bias, unsigned* signs, unsigned* amax, long pixels,
+                                               int c, int act, float slope, void* stream) {
+    if (pixels < 0 || c < 0 || act < 0 || act > 2 || !amax || (signs && act == 0)) return SBMC_HIP_EINVAL;
+    hipError_t e = hipMemsetAsync(amax, 0, 4, (hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    if (pixels == 0 || c == 0) return 0;
+    if (!y || !bias || !sbmc_bias_act_nhwc_supported(c) || (uintptr_t)y % 16 || (uintptr_t)bias % 16 ||
+        (uintptr_t)signs % 4) return SBMC_HIP_EINVAL;
+    const size_t total4 = (size_t)pixels * (c / 4);
+    if (signs)
+        hipLaunchKernelGGL(bias_act_nhwc_fwd_signs_kernel, dim3(grid_for(total4 / 4 + 1)), dim3(256), 0, (hipStream_t)stream,
+                           y, bias, signs, total4, c / 4, act == 1 ? 0.f : slope, amax);
+    else
+        hipLaunchKernelGGL(bias_act_nhwc_fwd_kernel, dim3(grid_for(total4 / 4 + 1)), dim3(256), 0, (hipStream_t)stream, y,
+                           bias, total4, c / 4, act == 1 ? 0.f : slope, act == 0, amax);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_bias_act_nhwc_bwd_amax_f32(const float* gy, const unsigned* signs, float* gx, float* partial,
+                                               unsigned* amax, long pixels, int c, int act, float slope, void* stream) {
+    if (pixels < 0 || c < 0 || act < 0 || act > 2 || !amax || ((signs == nullptr) != (act == 0))) return SBMC_HIP_EINVAL;
+    hipError_t e = hipMemsetAsync(amax, 0, 4, (hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    if (pixels == 0 || c == 0) return 0;
+    if (!gy || !gx || !partial || !sbmc_bias_act_nhwc_supported(c)) return SBMC_HIP_EINVAL;
+    if ((uintptr_t)gy % 16 || (uintptr_t)signs % 4 || (uintptr_t)gx % 16 || (uintptr_t)partial % 16) return SBMC_HIP_EINVAL;
+    const unsigned grid = (unsigned)sbmc_bias_act_nhwc_chunks(pixels, c);
+    if (signs)
+        hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gy,
+                           reinterpret_cast<const float*>(signs), gx, partial, (size_t)pixels, c / 4, act == 1 ? 0.f : slope, 0,
+                           amax);
+    else
+        hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, gy, gy, gx, partial,
+                           (size_t)pixels, c / 4, slope, 1, amax);
     return (int)hipGetLastError();
 }
 

@@ -803,7 +803,9 @@ class BiasActNHWC(th.autograd.Function):
                 and y.data_ptr() % 16 == 0 and bool(_lib.lib().sbmc_bias_act_nhwc_supported(int(y.shape[1]))))
 
     @staticmethod
-    def forward(ctx, y, bias, act, slope):
+    def forward(ctx, y, bias, act, slope, want_amax=False):
+        """want_amax: also returns the device word with the bit pattern of max |y| (the pass finds it on the way; the
+        3 x 3 convolution that reads y next scales by it: `tag_amax`)."""
         _require_f32("BiasActNHWC", y=y, bias=bias)
         b, c, h, w = y.shape
         bias = bias.contiguous()
@@ -813,8 +815,12 @@ class BiasActNHWC(th.autograd.Function):
         signs = None
         if act != 0 and any(ctx.needs_input_grad[:2]):
             signs = th.empty((y.numel() + 31) // 32, dtype=th.int32, device=dev)
+        amax = th.empty(1, dtype=th.int32, device=dev) if want_amax else None
         with th.cuda.device(dev):
-            if signs is not None:
+            if amax is not None:
+                rc = _lib.lib().sbmc_bias_act_nhwc_fwd_amax_f32(_lib.ptr(y), _lib.ptr(bias), _lib.ptr(signs), _lib.ptr(amax),
+                                                                b * h * w, c, act, slope, _lib.current_stream(dev))
+            elif signs is not None:
                 rc = _lib.lib().sbmc_bias_act_nhwc_fwd_signs_f32(_lib.ptr(y), _lib.ptr(bias), _lib.ptr(signs), b * h * w, c,
                                                                  act, slope, _lib.current_stream(dev))
             else:
@@ -825,26 +831,57 @@ class BiasActNHWC(th.autograd.Function):
         ctx.act, ctx.slope = act, slope
         if signs is not None:
             ctx.save_for_backward(signs)
+        if amax is not None:
+            ctx.mark_non_differentiable(amax)
+            return y, amax
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_):
         gy = gy.contiguous(memory_format=th.channels_last)
         b, c, h, w = gy.shape
         gx = th.empty_like(gy, memory_format=th.channels_last)
         L = _lib.lib()
         partial = gy.new_empty(L.sbmc_bias_act_nhwc_chunks(b * h * w, c), c)
         dev = gy.device
+        # (the largest magnitude of gx, for the convolution's data / weight gradient kernels that read it next)
+        amax = th.empty(1, dtype=th.int32, device=dev)
         with th.cuda.device(dev):
-            if ctx.act != 0:
-                rc = L.sbmc_bias_act_nhwc_bwd_signs_f32(_lib.ptr(gy), _lib.ptr(ctx.saved_tensors[0]), _lib.ptr(gx),
-                                                        _lib.ptr(partial), b * h * w, c, ctx.act, ctx.slope,
-                                                        _lib.current_stream(dev))
-            else:
-                rc = L.sbmc_bias_act_nhwc_bwd_f32(_lib.ptr(gy), _lib.ptr(gy), _lib.ptr(gx), _lib.ptr(partial),
-                                                  b * h * w, c, ctx.act, ctx.slope, _lib.current_stream(dev))
+            rc = L.sbmc_bias_act_nhwc_bwd_amax_f32(_lib.ptr(gy), _lib.ptr(ctx.saved_tensors[0]) if ctx.act != 0 else None,
+                                                   _lib.ptr(gx), _lib.ptr(partial), _lib.ptr(amax), b * h * w, c, ctx.act,
+                                                   ctx.slope, _lib.current_stream(dev))
         _lib.check(rc, "bias_act_nhwc_bwd")
-        return gx, partial.sum(0), None, None
+        tag_amax(gx, amax)
+        return gx, partial.sum(0), None, None, None
+
+
+def tag_amax(t, amax):
+    """Remembers ON THE TENSOR OBJECT the device word `amax` (int32 [1]: bit pattern of a float >= max |t|) that
+    the pass which produced `t` found on its way.  Valid only for this very object in this very state:
+    `known_amax` checks the version counter (any in-place change bumps it) and the storage address, and whoever
+    finds no tag runs csrc/conv3x3.hip's absmax pass instead -- a lost tag costs time, never accuracy."""
+    t._sbmc_amax = (amax, t._version, t.data_ptr())
+    return t
+
+
+def known_amax(t):
+    if os.environ.get("SBMC_AMAX_TAGS", "1") in ("0", "off", "no"):
+        return None
+    tag = getattr(t, "_sbmc_amax", None)
+    if tag is not None and tag[1] == t._version and tag[2] == t.data_ptr() and tag[0].device == t.device:
+        return tag[0]
+    return None
+
+
+def bound_amax(*amaxes):
+    """An upper bound of the largest magnitude of a tensor built from others without growing any value (max
+    pooling, bilinear interpolation, concatenation): the largest of theirs.  None if any is unknown."""
+    if not amaxes or any(a is None for a in amaxes):
+        return None
+    out = amaxes[0]
+    for a in amaxes[1:]:
+        out = th.maximum(out, a)            # (bit patterns of non-negative floats order like integers)
+    return out
 
 
 class Conv3x3NHWC(th.autograd.Function):
@@ -910,7 +947,9 @@ class Conv3x3NHWC(th.autograd.Function):
     def forward(ctx, x, w):
         _require_f32("Conv3x3NHWC", x=x, w=w)
         with th.cuda.device(x.device), _timed("conv3x3_fwd", x.device):
-            xmax = Conv3x3NHWC._absmax(x)
+            xmax = known_amax(x)
+            if xmax is None:
+                xmax = Conv3x3NHWC._absmax(x)
             y = Conv3x3NHWC._conv(x, xmax, Conv3x3NHWC._prepare(w, False), w.shape[0])
         ctx.save_for_backward(x, w, xmax)
         return y
@@ -925,7 +964,9 @@ class Conv3x3NHWC(th.autograd.Function):
         L = _lib.lib()
         dev = gy.device
         with th.cuda.device(dev):
-            gmax = Conv3x3NHWC._absmax(gy)
+            gmax = known_amax(gy)
+            if gmax is None:
+                gmax = Conv3x3NHWC._absmax(gy)
             if ctx.needs_input_grad[0]:
                 with _timed("conv3x3_bwd_data", dev):
                     gx = Conv3x3NHWC._conv(gy, gmax, Conv3x3NHWC._prepare(w, True), cin)

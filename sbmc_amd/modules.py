@@ -173,6 +173,25 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
 _LAYOUT_DECISIONS = {}
 
 
+def _convs_on_own_kernel(net, x):
+    """True if all spatial convolutions of `net` are 3 x 3 / stride 1 / padding 1 with channel counts the
+    split-precision kernel takes (functions.Conv3x3NHWC), at x's resolution or coarser."""
+    import os
+    if os.environ.get("SBMC_CONV3X3", "1") in ("0", "off", "no") or x.shape[2] * x.shape[3] < 2:
+        return False
+    convs = [m for m in net.modules() if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1)]
+    if not convs:
+        return False
+    L = funcs._lib.lib()
+    for m in convs:
+        if not (m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1)
+                and m.groups == 1 and m.padding_mode == "zeros"
+                and L.sbmc_conv3x3_supported(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), m.in_channels, m.out_channels)
+                and L.sbmc_conv3x3_supported(int(x.shape[0]), int(x.shape[2]), int(x.shape[3]), m.out_channels, m.in_channels)):
+            return False
+    return True
+
+
 def unet_channels_last(net, x, rows=None):
     """Should this U-net run channels-last on this input?  MEASURED, once per (channels, height, width,
     training?) and process: one 3x3 convolution of the net's width at the input's resolution, forward (and
@@ -189,6 +208,10 @@ def unet_channels_last(net, x, rows=None):
             or x.dtype not in (th.float32, th.float16) or (th.is_autocast_enabled() and not half)):
         return False
     if mode == "nhwc":
+        return True
+    if x.dtype == th.float32 and not half and _convs_on_own_kernel(net, x):
+        # every 3 x 3 convolution of the net runs on csrc/conv3x3.hip, which is channels-last by construction (and
+        # ~2-3x MIOpen's fp32 solvers in either layout): nothing to measure, no dependence on MIOpen's find-db
         return True
     grad = th.is_grad_enabled() and any(q.requires_grad for q in net.parameters())
     shape = (x.shape[0], x.shape[1], int(rows) if rows else x.shape[2], x.shape[3])
@@ -327,7 +350,9 @@ class ConvChain(nn.Module):
                 w = w.contiguous(memory_format=th.channels_last)
                 y = th.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
             if funcs.BiasActNHWC.supported(y):
-                return funcs.BiasActNHWC.apply(y, conv.bias, act, slope), act != 0
+                # (the pass also finds max |y|: the next 3 x 3 convolution scales by it)
+                y, amax = funcs.BiasActNHWC.apply(y, conv.bias, act, slope, True)
+                return funcs.tag_amax(y, amax), act != 0
             return y + conv.bias.view(1, -1, 1, 1), False
         y = th.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if not funcs.BiasAct.supported(y):
@@ -507,9 +532,14 @@ class Autoencoder(nn.Module):
             left = self.left(x)
             if self.is_last:
                 return left
-            coarse = self.next_level(self.downsample(left))
+            pooled = self.downsample(left)
+            if isinstance(self.downsample, (nn.MaxPool2d, nn.AvgPool2d)) and funcs.known_amax(left) is not None:
+                funcs.tag_amax(pooled, funcs.known_amax(left))        # pooling grows no magnitude
+            coarse = self.next_level(pooled)
             if funcs.upsample_cat_nhwc_supported(coarse, left):
-                return self.right(funcs.UpsampleCatNHWC.apply(coarse, left))
+                cat = funcs.UpsampleCatNHWC.apply(coarse, left)
+                bound = funcs.bound_amax(funcs.known_amax(coarse), funcs.known_amax(left))
+                return self.right(cat if bound is None else funcs.tag_amax(cat, bound))
             if funcs.upsample_cat_supported(coarse, left):
                 return self.right(funcs.UpsampleCat.apply(coarse, left))   # one pass, same values
             up = F.interpolate(coarse, size=left.shape[-2:], mode="bilinear",

@@ -135,19 +135,26 @@ def test_abi_rejects_unsupported_shapes():
     assert L.sbmc_conv3x3_nhwc_f32(None, None, None, None, 1, 8, 8, 128, 128, None) == -1
 
 
-def test_unet_is_the_same_function_with_and_without_the_kernel(monkeypatch):
-    """One U-net (the model's own module) forward + backward, every convolution on MIOpen vs on the kernel:
-    both against float64."""
+@pytest.mark.parametrize("activation", ["tanh", "leaky_relu"])
+def test_unet_is_the_same_function_with_and_without_the_kernel(monkeypatch, activation):
+    """One U-net (the model's own module) forward + backward, every convolution on MIOpen vs on the kernel: both
+    against float64.  With a smooth activation every tensor must be as close to float64 as the library's (2x).
+    With the model's leaky ReLU the gradients of ANY fp32 implementation jump where a pre-activation within
+    rounding of zero changes sign (tools' chain experiment: 1e-3 for either implementation at larger sizes), so
+    only the output and a loose bound on the gradients are compared there."""
     from sbmc_amd import modules as ops
     dev = _dev()
     th.manual_seed(3)
     net = ops.Autoencoder(128, 128, num_levels=3, increase_factor=2.0, num_convs=3, width=128, ksize=3,
-                          output_type="leaky_relu", pooling="max").to(dev)
+                          output_type="linear", activation=activation, pooling="max").to(dev)
     for m in net.modules():
         if isinstance(m, ops.ConvChain):
             m.fuse_bias_act = True
     x = th.randn(1, 128, 48, 80, device=dev)
     gy = th.randn(1, 128, 48, 80, device=dev)
+    used = []
+    real = funcs.Conv3x3NHWC._conv
+    monkeypatch.setattr(funcs.Conv3x3NHWC, "_conv", staticmethod(lambda *a: (used.append(1), real(*a))[1]))
 
     def run(flag, dtype=th.float32):
         monkeypatch.setenv("SBMC_CONV3X3", flag)
@@ -162,11 +169,48 @@ def test_unet_is_the_same_function_with_and_without_the_kernel(monkeypatch):
         return out
 
     ours = run("1")
+    assert len(used) == 30, len(used)                   # 15 convolutions forward, 15 data gradients
     lib = run("0")
+    assert len(used) == 30
     ref = run("0", th.float64)
-    worst = 0.0
-    for a, b, r in zip(ours, lib, ref):
+    for i, (a, b, r) in enumerate(zip(ours, lib, ref)):
         ea, eb = _err(a, r), _err(b, r)
-        worst = max(worst, ea)
-        assert ea <= max(2.0 * eb, 1e-6), (ea, eb)
-    assert worst < 2e-5
+        if activation == "tanh" or i == 0:
+            assert ea <= max(2.0 * eb, 2e-6), (i, ea, eb)
+        else:
+            assert ea <= max(2.0 * eb, 5e-5), (i, ea, eb)
+
+
+def test_amax_tags_replace_the_absmax_pass_and_expire(monkeypatch):
+    """The bias / activation passes leave max |.| of what they write on the tensor object; the convolution that
+    reads it next must use it (one absmax pass per U-net: its input) -- forward AND backward, where the tag has to
+    survive the autograd engine -- and a tag must die with any in-place change."""
+    from sbmc_amd import modules as ops
+    dev = _dev()
+    th.manual_seed(4)
+    net = ops.Autoencoder(128, 128, num_levels=3, increase_factor=2.0, num_convs=3, width=128, ksize=3,
+                          output_type="leaky_relu", pooling="max").to(dev)
+    for m in net.modules():
+        if isinstance(m, ops.ConvChain):
+            m.fuse_bias_act = True
+    calls = []
+    real = funcs.Conv3x3NHWC._absmax
+    monkeypatch.setattr(funcs.Conv3x3NHWC, "_absmax", staticmethod(lambda t: (calls.append(tuple(t.shape)), real(t))[1]))
+    x = th.randn(1, 128, 32, 48, device=dev, requires_grad=True)
+    y = net(x)
+    n_fwd = len(calls)
+    y.backward(th.randn_like(y))
+    n_bwd = len(calls) - n_fwd
+    assert n_fwd == 1, calls[:n_fwd]                    # the U-net's input only
+    assert n_bwd == 0, calls[n_fwd:]
+    # tags are bounds that hold: compare with a run that ignores them
+    monkeypatch.setenv("SBMC_AMAX_TAGS", "0")
+    y2 = net(x)
+    assert _err(y2, y.detach().double()) < 2e-6
+    monkeypatch.delenv("SBMC_AMAX_TAGS")
+    # expiry
+    t = _cl(th.randn(1, 128, 8, 8, device=dev))
+    funcs.tag_amax(t, real(t))
+    assert funcs.known_amax(t) is not None
+    t.mul_(2.0)
+    assert funcs.known_amax(t) is None
