@@ -562,74 +562,119 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     const unsigned long long t0 = p.total * (unsigned)split / (unsigned)p.nsplit;
     const unsigned long long t1 = p.total * (unsigned)(split + 1) / (unsigned)p.nsplit;
 
-    // ---- loaders: a wave owns pixel octet `wave` of the stage, a lane two channels (lane, lane + 64) ----
-    struct Rows { float g[2][8], x[2][10]; };
-    auto issue = [&](Rows& rr, unsigned long long t) {
-        const int y = (int)(t % (unsigned)p.H);
-        const unsigned long long rest = t / (unsigned)p.H;
-        const int x0 = (int)(rest % (unsigned)p.nstrips) * WG_TW, n = (int)(rest / (unsigned)p.nstrips);
-        {
-            const float* row = p.gy + ((long)n * p.H + y) * (long)p.W * p.Cout + cot * 128;
-            const rsrc_t r = cv_rsrc(row, 0x7FFFFFF0u);
+    // ---- loaders.  Waves 0, 1 stage the x row, waves 2, 3 the gy row: a thread owns pixel octet o (of 4) and
+    // channel quad q (of 32) -- its loads are 16-byte pieces, 32 lanes cover the 512 contiguous bytes of one
+    // pixel's 128 channels -- and turns its 8 (x: 10, with the two neighbours the shifted copies need) pixels x 4
+    // channels into one 16-byte entry per channel, plane (and kx).  Entry of channel 4 q + c inside its [128]
+    // row: 4 q + (c ^ ((q >> 1) & 3)) -- the four entries of a thread stay in its own 64 bytes, but 8 neighbouring
+    // lanes of one store instruction hit 8 different 16-byte slots of the 128-byte bank row, and the readers'
+    // lane groups still see 16 different slots of theirs. ----
+    const bool xrole = wave < 2;
+    const int uo = (tid & 127) >> 5, uq = tid & 31;
+    const int usw = (uq >> 1) & 3;
+    const int C = xrole ? p.Cin : p.Cout;
+    unsigned lvoff[10];                                 // byte offsets of the thread's pixels from the stage's first
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int px = x0 + 8 * wave + j;                          // wave-uniform
-                const bool in = px < p.W;
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    rr.g[q][j] = buf_load(r, in ? (unsigned)(lane + 64 * q) * 4u : CV_OOB, in ? (unsigned)(px * p.Cout) * 4u : 0u);
+    for (int j = 0; j < 10; ++j) lvoff[j] = (unsigned)(uq * 16 + (8 * uo + j) * C * 4);
+    struct Rows { u32x4 v[10]; };
+    // the stage the next request is for: walks down the rows of a strip, then to the next strip, the next image
+    int qy, qx0, qn;
+    {
+        qy = (int)(t0 % (unsigned)p.H);
+        const unsigned long long rest = t0 / (unsigned)p.H;
+        qx0 = (int)(rest % (unsigned)p.nstrips) * WG_TW;
+        qn = (int)(rest / (unsigned)p.nstrips);
+    }
+    auto issue = [&](Rows& rr) {
+        const int y = qy, x0 = qx0, n = qn;
+        if (++qy == p.H) {
+            qy = 0;
+            qx0 += WG_TW;
+            if (qx0 >= p.nstrips * WG_TW) {
+                qx0 = 0;
+                ++qn;
             }
         }
-        {
-            const int yy = y + ky - 1;                                     // (outside the image: zeros)
+        if (xrole) {
+            // pixels x0 - 1 .. x0 + 32 of image row y + ky - 1; what lies outside the image reads as zero: the
+            // descriptor ends with the row (and is empty for a row outside), the pixel before the row is masked
+            const int yy = y + ky - 1;
             const bool rowin = yy >= 0 && yy < p.H;
-            const float* row = p.x + ((long)n * p.H + (rowin ? yy : 0)) * (long)p.W * p.Cin + cit * 128;
-            const rsrc_t r = cv_rsrc(row, 0x7FFFFFF0u);
+            const float* base = p.x + (((long)n * p.H + (rowin ? yy : 0)) * (long)p.W + (x0 - 1)) * (long)p.Cin + cit * 128;
+            const rsrc_t r = cv_rsrc(base, rowin ? (unsigned)((p.W - x0 + 1) * p.Cin - cit * 128) * 4u : 0u);
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
-                const int px = x0 + 8 * wave - 1 + j;
-                const bool in = rowin && px >= 0 && px < p.W;
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    rr.x[q][j] = buf_load(r, in ? (unsigned)(lane + 64 * q) * 4u : CV_OOB, in ? (unsigned)(px * p.Cin) * 4u : 0u);
+                const unsigned vo = (j == 0 && x0 == 0 && uo == 0) ? CV_OOB : lvoff[j];
+                rr.v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, 0, 0);
             }
+        } else {
+            const float* base = p.gy + (((long)n * p.H + y) * (long)p.W + x0) * (long)p.Cout + cot * 128;
+            const rsrc_t r = cv_rsrc(base, (unsigned)((p.W - x0) * p.Cout - cot * 128) * 4u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr.v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, lvoff[j], 0, 0);
         }
     };
+    // two scaled values -> their h and l halves, packed (element 0 in the low half)
+    auto pair = [&](unsigned a, unsigned b, float c, unsigned& hp, unsigned& lp) {
+        const float fa = __builtin_bit_cast(float, a) * c, fb = __builtin_bit_cast(float, b) * c;
+        h2 hv;
+        hv[0] = (_Float16)fa;
+        hv[1] = (_Float16)fb;
+        hp = __builtin_bit_cast(unsigned, hv);
+        lp = cv_pack(fa - (float)hv[0], fb - (float)hv[1]);
+    };
     auto commit = [&](const Rows& rr, int par) {
+        if (xrole) {
+            u32x4* d = Xs + par * WG_X + uo * 128 + 4 * uq;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            float v[8];
+            for (int c = 0; c < 4; ++c) {
+                // pixels 8 o - 1 + j, j = 0 .. 9: pairs P_i = (2 i, 2 i + 1); the copy for kx = 0 is P0..P3, for
+                // kx = 2 P1..P4, for kx = 1 the pairs in between, Q_i = (P_i.hi, P_{i+1}.lo)
+                unsigned ph[5], pl[5];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = rr.g[q][j] * cg;
-            u32x4 hh, ll;
-            cv_split(v, hh, ll);
-            u32x4* d = Gs + par * WG_G + wave * 128 + lane + 64 * q;
-            d[0] = hh;
-            d[WG_OCT * 128] = ll;
-        }
+                for (int i = 0; i < 5; ++i) {
+                    const unsigned a = rr.v[2 * i][c], b = rr.v[2 * i + 1][c];
+                    pair(a, b, cx, ph[i], pl[i]);
+                }
+                u32x4 e0h, e0l, e1h, e1l, e2h, e2l;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            _Float16 h[10], l[10];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const float v = rr.x[q][j] * cx;
-                h[j] = (_Float16)v;
-                l[j] = (_Float16)(v - (float)h[j]);
+                for (int i = 0; i < 4; ++i) {
+                    e0h[i] = ph[i];
+                    e0l[i] = pl[i];
+                    e2h[i] = ph[i + 1];
+                    e2l[i] = pl[i + 1];
+                    e1h[i] = __builtin_amdgcn_alignbit(ph[i + 1], ph[i], 16);
+                    e1l[i] = __builtin_amdgcn_alignbit(pl[i + 1], pl[i], 16);
+                }
+                u32x4* e = d + (c ^ usw);
+                e[(0 * 2 + 0) * WG_OCT * 128] = e0h;
+                e[(0 * 2 + 1) * WG_OCT * 128] = e0l;
+                e[(1 * 2 + 0) * WG_OCT * 128] = e1h;
+                e[(1 * 2 + 1) * WG_OCT * 128] = e1l;
+                e[(2 * 2 + 0) * WG_OCT * 128] = e2h;
+                e[(2 * 2 + 1) * WG_OCT * 128] = e2l;
             }
-            u32x4* d = Xs + par * WG_X + wave * 128 + lane + 64 * q;
+        } else {
+            u32x4* d = Gs + par * WG_G + uo * 128 + 4 * uq;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
+            for (int c = 0; c < 4; ++c) {
                 u32x4 hh, ll;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    hh[i] = cv_pack_hh(h[kx + 2 * i], h[kx + 2 * i + 1]);
-                    ll[i] = cv_pack_hh(l[kx + 2 * i], l[kx + 2 * i + 1]);
+                    const unsigned a = rr.v[2 * i][c], b = rr.v[2 * i + 1][c];
+                    unsigned hp, lp;
+                    pair(a, b, cg, hp, lp);
+                    hh[i] = hp;
+                    ll[i] = lp;
                 }
-                d[(kx * 2 + 0) * WG_OCT * 128] = hh;
-                d[(kx * 2 + 1) * WG_OCT * 128] = ll;
+                u32x4* e = d + (c ^ usw);
+                e[0] = hh;
+                e[WG_OCT * 128] = ll;
             }
         }
     };
+    // where this lane's channel of a [128] row sits (the swizzle above), as a reader: channel w 64 + 32 i + l31
+    const int rsw = (l31 & ~3) + ((l31 & 3) ^ ((l31 >> 3) & 3));
 
     f32x16 acc[2][2][3];
 #pragma unroll
@@ -645,7 +690,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     struct OpA { u32x4 h[2], l[2]; };
     struct OpB { u32x4 h[2], l[2]; };
     auto load_a = [&](OpA& o, int par, int ks) {
-        const u32x4* Gb = Gs + par * WG_G + (2 * ks + lhi) * 128 + wm * 64 + l31;
+        const u32x4* Gb = Gs + par * WG_G + (2 * ks + lhi) * 128 + wm * 64 + rsw;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             o.h[mi] = Gb[mi * 32];
@@ -653,7 +698,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         }
     };
     auto load_b = [&](OpB& o, int par, int ks, int kx) {
-        const u32x4* Xb = Xs + par * WG_X + (2 * ks + lhi) * 128 + wn * 64 + l31;
+        const u32x4* Xb = Xs + par * WG_X + (2 * ks + lhi) * 128 + wn * 64 + rsw;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             o.h[ni] = Xb[(kx * 2 + 0) * WG_OCT * 128 + ni * 32];
@@ -675,15 +720,16 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(a.l[mi], b.h[ni], acc[mi][ni][kx]);
     };
 
-    // Pipeline.  Stage k (= t - t0) lives in LDS buffer k % 2.  Its rows are REQUESTED at the start of stage
-    // k - 2 (register set k % 2) and WRITTEN in the middle of stage k - 1, between two barriers: the first makes
-    // them visible, the second -- at the end of stage k - 1 -- frees the other buffer.  Operands are fetched one
-    // sub-step (12 MFMAs) ahead, across both barriers: the matrix pipe never waits for LDS after a barrier.
-    Rows r0, r1;
+    // Pipeline.  Stage k (= t - t0) lives in LDS buffer k % 2.  Its rows are REQUESTED in the middle of stage
+    // k - 2 and WRITTEN in the middle of stage k - 1 (one register set: it is free again the moment it has been
+    // written), between two barriers: the first makes them visible, the second -- at the end of stage k - 1 --
+    // frees the other buffer.  Operands are fetched one sub-step (12 MFMAs) ahead, across both barriers: the
+    // matrix pipe never waits for LDS after a barrier.
+    Rows rows;
     if (t0 < t1) {
-        issue(r0, t0);
-        if (t0 + 1 < t1) issue(r1, t0 + 1);
-        commit(r0, 0);
+        issue(rows);
+        commit(rows, 0);
+        if (t0 + 1 < t1) issue(rows);
     }
     __syncthreads();
     OpA a0, a1;
@@ -692,9 +738,8 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         load_a(a0, 0, 0);
         load_b(b0, 0, 0, 0);
     }
-    auto stage = [&](unsigned long long t, Rows& fill, const Rows& done, const int par) {
+    auto stage = [&](unsigned long long t, const int par) {
         const bool next = t + 1 < t1;
-        if (t + 2 < t1) issue(fill, t + 2);
         load_b(b1, par, 0, 1);
         mfmas(a0, b0, 0);
         load_b(b0, par, 0, 2);
@@ -702,7 +747,8 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         load_a(a1, par, 1);
         load_b(b1, par, 1, 0);
         mfmas(a0, b0, 2);
-        if (next) commit(done, par ^ 1);
+        if (next) commit(rows, par ^ 1);
+        if (t + 2 < t1) issue(rows);
         cv_lds_barrier();
         load_b(b0, par, 1, 1);
         mfmas(a1, b1, 0);
@@ -716,8 +762,8 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         cv_lds_barrier();
     };
     for (unsigned long long t = t0; t < t1; t += 2) {
-        stage(t, r0, r1, 0);
-        if (t + 1 < t1) stage(t + 1, r1, r0, 1);
+        stage(t, 0);
+        if (t + 1 < t1) stage(t + 1, 1);
     }
 
     // ---- partial sums of this pixel range: [wave][mi][ni][kx][r][lane] ----
