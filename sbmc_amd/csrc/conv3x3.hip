@@ -145,9 +145,12 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
 
     // ---- staging of a patch: unit u = (pixel u / 2, channels 16 (u % 2) ..), 64 contiguous bytes ----
     float areg[CV_AROUNDS][16];
-    auto issue_a = [&](const Tile& t, unsigned cc) {
+    // (valid = false: a request beyond the workgroup's last chunk -- an empty descriptor, every lane reads zero.  NO
+    // load of the main loop sits under a branch: at a control-flow join the compiler can no longer count which
+    // loads are outstanding and waits for ALL of them, i.e. for the request it has just made.)
+    auto issue_a = [&](const Tile& t, unsigned cc, bool valid) {
         const float* xb = p.x + (((long)t.n * p.H + (t.y0 - 1)) * (long)p.W + (t.x0 - 1)) * (long)p.Cin;
-        const rsrc_t rx = cv_rsrc(xb, 0x7FFFFFF0u);
+        const rsrc_t rx = cv_rsrc(valid ? xb : p.x, valid ? 0x7FFFFFF0u : 0u);
 #pragma unroll
         for (int j = 0; j < CV_AROUNDS; ++j) {
             const int u = tid + 256 * j, q = u >> 1, half = u & 1;
@@ -189,10 +192,11 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     // ---- staging of a weight stage (h, st): 1536 entries, 6 per thread; two register sets: a stage's loads are
     // in flight for two stages ----
     u32x4 wregA[6], wregB[6];
-    const rsrc_t rw = cv_rsrc(p.wp, (unsigned)p.ncot * ((unsigned)p.Cin / 16u) * 3u * (unsigned)CV_WSTAGE * 16u);
-    auto issue_w = [&](u32x4 (&wreg)[6], const Tile& t, unsigned cc, int st) {
+    const unsigned wbytes = (unsigned)p.ncot * ((unsigned)p.Cin / 16u) * 3u * (unsigned)CV_WSTAGE * 16u;
+    auto issue_w = [&](u32x4 (&wreg)[6], const Tile& t, unsigned cc, int st, bool valid) {
+        const rsrc_t rw = cv_rsrc(p.wp, valid ? wbytes : 0u);
         const unsigned k16 = cc * 2u + (unsigned)(st / 3), ky = (unsigned)(st % 3);
-        const unsigned block = ((unsigned)t.ct * ((unsigned)p.Cin / 16u) + k16) * 3u + ky;
+        const unsigned block = valid ? ((unsigned)t.ct * ((unsigned)p.Cin / 16u) + k16) * 3u + ky : 0u;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(tid + 256 * i) * 16u,
@@ -262,14 +266,14 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     // barrier), so every stage finds its weights -- and its patch: written in stage 3 of the previous chunk --
     // in LDS one whole stage early, and the operands of its first tap are fetched during the last tap of the
     // stage before: after a barrier the matrix pipe continues at once.
-    issue_a(tcur, 0);
-    issue_w(wregA, tcur, 0, 0);
-    issue_w(wregB, tcur, 0, 1);
+    issue_a(tcur, 0, true);
+    issue_w(wregA, tcur, 0, 0, true);
+    issue_w(wregB, tcur, 0, 1, true);
     commit_a(0);
     commit_w(wregA, 0);
     commit_w(wregB, 1);
     __syncthreads();
-    issue_w(wregA, tcur, 0, 2);
+    issue_w(wregA, tcur, 0, 2, true);
     Ops o0, o1;
     load_ops(o0, a_ptr(0, 0), w_ptr(0), 0);
 
@@ -283,10 +287,10 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         // between the taps' MFMAs, in stage 4: visible when stage 5 fetches the next chunk's first operands)
         auto stage = [&](Ops& cur, Ops& other, u32x4 (&wfill)[6], const u32x4 (&wdone)[6], const int st) {
             if (!(DBG & 2)) {
-                if (st < 3) issue_w(wfill, tcur, cc, st + 3);
-                else if (more) issue_w(wfill, tn, ccn, st - 3);
+                if (st < 3) issue_w(wfill, tcur, cc, st + 3, true);
+                else issue_w(wfill, tn, ccn, st - 3, more);
             }
-            if (!(DBG & 4) && !(DBG & 32) && st == 2 && more) issue_a(tn, ccn);
+            if (!(DBG & 4) && !(DBG & 32) && st == 2) issue_a(tn, ccn, more);
             const bool ca = !(DBG & 4) && !(DBG & 16) && st == 4;
             const int nbuf = (int)((h + 1) & 1u);
             const u32x4* Ab = a_ptr(h, st);
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
             interleave();
             if (ca) commit_a_round(nbuf, 1);
             if (st < 5) load_ops(other, a_ptr(h, st + 1), w_ptr(st + 1), 0);
-            else if (more) load_ops(other, a_ptr(h + 1, 0), w_ptr(0), 0);
+            else load_ops(other, a_ptr(h + 1, 0), w_ptr(0), 0);
             mfmas(cur);
             interleave();
             if (ca) commit_a_round(nbuf, 2);
@@ -546,6 +550,7 @@ __device__ __forceinline__ unsigned cv_pack_hh(_Float16 a, _Float16 b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+template <int DBG>
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     extern __shared__ float4 cv_lds[];
     u32x4* Gs = reinterpret_cast<u32x4*>(cv_lds);       // [2][WG_G]
@@ -585,7 +590,11 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         qx0 = (int)(rest % (unsigned)p.nstrips) * WG_TW;
         qn = (int)(rest / (unsigned)p.nstrips);
     }
-    auto issue = [&](Rows& rr) {
+    // One request: ten 16-byte loads in EITHER role and under no branch (the gy role's last two, and everything beyond
+    // the workgroup's range, through out-of-range offsets / an empty descriptor: zeros): at a control-flow join the
+    // compiler can no longer count which loads are outstanding and waits for all of them -- for the request it
+    // has just made.
+    auto issue = [&](Rows& rr, bool valid) {
         const int y = qy, x0 = qx0, n = qn;
         if (++qy == p.H) {
             qy = 0;
@@ -595,23 +604,18 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
                 ++qn;
             }
         }
-        if (xrole) {
-            // pixels x0 - 1 .. x0 + 32 of image row y + ky - 1; what lies outside the image reads as zero: the
-            // descriptor ends with the row (and is empty for a row outside), the pixel before the row is masked
-            const int yy = y + ky - 1;
-            const bool rowin = yy >= 0 && yy < p.H;
-            const float* base = p.x + (((long)n * p.H + (rowin ? yy : 0)) * (long)p.W + (x0 - 1)) * (long)p.Cin + cit * 128;
-            const rsrc_t r = cv_rsrc(base, rowin ? (unsigned)((p.W - x0 + 1) * p.Cin - cit * 128) * 4u : 0u);
+        // x: pixels x0 - 1 .. x0 + 32 of image row y + ky - 1; what lies outside the image reads as zero: the
+        // descriptor ends with the row (and is empty for a row outside), the pixel before the row is masked
+        const int yy = xrole ? y + ky - 1 : y;
+        const bool rowin = valid && yy >= 0 && yy < p.H;
+        const int xs = xrole ? x0 - 1 : x0;
+        const float* base = (xrole ? p.x : p.gy) + (((long)n * p.H + (rowin ? yy : 0)) * (long)p.W + xs) * (long)C +
+                            (xrole ? cit : cot) * 128;
+        const rsrc_t r = cv_rsrc(rowin ? base : p.x, rowin ? (unsigned)((p.W - xs) * C - (xrole ? cit : cot) * 128) * 4u : 0u);
 #pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const unsigned vo = (j == 0 && x0 == 0 && uo == 0) ? CV_OOB : lvoff[j];
-                rr.v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, 0, 0);
-            }
-        } else {
-            const float* base = p.gy + (((long)n * p.H + y) * (long)p.W + x0) * (long)p.Cout + cot * 128;
-            const rsrc_t r = cv_rsrc(base, (unsigned)((p.W - x0) * p.Cout - cot * 128) * 4u);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) rr.v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, lvoff[j], 0, 0);
+        for (int j = 0; j < 10; ++j) {
+            const bool off = j == 0 ? (xrole && x0 == 0 && uo == 0) : (j >= 8 && !xrole);
+            rr.v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, off ? CV_OOB : lvoff[j], 0, 0);
         }
     };
     // two scaled values -> their h and l halves, packed (element 0 in the low half)
@@ -725,21 +729,21 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     // written), between two barriers: the first makes them visible, the second -- at the end of stage k - 1 --
     // frees the other buffer.  Operands are fetched one sub-step (12 MFMAs) ahead, across both barriers: the
     // matrix pipe never waits for LDS after a barrier.
-    Rows rows;
-    if (t0 < t1) {
-        issue(rows);
-        commit(rows, 0);
-        if (t0 + 1 < t1) issue(rows);
-    }
+    // (an odd number of stages is rounded up: the extra one reads zeros and adds nothing)
+    const unsigned long long t1e = t1 + ((t1 - t0) & 1ull);
+    Rows r0, r1;
+    issue(r0, t0 < t1);
+    commit(r0, 0);
+    issue(r1, t0 + 1 < t1);
+    issue(r0, t0 + 2 < t1);
     __syncthreads();
     OpA a0, a1;
     OpB b0, b1;
-    if (t0 < t1) {
-        load_a(a0, 0, 0);
-        load_b(b0, 0, 0, 0);
-    }
-    auto stage = [&](unsigned long long t, const int par) {
-        const bool next = t + 1 < t1;
+    load_a(a0, 0, 0);
+    load_b(b0, 0, 0, 0);
+    // (two register sets: the rows of stage t + 1 are written from `done` in the middle of stage t, and `done` is
+    // at once requested again for stage t + 3: two stages in flight)
+    auto stage = [&](unsigned long long t, Rows& done, const int par) {
         load_b(b1, par, 0, 1);
         mfmas(a0, b0, 0);
         load_b(b0, par, 0, 2);
@@ -747,23 +751,21 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         load_a(a1, par, 1);
         load_b(b1, par, 1, 0);
         mfmas(a0, b0, 2);
-        if (next) commit(rows, par ^ 1);
-        if (t + 2 < t1) issue(rows);
-        cv_lds_barrier();
+        if (!(DBG & 4)) commit(done, par ^ 1);
+        if (!(DBG & 2)) issue(done, t + 3 < t1);
+        if (!(DBG & 1)) cv_lds_barrier();
         load_b(b0, par, 1, 1);
         mfmas(a1, b1, 0);
         load_b(b1, par, 1, 2);
         mfmas(a1, b0, 1);
-        if (next) {
-            load_a(a0, par ^ 1, 0);
-            load_b(b0, par ^ 1, 0, 0);
-        }
+        load_a(a0, par ^ 1, 0);
+        load_b(b0, par ^ 1, 0, 0);
         mfmas(a1, b1, 2);
-        cv_lds_barrier();
+        if (!(DBG & 1)) cv_lds_barrier();
     };
-    for (unsigned long long t = t0; t < t1; t += 2) {
-        stage(t, 0);
-        if (t + 1 < t1) stage(t + 1, 1);
+    for (unsigned long long t = t0; t < t1e; t += 2) {
+        stage(t, r1, 0);
+        stage(t + 1, r0, 1);
     }
 
     // ---- partial sums of this pixel range: [wave][mi][ni][kx][r][lane] ----
@@ -844,10 +846,21 @@ extern "C" int sbmc_conv3x3_wgrad_f32(const float* gy, const unsigned* gmax, con
     p.total = (unsigned long long)n * h * p.nstrips;
     p.nsplit = wgrad_splits(cin, cout, (long long)p.total);
     const int ncombo = p.ncot * p.ncit * 3;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_wgrad_kernel),
+    const char* dbg = getenv("SBMC_CONV3_DBG");
+    const int d = dbg ? atoi(dbg) : 0;
+    auto kern = conv3_wgrad_kernel<0>;
+    switch (d) {
+        case 1: kern = conv3_wgrad_kernel<1>; break;
+        case 2: kern = conv3_wgrad_kernel<2>; break;
+        case 4: kern = conv3_wgrad_kernel<4>; break;
+        case 6: kern = conv3_wgrad_kernel<6>; break;
+        case 7: kern = conv3_wgrad_kernel<7>; break;
+        default: break;
+    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
-    hipLaunchKernelGGL(conv3_wgrad_kernel, dim3((unsigned)(ncombo * p.nsplit)), dim3(256), WG_LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ncombo * p.nsplit)), dim3(256), WG_LDS_BYTES, (hipStream_t)stream, p);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     WreduceParams q;
