@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 / bf16, dense, at 2.4 GHz (same guide; ~2.0-2.1 GHz sustained)
 
 
 def fwd_bytes_per_pixel(k, c=3):
@@ -629,6 +630,25 @@ def main():
                         "TFLOPs": round(flop / (avg * 1e-3) / 1e12, 1),
                         "frac_of_fp32_mfma_peak": round(flop / (avg * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)}
 
+    # the U-nets' 3 x 3 convolutions (csrc/conv3x3.hip: fp32 values from three f16 matrix products per term), as
+    # the model issues them -- scale lookup and weight preparation included -- from the same two instrumented steps
+    convs = {}
+    for name, a, b in model_timings:
+        if name.startswith("conv3x3"):
+            kind, dims = name.split(" ")
+            cout, cin = (int(t) for t in dims.split("@")[0].split("x"))
+            bb, hh, ww = (int(t) for t in dims.split("@")[1].split("x"))
+            c = convs.setdefault(kind, {"calls": 0, "ms": 0.0, "flop": 0.0})
+            c["calls"] += 1
+            c["ms"] += a.elapsed_time(b)
+            c["flop"] += 2.0 * 9 * cin * cout * bb * hh * ww
+    for kind in list(convs):
+        c = convs[kind]
+        tf = c["flop"] / (c["ms"] * 1e-3) / 1e12
+        convs[kind] = {"calls_per_step": c["calls"] // 2, "ms_per_step": round(c["ms"] / 2, 2),
+                       "TFLOPs_fp32_equivalent": round(tf, 1), "TFLOPs_f16_issued": round(3 * tf, 1),
+                       "frac_of_f16_mfma_peak": round(3 * tf / F16_MFMA_PEAK_TFLOPS, 3)}
+
     if rank == 0:
         ms = dt / steps * 1e3
         value = S * H * W / (dt / steps) / 1e6
@@ -661,6 +681,8 @@ def main():
         }
         if step_flops is not None:
             res["whole_step_tflops"] = round(step_flops / (dt / steps) / 1e12, 1)
+            # (above 1 since round 3: the 3 x 3 convolutions and the fp32 1 x 1 layers run on the f16 / bf16 matrix pipe
+            # at fp32 accuracy -- three resp. six low-precision products per fp32 multiply-add)
             res["frac_of_fp32_mfma_peak"] = round(step_flops / (dt / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)
             res["unet_layout"] = layout
         if per_rank is not None:
@@ -679,6 +701,18 @@ def main():
             res["kernels"] = kern
         if layers:
             res["pointwise_layers"] = layers
+        if convs:
+            res["conv3x3"] = convs
+            tot_flop = sum(v["TFLOPs_fp32_equivalent"] * v["ms_per_step"] for v in convs.values())
+            tot_ms = sum(v["ms_per_step"] for v in convs.values())
+            res["roofline_conv3x3"] = {
+                "kernel": "sbmc::conv3_kernel / conv3_wgrad_kernel (all U-net convolutions of a step, forward + both "
+                          "gradients; the timed calls also hold the weight preparation)",
+                "bound": "mfma", "achieved": round(3 * tot_flop / tot_ms, 1), "peak": F16_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(3 * tot_flop / tot_ms / F16_MFMA_PEAK_TFLOPS, 3), "traffic": None,
+                "note": "f16 matrix operations issued = 3 per fp32 multiply-add (split precision); the same work on "
+                        "the fp32 matrix pipe is bounded by %d TFLOP/s" % int(FP32_MFMA_PEAK_TFLOPS),
+                "ms_per_step": round(tot_ms, 2)}
         rk = "splat_update_bwd_all" if "splat_update_bwd_all" in kern else "splat_update_bwd"
         if rk in kern:
             kb = kern[rk]

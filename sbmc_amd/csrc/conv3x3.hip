@@ -105,7 +105,6 @@ struct Conv3Params {
     unsigned ntiles;         // N * tiles_y * tiles_x * ncot
 };
 
-template <int DBG>
 __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     extern __shared__ float4 cv_lds[];
     u32x4* As = reinterpret_cast<u32x4*>(cv_lds);
@@ -286,12 +285,10 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         // order, and no weight stage may have to wait for the patch's HBM burst -- and written, round by round
         // between the taps' MFMAs, in stage 4: visible when stage 5 fetches the next chunk's first operands)
         auto stage = [&](Ops& cur, Ops& other, u32x4 (&wfill)[6], const u32x4 (&wdone)[6], const int st) {
-            if (!(DBG & 2)) {
-                if (st < 3) issue_w(wfill, tcur, cc, st + 3, true);
-                else issue_w(wfill, tn, ccn, st - 3, more);
-            }
-            if (!(DBG & 4) && !(DBG & 32) && st == 2) issue_a(tn, ccn, more);
-            const bool ca = !(DBG & 4) && !(DBG & 16) && st == 4;
+            if (st < 3) issue_w(wfill, tcur, cc, st + 3, true);
+            else issue_w(wfill, tn, ccn, st - 3, more);
+            if (st == 2) issue_a(tn, ccn, more);
+            const bool ca = st == 4;
             const int nbuf = (int)((h + 1) & 1u);
             const u32x4* Ab = a_ptr(h, st);
             const u32x4* Wb = w_ptr(st);
@@ -308,8 +305,8 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
             mfmas(cur);
             interleave();
             if (ca) commit_a_round(nbuf, 2);
-            if (!(DBG & 2)) commit_w(wdone, (st + 2) % 3);
-            if (!(DBG & 1)) cv_lds_barrier();
+            commit_w(wdone, (st + 2) % 3);
+            cv_lds_barrier();
         };
         stage(o0, o1, wregB, wregA, 0);
         stage(o1, o0, wregA, wregB, 1);
@@ -317,7 +314,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         stage(o1, o0, wregA, wregB, 3);
         stage(o0, o1, wregB, wregA, 4);
         stage(o1, o0, wregA, wregB, 5);
-        if (!(DBG & 8) && last) {
+        if (last) {
             // ---- the tile is complete: scale back, store, clear ----
             const Tile t = tcur;
             float* yb = p.y + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)p.Cout + t.ct * 128;
@@ -484,21 +481,7 @@ extern "C" int sbmc_conv3x3_nhwc_f32(const float* x, const unsigned* xmax, const
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     unsigned grid = p.ntiles < (unsigned)cus ? p.ntiles : (unsigned)cus;
-    const char* dbg = getenv("SBMC_CONV3_DBG");
-    const int d = dbg ? atoi(dbg) : 0;
-    auto kern = conv3_kernel<0>;
-    switch (d) {
-        case 1: kern = conv3_kernel<1>; break;
-        case 2: kern = conv3_kernel<2>; break;
-        case 4: kern = conv3_kernel<4>; break;
-        case 6: kern = conv3_kernel<6>; break;
-        case 7: kern = conv3_kernel<7>; break;
-        case 8: kern = conv3_kernel<8>; break;
-        case 15: kern = conv3_kernel<15>; break;
-        case 16: kern = conv3_kernel<16>; break;
-        case 32: kern = conv3_kernel<32>; break;
-        default: break;
-    }
+    auto kern = conv3_kernel;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
@@ -550,7 +533,6 @@ __device__ __forceinline__ unsigned cv_pack_hh(_Float16 a, _Float16 b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int DBG>
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     extern __shared__ float4 cv_lds[];
     u32x4* Gs = reinterpret_cast<u32x4*>(cv_lds);       // [2][WG_G]
@@ -751,9 +733,9 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         load_a(a1, par, 1);
         load_b(b1, par, 1, 0);
         mfmas(a0, b0, 2);
-        if (!(DBG & 4)) commit(done, par ^ 1);
-        if (!(DBG & 2)) issue(done, t + 3 < t1);
-        if (!(DBG & 1)) cv_lds_barrier();
+        commit(done, par ^ 1);
+        issue(done, t + 3 < t1);
+        cv_lds_barrier();
         load_b(b0, par, 1, 1);
         mfmas(a1, b1, 0);
         load_b(b1, par, 1, 2);
@@ -761,7 +743,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         load_a(a0, par ^ 1, 0);
         load_b(b0, par ^ 1, 0, 0);
         mfmas(a1, b1, 2);
-        if (!(DBG & 1)) cv_lds_barrier();
+        cv_lds_barrier();
     };
     for (unsigned long long t = t0; t < t1e; t += 2) {
         stage(t, r1, 0);
@@ -846,17 +828,7 @@ extern "C" int sbmc_conv3x3_wgrad_f32(const float* gy, const unsigned* gmax, con
     p.total = (unsigned long long)n * h * p.nstrips;
     p.nsplit = wgrad_splits(cin, cout, (long long)p.total);
     const int ncombo = p.ncot * p.ncit * 3;
-    const char* dbg = getenv("SBMC_CONV3_DBG");
-    const int d = dbg ? atoi(dbg) : 0;
-    auto kern = conv3_wgrad_kernel<0>;
-    switch (d) {
-        case 1: kern = conv3_wgrad_kernel<1>; break;
-        case 2: kern = conv3_wgrad_kernel<2>; break;
-        case 4: kern = conv3_wgrad_kernel<4>; break;
-        case 6: kern = conv3_wgrad_kernel<6>; break;
-        case 7: kern = conv3_wgrad_kernel<7>; break;
-        default: break;
-    }
+    auto kern = conv3_wgrad_kernel;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }

@@ -946,7 +946,8 @@ class Conv3x3NHWC(th.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         _require_f32("Conv3x3NHWC", x=x, w=w)
-        with th.cuda.device(x.device), _timed("conv3x3_fwd", x.device):
+        with th.cuda.device(x.device), _timed("conv3x3_fwd %dx%d@%dx%dx%d" % (w.shape[0], w.shape[1], x.shape[0], x.shape[2], x.shape[3]),
+                                              x.device):
             xmax = known_amax(x)
             if xmax is None:
                 xmax = Conv3x3NHWC._absmax(x)
@@ -968,10 +969,10 @@ class Conv3x3NHWC(th.autograd.Function):
             if gmax is None:
                 gmax = Conv3x3NHWC._absmax(gy)
             if ctx.needs_input_grad[0]:
-                with _timed("conv3x3_bwd_data", dev):
+                with _timed("conv3x3_bwd_data %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
                     gx = Conv3x3NHWC._conv(gy, gmax, Conv3x3NHWC._prepare(w, True), cin)
             if ctx.needs_input_grad[1]:
-                with _timed("conv3x3_bwd_weight", dev):
+                with _timed("conv3x3_bwd_weight %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
                     if (os.environ.get("SBMC_CONV3X3_WGRAD", "1") not in ("0", "off", "no")
                             and L.sbmc_conv3x3_wgrad_supported(b, h, wd, cin, cout)):
                         gw = th.empty((cout, cin, 3, 3), dtype=th.float32, device=dev, memory_format=th.channels_last)

@@ -70,3 +70,14 @@ def test_pointwise_kernels_do_not_spill(pointwise_kernels, pattern):
     for r in rows:
         assert r["scratch"] == 0 and r["spill"] == 0, r
         assert r["occupancy"] >= 2, r
+
+
+def test_conv3x3_kernels_do_not_spill():
+    """The 3 x 3 convolution kernels run one wave per SIMD on the whole register file (accumulators in the
+    accumulation registers): a spill there goes to scratch memory in the middle of the MFMA stream."""
+    import kernel_resources
+    rows = kernel_resources.resources(os.path.join(ROOT, "sbmc_amd", "csrc", "conv3x3.hip"))
+    names = [r["name"] for r in rows]
+    assert any("conv3_kernel" in n for n in names) and any("conv3_wgrad_kernel" in n for n in names), names
+    for r in rows:
+        assert r["scratch"] == 0 and r["spill"] == 0, r
