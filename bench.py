@@ -105,6 +105,8 @@ def unet_layout():
         return {"nchw": "planar (forced)", "nhwc": "channels_last (forced)"}[mode]
     if not picks:
         return None
+    if any(len(k) == 2 and k[1] == "own 3x3 kernel" for k in modules._LAYOUT_DECISIONS):
+        return "channels_last (own 3x3 convolution kernel)" if picks == {True} else "mixed"
     return "channels_last (measured)" if picks == {True} else "planar (measured)" if picks == {False} else "mixed"
 
 

@@ -212,6 +212,7 @@ def unet_channels_last(net, x, rows=None):
     if x.dtype == th.float32 and not half and _convs_on_own_kernel(net, x):
         # every 3 x 3 convolution of the net runs on csrc/conv3x3.hip, which is channels-last by construction (and
         # ~2-3x MIOpen's fp32 solvers in either layout): nothing to measure, no dependence on MIOpen's find-db
+        _LAYOUT_DECISIONS.setdefault((x.device.index, "own 3x3 kernel"), True)
         return True
     grad = th.is_grad_enabled() and any(q.requires_grad for q in net.parameters())
     shape = (x.shape[0], x.shape[1], int(rows) if rows else x.shape[2], x.shape[3])
