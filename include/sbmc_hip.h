@@ -582,6 +582,13 @@ SBMC_API int sbmc_conv3x3_prepare_weights_f32(const float *w, long s_co, long s_
                                      long storage_elems, int cin, int cout, int flip, void *wp, void *stream);
 SBMC_API int sbmc_conv3x3_nhwc_f32(const float *x, const unsigned *xmax, const void *wp, float *y, int n, int h,
                           int w, int cin, int cout, void *stream);
+/* The same convolution with the bias + activation pass behind it (reference sbmc/modules.py:154-175) in its
+ * epilogue: y = act(conv(x) + bias[cout]), act 0 linear / 1 ReLU / 2 LeakyReLU(slope).  signs (or NULL): one bit
+ * per output (pre-activation > 0), bit e % 32 of word e / 32 of the channels-last element index e -- what
+ * sbmc_bias_act_nhwc_bwd_signs_f32 / _bwd_amax_f32 read; amax (or NULL): bit pattern of max |y|. */
+SBMC_API int sbmc_conv3x3_bias_act_nhwc_f32(const float *x, const unsigned *xmax, const void *wp, const float *bias,
+                                   float *y, unsigned *signs, unsigned *amax, int n, int h, int w, int cin,
+                                   int cout, int act, float slope, void *stream);
 /* Weight gradient of the same convolution: gw[co][ci][ky][kx] (element strides s_*) = sum over the pixels of
  * gy[n][y][x][co] x[n][y + ky - 1][x + kx - 1][ci]; gmax / xmax: the tensors' largest magnitudes as written by
  * sbmc_conv3x3_absmax_f32; scratch: wgrad_scratch_bytes of device memory (partial sums of the pixel ranges,

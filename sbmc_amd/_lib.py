@@ -95,6 +95,7 @@ SYMBOLS = (
     "sbmc_conv3x3_absmax_f32",
     "sbmc_conv3x3_prepare_weights_f32",
     "sbmc_conv3x3_nhwc_f32",
+    "sbmc_conv3x3_bias_act_nhwc_f32",
     "sbmc_conv3x3_wgrad_supported",
     "sbmc_conv3x3_wgrad_scratch_bytes",
     "sbmc_conv3x3_wgrad_f32",
@@ -225,6 +226,7 @@ def lib():
     handle.sbmc_conv3x3_absmax_f32.argtypes = [p, lg, p, p]
     handle.sbmc_conv3x3_prepare_weights_f32.argtypes = [p, lg, lg, lg, lg, lg, i, i, i, p, p]
     handle.sbmc_conv3x3_nhwc_f32.argtypes = [p, p, p, p, i, i, i, i, i, p]
+    handle.sbmc_conv3x3_bias_act_nhwc_f32.argtypes = [p] * 7 + [i] * 6 + [ctypes.c_float, p]
     handle.sbmc_conv3x3_wgrad_supported.argtypes = [i] * 5
     handle.sbmc_conv3x3_wgrad_scratch_bytes.argtypes = [i] * 5
     handle.sbmc_conv3x3_wgrad_f32.argtypes = [p, p, p, p, p, lg, lg, lg, lg, p, i, i, i, i, i, p]

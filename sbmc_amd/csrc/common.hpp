@@ -147,6 +147,32 @@ __device__ __forceinline__ int wave_id() {
     return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 
+// Largest magnitude seen by a workgroup -> *amax (bit pattern; magnitudes order like unsigned integers).  The 3 x 3
+// convolution that consumes the tensor takes its power-of-two scale from it (csrc/conv3x3.hip): the producer's
+// pass finds it on the way instead of a pass of its own.
+__device__ __forceinline__ unsigned abits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu; }
+__device__ __forceinline__ unsigned amax4(unsigned m, const float4& v) {
+    const unsigned a = abits(v.x), b = abits(v.y), c = abits(v.z), d = abits(v.w);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+    return m > q ? m : q;
+}
+__device__ __forceinline__ void amax_publish(unsigned m, unsigned* amax) {
+    __shared__ unsigned wave_max[16];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, s, 64);
+        m = m > o ? m : o;
+    }
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup at most -- and none once the word already holds something at least as large (a
+    // stale read only costs a superfluous atomic): a hundred thousand waves on one address would take a millisecond
+    if (threadIdx.x == 0) {
+        for (unsigned w = 1; w < (blockDim.x + 63) / 64; ++w) m = m > wave_max[w] ? m : wave_max[w];
+        if (m > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, m);
+    }
+}
+
 }  // namespace sbmc
 
 #define SBMC_DISPATCH_C(CVAL, ...)                                   \

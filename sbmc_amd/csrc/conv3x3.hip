@@ -103,8 +103,15 @@ struct Conv3Params {
     int N, H, W, Cin, Cout;
     int tiles_x, tiles_y, ncot;
     unsigned ntiles;         // N * tiles_y * tiles_x * ncot
+    // EPI: y = act(conv + bias) -- the bias + ReLU / LeakyReLU pass behind the convolution (reference
+    // sbmc/modules.py:154-175) in the epilogue, with what that pass produces besides
+    const float* bias;       // [Cout]
+    float slope;             // 1: linear, 0: ReLU, else LeakyReLU
+    unsigned* signs;         // one bit per output (pre-activation > 0), bit e % 32 of word e / 32 of the NHWC element index e; or nullptr
+    unsigned* amax;          // bit pattern of max |y| (zeroed by the caller); or nullptr
 };
 
+template <bool EPI>
 __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     extern __shared__ float4 cv_lds[];
     u32x4* As = reinterpret_cast<u32x4*>(cv_lds);
@@ -214,6 +221,8 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+    unsigned amax_run = 0;
+    const bool sign_lane = l31 == 0;
     if (total == 0) return;
 
     // operands of one tap: A 4 m-blocks x 2 planes, B 2 n-blocks x 2 planes
@@ -315,10 +324,19 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         stage(o0, o1, wregB, wregA, 4);
         stage(o1, o0, wregA, wregB, 5);
         if (last) {
-            // ---- the tile is complete: scale back, store, clear ----
+            // ---- the tile is complete: scale back (+ bias, activation, sign bits, largest magnitude), store, clear ----
             const Tile t = tcur;
             float* yb = p.y + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)p.Cout + t.ct * 128;
             const rsrc_t ry = cv_rsrc(yb, 0x7FFFFFF0u);
+            float bv[2] = {0.f, 0.f};
+            rsrc_t rs = ry;
+            if constexpr (EPI) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) bv[ni] = p.bias[t.ct * 128 + nh * 64 + ni * 32 + l31];
+                // sign words of this tile's first pixel and output-channel tile: word = pixel (Cout / 32) + channel / 32
+                rs = cv_rsrc(p.signs + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)(p.Cout / 32) + t.ct * 4,
+                             p.signs ? 0x7FFFFFF0u : 0u);
+            }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -331,9 +349,28 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
                         const unsigned voff = ok ? (unsigned)((row * p.W + col) * p.Cout + nh * 64 + ni * 32 + l31) * 4u : CV_OOB;
-                        buf_store(acc[mi][ni][r] * oscale, ry, voff, 0);
+                        float v = acc[mi][ni][r] * oscale;
+                        if constexpr (EPI) {
+                            v += bv[ni];
+                            const bool pos = v > 0.f;
+                            {
+                                // lanes 0-31 are the 32 channels of one sign word (pixel of the lower half), 32-63 the next
+                                // pixel's; no branch on `signs`: without them every lane's offset is out of range
+                                const unsigned long long bal = __builtin_amdgcn_ballot_w64(pos);
+                                const unsigned word = lhi ? (unsigned)(bal >> 32) : (unsigned)bal;
+                                const unsigned so = (ok && sign_lane) ? (unsigned)((row * p.W + col) * (p.Cout / 32) + nh * 2 + ni) * 4u : CV_OOB;
+                                __builtin_amdgcn_raw_buffer_store_b32(word, rs, so, 0, 0);
+                            }
+                            v = pos ? v : v * p.slope;
+                            if (ok) {
+                                const unsigned a = abits(v);
+                                amax_run = amax_run > a ? amax_run : a;
+                            }
+                        }
+                        buf_store(v, ry, voff, 0);
                         acc[mi][ni][r] = 0.f;
                     }
+                    if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);      // (one register's ballots and stores at a time)
                 }
             }
         }
@@ -344,6 +381,9 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         } else {
             ++cc;
         }
+    }
+    if constexpr (EPI) {
+        if (p.amax) amax_publish(amax_run, p.amax);
     }
 }
 
@@ -461,8 +501,9 @@ extern "C" int sbmc_conv3x3_prepare_weights_f32(const float* w, long s_co, long 
     return (int)hipGetLastError();
 }
 
-extern "C" int sbmc_conv3x3_nhwc_f32(const float* x, const unsigned* xmax, const void* wp, float* y, int n, int h,
-                                      int w, int cin, int cout, void* stream) {
+static int conv3_launch(const float* x, const unsigned* xmax, const void* wp, float* y, int n, int h, int w, int cin,
+                        int cout, const float* bias, int act, float slope, unsigned* signs, unsigned* amax, bool epi,
+                        void* stream) {
     if (!conv3_dims_ok(n, h, w, cin, cout) || !x || !xmax || !wp || !y) return SBMC_HIP_EINVAL;
     if ((uintptr_t)x % 16 || (uintptr_t)wp % 16) return SBMC_HIP_EINVAL;
     Conv3Params p;
@@ -471,6 +512,7 @@ extern "C" int sbmc_conv3x3_nhwc_f32(const float* x, const unsigned* xmax, const
     p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout;
     p.tiles_x = (w + CV_TS - 1) / CV_TS; p.tiles_y = (h + CV_TS - 1) / CV_TS; p.ncot = cout / 128;
     p.ntiles = (unsigned)((long long)n * p.tiles_y * p.tiles_x * p.ncot);
+    p.bias = bias; p.slope = act == 0 ? 1.f : (act == 1 ? 0.f : slope); p.signs = signs; p.amax = amax;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -481,12 +523,28 @@ extern "C" int sbmc_conv3x3_nhwc_f32(const float* x, const unsigned* xmax, const
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     unsigned grid = p.ntiles < (unsigned)cus ? p.ntiles : (unsigned)cus;
-    auto kern = conv3_kernel;
+    auto kern = epi ? conv3_kernel<true> : conv3_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, p);
     return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_conv3x3_nhwc_f32(const float* x, const unsigned* xmax, const void* wp, float* y, int n, int h,
+                                      int w, int cin, int cout, void* stream) {
+    return conv3_launch(x, xmax, wp, y, n, h, w, cin, cout, nullptr, 0, 1.f, nullptr, nullptr, false, stream);
+}
+
+extern "C" int sbmc_conv3x3_bias_act_nhwc_f32(const float* x, const unsigned* xmax, const void* wp, const float* bias,
+                                               float* y, unsigned* signs, unsigned* amax, int n, int h, int w, int cin,
+                                               int cout, int act, float slope, void* stream) {
+    if (!bias || act < 0 || act > 2 || (uintptr_t)signs % 4) return SBMC_HIP_EINVAL;
+    if (amax) {
+        hipError_t e = hipMemsetAsync(amax, 0, 4, (hipStream_t)stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    }
+    return conv3_launch(x, xmax, wp, y, n, h, w, cin, cout, bias, act, slope, signs, amax, true, stream);
 }
 
 // =============================================================================================================

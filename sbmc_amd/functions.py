@@ -958,7 +958,11 @@ class Conv3x3NHWC(th.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, xmax = ctx.saved_tensors
-        gy = gy.contiguous(memory_format=th.channels_last)
+        return Conv3x3NHWC._backward(x, w, xmax, gy.contiguous(memory_format=th.channels_last),
+                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+    @staticmethod
+    def _backward(x, w, xmax, gy, want_gx, want_gw):
         b, cin, h, wd = x.shape
         cout = w.shape[0]
         gx = gw = None
@@ -968,10 +972,10 @@ class Conv3x3NHWC(th.autograd.Function):
             gmax = known_amax(gy)
             if gmax is None:
                 gmax = Conv3x3NHWC._absmax(gy)
-            if ctx.needs_input_grad[0]:
+            if want_gx:
                 with _timed("conv3x3_bwd_data %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
                     gx = Conv3x3NHWC._conv(gy, gmax, Conv3x3NHWC._prepare(w, True), cin)
-            if ctx.needs_input_grad[1]:
+            if want_gw:
                 with _timed("conv3x3_bwd_weight %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
                     if (os.environ.get("SBMC_CONV3X3_WGRAD", "1") not in ("0", "off", "no")
                             and L.sbmc_conv3x3_wgrad_supported(b, h, wd, cin, cout)):
@@ -986,6 +990,57 @@ class Conv3x3NHWC(th.autograd.Function):
                         gw = th.ops.aten.convolution_backward(gy, x, wcl, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                               [False, True, False])[1]
         return gx, gw
+
+
+class Conv3x3BiasActNHWC(th.autograd.Function):
+    """`Conv3x3NHWC` with the bias + ReLU / LeakyReLU pass behind it (reference sbmc/modules.py:154-175) in the
+    kernel's epilogue: the activated output is written once instead of written, read and rewritten; the epilogue
+    also leaves the sign bits the adjoint needs and the largest magnitude the next convolution scales by (returned as
+    second output: `tag_amax`).  Backward: the activation's adjoint + bias gradient pass (`bias_act_nhwc_bwd`), then
+    `Conv3x3NHWC`'s two gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act, slope):
+        _require_f32("Conv3x3BiasActNHWC", x=x, w=w, bias=bias)
+        L = _lib.lib()
+        b, cin, h, wd = x.shape
+        cout = w.shape[0]
+        dev = x.device
+        bias = bias.contiguous()
+        need_grad = any(ctx.needs_input_grad[:3])
+        with th.cuda.device(dev), _timed("conv3x3_fwd %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
+            xmax = known_amax(x)
+            if xmax is None:
+                xmax = Conv3x3NHWC._absmax(x)
+            wp = Conv3x3NHWC._prepare(w, False)
+            y = th.empty((b, cout, h, wd), dtype=th.float32, device=dev, memory_format=th.channels_last)
+            signs = th.empty((y.numel() + 31) // 32, dtype=th.int32, device=dev) if (act != 0 and need_grad) else None
+            amax = th.empty(1, dtype=th.int32, device=dev)
+            _lib.check(L.sbmc_conv3x3_bias_act_nhwc_f32(_lib.ptr(x), _lib.ptr(xmax), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y),
+                                                        _lib.ptr(signs), _lib.ptr(amax), b, h, wd, cin, cout, act, slope,
+                                                        _lib.current_stream(dev)), "conv3x3_bias_act_nhwc")
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(x, w, xmax, signs if signs is not None else xmax)
+        ctx.mark_non_differentiable(amax)
+        return y, amax
+
+    @staticmethod
+    def backward(ctx, gy, _gamax):
+        x, w, xmax, signs = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=th.channels_last)
+        b, cout, h, wd = gy.shape
+        L = _lib.lib()
+        dev = gy.device
+        gz = th.empty_like(gy, memory_format=th.channels_last)
+        partial = gy.new_empty(L.sbmc_bias_act_nhwc_chunks(b * h * wd, cout), cout)
+        gmax = th.empty(1, dtype=th.int32, device=dev)
+        with th.cuda.device(dev):
+            _lib.check(L.sbmc_bias_act_nhwc_bwd_amax_f32(_lib.ptr(gy), _lib.ptr(signs) if ctx.act != 0 else None, _lib.ptr(gz),
+                                                         _lib.ptr(partial), _lib.ptr(gmax), b * h * wd, cout, ctx.act, ctx.slope,
+                                                         _lib.current_stream(dev)), "bias_act_nhwc_bwd")
+        tag_amax(gz, gmax)
+        gx, gw = Conv3x3NHWC._backward(x, w, xmax, gz, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, gw, (partial.sum(0) if ctx.needs_input_grad[2] else None), None, None
 
 
 def upsample_cat_nhwc_supported(coarse, left, top=0, bot=0):

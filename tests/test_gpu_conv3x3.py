@@ -153,8 +153,8 @@ def test_unet_is_the_same_function_with_and_without_the_kernel(monkeypatch, acti
     x = th.randn(1, 128, 48, 80, device=dev)
     gy = th.randn(1, 128, 48, 80, device=dev)
     used = []
-    real = funcs.Conv3x3NHWC._conv
-    monkeypatch.setattr(funcs.Conv3x3NHWC, "_conv", staticmethod(lambda *a: (used.append(1), real(*a))[1]))
+    real = funcs.Conv3x3NHWC._prepare
+    monkeypatch.setattr(funcs.Conv3x3NHWC, "_prepare", staticmethod(lambda *a: (used.append(1), real(*a))[1]))
 
     def run(flag, dtype=th.float32):
         monkeypatch.setenv("SBMC_CONV3X3", flag)
@@ -169,7 +169,7 @@ def test_unet_is_the_same_function_with_and_without_the_kernel(monkeypatch, acti
         return out
 
     ours = run("1")
-    assert len(used) == 30, len(used)                   # 15 convolutions forward, 15 data gradients
+    assert len(used) == 30, len(used)                   # weights prepared for 15 convolutions forward, 15 data gradients
     lib = run("0")
     assert len(used) == 30
     ref = run("0", th.float64)
@@ -214,3 +214,29 @@ def test_amax_tags_replace_the_absmax_pass_and_expire(monkeypatch):
     assert funcs.known_amax(t) is not None
     t.mul_(2.0)
     assert funcs.known_amax(t) is None
+
+
+@pytest.mark.parametrize("act,slope", [(0, 0.0), (1, 0.0), (2, 0.01)])
+def test_fused_epilogue_equals_the_two_passes(act, slope):
+    """Bias + activation (+ sign bits, + largest magnitude) in the convolution's epilogue: the same arithmetic in the
+    same order as the convolution followed by the bias / activation pass -- equal to the bit, forward and backward."""
+    dev = _dev()
+    g = th.Generator(device="cpu").manual_seed(11 + act)
+    x = _cl((th.randn(2, 128, 21, 37, generator=g)).to(dev))
+    wt = (th.randn(256, 128, 3, 3, generator=g) * 0.03).to(dev)
+    bias = th.randn(256, generator=g).to(dev)
+    gy = _cl(th.randn(2, 256, 21, 37, generator=g).to(dev))
+
+    def two_passes():
+        xs, ws, bs = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        y = funcs.BiasActNHWC.apply(funcs.Conv3x3NHWC.apply(xs, ws), bs, act, slope)
+        return (y.detach().clone(),) + th.autograd.grad(y, (xs, ws, bs), gy)
+
+    def fused():
+        xs, ws, bs = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        y, amax = funcs.Conv3x3BiasActNHWC.apply(xs, ws, bs, act, slope)
+        assert amax.view(th.float32).item() == y.abs().max().item()
+        return (y.detach().clone(),) + th.autograd.grad(y, (xs, ws, bs), gy)
+
+    for a, b in zip(two_passes(), fused()):
+        assert th.equal(a, b)
