@@ -569,8 +569,8 @@ namespace sbmc {
 constexpr int WG_TW = 32;                       // pixels of a row stage
 constexpr int WG_OCT = WG_TW / 8;
 constexpr int WG_G = 2 * WG_OCT * 128;          // entries of a gy row: [plane][octet][co 128]
-constexpr int WG_X = 3 * 2 * WG_OCT * 128;      // entries of an x row: [kx][plane][octet][ci 128]
-constexpr unsigned WG_LDS_BYTES = (2 * WG_G + 2 * WG_X) * 16;      // 131072
+constexpr int WG_XR = 2 * WG_OCT * 128;         // entries of an x row: [plane][octet][ci 128]
+constexpr unsigned WG_LDS_BYTES = (2 * WG_G + 4 * WG_XR) * 16;     // 98304: two gy rows + a ring of four x rows
 constexpr int WG_TILE = 128 * 128 * 3;          // outputs of a workgroup
 
 struct WgradParams {
@@ -594,7 +594,7 @@ __device__ __forceinline__ unsigned cv_pack_hh(_Float16 a, _Float16 b) {
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     extern __shared__ float4 cv_lds[];
     u32x4* Gs = reinterpret_cast<u32x4*>(cv_lds);       // [2][WG_G]
-    u32x4* Xs = Gs + 2 * WG_G;                          // [2][WG_X]
+    u32x4* Xs = Gs + 2 * WG_G;                          // [4][WG_XR]: ring of x rows
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int l31 = lane & 31, lhi = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
@@ -603,25 +603,26 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     const unsigned logical = logical_block_id();
     const int ncombo = p.ncot * p.ncit * 3;
     const int combo = (int)(logical % (unsigned)ncombo), split = (int)(logical / (unsigned)ncombo);
-    const int ky = combo % 3, cit = (combo / 3) % p.ncit, cot = combo / (3 * p.ncit);
+    const int kx = combo % 3, cit = (combo / 3) % p.ncit, cot = combo / (3 * p.ncit);
     const unsigned long long t0 = p.total * (unsigned)split / (unsigned)p.nsplit;
     const unsigned long long t1 = p.total * (unsigned)(split + 1) / (unsigned)p.nsplit;
 
-    // ---- loaders.  Waves 0, 1 stage the x row, waves 2, 3 the gy row: a thread owns pixel octet o (of 4) and
-    // channel quad q (of 32) -- its loads are 16-byte pieces, 32 lanes cover the 512 contiguous bytes of one
-    // pixel's 128 channels -- and turns its 8 (x: 10, with the two neighbours the shifted copies need) pixels x 4
-    // channels into one 16-byte entry per channel, plane (and kx).  Entry of channel 4 q + c inside its [128]
-    // row: 4 q + (c ^ ((q >> 1) & 3)) -- the four entries of a thread stay in its own 64 bytes, but 8 neighbouring
-    // lanes of one store instruction hit 8 different 16-byte slots of the 128-byte bank row, and the readers'
-    // lane groups still see 16 different slots of theirs. ----
+    // ---- loaders.  Waves 0, 1 stage x rows, waves 2, 3 gy rows: a thread owns pixel octet o (of 4) and channel
+    // quad q (of 32) -- its loads are 16-byte pieces, 32 lanes cover the 512 contiguous bytes of one pixel's 128
+    // channels -- and turns its 8 pixels x 4 channels into one 16-byte entry per channel and plane.  For x the 8
+    // pixels are the octet shifted by kx - 1: the workgroup's tap column is folded into the addresses.  Entry of
+    // channel 4 q + c inside its [128] row: 4 q + (c ^ ((q >> 1) & 3)) -- the four entries of a thread stay in its own
+    // 64 bytes, but 8 neighbouring lanes of one store instruction hit 8 different 16-byte slots of the 128-byte bank
+    // row, and the readers' lane groups still see 16 different slots of theirs. ----
     const bool xrole = wave < 2;
     const int uo = (tid & 127) >> 5, uq = tid & 31;
     const int usw = (uq >> 1) & 3;
     const int C = xrole ? p.Cin : p.Cout;
-    unsigned lvoff[10];                                 // byte offsets of the thread's pixels from the stage's first
+    const int shift = xrole ? kx - 1 : 0;               // first pixel of the stage's 32, relative to x0
+    unsigned lvoff[8];                                  // byte offsets of the thread's pixels from that pixel
 #pragma unroll
-    for (int j = 0; j < 10; ++j) lvoff[j] = (unsigned)(uq * 16 + (8 * uo + j) * C * 4);
-    struct Rows { u32x4 v[10]; };
+    for (int j = 0; j < 8; ++j) lvoff[j] = (unsigned)(uq * 16 + (8 * uo + j) * C * 4);
+    struct Rows { u32x4 v[8]; };
     // the stage the next request is for: walks down the rows of a strip, then to the next strip, the next image
     int qy, qx0, qn;
     {
@@ -630,10 +631,23 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         qx0 = (int)(rest % (unsigned)p.nstrips) * WG_TW;
         qn = (int)(rest / (unsigned)p.nstrips);
     }
-    // One request: ten 16-byte loads in EITHER role and under no branch (the gy role's last two, and everything beyond
-    // the workgroup's range, through out-of-range offsets / an empty descriptor: zeros): at a control-flow join the
-    // compiler can no longer count which loads are outstanding and waits for all of them -- for the request it
-    // has just made.
+    // Row `row` (x role: of x, may lie outside the image; gy role: of gy) of strip x0: eight 16-byte loads under no
+    // branch.  What lies outside the image reads as zero: the descriptor ends with the image row (and is empty for a
+    // row outside or a request beyond the workgroup's range), the pixel before the row is masked.
+    auto load_row = [&](Rows& rr, int n, int row, int x0, bool valid) {
+        const bool rowin = valid && row >= 0 && row < p.H;
+        const int xs = x0 + shift;
+        const float* base = (xrole ? p.x : p.gy) + (((long)n * p.H + (rowin ? row : 0)) * (long)p.W + xs) * (long)C +
+                            (xrole ? cit : cot) * 128;
+        const rsrc_t r = cv_rsrc(rowin ? base : p.x, rowin ? (unsigned)((p.W - xs) * C - (xrole ? cit : cot) * 128) * 4u : 0u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool off = j == 0 && xs < 0 && uo == 0;
+            rr.v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, off ? CV_OOB : lvoff[j], 0, 0);
+        }
+    };
+    // One request = what stage (qn, qx0, qy) still lacks in the steady state: its gy row, and x row qy + 1 (rows
+    // qy - 1 and qy are in the ring from the two stages before; a stage that opens a strip primes them itself)
     auto issue = [&](Rows& rr, bool valid) {
         const int y = qy, x0 = qx0, n = qn;
         if (++qy == p.H) {
@@ -644,19 +658,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
                 ++qn;
             }
         }
-        // x: pixels x0 - 1 .. x0 + 32 of image row y + ky - 1; what lies outside the image reads as zero: the
-        // descriptor ends with the row (and is empty for a row outside), the pixel before the row is masked
-        const int yy = xrole ? y + ky - 1 : y;
-        const bool rowin = valid && yy >= 0 && yy < p.H;
-        const int xs = xrole ? x0 - 1 : x0;
-        const float* base = (xrole ? p.x : p.gy) + (((long)n * p.H + (rowin ? yy : 0)) * (long)p.W + xs) * (long)C +
-                            (xrole ? cit : cot) * 128;
-        const rsrc_t r = cv_rsrc(rowin ? base : p.x, rowin ? (unsigned)((p.W - xs) * C - (xrole ? cit : cot) * 128) * 4u : 0u);
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const bool off = j == 0 ? (xrole && x0 == 0 && uo == 0) : (j >= 8 && !xrole);
-            rr.v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, off ? CV_OOB : lvoff[j], 0, 0);
-        }
+        load_row(rr, n, xrole ? y + 1 : y, x0, valid);
     };
     // two scaled values -> their h and l halves, packed (element 0 in the low half)
     auto pair = [&](unsigned a, unsigned b, float c, unsigned& hp, unsigned& lp) {
@@ -667,55 +669,28 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         hp = __builtin_bit_cast(unsigned, hv);
         lp = cv_pack(fa - (float)hv[0], fb - (float)hv[1]);
     };
-    auto commit = [&](const Rows& rr, int par) {
-        if (xrole) {
-            u32x4* d = Xs + par * WG_X + uo * 128 + 4 * uq;
+    // the thread's 8 pixels x 4 channels -> entries of row buffer `dst` ([plane][octet][128])
+    auto write_row = [&](const Rows& rr, u32x4* dst, float c) {
+        u32x4* d = dst + uo * 128 + 4 * uq;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                // pixels 8 o - 1 + j, j = 0 .. 9: pairs P_i = (2 i, 2 i + 1); the copy for kx = 0 is P0..P3, for
-                // kx = 2 P1..P4, for kx = 1 the pairs in between, Q_i = (P_i.hi, P_{i+1}.lo)
-                unsigned ph[5], pl[5];
+        for (int ch = 0; ch < 4; ++ch) {
+            u32x4 hh, ll;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const unsigned a = rr.v[2 * i][c], b = rr.v[2 * i + 1][c];
-                    pair(a, b, cx, ph[i], pl[i]);
-                }
-                u32x4 e0h, e0l, e1h, e1l, e2h, e2l;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    e0h[i] = ph[i];
-                    e0l[i] = pl[i];
-                    e2h[i] = ph[i + 1];
-                    e2l[i] = pl[i + 1];
-                    e1h[i] = __builtin_amdgcn_alignbit(ph[i + 1], ph[i], 16);
-                    e1l[i] = __builtin_amdgcn_alignbit(pl[i + 1], pl[i], 16);
-                }
-                u32x4* e = d + (c ^ usw);
-                e[(0 * 2 + 0) * WG_OCT * 128] = e0h;
-                e[(0 * 2 + 1) * WG_OCT * 128] = e0l;
-                e[(1 * 2 + 0) * WG_OCT * 128] = e1h;
-                e[(1 * 2 + 1) * WG_OCT * 128] = e1l;
-                e[(2 * 2 + 0) * WG_OCT * 128] = e2h;
-                e[(2 * 2 + 1) * WG_OCT * 128] = e2l;
+            for (int i = 0; i < 4; ++i) {
+                const unsigned a = rr.v[2 * i][ch], b = rr.v[2 * i + 1][ch];
+                unsigned hp, lp;
+                pair(a, b, c, hp, lp);
+                hh[i] = hp;
+                ll[i] = lp;
             }
-        } else {
-            u32x4* d = Gs + par * WG_G + uo * 128 + 4 * uq;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                u32x4 hh, ll;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned a = rr.v[2 * i][c], b = rr.v[2 * i + 1][c];
-                    unsigned hp, lp;
-                    pair(a, b, cg, hp, lp);
-                    hh[i] = hp;
-                    ll[i] = lp;
-                }
-                u32x4* e = d + (c ^ usw);
-                e[0] = hh;
-                e[WG_OCT * 128] = ll;
-            }
+            u32x4* e = d + (ch ^ usw);
+            e[0] = hh;
+            e[WG_OCT * 128] = ll;
         }
+    };
+    // stage k's rows: gy -> Gs[k % 2]; x row (y + 1) -> ring slot (k + 1) % 4 (y - 1, y: slots (k - 1) % 4, k % 4)
+    auto commit = [&](const Rows& rr, unsigned k) {
+        write_row(rr, xrole ? Xs + ((k + 1) & 3u) * WG_XR : Gs + (k & 1u) * WG_G, xrole ? cx : cg);
     };
     // where this lane's channel of a [128] row sits (the swizzle above), as a reader: channel w 64 + 32 i + l31
     const int rsw = (l31 & ~3) + ((l31 & 3) ^ ((l31 >> 3) & 3));
@@ -726,98 +701,121 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][kx][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[mi][ni][ky][r] = 0.f;
 
-    // operands: gy (A) per k-step, x (B) per (k-step, kx) sub-step
+    // operands: gy (A) per k-step, x (B) per (k-step, ky) sub-step
     struct OpA { u32x4 h[2], l[2]; };
     struct OpB { u32x4 h[2], l[2]; };
-    auto load_a = [&](OpA& o, int par, int ks) {
-        const u32x4* Gb = Gs + par * WG_G + (2 * ks + lhi) * 128 + wm * 64 + rsw;
+    auto load_a = [&](OpA& o, unsigned k, int ks) {
+        const u32x4* Gb = Gs + (k & 1u) * WG_G + (2 * ks + lhi) * 128 + wm * 64 + rsw;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             o.h[mi] = Gb[mi * 32];
             o.l[mi] = Gb[WG_OCT * 128 + mi * 32];
         }
     };
-    auto load_b = [&](OpB& o, int par, int ks, int kx) {
-        const u32x4* Xb = Xs + par * WG_X + (2 * ks + lhi) * 128 + wn * 64 + rsw;
+    auto load_b = [&](OpB& o, unsigned k, int ks, int ky) {
+        const u32x4* Xb = Xs + ((k + (unsigned)ky + 3u) & 3u) * WG_XR + (2 * ks + lhi) * 128 + wn * 64 + rsw;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            o.h[ni] = Xb[(kx * 2 + 0) * WG_OCT * 128 + ni * 32];
-            o.l[ni] = Xb[(kx * 2 + 1) * WG_OCT * 128 + ni * 32];
+            o.h[ni] = Xb[ni * 32];
+            o.l[ni] = Xb[WG_OCT * 128 + ni * 32];
         }
     };
-    auto mfmas = [&](const OpA& a, const OpB& b, int kx) {
+    auto mfmas = [&](const OpA& a, const OpB& b, int ky) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(a.h[mi], b.h[ni], acc[mi][ni][kx]);
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.h[mi], b.h[ni], acc[mi][ni][ky]);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(a.h[mi], b.l[ni], acc[mi][ni][kx]);
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.h[mi], b.l[ni], acc[mi][ni][ky]);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][kx] = cv_mfma(a.l[mi], b.h[ni], acc[mi][ni][kx]);
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.l[mi], b.h[ni], acc[mi][ni][ky]);
     };
 
-    // Pipeline.  Stage k (= t - t0) lives in LDS buffer k % 2.  Its rows are REQUESTED in the middle of stage
-    // k - 2 and WRITTEN in the middle of stage k - 1 (one register set: it is free again the moment it has been
-    // written), between two barriers: the first makes them visible, the second -- at the end of stage k - 1 --
-    // frees the other buffer.  Operands are fetched one sub-step (12 MFMAs) ahead, across both barriers: the
-    // matrix pipe never waits for LDS after a barrier.
-    // (an odd number of stages is rounded up: the extra one reads zeros and adds nothing)
+    // Pipeline.  Stage k (= t - t0): its gy row and its last x row are REQUESTED in the middle of stage k - 3
+    // (two register sets) and WRITTEN in the middle of stage k - 1, between two barriers: the first makes them
+    // visible, the second -- at the end of stage k - 1 -- frees what stage k - 1 read.  Operands are fetched one
+    // sub-step (12 MFMAs) ahead, across both barriers.  A stage that opens a strip (or the range) loads its first
+    // two x rows itself, not overlapped (once or twice per workgroup).  An odd number of stages is rounded up:
+    // the extra one reads zeros and adds nothing.
     const unsigned long long t1e = t1 + ((t1 - t0) & 1ull);
     Rows r0, r1;
     issue(r0, t0 < t1);
     commit(r0, 0);
     issue(r1, t0 + 1 < t1);
     issue(r0, t0 + 2 < t1);
-    __syncthreads();
     OpA a0, a1;
     OpB b0, b1;
-    load_a(a0, 0, 0);
-    load_b(b0, 0, 0, 0);
-    // (two register sets: the rows of stage t + 1 are written from `done` in the middle of stage t, and `done` is
-    // at once requested again for stage t + 3: two stages in flight)
-    auto stage = [&](unsigned long long t, Rows& done, const int par) {
-        load_b(b1, par, 0, 1);
+    int sy, sx0, sn;                                    // the stage being computed
+    {
+        sy = (int)(t0 % (unsigned)p.H);
+        const unsigned long long rest = t0 / (unsigned)p.H;
+        sx0 = (int)(rest % (unsigned)p.nstrips) * WG_TW;
+        sn = (int)(rest / (unsigned)p.nstrips);
+    }
+    auto stage = [&](unsigned long long t, Rows& done, const unsigned k) {
+        if (k == 0 || sy == 0) {
+            // x rows sy - 1 and sy of a new strip
+            cv_lds_barrier();
+            Rows pr;
+            load_row(pr, sn, sy - 1, sx0, xrole && t < t1);
+            if (xrole) write_row(pr, Xs + ((k + 3u) & 3u) * WG_XR, cx);
+            load_row(pr, sn, sy, sx0, xrole && t < t1);
+            if (xrole) write_row(pr, Xs + (k & 3u) * WG_XR, cx);
+            __syncthreads();
+            load_a(a0, k, 0);
+            load_b(b0, k, 0, 0);
+        }
+        if (++sy == p.H) {
+            sy = 0;
+            sx0 += WG_TW;
+            if (sx0 >= p.nstrips * WG_TW) {
+                sx0 = 0;
+                ++sn;
+            }
+        }
+        load_b(b1, k, 0, 1);
         mfmas(a0, b0, 0);
-        load_b(b0, par, 0, 2);
+        load_b(b0, k, 0, 2);
         mfmas(a0, b1, 1);
-        load_a(a1, par, 1);
-        load_b(b1, par, 1, 0);
+        load_a(a1, k, 1);
+        load_b(b1, k, 1, 0);
         mfmas(a0, b0, 2);
-        commit(done, par ^ 1);
+        commit(done, k + 1);
         issue(done, t + 3 < t1);
         cv_lds_barrier();
-        load_b(b0, par, 1, 1);
+        load_b(b0, k, 1, 1);
         mfmas(a1, b1, 0);
-        load_b(b1, par, 1, 2);
+        load_b(b1, k, 1, 2);
         mfmas(a1, b0, 1);
-        load_a(a0, par ^ 1, 0);
-        load_b(b0, par ^ 1, 0, 0);
+        load_a(a0, k + 1, 0);
+        load_b(b0, k + 1, 0, 0);
         mfmas(a1, b1, 2);
         cv_lds_barrier();
     };
-    for (unsigned long long t = t0; t < t1e; t += 2) {
-        stage(t, r1, 0);
-        stage(t + 1, r0, 1);
+    unsigned k = 0;
+    for (unsigned long long t = t0; t < t1e; t += 2, k += 2) {
+        stage(t, r1, k);
+        stage(t + 1, r0, k + 1);
     }
 
-    // ---- partial sums of this pixel range: [wave][mi][ni][kx][r][lane] ----
+    // ---- partial sums of this pixel range: [wave][mi][ni][ky][r][lane] ----
     float* out = p.partial + ((size_t)combo * p.nsplit + split) * WG_TILE + (size_t)wave * (12 * 16 * 64) + lane;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[(((mi * 2 + ni) * 3 + kx) * 16 + r) * 64] = acc[mi][ni][kx][r];
+                for (int r = 0; r < 16; ++r) out[(((mi * 2 + ni) * 3 + ky) * 16 + r) * 64] = acc[mi][ni][ky][r];
 }
 
 struct WreduceParams {
@@ -837,8 +835,8 @@ __global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(WreduceParams p
     for (int i = 0; i < p.nsplit; ++i) s += src[(size_t)i * WG_TILE];
     const float oscale = (1.f / cv_scale_of(*p.gmax)) * (1.f / cv_scale_of(*p.xmax));
     const int lane = e & 63, r = (e >> 6) & 15;
-    const int rest = e >> 10, kx = rest % 3, ni = (rest / 3) & 1, mi = (rest / 6) & 1, wave = rest / 12;
-    const int ky = combo % 3, cit = (combo / 3) % p.ncit, cot = combo / (3 * p.ncit);
+    const int rest = e >> 10, ky = rest % 3, ni = (rest / 3) & 1, mi = (rest / 6) & 1, wave = rest / 12;
+    const int kx = combo % 3, cit = (combo / 3) % p.ncit, cot = combo / (3 * p.ncit);
     const int co = cot * 128 + (wave & 1) * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int ci = cit * 128 + (wave >> 1) * 64 + ni * 32 + (lane & 31);
     p.gw[co * p.s_co + ci * p.s_ci + ky * p.s_ky + kx * p.s_kx] = s * oscale;
