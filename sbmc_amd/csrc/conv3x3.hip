@@ -552,16 +552,18 @@ extern "C" int sbmc_conv3x3_bias_act_nhwc_f32(const float* x, const unsigned* xm
 //
 // A GEMM whose REDUCTION runs over the pixels: the matrix instruction wants 8 consecutive pixels of one channel
 // per lane, the channels-last image has them Cin floats apart.  The staging does the transposition: a thread owns
-// one channel (lane = channel: every global load of a wave is 256 contiguous bytes of one pixel) and 8 pixels of
-// a row, splits them and writes ONE 16-byte entry per plane, [plane][pixel octet][channel] in LDS -- conflict
-// free both ways.  The tap's column shift kx - 1 breaks the octets' alignment, so the x row is kept in three
-// copies, one per kx (same registers, three packings); the row shift ky - 1 is simply another image row.
-//   * a workgroup owns 128 output x 128 input channels x the 3 taps of ONE kernel row ky (a wave: 64 x 64 x 3 =
+// a pixel octet and a channel quad (16-byte loads: 32 lanes = the 512 contiguous bytes of one pixel's 128
+// channels), splits its 8 pixels x 4 channels and writes ONE 16-byte entry per channel and plane,
+// [plane][pixel octet][channel] in LDS -- conflict free both ways (see the swizzle in the kernel).  The tap's
+// column shift kx - 1 would break the octets' alignment: a workgroup owns ONE tap column and folds the shift into
+// its addresses; the row shift ky - 1 is another row of a ring of four x rows in LDS.
+//   * a workgroup owns 128 output x 128 input channels x the 3 taps of one kernel column (a wave: 64 x 64 x 3 =
 //     12 accumulators of 32 x 32 -- 9 taps would be 288 registers, more than the 256 accumulation registers) and
-//     a contiguous range of ROW STAGES (32 pixels of one image row: 2 k-steps of 16); the three ky workgroups of
-//     a range are neighbours on one XCD and read the same rows through its L2;
-//   * per k-step a wave reads 4 gy operands + 12 x operands for 36 MFMAs (0.44 of the LDS bandwidth at full
-//     matrix rate); the next stage's rows are in flight meanwhile;
+//     a contiguous range of ROW STAGES (32 pixels of one image row: 2 k-steps of 16), walking down the rows: each
+//     x row is fetched once and used by three gy rows; the three kx workgroups of a range are neighbours on one
+//     XCD and read the same rows through its L2;
+//   * per k-step a wave reads 4 gy operands + 12 x operands for 36 MFMAs; the next stages' rows are in flight
+//     meanwhile (two register sets, no load under a branch);
 //   * the ranges' partial sums go to a scratch buffer and a second kernel adds them in a FIXED order (no
 //     atomics: the result does not depend on the run) and scales back.
 namespace sbmc {
