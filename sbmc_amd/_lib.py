@@ -88,6 +88,7 @@ SYMBOLS = (
     "sbmc_halo_get",
     "sbmc_halo_merge_state_fwd_f32",
     "sbmc_halo_merge_state_bwd_f32",
+    "sbmc_transpose2d_amax_f32",
     "sbmc_bias_act_nhwc_fwd_amax_f32",
     "sbmc_bias_act_nhwc_bwd_amax_f32",
     "sbmc_conv3x3_supported",
@@ -219,6 +220,7 @@ def lib():
     handle.sbmc_halo_merge_state_fwd_f32.argtypes = [p] * 7 + [i] * 7 + [u, u, i, ll, ll, p]
     handle.sbmc_halo_merge_state_bwd_f32.argtypes = [p] * 7 + [i] * 7 + [p]
     lg = ctypes.c_long
+    handle.sbmc_transpose2d_amax_f32.argtypes = [p, p, p, i, i, i, p]
     handle.sbmc_bias_act_nhwc_fwd_amax_f32.argtypes = [p, p, p, p, lg, i, i, ctypes.c_float, p]
     handle.sbmc_bias_act_nhwc_bwd_amax_f32.argtypes = [p, p, p, p, p, lg, i, i, ctypes.c_float, p]
     handle.sbmc_conv3x3_supported.argtypes = [i] * 5

@@ -232,8 +232,10 @@ __global__ __launch_bounds__(256) void slice_channels_nhwc_kernel(const T* __res
 // copy rate.  R and Cn multiples of 4.
 constexpr int TT = 64;
 __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                         int R, int Cn, int tiles_r, int tiles_c) {
+                                                         int R, int Cn, int tiles_r, int tiles_c,
+                                                         unsigned* __restrict__ amax) {
     __shared__ float tile[TT][TT + 1];
+    unsigned m = 0;
     unsigned blk = blockIdx.x;
     const int tc = blk % tiles_c; blk /= tiles_c;
     const int tr = blk % tiles_r;
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
         const int r = r0 + line + 16 * i, c = c0 + 4 * q;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < R && c < Cn) v = *reinterpret_cast<const float4*>(s + (size_t)r * Cn + c);
+        m = amax4(m, v);
         float* t = &tile[line + 16 * i][4 * q];
         t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
     }
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restric
             *reinterpret_cast<float4*>(d + (size_t)c * R + r) = v;
         }
     }
+    if (amax) amax_publish(m, amax);
 }
 
 static inline unsigned grid_for(size_t n) {
@@ -450,6 +454,23 @@ extern "C" int sbmc_transpose2d_f32(const float* src, float* dst, int b, int row
     const unsigned long long blocks = (unsigned long long)b * tr * tc;
     if (blocks > 0x7fffffffull) return SBMC_HIP_EINVAL;
     hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, rows,
-                       cols, tr, tc);
+                       cols, tr, tc, (unsigned*)nullptr);
+    return (int)hipGetLastError();
+}
+
+// The same transpose, also leaving the bit pattern of the tensor's largest magnitude in *amax (the U-net's first
+// convolution scales by it: csrc/conv3x3.hip).
+extern "C" int sbmc_transpose2d_amax_f32(const float* src, float* dst, unsigned* amax, int b, int rows, int cols,
+                                         void* stream) {
+    if (b < 0 || rows < 0 || cols < 0 || !amax) return SBMC_HIP_EINVAL;
+    hipError_t e = hipMemsetAsync(amax, 0, 4, (hipStream_t)stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    if (b == 0 || rows == 0 || cols == 0) return 0;
+    if (!src || !dst || rows % 4 || cols % 4 || (uintptr_t)src % 16 || (uintptr_t)dst % 16) return SBMC_HIP_EINVAL;
+    const int tr = (rows + TT - 1) / TT, tc = (cols + TT - 1) / TT;
+    const unsigned long long blocks = (unsigned long long)b * tr * tc;
+    if (blocks > 0x7fffffffull) return SBMC_HIP_EINVAL;
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, rows,
+                       cols, tr, tc, amax);
     return (int)hipGetLastError();
 }

@@ -700,18 +700,27 @@ class ToChannelsLast(th.autograd.Function):
                 and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0)
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, want_amax=False):
+        """want_amax: also returns the device word with max |x| that the pass finds on its way (`tag_amax`)."""
         b, c, h, w = x.shape
         out = th.empty(b, c, h, w, dtype=x.dtype, device=x.device, memory_format=th.channels_last)
         dev = x.device
+        amax = th.empty(1, dtype=th.int32, device=dev) if want_amax else None
         with th.cuda.device(dev):
-            rc = _lib.lib().sbmc_transpose2d_f32(_lib.ptr(x), _lib.ptr(out), b, c, h * w, _lib.current_stream(dev))
+            if want_amax:
+                rc = _lib.lib().sbmc_transpose2d_amax_f32(_lib.ptr(x), _lib.ptr(out), _lib.ptr(amax), b, c, h * w,
+                                                          _lib.current_stream(dev))
+            else:
+                rc = _lib.lib().sbmc_transpose2d_f32(_lib.ptr(x), _lib.ptr(out), b, c, h * w, _lib.current_stream(dev))
         _lib.check(rc, "transpose2d")
+        if want_amax:
+            ctx.mark_non_differentiable(amax)
+            return out, amax
         return out
 
     @staticmethod
-    def backward(ctx, g):
-        return FromChannelsLast.apply(g.contiguous(memory_format=th.channels_last))
+    def backward(ctx, g, *_):
+        return FromChannelsLast.apply(g.contiguous(memory_format=th.channels_last)), None
 
 
 class FromChannelsLast(th.autograd.Function):

@@ -494,8 +494,11 @@ class Autoencoder(nn.Module):
     def forward(self, x):
         if unet_channels_last(self, x):
             # channels-last between the convolutions: MIOpen's NHWC-native solvers need no transposes then
-            xin = funcs.ToChannelsLast.apply(x) if funcs.ToChannelsLast.supported(x) \
-                else x.contiguous(memory_format=th.channels_last)
+            if funcs.ToChannelsLast.supported(x):
+                xin, amax = funcs.ToChannelsLast.apply(x, True)       # (the first convolution's scale, found on the way)
+                funcs.tag_amax(xin, amax)
+            else:
+                xin = x.contiguous(memory_format=th.channels_last)
             y = self.net(xin)
             if self.keep_channels_last:
                 return y

@@ -183,7 +183,7 @@ def test_unet_is_the_same_function_with_and_without_the_kernel(monkeypatch, acti
 
 def test_amax_tags_replace_the_absmax_pass_and_expire(monkeypatch):
     """The bias / activation passes leave max |.| of what they write on the tensor object; the convolution that
-    reads it next must use it (one absmax pass per U-net: its input) -- forward AND backward, where the tag has to
+    reads it next must use it (no absmax pass of activations at all) -- forward AND backward, where the tag has to
     survive the autograd engine -- and a tag must die with any in-place change."""
     from sbmc_amd import modules as ops
     dev = _dev()
@@ -201,7 +201,7 @@ def test_amax_tags_replace_the_absmax_pass_and_expire(monkeypatch):
     n_fwd = len(calls)
     y.backward(th.randn_like(y))
     n_bwd = len(calls) - n_fwd
-    assert n_fwd == 1, calls[:n_fwd]                    # the U-net's input only
+    assert n_fwd == 0, calls[:n_fwd]                    # (the U-net's input: from its entry transpose)
     assert n_bwd == 0, calls[n_fwd:]
     # tags are bounds that hold: compare with a run that ignores them
     monkeypatch.setenv("SBMC_AMAX_TAGS", "0")
@@ -240,3 +240,20 @@ def test_fused_epilogue_equals_the_two_passes(act, slope):
 
     for a, b in zip(two_passes(), fused()):
         assert th.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 48, 80), (2, 64, 31, 44), (1, 128, 720, 1280)])
+def test_every_pass_that_leaves_a_scale_leaves_the_largest_magnitude(shape):
+    """A word that is too small would overflow the f16 planes of the convolution that trusts it."""
+    dev = _dev()
+    x = th.randn(*shape, device=dev) * 3.0
+    out, amax = funcs.ToChannelsLast.apply(x, True)
+    assert th.equal(out, _cl(x)) and amax.view(th.float32).item() == x.abs().max().item()
+    bias = th.randn(shape[1], device=dev)
+    for act, slope in ((0, 0.0), (2, 0.01)):
+        y = _cl(x).clone().requires_grad_(True)
+        z, am = funcs.BiasActNHWC.apply(y * 1.0, bias, act, slope, True)
+        assert am.view(th.float32).item() == z.abs().max().item()
+        g = _cl(th.randn(*shape, device=dev))
+        (gz,) = th.autograd.grad(z, y, g)
+    # the adjoint's word rides on the gradient it returns (checked where it is consumed: the tag test above)
