@@ -637,8 +637,10 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     // branch.  What lies outside the image reads as zero: the descriptor ends with the image row (and is empty for a
     // row outside or a request beyond the workgroup's range), the pixel before the row is masked.
     auto load_row = [&](Rows& rr, int n, int row, int x0, bool valid) {
-        const bool rowin = valid && row >= 0 && row < p.H;
         const int xs = x0 + shift;
+        // (xs >= W: the last strip's single column shifted right -- nothing of the row is left, and the byte count
+        // below must not wrap)
+        const bool rowin = valid && row >= 0 && row < p.H && xs < p.W;
         const float* base = (xrole ? p.x : p.gy) + (((long)n * p.H + (rowin ? row : 0)) * (long)p.W + xs) * (long)C +
                             (xrole ? cit : cot) * 128;
         const rsrc_t r = cv_rsrc(rowin ? base : p.x, rowin ? (unsigned)((p.W - xs) * C - (xrole ? cit : cot) * 128) * 4u : 0u);

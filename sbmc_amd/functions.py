@@ -1009,6 +1009,11 @@ class Conv3x3BiasActNHWC(th.autograd.Function):
     `Conv3x3NHWC`'s two gradient kernels."""
 
     @staticmethod
+    def supported(conv):
+        """(on top of Conv3x3NHWC.supported) the adjoint of the bias + activation pass takes these output channels"""
+        return conv.bias is not None and bool(_lib.lib().sbmc_bias_act_nhwc_supported(int(conv.out_channels)))
+
+    @staticmethod
     def forward(ctx, x, w, bias, act, slope):
         _require_f32("Conv3x3BiasActNHWC", x=x, w=w, bias=bias)
         L = _lib.lib()

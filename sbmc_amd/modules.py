@@ -345,10 +345,12 @@ class ConvChain(nn.Module):
         if funcs._is_channels_last(x):
             # the U-net runs channels-last (Autoencoder.forward): MIOpen's NHWC solvers without any layout
             # change around them, bias + activation by the NHWC pass
-            if funcs.Conv3x3NHWC.supported(x, conv):
+            if funcs.Conv3x3NHWC.supported(x, conv) and funcs.Conv3x3BiasActNHWC.supported(conv):
                 # csrc/conv3x3.hip: fp32 values on the f16 matrix pipe, bias + activation in the kernel's epilogue
                 y, amax = funcs.Conv3x3BiasActNHWC.apply(x, w, conv.bias, act, slope)
                 return funcs.tag_amax(y, amax), act != 0
+            elif funcs.Conv3x3NHWC.supported(x, conv):
+                y = funcs.Conv3x3NHWC.apply(x, w)             # (a channel count the bias / activation adjoint does not take)
             else:
                 w = w.contiguous(memory_format=th.channels_last)
                 y = th.nn.functional.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)

@@ -46,6 +46,8 @@ SHAPES = [
     (2, 128, 256, 24, 40),        # batch of two, two output-channel tiles
     (1, 384, 128, 19, 70),        # the U-net's skip concatenation
     (1, 256, 128, 5, 3),          # smaller than a tile
+    (1, 384, 256, 47, 33),        # a last strip of ONE column: shifted right by the tap, nothing of the row is left
+    (2, 128, 128, 9, 65),
     (1, 128, 128, 1, 1),
 ]
 
