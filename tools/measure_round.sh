@@ -34,5 +34,9 @@ bash tools/prof_half_splat.sh > $o/prof_half.log 2>&1; cp gpurun_out/half_splat/
 bash tools/prof_conv_stack.sh > $o/prof_conv.log 2>&1; cp gpurun_out/conv_stack/r02_conv_stack_mfma.txt $o/${tag}_conv_stack_mfma.txt; tail -3 $o/${tag}_conv_stack_mfma.txt; rm -rf gpurun_out/conv_stack
 bash tools/prof_rank.sh 8 --ipc-self > $o/prof_rank.log 2>&1; cp gpurun_out/q/rank8_stats.csv $o/${tag}_rank8_kernel_stats.csv; rm -rf gpurun_out/q
 ( timeout 300 python tools/fuzz_gpu.py --seconds 120 2>&1 | tail -2; timeout 300 python tools/fuzz_slab.py --seconds 120 2>&1 | tail -1; timeout 200 python tools/fuzz_pointwise.py --seconds 60 2>&1 | tail -1 ) > $o/${tag}_fuzz.txt; cat $o/${tag}_fuzz.txt | cut -c1-300
+# the 3x3 convolution kernels: against MIOpen and float64 at every U-net shape, PMC passes, random sweep
+timeout 400 python tools/conv3x3_experiment.py --shapes all > $o/${tag}_conv3x3_experiment.txt 2>&1; tail -2 $o/${tag}_conv3x3_experiment.txt
+bash tools/prof_conv3x3.sh all > $o/prof_conv3.log 2>&1; cp gpurun_out/conv3x3_pmc.txt $o/${tag}_conv3x3_pmc.txt; grep "sbmc::conv3" $o/${tag}_conv3x3_pmc.txt | cut -c1-200
+timeout 900 python tools/fuzz_conv3x3.py --cases 400 2>&1 | tail -1 > $o/${tag}_conv3x3_fuzz.txt; cat $o/${tag}_conv3x3_fuzz.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 rm -f $o/*.err $o/prof*.log; du -sh gpurun_out
