@@ -1,6 +1,10 @@
 """MIOpen find results for the U-nets' convolutions, shipped with the package.
 
-Why: the fastest fp32 3x3 solvers MIOpen has on gfx950 are NHWC-native implicit-GEMM kernels.  PyTorch picks
+Since round 3 the fp32 3x3 convolutions run on the package's own kernels (csrc/conv3x3.hip) and MIOpen convolves only
+what those do not take: half activations under torch.autocast(float16), channel counts that are not multiples of
+32 / 128, or everything with SBMC_CONV3X3=0.  For that path:
+
+The fastest fp32 3x3 solvers MIOpen has on gfx950 are NHWC-native implicit-GEMM kernels.  PyTorch picks
 a solver through MIOpen's "find"; this package runs MIOpen in its FAST find mode (a full find costs minutes
 on the first step), which takes a find-db record when there is one and a heuristic otherwise -- and the
 heuristic's choice for channels-last fp32 tensors is up to 50x off (a grouped-convolution kernel for the
