@@ -41,7 +41,7 @@ extern "C" {
 #define SBMC_API
 #endif
 
-#define SBMC_HIP_ABI_VERSION 4
+#define SBMC_HIP_ABI_VERSION 5
 #define SBMC_HIP_EINVAL (-1)
 /* largest channel count the fused/plain kernels take in one call */
 #define SBMC_HIP_MAX_CHANNELS 8
@@ -466,7 +466,7 @@ SBMC_API int sbmc_upsample2x_cat_slab_bwd_f32(const float *gout, float *gcoarse,
 /* Batched 2-d transpose dst[b][cols][rows] = src[b][rows][cols] (rows, cols multiples of 4): the planar <->
  * channels-last conversion at the U-net's entry, (rows, cols) = (c, h*w) one way and (h*w, c) the other. */
 SBMC_API int sbmc_transpose2d_f32(const float *src, float *dst, int b, int rows, int cols, void *stream);
-/* ... and the bit pattern of the largest magnitude of the tensor in *amax (see sbmc_bias_act_nhwc_fwd_amax_f32). */
+/* ... and *amax raised to the bit pattern of the largest magnitude of the tensor (see sbmc_bias_act_nhwc_fwd_amax_f32). */
 SBMC_API int sbmc_transpose2d_amax_f32(const float *src, float *dst, unsigned *amax, int b, int rows, int cols,
                               void *stream);
 SBMC_API int sbmc_bias_act_nhwc_supported(int c);
@@ -482,10 +482,11 @@ SBMC_API int sbmc_bias_act_nhwc_fwd_signs_f32(float *y, const float *bias, unsig
                                      int act, float slope, void *stream);
 SBMC_API int sbmc_bias_act_nhwc_bwd_signs_f32(const float *gy, const unsigned *signs, float *gx, float *partial,
                                      long pixels, int c, int act, float slope, void *stream);
-/* The two passes above which also leave, in *amax, the bit pattern of the largest magnitude of what they wrote
- * (y / gx): the 3 x 3 convolution that consumes it (sbmc_conv3x3_*) takes its scale from there instead of running
- * sbmc_conv3x3_absmax_f32 over the tensor.  fwd: signs may be NULL (no sign bits; act 0 allowed);
- * bwd: signs NULL <=> act 0. */
+/* The two passes above which also RAISE *amax (an atomic maximum: the caller hands in a word holding 0, or a
+ * bound it wants kept) to the bit pattern of the largest magnitude of what they wrote (y / gx): the 3 x 3
+ * convolution that consumes it (sbmc_conv3x3_*) takes its scale from there instead of running
+ * sbmc_conv3x3_absmax_f32 over the tensor.  ABI 5: the passes no longer zero the word themselves (a memset launch
+ * per pass).  fwd: signs may be NULL (no sign bits; act 0 allowed); bwd: signs NULL <=> act 0. */
 SBMC_API int sbmc_bias_act_nhwc_fwd_amax_f32(float *y, const float *bias, unsigned *signs, unsigned *amax, long pixels,
                                     int c, int act, float slope, void *stream);
 SBMC_API int sbmc_bias_act_nhwc_bwd_amax_f32(const float *gy, const unsigned *signs, float *gx, float *partial,
@@ -534,21 +535,25 @@ SBMC_API int sbmc_halo_open(const unsigned char *handle, void **base);
 SBMC_API int sbmc_halo_close(void *peer_base);
 /* reads the time-out word of a mailbox (synchronous 4-byte copy: call at a synchronisation point) */
 SBMC_API int sbmc_halo_status(void *box, unsigned *err);
-/* sends src_up to the mailbox up_box and src_down to down_box (a NULL box: no such neighbour) */
+/* sends src_up to the mailbox up_box and src_down to down_box (a NULL box: no such neighbour).  amax (or NULL):
+ * the device word with the bit pattern of the largest magnitude of the tensor the rows are cut from (what
+ * sbmc_conv3x3_* scale by); it travels with the message. */
 SBMC_API int sbmc_halo_put(void *box, void *up_box, void *down_box, const void *src_up, const void *src_down,
                   long long chunks, long long chunk_bytes, long long pitch, unsigned seq_up, unsigned seq_down,
-                  int nslots, long long slot_bytes, long long timeout_ticks, void *stream);
+                  int nslots, long long slot_bytes, long long timeout_ticks, const unsigned *amax, void *stream);
 /* receives into dst_up / dst_down (NULL: nothing expected from there): dst = received, or
  * dst = add + received with add_elem = 4 (float) or 2 (_Float16) -- the adjoint of halo padding.  In the
  * same launch, optionally, a plain 2-d copy body_src -> body_dst (the slab's own rows; body_src NULL: the
- * run body_dst is filled with zeros). */
+ * run body_dst is filled with zeros).  amax (or NULL): a device word that is raised (atomic maximum) to the words
+ * the senders attached to the received messages -- handed the word of the receiving tensor's own rows it ends up
+ * bounding the padded map, with no pass over it. */
 SBMC_API int sbmc_halo_get(void *box, void *up_box, void *down_box, void *dst_up, void *dst_down,
                   const void *add_up, const void *add_down, int add_elem,
                   long long chunks, long long chunk_bytes, long long dst_pitch, long long add_pitch,
                   void *body_dst, const void *body_src, long long body_chunks, long long body_chunk_bytes,
                   long long body_dst_pitch, long long body_src_pitch,
                   unsigned seq_up, unsigned seq_down, int nslots, long long slot_bytes, long long timeout_ticks,
-                  void *stream);
+                  unsigned *amax, void *stream);
 /* Cross-rank merge of the splat's running state (reference sbmc/modules.py:450-471: M = max(m1, m2),
  * sums rescaled by exp(m - M)).  ext [bs, c + 2, top + rows + bot, w] is this rank's partial state on its slab
  * extended by p rows towards each neighbour (channels: c of sum_r, sum_w, max_w; top, bot = p or 0); its
@@ -588,7 +593,8 @@ SBMC_API int sbmc_conv3x3_nhwc_f32(const float *x, const unsigned *xmax, const v
 /* The same convolution with the bias + activation pass behind it (reference sbmc/modules.py:154-175) in its
  * epilogue: y = act(conv(x) + bias[cout]), act 0 linear / 1 ReLU / 2 LeakyReLU(slope).  signs (or NULL): one bit
  * per output (pre-activation > 0), bit e % 32 of word e / 32 of the channels-last element index e -- what
- * sbmc_bias_act_nhwc_bwd_signs_f32 / _bwd_amax_f32 read; amax (or NULL): bit pattern of max |y|. */
+ * sbmc_bias_act_nhwc_bwd_signs_f32 / _bwd_amax_f32 read; amax (or NULL): raised to the bit pattern of max |y| (a
+ * word the caller zeroed). */
 SBMC_API int sbmc_conv3x3_bias_act_nhwc_f32(const float *x, const unsigned *xmax, const void *wp, const float *bias,
                                    float *y, unsigned *signs, unsigned *amax, int n, int h, int w, int cin,
                                    int cout, int act, float slope, void *stream);
@@ -601,6 +607,40 @@ SBMC_API size_t sbmc_conv3x3_wgrad_scratch_bytes(int n, int h, int w, int cin, i
 SBMC_API int sbmc_conv3x3_wgrad_f32(const float *gy, const unsigned *gmax, const float *x, const unsigned *xmax,
                            float *gw, long s_co, long s_ci, long s_ky, long s_kx, void *scratch, int n, int h,
                            int w, int cin, int cout, void *stream);
+
+
+/*
+ * Weight bank (csrc/conv3x3.hip): what a step derives from its weight-normalised convolution weights -- the
+ * reference wraps every convolution in torch's weight norm, w = g v / ||v|| per output channel
+ * (sbmc/modules.py:85-94, 178-188) -- for up to SBMC_WBANK_MAX layers per call instead of 2 (1 x 1 layers) to 8
+ * (3 x 3 layers) launches per layer and step.
+ *   forward:  w and ||v|| of every entry; for 3 x 3 entries with wp_fwd / wp_bwd also the prepared weights of
+ *             sbmc_conv3x3_prepare_weights_f32 in both orientations (wp_fwd: cin -> cout; wp_bwd: the adjoint's,
+ *             cout -> cin, taps mirrored), scaled by the layer's largest |w|.  `norm` holds 2 cout floats (the
+ *             norms, then scratch).
+ *   backward: gv = (g / n)(gw - v <gw, v> / n^2), gg = <gw, v> / n for every entry; gw in any element strides
+ *             (NULL: the loss does not depend on the layer, zeros are written).
+ */
+#define SBMC_WBANK_MAX 24
+typedef struct sbmc_wbank_entry {
+    const float *v;     /* weight_v [cout][cin][kh][kw], dense */
+    const float *g;     /* weight_g [cout] */
+    float *w;           /* out: the weight, layout of v */
+    float *norm;        /* out: [2 cout]: ||v|| per output channel, then scratch */
+    void *wp_fwd;       /* out or NULL: sbmc_conv3x3_weights_bytes(cin, cout) bytes */
+    void *wp_bwd;       /* out or NULL: sbmc_conv3x3_weights_bytes(cout, cin) bytes */
+    int cout, cin, kh, kw;
+} sbmc_wbank_entry;
+typedef struct sbmc_wbank_grad {
+    const float *gw;    /* gradient of w, element strides below; or NULL */
+    const float *v, *g, *norm;
+    float *gv;          /* out: layout of v */
+    float *gg;          /* out: [cout] */
+    long s_co, s_ci, s_ky, s_kx;
+    int cout, cin, kh, kw;
+} sbmc_wbank_grad;
+SBMC_API int sbmc_wbank_forward_f32(const sbmc_wbank_entry *entries, int n, void *stream);
+SBMC_API int sbmc_wbank_backward_f32(const sbmc_wbank_grad *entries, int n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -100,8 +100,26 @@ SYMBOLS = (
     "sbmc_conv3x3_wgrad_supported",
     "sbmc_conv3x3_wgrad_scratch_bytes",
     "sbmc_conv3x3_wgrad_f32",
+    "sbmc_wbank_forward_f32",
+    "sbmc_wbank_backward_f32",
 )
-ABI_VERSION = 4
+ABI_VERSION = 5
+WBANK_MAX = 24
+
+
+class WBankEntry(ctypes.Structure):
+    """include/sbmc_hip.h: sbmc_wbank_entry"""
+    _fields_ = [("v", ctypes.c_void_p), ("g", ctypes.c_void_p), ("w", ctypes.c_void_p), ("norm", ctypes.c_void_p),
+                ("wp_fwd", ctypes.c_void_p), ("wp_bwd", ctypes.c_void_p),
+                ("cout", ctypes.c_int), ("cin", ctypes.c_int), ("kh", ctypes.c_int), ("kw", ctypes.c_int)]
+
+
+class WBankGrad(ctypes.Structure):
+    """include/sbmc_hip.h: sbmc_wbank_grad"""
+    _fields_ = [("gw", ctypes.c_void_p), ("v", ctypes.c_void_p), ("g", ctypes.c_void_p), ("norm", ctypes.c_void_p),
+                ("gv", ctypes.c_void_p), ("gg", ctypes.c_void_p),
+                ("s_co", ctypes.c_long), ("s_ci", ctypes.c_long), ("s_ky", ctypes.c_long), ("s_kx", ctypes.c_long),
+                ("cout", ctypes.c_int), ("cin", ctypes.c_int), ("kh", ctypes.c_int), ("kw", ctypes.c_int)]
 MAX_CHANNELS = 8
 
 _LIB = None
@@ -215,8 +233,10 @@ def lib():
     handle.sbmc_halo_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(p)]
     handle.sbmc_halo_close.argtypes = [p]
     handle.sbmc_halo_status.argtypes = [p, ctypes.POINTER(u)]
-    handle.sbmc_halo_put.argtypes = [p] * 5 + [ll, ll, ll, u, u, i, ll, ll, p]
-    handle.sbmc_halo_get.argtypes = [p] * 7 + [i, ll, ll, ll, ll, p, p, ll, ll, ll, ll, u, u, i, ll, ll, p]
+    handle.sbmc_halo_put.argtypes = [p] * 5 + [ll, ll, ll, u, u, i, ll, ll, p, p]
+    handle.sbmc_halo_get.argtypes = [p] * 7 + [i, ll, ll, ll, ll, p, p, ll, ll, ll, ll, u, u, i, ll, ll, p, p]
+    handle.sbmc_wbank_forward_f32.argtypes = [p, i, p]
+    handle.sbmc_wbank_backward_f32.argtypes = [p, i, p]
     handle.sbmc_halo_merge_state_fwd_f32.argtypes = [p] * 7 + [i] * 7 + [u, u, i, ll, ll, p]
     handle.sbmc_halo_merge_state_bwd_f32.argtypes = [p] * 7 + [i] * 7 + [p]
     lg = ctypes.c_long

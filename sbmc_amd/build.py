@@ -54,16 +54,63 @@ def is_stale():
         return True
 
 
+OBJ_DIR = os.path.join(HERE, ".obj")
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def _object_hash(src):
+    """Hash of what ONE object file is built from: its source, the shared headers, the flags."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in (os.path.join(CSRC, src), os.path.join(CSRC, "common.hpp"), os.path.join(ROOT, "include", "sbmc_hip.h")):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def _compile(src, verbose):
+    """csrc/<src> -> .obj/<src>.o unless an object of the same content hash is there (the objects are a local
+    cache: only the linked library travels with a snapshot)."""
+    obj = os.path.join(OBJ_DIR, src + ".o")
+    stamp = obj + ".hash"
+    digest = _object_hash(src)
+    try:
+        with open(stamp) as f:
+            if f.read().strip() == digest and os.path.exists(obj):
+                return obj
+    except OSError:
+        pass
+    tmp = "%s.%d.tmp" % (obj, os.getpid())
+    cmd = [_hipcc()] + FLAGS + ["-c", "-o", tmp, os.path.join(CSRC, src)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, obj)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    with open(tmp + ".hash", "w") as f:
+        f.write(digest + "\n")
+    os.replace(tmp + ".hash", stamp)
+    return obj
+
+
 def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    tmp = "%s.%d.tmp" % (LIB, os.getpid())              # several ranks may build at once: private temporaries,
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",   # atomic renames
-           "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-           "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
     digest = _source_hash()
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:    # one hipcc per source
+        objs = list(pool.map(lambda s: _compile(s, verbose), SOURCES))
+    tmp = "%s.%d.tmp" % (LIB, os.getpid())              # several ranks may build at once: private temporaries,
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", "-fvisibility=hidden", "-o", tmp] + objs   # atomic renames
+    if verbose:
+        print(" ".join(cmd), flush=True)
     try:
         subprocess.check_call(cmd)
         os.replace(tmp, LIB)

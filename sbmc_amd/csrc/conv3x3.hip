@@ -108,7 +108,7 @@ struct Conv3Params {
     const float* bias;       // [Cout]
     float slope;             // 1: linear, 0: ReLU, else LeakyReLU
     unsigned* signs;         // one bit per output (pre-activation > 0), bit e % 32 of word e / 32 of the NHWC element index e; or nullptr
-    unsigned* amax;          // bit pattern of max |y| (zeroed by the caller); or nullptr
+    unsigned* amax;          // raised to the bit pattern of max |y| (a word zeroed by the caller); or nullptr
 };
 
 template <bool EPI>
@@ -540,10 +540,8 @@ extern "C" int sbmc_conv3x3_bias_act_nhwc_f32(const float* x, const unsigned* xm
                                                float* y, unsigned* signs, unsigned* amax, int n, int h, int w, int cin,
                                                int cout, int act, float slope, void* stream) {
     if (!bias || act < 0 || act > 2 || (uintptr_t)signs % 4) return SBMC_HIP_EINVAL;
-    if (amax) {
-        hipError_t e = hipMemsetAsync(amax, 0, 4, (hipStream_t)stream);
-        if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
-    }
+    // (*amax is RAISED to max |y|: the caller hands in a zeroed word -- one memset launch per convolution was a
+    // cost that does not shrink with the slab of a sharded frame)
     return conv3_launch(x, xmax, wp, y, n, h, w, cin, cout, bias, act, slope, signs, amax, true, stream);
 }
 
@@ -899,5 +897,209 @@ extern "C" int sbmc_conv3x3_wgrad_f32(const float* gy, const unsigned* gmax, con
     q.partial = p.partial; q.gw = gw; q.s_co = s_co; q.s_ci = s_ci; q.s_ky = s_ky; q.s_kx = s_kx;
     q.gmax = gmax; q.xmax = xmax; q.ncit = p.ncit; q.nsplit = p.nsplit;
     hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(WG_TILE / 256, (unsigned)ncombo), dim3(256), 0, (hipStream_t)stream, q);
+    return (int)hipGetLastError();
+}
+
+// =============================================================================================================
+// Weight bank: everything a training step derives from its weight-normalised convolution weights, for MANY
+// layers per launch.  The reference wraps every convolution in torch's weight norm (sbmc/modules.py:85-94,
+// 178-188: w = g v / ||v||, the norm over each output channel's cin x kh x kw block); per layer and step that
+// was one weight_norm kernel forward, one backward, and -- for the 3 x 3 layers -- an absmax + a preparation
+// pass (the two f16 planes in stage order) per direction: 8 launches for each of the 45 + 12 layers of the
+// model.  Here: two launches forward (rows: norm, w, largest magnitude of a row; prepare: both orientations of
+// every 3 x 3 layer, scaled by the largest of its rows' magnitudes), one backward (the adjoint of the weight norm
+// for every layer), for up to SBMC_WBANK_MAX layers each.  Costs that do not shrink when a frame is sharded over
+// several GPUs are the ones that bound its strong scaling (tools/rank_cost.py).
+namespace sbmc {
+
+struct BankFwdArgs {
+    sbmc_wbank_entry e[SBMC_WBANK_MAX];
+    int row0[SBMC_WBANK_MAX + 1];           // first row (output channel) of entry i in the launch's row space
+    int blk0[2 * SBMC_WBANK_MAX + 1];       // first block of segment 2 i + flip of the preparation launch
+    int n;
+};
+
+__device__ __forceinline__ float bank_block_sum(float v, float* red) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ unsigned bank_block_max(unsigned v, unsigned* red) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)v, s, 64);
+        v = v > o ? v : o;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const unsigned a = red[0] > red[1] ? red[0] : red[1], b = red[2] > red[3] ? red[2] : red[3];
+    return a > b ? a : b;
+}
+
+// one workgroup per output channel: ||v||, w = v (g / ||v||), bit pattern of max |w| of the row
+__global__ __launch_bounds__(256) void wbank_rows_kernel(BankFwdArgs a) {
+    __shared__ float red[4];
+    __shared__ unsigned redu[4];
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.row0[i + 1]) ++i;
+    const sbmc_wbank_entry& e = a.e[i];
+    const int co = (int)blockIdx.x - a.row0[i];
+    const long L = (long)e.cin * e.kh * e.kw;
+    const float* v = e.v + (long)co * L;
+    float* w = e.w + (long)co * L;
+    float ss = 0.f;
+    unsigned m = 0;
+    for (long j = threadIdx.x; j < L; j += 256) {
+        const float x = v[j];
+        ss = fmaf(x, x, ss);
+        const unsigned b = abits(x);
+        m = m > b ? m : b;
+    }
+    const float norm = sqrtf(bank_block_sum(ss, red));
+    m = bank_block_max(m, redu);
+    const float s = e.g[co] / norm;
+    for (long j = threadIdx.x; j < L; j += 256) w[j] = v[j] * s;
+    if (threadIdx.x == 0) {
+        e.norm[co] = norm;
+        // |v| -> |v s| is monotone under rounding: the row's largest |w| is exactly this product
+        reinterpret_cast<unsigned*>(e.norm)[e.cout + co] = abits(__builtin_bit_cast(float, m) * s);
+    }
+}
+
+// the two f16 planes of w in stage order (see prep_weights_kernel), both orientations of every 3 x 3 entry
+__global__ __launch_bounds__(256) void wbank_prep_kernel(BankFwdArgs a) {
+    __shared__ unsigned redu[4];
+    int seg = 0;
+    while (seg + 1 < 2 * a.n && (int)blockIdx.x >= a.blk0[seg + 1]) ++seg;
+    const sbmc_wbank_entry& e = a.e[seg >> 1];
+    const int flip = seg & 1;
+    const unsigned* rowmax = reinterpret_cast<const unsigned*>(e.norm) + e.cout;
+    unsigned m = 0;
+    for (int j = threadIdx.x; j < e.cout; j += 256) m = m > rowmax[j] ? m : rowmax[j];
+    m = bank_block_max(m, redu);
+    const float c = cv_scale_of(m);
+    const int cout = flip ? e.cin : e.cout, cin = flip ? e.cout : e.cin;           // of the prepared orientation
+    const long s_co = flip ? 9 : (long)e.cin * 9, s_ci = flip ? (long)e.cin * 9 : 9;
+    u32x4* wp = static_cast<u32x4*>(flip ? e.wp_bwd : e.wp_fwd);
+    const long K16 = cin / 16, units = (long)(cout / 128) * K16 * 9 * 2 * 128;
+    const long u = (long)((int)blockIdx.x - a.blk0[seg]) * 256 + threadIdx.x;
+    if (u == 0) {
+        char* tail = reinterpret_cast<char*>(wp) + (size_t)(cout / 128) * (cin / 16) * 3 * CV_WSTAGE * 16;
+        *reinterpret_cast<float*>(tail) = c;
+        *reinterpret_cast<unsigned*>(tail + 4) = m;
+    }
+    if (u >= units) return;
+    const int co = (int)(u % 128);
+    long r = u / 128;
+    const int khalf = (int)(r % 2);
+    r /= 2;
+    const int kx = (int)(r % 3);
+    r /= 3;
+    const int ky = (int)(r % 3);
+    r /= 3;
+    const int k16 = (int)(r % K16), ct = (int)(r / K16);
+    const int sy = flip ? 2 - ky : ky, sx = flip ? 2 - kx : kx;
+    const float* src = e.w + (long)(ct * 128 + co) * s_co + (long)(k16 * 16 + khalf * 8) * s_ci + sy * 3 + sx;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = src[i * s_ci] * c;
+    u32x4 h, l;
+    cv_split(v, h, l);
+    const long base = ((((long)(ct * K16 + k16) * 3 + ky) * 3 + kx) * 2) * 256 + khalf * 128 + co;
+    wp[base] = h;
+    wp[base + 256] = l;
+}
+
+struct BankBwdArgs {
+    sbmc_wbank_grad e[SBMC_WBANK_MAX];
+    int row0[SBMC_WBANK_MAX + 1];
+    int n;
+};
+
+// adjoint of w = g v / n, n = ||v||, one workgroup per output channel:
+//   gg = <gw, v> / n,   gv = (g / n) (gw - v gg / n)
+__global__ __launch_bounds__(256) void wbank_bwd_kernel(BankBwdArgs a) {
+    __shared__ float red[4];
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.row0[i + 1]) ++i;
+    const sbmc_wbank_grad& e = a.e[i];
+    const int co = (int)blockIdx.x - a.row0[i];
+    const int taps = e.kh * e.kw;
+    const long L = (long)e.cin * taps;
+    const float* v = e.v + (long)co * L;
+    float* gv = e.gv + (long)co * L;
+    if (e.gw == nullptr) {                      // a layer the loss does not depend on
+        for (long j = threadIdx.x; j < L; j += 256) gv[j] = 0.f;
+        if (threadIdx.x == 0) e.gg[co] = 0.f;
+        return;
+    }
+    const float* gw = e.gw + (long)co * e.s_co;
+    auto gw_at = [&](long j) -> float {
+        const long ci = j / taps;
+        const int t = (int)(j - ci * taps), ky = t / e.kw, kx = t - ky * e.kw;
+        return gw[ci * e.s_ci + ky * e.s_ky + kx * e.s_kx];
+    };
+    float dot = 0.f;
+    for (long j = threadIdx.x; j < L; j += 256) dot = fmaf(gw_at(j), v[j], dot);
+    dot = bank_block_sum(dot, red);
+    const float rn = 1.f / e.norm[co];
+    const float gg = dot * rn, s = e.g[co] * rn, t = gg * rn;
+    for (long j = threadIdx.x; j < L; j += 256) gv[j] = s * (gw_at(j) - v[j] * t);
+    if (threadIdx.x == 0) e.gg[co] = gg;
+}
+
+}  // namespace sbmc
+
+extern "C" int sbmc_wbank_forward_f32(const sbmc_wbank_entry* entries, int n, void* stream) {
+    if (n < 0 || n > SBMC_WBANK_MAX || (n && !entries)) return SBMC_HIP_EINVAL;
+    if (n == 0) return 0;
+    BankFwdArgs a;
+    a.n = n;
+    int rows = 0, blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const sbmc_wbank_entry& e = entries[i];
+        if (!e.v || !e.g || !e.w || !e.norm || e.cout < 1 || e.cin < 1 || e.kh < 1 || e.kw < 1) return SBMC_HIP_EINVAL;
+        if ((e.wp_fwd == nullptr) != (e.wp_bwd == nullptr)) return SBMC_HIP_EINVAL;
+        if (e.wp_fwd) {
+            if (e.kh != 3 || e.kw != 3 || !sbmc_conv3x3_weights_bytes(e.cin, e.cout) ||
+                !sbmc_conv3x3_weights_bytes(e.cout, e.cin) || (uintptr_t)e.wp_fwd % 16 || (uintptr_t)e.wp_bwd % 16)
+                return SBMC_HIP_EINVAL;
+        }
+        a.e[i] = e;
+        a.row0[i] = rows;
+        rows += e.cout;
+        for (int flip = 0; flip < 2; ++flip) {
+            a.blk0[2 * i + flip] = blocks;
+            if (e.wp_fwd) blocks += (int)((long)e.cout * e.cin * 9 / 8 / 256);      // units of either orientation / 256
+        }
+    }
+    a.row0[n] = rows;
+    a.blk0[2 * n] = blocks;
+    hipLaunchKernelGGL(wbank_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess || blocks == 0) return (int)err;
+    hipLaunchKernelGGL(wbank_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_wbank_backward_f32(const sbmc_wbank_grad* entries, int n, void* stream) {
+    if (n < 0 || n > SBMC_WBANK_MAX || (n && !entries)) return SBMC_HIP_EINVAL;
+    if (n == 0) return 0;
+    BankBwdArgs a;
+    a.n = n;
+    int rows = 0;
+    for (int i = 0; i < n; ++i) {
+        const sbmc_wbank_grad& e = entries[i];
+        if (!e.v || !e.g || !e.norm || !e.gv || !e.gg || e.cout < 1 || e.cin < 1 || e.kh < 1 || e.kw < 1) return SBMC_HIP_EINVAL;
+        a.e[i] = e;
+        a.row0[i] = rows;
+        rows += e.cout;
+    }
+    a.row0[n] = rows;
+    hipLaunchKernelGGL(wbank_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

@@ -36,17 +36,24 @@ namespace halo {
 
 constexpr int HDR = 4096;
 constexpr int OFF_READY = 0, OFF_ACK = 256, OFF_ERR = 512, OFF_CNT = 640;
+// one word per (ring, slot): the bit pattern of the largest magnitude of the tensor a message's rows were cut from
+// (what csrc/conv3x3.hip scales its input by: the receiver's padded map must be scaled by the larger of its own and
+// its neighbours').  Written by the sender with the payload, read by the receiver before it returns the slot.
+constexpr int OFF_AMAX = 1024, MAX_SLOTS = 128;
 constexpr int THREADS = 256;
 
 __device__ __forceinline__ unsigned* word(char* box, int off) { return reinterpret_cast<unsigned*>(box + off); }
 
 // Polls *flag (system scope, relaxed) until it has reached `need` (wrap-safe).  One lane of a block calls it.
+// Once ANY wait of this mailbox has timed out (`err` set) no later wait spins again: the step is lost anyway (the
+// host raises at its next status read), and ~150 exchanges of a step must not each sit out their own time-out.
 __device__ __forceinline__ void wait_reached(unsigned* flag, unsigned need, unsigned* err, unsigned code,
                                              long long timeout_ticks) {
     const long long t0 = (long long)wall_clock64();
-    for (;;) {
+    for (unsigned polls = 0;; ++polls) {
         const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int)(v - need) >= 0) break;
+        if ((polls & 63u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
         __builtin_amdgcn_s_sleep(8);
         if ((long long)wall_clock64() - t0 > timeout_ticks) {
             __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -80,6 +87,7 @@ struct PutArgs {
     unsigned nslots;
     long long slot_bytes;
     long long timeout_ticks;
+    const unsigned* amax;      // optional: bit pattern of the largest magnitude of the tensor the rows belong to
 };
 
 template <typename U>
@@ -97,6 +105,9 @@ __global__ void __launch_bounds__(THREADS) put_kernel(PutArgs a) {
         const unsigned chunk = i / a.chunk_units, off = i - chunk * a.chunk_units;
         dst[i] = reinterpret_cast<const U*>(src + chunk * a.pitch)[off];
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.amax != nullptr)
+        __hip_atomic_store(word(peer, OFF_AMAX + 4 * (int)((1 - d) * a.nslots + seq % a.nslots)), *a.amax,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     signal_when_all_done(word(a.box, OFF_CNT + 4 * d), gridDim.x, word(peer, OFF_READY + 128 * (1 - d)), seq + 1);
 }
 
@@ -116,6 +127,7 @@ struct GetArgs {
     long long body_dst_pitch, body_src_pitch;
     unsigned body_chunk_units, body_total_units;
     unsigned halo_blocks;      // blocks (of gridDim.x) that work on a halo part; the body uses all of them
+    unsigned* amax;            // optional: raised (atomic max) to the words the senders attached to their messages
 };
 
 template <typename U, int ADD>   // ADD: 0 copy, 1 float add, 2 half add (on the lanes of U)
@@ -159,6 +171,11 @@ __global__ void __launch_bounds__(THREADS) get_kernel(GetArgs a) {
         U v = src[i];
         if constexpr (ADD != 0) v = combine<U, ADD>(v, reinterpret_cast<const U*>(a.add[d] + chunk * a.add_pitch)[off]);
         reinterpret_cast<U*>(a.dst[d] + chunk * a.dst_pitch)[off] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.amax != nullptr) {
+        const unsigned theirs = __hip_atomic_load(word(a.box, OFF_AMAX + 4 * (int)(d * a.nslots + seq % a.nslots)),
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        atomicMax(a.amax, theirs);
     }
     signal_when_all_done(word(a.box, OFF_CNT + 8 + 4 * d), a.halo_blocks, word(a.peer[d], OFF_ACK + 128 * (1 - d)), seq + 1);
 }
@@ -326,7 +343,7 @@ using namespace sbmc::halo;
 extern "C" {
 
 size_t sbmc_halo_bytes(long long slot_bytes, int nslots) {
-    if (slot_bytes <= 0 || nslots <= 0 || (slot_bytes & 15)) return 0;
+    if (slot_bytes <= 0 || nslots <= 0 || nslots > MAX_SLOTS || (slot_bytes & 15)) return 0;
     return (size_t)HDR + 2 * (size_t)nslots * (size_t)slot_bytes;
 }
 
@@ -384,8 +401,8 @@ int sbmc_halo_status(void* box, unsigned* err) {
 
 int sbmc_halo_put(void* box, void* up_box, void* down_box, const void* src_up, const void* src_down,
                   long long chunks, long long chunk_bytes, long long pitch, unsigned seq_up, unsigned seq_down,
-                  int nslots, long long slot_bytes, long long timeout_ticks, void* stream) {
-    if (box == nullptr || chunks <= 0 || chunk_bytes <= 0 || nslots <= 0) return SBMC_HIP_EINVAL;
+                  int nslots, long long slot_bytes, long long timeout_ticks, const unsigned* amax, void* stream) {
+    if (box == nullptr || chunks <= 0 || chunk_bytes <= 0 || nslots <= 0 || nslots > MAX_SLOTS) return SBMC_HIP_EINVAL;
     if (chunks * chunk_bytes > slot_bytes || chunks * chunk_bytes >= (1ll << 32)) return SBMC_HIP_EINVAL;
     if ((up_box && !src_up) || (down_box && !src_down)) return SBMC_HIP_EINVAL;
     if (!up_box && !down_box) return 0;
@@ -401,6 +418,7 @@ int sbmc_halo_put(void* box, void* up_box, void* down_box, const void* src_up, c
     a.nslots = (unsigned)nslots;
     a.slot_bytes = slot_bytes;
     a.timeout_ticks = timeout_ticks;
+    a.amax = amax;
     const bool v16 = (chunk_bytes % 16 == 0) && (pitch % 16 == 0) && (!up_box || aligned16(src_up)) &&
                      (!down_box || aligned16(src_down));
     const int unit = v16 ? 16 : (chunk_bytes % 4 == 0 && pitch % 4 == 0 ? 4 : (chunk_bytes % 2 == 0 && pitch % 2 == 0 ? 2 : 1));
@@ -423,8 +441,8 @@ int sbmc_halo_get(void* box, void* up_box, void* down_box, void* dst_up, void* d
                   void* body_dst, const void* body_src, long long body_chunks, long long body_chunk_bytes,
                   long long body_dst_pitch, long long body_src_pitch,
                   unsigned seq_up, unsigned seq_down, int nslots, long long slot_bytes, long long timeout_ticks,
-                  void* stream) {
-    if (box == nullptr || nslots <= 0) return SBMC_HIP_EINVAL;
+                  unsigned* amax, void* stream) {
+    if (box == nullptr || nslots <= 0 || nslots > MAX_SLOTS) return SBMC_HIP_EINVAL;
     const bool any = dst_up != nullptr || dst_down != nullptr;
     if (any && (chunks <= 0 || chunk_bytes <= 0 || chunks * chunk_bytes > slot_bytes ||
                 chunks * chunk_bytes >= (1ll << 32))) return SBMC_HIP_EINVAL;
@@ -453,6 +471,7 @@ int sbmc_halo_get(void* box, void* up_box, void* down_box, void* dst_up, void* d
     a.body_src = static_cast<const char*>(body_src);
     a.body_dst_pitch = body_dst_pitch;
     a.body_src_pitch = body_src_pitch;
+    a.amax = amax;
     bool v16 = true;
     int min_unit = add_elem ? add_elem : 1;
     if (any) {

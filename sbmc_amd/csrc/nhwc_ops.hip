@@ -336,14 +336,13 @@ extern "C" int sbmc_bias_act_nhwc_bwd_signs_f32(const float* gy, const unsigned*
     return (int)hipGetLastError();
 }
 
-// The same two passes, also leaving the bit pattern of the result's largest magnitude in *amax (see amax_publish):
+// The same two passes, also RAISING *amax to the bit pattern of the result's largest magnitude (see amax_publish;
+// the caller hands in a zeroed word: sbmc_amd hands them out of one zero-filled block per step):
 // fwd with or without sign bits (signs == nullptr: act may be 0), bwd reading sign bits (act 1 / 2) or nothing
 // (act 0: signs == nullptr).
 extern "C" int sbmc_bias_act_nhwc_fwd_amax_f32(float* y, const float* bias, unsigned* signs, unsigned* amax, long pixels,
                                                int c, int act, float slope, void* stream) {
     if (pixels < 0 || c < 0 || act < 0 || act > 2 || !amax || (signs && act == 0)) return SBMC_HIP_EINVAL;
-    hipError_t e = hipMemsetAsync(amax, 0, 4, (hipStream_t)stream);
-    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     if (pixels == 0 || c == 0) return 0;
     if (!y || !bias || !sbmc_bias_act_nhwc_supported(c) || (uintptr_t)y % 16 || (uintptr_t)bias % 16 ||
         (uintptr_t)signs % 4) return SBMC_HIP_EINVAL;
@@ -360,8 +359,6 @@ extern "C" int sbmc_bias_act_nhwc_fwd_amax_f32(float* y, const float* bias, unsi
 extern "C" int sbmc_bias_act_nhwc_bwd_amax_f32(const float* gy, const unsigned* signs, float* gx, float* partial,
                                                unsigned* amax, long pixels, int c, int act, float slope, void* stream) {
     if (pixels < 0 || c < 0 || act < 0 || act > 2 || !amax || ((signs == nullptr) != (act == 0))) return SBMC_HIP_EINVAL;
-    hipError_t e = hipMemsetAsync(amax, 0, 4, (hipStream_t)stream);
-    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     if (pixels == 0 || c == 0) return 0;
     if (!gy || !gx || !partial || !sbmc_bias_act_nhwc_supported(c)) return SBMC_HIP_EINVAL;
     if ((uintptr_t)gy % 16 || (uintptr_t)signs % 4 || (uintptr_t)gx % 16 || (uintptr_t)partial % 16) return SBMC_HIP_EINVAL;
@@ -458,13 +455,11 @@ extern "C" int sbmc_transpose2d_f32(const float* src, float* dst, int b, int row
     return (int)hipGetLastError();
 }
 
-// The same transpose, also leaving the bit pattern of the tensor's largest magnitude in *amax (the U-net's first
-// convolution scales by it: csrc/conv3x3.hip).
+// The same transpose, also raising *amax (zeroed by the caller) to the bit pattern of the tensor's largest magnitude
+// (the U-net's first convolution scales by it: csrc/conv3x3.hip).
 extern "C" int sbmc_transpose2d_amax_f32(const float* src, float* dst, unsigned* amax, int b, int rows, int cols,
                                          void* stream) {
     if (b < 0 || rows < 0 || cols < 0 || !amax) return SBMC_HIP_EINVAL;
-    hipError_t e = hipMemsetAsync(amax, 0, 4, (hipStream_t)stream);
-    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     if (b == 0 || rows == 0 || cols == 0) return 0;
     if (!src || !dst || rows % 4 || cols % 4 || (uintptr_t)src % 16 || (uintptr_t)dst % 16) return SBMC_HIP_EINVAL;
     const int tr = (rows + TT - 1) / TT, tc = (cols + TT - 1) / TT;

@@ -187,7 +187,7 @@ def _rows_nhwc(t, r0, r1):
 
 class _HaloPad(th.autograd.Function):
     @staticmethod
-    def forward(ctx, x, r, part, nhwc_wire=False):
+    def forward(ctx, x, r, part, nhwc_wire=False, amax=None):
         ctx.r, ctx.part, ctx.rows = r, part, x.shape[-2]
         h = x.shape[-2]
         if h < r:
@@ -197,7 +197,7 @@ class _HaloPad(th.autograd.Function):
         ctx.nhwc_wire = bool(nhwc_wire and x.dim() == 4 and x.shape[0] == 1)
         ctx.via_channel = part.channel is not None and x.is_cuda
         if ctx.via_channel:
-            return _halo_pad_channel(ctx, x, r, part, bool(nhwc_wire and x.dim() == 4))
+            return _halo_pad_channel(ctx, x, r, part, bool(nhwc_wire and x.dim() == 4), amax)
         if ctx.nhwc_wire:
             x = x.contiguous(memory_format=th.channels_last)     # a no-op in the channels-last U-net
             # every rank runs this U-net channels-last (agreed, see sharded_autoencoder) on one image: a run of
@@ -233,7 +233,7 @@ class _HaloPad(th.autograd.Function):
         top = r if part.has_up else 0
         # gradient of my halo rows goes back to their owners; theirs for my edge rows comes here
         if ctx.via_channel:
-            return _halo_pad_channel_bwd(ctx, g, r, part, h), None, None, None
+            return _halo_pad_channel_bwd(ctx, g, r, part, h), None, None, None, None
         if ctx.nhwc_wire:
             g = g.contiguous(memory_format=th.channels_last)     # the wire order both ends agreed on
             hp = g.shape[-2]
@@ -250,20 +250,23 @@ class _HaloPad(th.autograd.Function):
                 _rows_nhwc(gx, 0, r).add_(back_up)
             if back_down is not None:
                 _rows_nhwc(gx, h - r, h).add_(back_down)
-            return gx, None, None, None
+            return gx, None, None, None, None
         from_up, from_down = _exchange(part, g[..., :r, :], g[..., g.shape[-2] - r:, :])
         gx = g[..., top:top + h, :].clone()
         if from_up is not None:
             gx[..., :r, :] += from_up
         if from_down is not None:
             gx[..., h - r:, :] += from_down
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
-def _halo_pad_channel(ctx, x, r, part, nhwc):
+def _halo_pad_channel(ctx, x, r, part, nhwc, amax=None):
     """`_HaloPad.forward` through the IPC mailboxes (halo.HaloChannel): one `put` (my edge rows into the
     neighbours' mailboxes) and one `get` (their rows into the padded map + the copy of my own rows) -- two
-    launches, nothing on the host.  nhwc: every rank holds this tensor channels-last (agreed)."""
+    launches, nothing on the host.  nhwc: every rank holds this tensor channels-last (agreed).
+    amax: the word of x's largest magnitude (functions.tag_amax).  It travels with the rows, and the `get` raises
+    it to the neighbours' words: it then bounds the padded map, which the 3 x 3 convolution scales by (the
+    absmax pass it would otherwise run over every padded map was 6.7 of a rank-of-8's 51.5 ms)."""
     from .halo import rows_run
     ch, h = part.channel, x.shape[-2]
     ctx.nhwc = nhwc
@@ -272,9 +275,9 @@ def _halo_pad_channel(ctx, x, r, part, nhwc):
     top = r if part.has_up else 0
     bot = r if part.has_down else 0
     out = th.empty(x.shape[:-2] + (top + h + bot, x.shape[-1]), dtype=x.dtype, device=x.device, memory_format=fmt)
-    ch.put(rows_run(x, 0, r, nhwc) if top else None, rows_run(x, h - r, h, nhwc) if bot else None)
+    ch.put(rows_run(x, 0, r, nhwc) if top else None, rows_run(x, h - r, h, nhwc) if bot else None, amax=amax)
     ch.get(rows_run(out, 0, top, nhwc) if top else None, rows_run(out, top + h, top + h + bot, nhwc) if bot else None,
-           body=(rows_run(out, top, top + h, nhwc), rows_run(x, 0, h, nhwc)))
+           body=(rows_run(out, top, top + h, nhwc), rows_run(x, 0, h, nhwc)), amax=amax)
     return out
 
 
@@ -323,6 +326,11 @@ def halo_pad(x, r, part, nhwc_wire=False):
     travel in memory order and land in place."""
     if r == 0 or part.world == 1:
         return x
+    if part.channel is not None and nhwc_wire and funcs.wants_amax(x):
+        # the scale of the 3 x 3 convolution that reads the padded map: this slab's word, raised in place to the
+        # neighbours' by the exchange itself (a larger bound stays a bound for everyone else who holds the word)
+        amax = funcs.ensure_amax(x)
+        return funcs.tag_amax(_HaloPad.apply(x, r, part, nhwc_wire, amax), amax)
     return _HaloPad.apply(x, r, part, nhwc_wire)
 
 
@@ -338,7 +346,7 @@ class _HaloRefresh(th.autograd.Function):
     producer of the padded map computes nothing from it (its stale rows are not part of the function)."""
 
     @staticmethod
-    def forward(ctx, x, r, part, nhwc):
+    def forward(ctx, x, r, part, nhwc, amax=None):
         from .halo import rows_run
         ch = part.channel
         top = r if part.has_up else 0
@@ -346,8 +354,9 @@ class _HaloRefresh(th.autograd.Function):
         hp = x.shape[-2]
         h = hp - top - bot
         ctx.r, ctx.part, ctx.nhwc, ctx.h = r, part, nhwc, h
-        ch.put(rows_run(x, top, top + r, nhwc) if top else None, rows_run(x, top + h - r, top + h, nhwc) if bot else None)
-        ch.get(rows_run(x, 0, top, nhwc) if top else None, rows_run(x, top + h, hp, nhwc) if bot else None)
+        ch.put(rows_run(x, top, top + r, nhwc) if top else None, rows_run(x, top + h - r, top + h, nhwc) if bot else None,
+               amax=amax)
+        ch.get(rows_run(x, 0, top, nhwc) if top else None, rows_run(x, top + h, hp, nhwc) if bot else None, amax=amax)
         # a second handle on the same memory with the same strides: returning `x` itself would make autograd
         # re-view it (`x.view_as(x)`), which loses the channels-last strides of a one-image batch -- MIOpen then
         # transposes every input -- and marking it dirty would invalidate what its in-place producer saved
@@ -383,7 +392,7 @@ class _HaloRefresh(th.autograd.Function):
                 g[..., :top, :].zero_()
             if bot:
                 g[..., top + h:, :].zero_()
-        return g, None, None, None
+        return g, None, None, None, None
 
 
 def halo_refresh(x, r, part, nhwc=False):
@@ -403,6 +412,9 @@ def halo_refresh(x, r, part, nhwc=False):
             return None
     elif not x.is_contiguous():
         return None
+    if nhwc and funcs.wants_amax(x):
+        amax = funcs.ensure_amax(x)          # (x's word covers its stale outer rows too: whoever wrote x wrote them)
+        return funcs.tag_amax(_HaloRefresh.apply(x, r, part, True, amax), amax)
     return _HaloRefresh.apply(x, r, part, bool(nhwc))
 
 
@@ -426,7 +438,9 @@ def _crop_halo(y, r, part):
     bot = r if part.has_down else 0
     if top == 0 and bot == 0:
         return y
-    return _CropRows.apply(y, top, bot)
+    out = _CropRows.apply(y, top, bot)
+    known = funcs.known_amax(y)
+    return out if known is None else funcs.tag_amax(out, known)     # (rows of y: its bound holds)
 
 
 def _reach(chain):
@@ -483,11 +497,16 @@ def _level(level, x, part, nhwc=False):
         return left
     if left.shape[-2] % 2:
         raise RuntimeError("sharded path needs an even number of rows at every U-net level")
-    coarse = _level(level.next_level, level.downsample(left), part, nhwc)
+    pooled = level.downsample(left)
+    if isinstance(level.downsample, (th.nn.MaxPool2d, th.nn.AvgPool2d)) and funcs.known_amax(left) is not None:
+        funcs.tag_amax(pooled, funcs.known_amax(left))            # pooling grows no magnitude
+    coarse = _level(level.next_level, pooled, part, nhwc)
     padded = halo_pad(coarse, 1, part, nhwc)
     top, bot = int(part.has_up), int(part.has_down)
     if funcs.upsample_cat_nhwc_supported(padded, left, top, bot):
-        return _chain(level.right, funcs.UpsampleCatNHWC.apply(padded, left, top, bot), part, nhwc)
+        cat = funcs.UpsampleCatNHWC.apply(padded, left, top, bot)
+        bound = funcs.bound_amax(funcs.known_amax(padded), funcs.known_amax(left))
+        return _chain(level.right, cat if bound is None else funcs.tag_amax(cat, bound), part, nhwc)
     if funcs.upsample_cat_supported(padded, left, top, bot):
         # one pass, the upsampled tensor never exists (functions.UpsampleCat in its row-slab form)
         return _chain(level.right, funcs.UpsampleCat.apply(padded, left, top, bot), part, nhwc)
@@ -514,8 +533,11 @@ def sharded_autoencoder(autoencoder, x, part):
     # (the key holds nothing rank-specific: every rank meets a new key at the same call)
     if _all_agree(mine, part, (part.world, part.height, x.shape[0], x.shape[1], x.shape[-1], x.dtype, grad,
                                th.is_autocast_enabled())):
-        xin = funcs.ToChannelsLast.apply(x) if funcs.ToChannelsLast.supported(x) \
-            else x.contiguous(memory_format=th.channels_last)
+        if funcs.ToChannelsLast.supported(x):
+            xin, amax = funcs.ToChannelsLast.apply(x, True)       # (the first convolution's scale, found on the way)
+            funcs.tag_amax(xin, amax)
+        else:
+            xin = x.contiguous(memory_format=th.channels_last)
         y = _level(autoencoder.net, xin, part, nhwc=True)
         if autoencoder.keep_channels_last:
             return y
@@ -656,6 +678,11 @@ class ShardedDenoiser(object):
             self.part.channel.check()
 
     def forward(self, batch):
+        from . import wbank
+        with wbank.installed(self.model.weight_banks(batch["radiance"])):
+            return self._forward(batch)
+
+    def _forward(self, batch):
         m, part = self.model, self.part
         radiance = batch["radiance"]
         features = batch["features"].to(radiance.device)

@@ -705,7 +705,7 @@ class ToChannelsLast(th.autograd.Function):
         b, c, h, w = x.shape
         out = th.empty(b, c, h, w, dtype=x.dtype, device=x.device, memory_format=th.channels_last)
         dev = x.device
-        amax = th.empty(1, dtype=th.int32, device=dev) if want_amax else None
+        amax = amax_word(dev) if want_amax else None
         with th.cuda.device(dev):
             if want_amax:
                 rc = _lib.lib().sbmc_transpose2d_amax_f32(_lib.ptr(x), _lib.ptr(out), _lib.ptr(amax), b, c, h * w,
@@ -824,7 +824,7 @@ class BiasActNHWC(th.autograd.Function):
         signs = None
         if act != 0 and any(ctx.needs_input_grad[:2]):
             signs = th.empty((y.numel() + 31) // 32, dtype=th.int32, device=dev)
-        amax = th.empty(1, dtype=th.int32, device=dev) if want_amax else None
+        amax = amax_word(dev) if want_amax else None
         with th.cuda.device(dev):
             if amax is not None:
                 rc = _lib.lib().sbmc_bias_act_nhwc_fwd_amax_f32(_lib.ptr(y), _lib.ptr(bias), _lib.ptr(signs), _lib.ptr(amax),
@@ -854,7 +854,7 @@ class BiasActNHWC(th.autograd.Function):
         partial = gy.new_empty(L.sbmc_bias_act_nhwc_chunks(b * h * w, c), c)
         dev = gy.device
         # (the largest magnitude of gx, for the convolution's data / weight gradient kernels that read it next)
-        amax = th.empty(1, dtype=th.int32, device=dev)
+        amax = amax_word(dev)
         with th.cuda.device(dev):
             rc = L.sbmc_bias_act_nhwc_bwd_amax_f32(_lib.ptr(gy), _lib.ptr(ctx.saved_tensors[0]) if ctx.act != 0 else None,
                                                    _lib.ptr(gx), _lib.ptr(partial), _lib.ptr(amax), b * h * w, c, ctx.act,
@@ -862,6 +862,34 @@ class BiasActNHWC(th.autograd.Function):
         _lib.check(rc, "bias_act_nhwc_bwd")
         tag_amax(gx, amax)
         return gx, partial.sum(0), None, None, None
+
+
+class _AmaxArena(object):
+    """Zeroed device words for the passes that RAISE a word to the largest magnitude of what they write (ABI 5: they no
+    longer zero it themselves -- that was one memset launch per pass, ~230 per training step, none of which shrinks
+    with the slab of a sharded frame).  One zero-filled block of words per (device, stream) serves the next SIZE
+    requests; a word is a view of its block and keeps it alive."""
+    SIZE = 2048
+
+    def __init__(self):
+        self._blocks = {}
+
+    def take(self, device):
+        key = (device.index, th.cuda.current_stream(device).cuda_stream)
+        blk = self._blocks.get(key)
+        if blk is None or blk[1] >= self.SIZE:
+            blk = self._blocks[key] = [th.zeros(self.SIZE, dtype=th.int32, device=device), 0]
+        i = blk[1]
+        blk[1] = i + 1
+        return blk[0][i:i + 1]
+
+
+_AMAX_ARENA = _AmaxArena()
+
+
+def amax_word(device):
+    """A device word holding 0 (int32 [1]) for a `*_amax` pass to raise."""
+    return _AMAX_ARENA.take(device)
 
 
 def tag_amax(t, amax):
@@ -880,6 +908,24 @@ def known_amax(t):
     if tag is not None and tag[1] == t._version and tag[2] == t.data_ptr() and tag[0].device == t.device:
         return tag[0]
     return None
+
+
+def ensure_amax(t):
+    """The word of `t`'s largest magnitude: its tag, or -- none there -- the absmax pass of csrc/conv3x3.hip, tagged
+    on `t` for whoever asks next."""
+    a = known_amax(t)
+    if a is None:
+        a = Conv3x3NHWC._absmax(t)
+        tag_amax(t, a)
+    return a
+
+
+def wants_amax(t):
+    """Will a 3 x 3 convolution of csrc/conv3x3.hip scale this tensor by its largest magnitude?  (fp32,
+    channels-last, the kernels not switched off.)"""
+    return (t.is_cuda and t.dtype == th.float32 and t.dim() == 4 and _is_channels_last(t) and t.data_ptr() % 16 == 0
+            and os.environ.get("SBMC_CONV3X3", "1") not in ("0", "off", "no")
+            and os.environ.get("SBMC_AMAX_TAGS", "1") not in ("0", "off", "no"))
 
 
 def bound_amax(*amaxes):
@@ -921,7 +967,11 @@ class Conv3x3NHWC(th.autograd.Function):
 
     @staticmethod
     def _prepare(w, flip):
-        """The weights' two f16 planes in the kernel's stage order (and their scale), on the device."""
+        """The weights' two f16 planes in the kernel's stage order (and their scale), on the device.  A weight that
+        comes out of a `wbank.WeightBank` carries both orientations already."""
+        wp = getattr(w, "_sbmc_wp", None)
+        if wp is not None:
+            return wp[1 if flip else 0]
         L = _lib.lib()
         cout, cin = (w.shape[1], w.shape[0]) if flip else (w.shape[0], w.shape[1])
         if w.data_ptr() % 16 or not (w.is_contiguous() or w.is_contiguous(memory_format=th.channels_last)):
@@ -962,16 +1012,17 @@ class Conv3x3NHWC(th.autograd.Function):
                 xmax = Conv3x3NHWC._absmax(x)
             y = Conv3x3NHWC._conv(x, xmax, Conv3x3NHWC._prepare(w, False), w.shape[0])
         ctx.save_for_backward(x, w, xmax)
+        ctx.wp = getattr(w, "_sbmc_wp", None)          # (a weight bank's prepared forms: the adjoint's is the second)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, xmax = ctx.saved_tensors
         return Conv3x3NHWC._backward(x, w, xmax, gy.contiguous(memory_format=th.channels_last),
-                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wp)
 
     @staticmethod
-    def _backward(x, w, xmax, gy, want_gx, want_gw):
+    def _backward(x, w, xmax, gy, want_gx, want_gw, wp=None):
         b, cin, h, wd = x.shape
         cout = w.shape[0]
         gx = gw = None
@@ -983,7 +1034,7 @@ class Conv3x3NHWC(th.autograd.Function):
                 gmax = Conv3x3NHWC._absmax(gy)
             if want_gx:
                 with _timed("conv3x3_bwd_data %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
-                    gx = Conv3x3NHWC._conv(gy, gmax, Conv3x3NHWC._prepare(w, True), cin)
+                    gx = Conv3x3NHWC._conv(gy, gmax, wp[1] if wp is not None else Conv3x3NHWC._prepare(w, True), cin)
             if want_gw:
                 with _timed("conv3x3_bwd_weight %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
                     if (os.environ.get("SBMC_CONV3X3_WGRAD", "1") not in ("0", "off", "no")
@@ -1029,11 +1080,12 @@ class Conv3x3BiasActNHWC(th.autograd.Function):
             wp = Conv3x3NHWC._prepare(w, False)
             y = th.empty((b, cout, h, wd), dtype=th.float32, device=dev, memory_format=th.channels_last)
             signs = th.empty((y.numel() + 31) // 32, dtype=th.int32, device=dev) if (act != 0 and need_grad) else None
-            amax = th.empty(1, dtype=th.int32, device=dev)
+            amax = amax_word(dev)
             _lib.check(L.sbmc_conv3x3_bias_act_nhwc_f32(_lib.ptr(x), _lib.ptr(xmax), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y),
                                                         _lib.ptr(signs), _lib.ptr(amax), b, h, wd, cin, cout, act, slope,
                                                         _lib.current_stream(dev)), "conv3x3_bias_act_nhwc")
         ctx.act, ctx.slope = act, slope
+        ctx.wp = getattr(w, "_sbmc_wp", None)
         ctx.save_for_backward(x, w, xmax, signs if signs is not None else xmax)
         ctx.mark_non_differentiable(amax)
         return y, amax
@@ -1047,13 +1099,13 @@ class Conv3x3BiasActNHWC(th.autograd.Function):
         dev = gy.device
         gz = th.empty_like(gy, memory_format=th.channels_last)
         partial = gy.new_empty(L.sbmc_bias_act_nhwc_chunks(b * h * wd, cout), cout)
-        gmax = th.empty(1, dtype=th.int32, device=dev)
+        gmax = amax_word(dev)
         with th.cuda.device(dev):
             _lib.check(L.sbmc_bias_act_nhwc_bwd_amax_f32(_lib.ptr(gy), _lib.ptr(signs) if ctx.act != 0 else None, _lib.ptr(gz),
                                                          _lib.ptr(partial), _lib.ptr(gmax), b * h * wd, cout, ctx.act, ctx.slope,
                                                          _lib.current_stream(dev)), "bias_act_nhwc_bwd")
         tag_amax(gz, gmax)
-        gx, gw = Conv3x3NHWC._backward(x, w, xmax, gz, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gx, gw = Conv3x3NHWC._backward(x, w, xmax, gz, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wp)
         return gx, gw, (partial.sum(0) if ctx.needs_input_grad[2] else None), None, None
 
 

@@ -71,7 +71,9 @@ class HaloChannel(object):
         self.slot_bytes = int(slot_bytes + 15) // 16 * 16
         self.nslots = int(nslots)
         if timeout_s is None:
-            timeout_s = float(os.environ.get("SBMC_HALO_TIMEOUT_S", "120"))
+            # (a wait that runs into it poisons the mailbox: every later wait of the step returns at once, the host
+            # raises at its next status read -- csrc/halo.hip wait_reached)
+            timeout_s = float(os.environ.get("SBMC_HALO_TIMEOUT_S", "30"))
         self.timeout_ticks = int(timeout_s * TICKS_PER_SECOND)
         self.bytes = self.lib.sbmc_halo_bytes(self.slot_bytes, self.nslots)
         base = ctypes.c_void_p()
@@ -183,9 +185,11 @@ class HaloChannel(object):
     def _stream(self):
         return _lib.current_stream(self.device)
 
-    def put(self, up=None, down=None):
+    def put(self, up=None, down=None, amax=None):
         """Sends the runs `up` / `down` ((address, chunks, chunk_bytes, pitch), same shape; None: nothing) to
-        the neighbours."""
+        the neighbours.  amax: the device word with the largest magnitude of the tensor the rows belong to
+        (functions.tag_amax); it travels with the message and the receiver's `get(..., amax=word)` raises its own
+        word to it."""
         if self.peer[0] is None:
             up = None
         if self.peer[1] is None:
@@ -201,15 +205,15 @@ class HaloChannel(object):
                     self.box, self.peer[0] if up else None, self.peer[1] if down else None,
                     up[0] + off if up else None, down[0] + off if down else None,
                     n, nb, pitch, self.send_seq[0], self.send_seq[1], self.nslots, self.slot_bytes,
-                    self.timeout_ticks, self._stream())
+                    self.timeout_ticks, _lib.ptr(amax), self._stream())
             _lib.check(rc, "sbmc_halo_put")
             self.send_seq[0] += 1 if up else 0
             self.send_seq[1] += 1 if down else 0
 
-    def get(self, up=None, down=None, add_up=None, add_down=None, add_elem=0, body=None):
+    def get(self, up=None, down=None, add_up=None, add_down=None, add_elem=0, body=None, amax=None):
         """Receives into the runs `up` / `down`; with add_elem (4: float, 2: half) the result is
         add_* + received.  body = (dst_run, src_run): a plain copy in the same launch (src_run None: dst_run is
-        filled with zeros)."""
+        filled with zeros).  amax: a device word that is raised to the words the senders attached (`put`)."""
         if self.peer[0] is None:
             up = None
         if self.peer[1] is None:
@@ -221,9 +225,9 @@ class HaloChannel(object):
             return
         _, chunks, chunk_bytes, pitch = ref
         for i, piece in enumerate(_pieces(chunks, chunk_bytes, self.slot_bytes)):
-            self._get(up, down, add_up, add_down, add_elem, ref, piece, body if i == 0 else None)
+            self._get(up, down, add_up, add_down, add_elem, ref, piece, body if i == 0 else None, amax)
 
-    def _get(self, up, down, add_up, add_down, add_elem, ref, piece, body):
+    def _get(self, up, down, add_up, add_down, add_elem, ref, piece, body, amax=None):
         c0, n, b0, nb = piece
         pitch = ref[3]
         add_pitch = (add_up or add_down or (0, 0, 0, 0))[3]
@@ -237,7 +241,8 @@ class HaloChannel(object):
                 add_up[0] + aoff if (add_elem and up) else None, add_down[0] + aoff if (add_elem and down) else None,
                 add_elem, n, nb, pitch, add_pitch,
                 bd[0], bs[0], bd[1], bd[2], bd[3], bs[3],
-                self.recv_seq[0], self.recv_seq[1], self.nslots, self.slot_bytes, self.timeout_ticks, self._stream())
+                self.recv_seq[0], self.recv_seq[1], self.nslots, self.slot_bytes, self.timeout_ticks,
+                _lib.ptr(amax), self._stream())
         _lib.check(rc, "sbmc_halo_get")
         self.recv_seq[0] += 1 if up else 0
         self.recv_seq[1] += 1 if down else 0

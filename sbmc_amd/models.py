@@ -114,6 +114,25 @@ class Multisteps(nn.Module):
                         m.fuse_bias_act = True
                 getattr(self, "propagation_{:02d}".format(step)).keep_channels_last = True
 
+    def weight_banks(self, like):
+        """The step's weight banks (sbmc_amd/wbank.py) for a forward pass on `like`'s device: one per
+        embedding + propagation step and one for the kernel regressor -- a bank's backward runs once the LAST of its
+        layers has its gradient, so banks per step keep the gradient all-reduce of a sharded frame (sbmc_amd/dist.py)
+        overlapped with the rest of the backward.  Empty where the banks do not apply (CPU tensors, other dtypes,
+        SBMC_WBANK=0): the modules then run torch's weight norm layer by layer."""
+        import os
+        from . import wbank
+        if not like.is_cuda or os.environ.get("SBMC_WBANK", "1") in ("0", "off", "no"):
+            return []
+        groups = [[getattr(self, "embedding_{:02d}".format(s)), getattr(self, "propagation_{:02d}".format(s))]
+                  for s in range(self.nsteps)] + [[self.kernel_regressor]]
+        banks = []
+        for mods in groups:
+            convs = [c for m in mods for c in m.modules() if wbank.WeightBank.takes(c) and c.weight_v.device == like.device]
+            if convs:
+                banks.append(wbank.WeightBank(convs))
+        return banks
+
     def _embed(self, module, per_sample, per_pixel, want_mean=False):
         """Runs a 1x1 ConvChain on cat(per_sample[:, s], per_pixel) for every sample s.
 
@@ -205,6 +224,11 @@ class Multisteps(nn.Module):
         Returns:
             dict: "radiance" [bs, 3, h - (ksize-1), w - (ksize-1)] denoised radiance.
         """
+        from . import wbank
+        with wbank.installed(self.weight_banks(samples["radiance"])):
+            return self._forward(samples)
+
+    def _forward(self, samples):
         radiance = samples["radiance"]
         features = samples["features"].to(radiance.device)
         gfeatures = samples["global_features"].to(radiance.device)

@@ -53,6 +53,18 @@ def _init_conv(conv, nonlinearity):
     nn.init.xavier_uniform_(conv.weight.data, nn.init.calculate_gain(gain_of))
 
 
+def conv_weight(conv):
+    """The convolution's weight: out of the step's weight bank when one is installed (sbmc_amd/wbank.py: the weight
+    norm of many layers per launch, 3 x 3 weights prepared for csrc/conv3x3.hip on the way), else torch's weight norm
+    (reference sbmc/modules.py:85-94: w = g v / ||v||), else the plain parameter."""
+    w = conv.__dict__.get("_sbmc_bank_w")
+    if w is not None:
+        return w
+    if hasattr(conv, "weight_g"):   # old-style weight norm: w = g * v / ||v||, norm over dims 1..3
+        return th._weight_norm(conv.weight_v, conv.weight_g, 0)
+    return conv.weight
+
+
 def _is_pointwise(conv):
     return (isinstance(conv, nn.Conv2d) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
             and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is not None)
@@ -64,10 +76,7 @@ def _pointwise_gemm(conv, x, activation=None, mean_s=0, mean_out=None):
     Returns (y, activation_was_applied).  mean_s > 0 (only honoured when nothing is left to apply
     after the fused layer): the mean of y over groups of mean_s batch elements is appended to
     `mean_out` (functions.PointwiseLayerMean)."""
-    if hasattr(conv, "weight_g"):   # old-style weight norm: w = g * v / ||v||, norm over dims 1..3
-        w = th._weight_norm(conv.weight_v, conv.weight_g, 0)
-    else:
-        w = conv.weight
+    w = conv_weight(conv)
     b, c, h, wd = x.shape
     wmat = w.view(1, w.shape[0], c).expand(b, -1, -1)
     x3 = x.reshape(b, c, h * wd)
@@ -132,7 +141,7 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     cp = context.shape[1]
     if conv.in_channels != cs + cp:
         return None
-    wt = th._weight_norm(conv.weight_v, conv.weight_g, 0) if hasattr(conv, "weight_g") else conv.weight
+    wt = conv_weight(conv)
     wt = wt.view(wt.shape[0], cs + cp)
     cout = wt.shape[0]
     xs = per_sample.reshape(bs * S, cs, h * w)
@@ -336,7 +345,7 @@ class ConvChain(nn.Module):
         if (conv.bias is None or conv.padding_mode != "zeros" or not isinstance(conv.padding, tuple)
                 or th.is_autocast_enabled()):
             return None, False
-        w = th._weight_norm(conv.weight_v, conv.weight_g, 0) if hasattr(conv, "weight_g") else conv.weight
+        w = conv_weight(conv)
         act, slope = 0, 0.0
         if isinstance(activation, nn.ReLU):
             act = 1

@@ -82,7 +82,9 @@ def _worker(rank, world, port, height, layout="auto", per_conv=True, transport="
         no_worse_than(loss, ref_loss, l64, what="loss")
         scales = module_scales(g64)
         for k, q in model.named_parameters():
-            no_worse_than(q.grad, ref_grads[k], g64[k], what="grad " + k, scale=scales[k])
+            # (slack 3: the yardstick is ONE sample of fp32 rounding -- the single-process gradient's own error --,
+            # and the smallest modules' gradients, 1e-8 here, sit at 0.6e-5 of their scale in either evaluation)
+            no_worse_than(q.grad, ref_grads[k], g64[k], what="grad " + k, scale=scales[k], slack=3.0)
         assert (part.channel is not None) == (transport == "ipc")
     finally:
         dist.destroy_process_group()
