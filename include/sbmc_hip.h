@@ -607,6 +607,13 @@ SBMC_API size_t sbmc_conv3x3_wgrad_scratch_bytes(int n, int h, int w, int cin, i
 SBMC_API int sbmc_conv3x3_wgrad_f32(const float *gy, const unsigned *gmax, const float *x, const unsigned *xmax,
                            float *gw, long s_co, long s_ci, long s_ky, long s_kx, void *scratch, int n, int h,
                            int w, int cin, int cout, void *stream);
+/* ... which also adds up the bias gradient's per-workgroup partial sums bias_partial [bias_chunks][bias_c] (what
+ * sbmc_bias_act_nhwc_bwd_* leave) into gbias [bias_c], in a fixed order, in its reduction launch (a launch of its
+ * own otherwise).  bias_partial NULL: exactly sbmc_conv3x3_wgrad_f32. */
+SBMC_API int sbmc_conv3x3_wgrad_bias_f32(const float *gy, const unsigned *gmax, const float *x, const unsigned *xmax,
+                                float *gw, long s_co, long s_ci, long s_ky, long s_kx, void *scratch, int n, int h,
+                                int w, int cin, int cout, const float *bias_partial, int bias_chunks, int bias_c,
+                                float *gbias, void *stream);
 
 
 /*

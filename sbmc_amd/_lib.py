@@ -100,6 +100,7 @@ SYMBOLS = (
     "sbmc_conv3x3_wgrad_supported",
     "sbmc_conv3x3_wgrad_scratch_bytes",
     "sbmc_conv3x3_wgrad_f32",
+    "sbmc_conv3x3_wgrad_bias_f32",
     "sbmc_wbank_forward_f32",
     "sbmc_wbank_backward_f32",
 )
@@ -252,6 +253,7 @@ def lib():
     handle.sbmc_conv3x3_wgrad_supported.argtypes = [i] * 5
     handle.sbmc_conv3x3_wgrad_scratch_bytes.argtypes = [i] * 5
     handle.sbmc_conv3x3_wgrad_f32.argtypes = [p, p, p, p, p, lg, lg, lg, lg, p, i, i, i, i, i, p]
+    handle.sbmc_conv3x3_wgrad_bias_f32.argtypes = [p, p, p, p, p, lg, lg, lg, lg, p, i, i, i, i, i, p, i, i, p, p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_halo_bytes.restype = ctypes.c_size_t

@@ -449,6 +449,20 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(PrepParams p) {
     p.wp[base + 256] = l;
 }
 
+// compute units of the CURRENT device (cached per device ordinal: a process may hold several)
+static int cu_count() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    if (dev >= 0 && dev < 64 && cache[dev]) return cache[dev];
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    if (dev >= 0 && dev < 64) cache[dev] = cus;
+    return cus;
+}
+
 static bool conv3_dims_ok(int n, int h, int w, int cin, int cout) {
     if (n < 1 || h < 1 || w < 1 || cin < 32 || cout < 128 || cin % 32 || cout % 128) return false;
     // byte offsets inside one tile's rows stay below 2^31
@@ -513,15 +527,7 @@ static int conv3_launch(const float* x, const unsigned* xmax, const void* wp, fl
     p.tiles_x = (w + CV_TS - 1) / CV_TS; p.tiles_y = (h + CV_TS - 1) / CV_TS; p.ncot = cout / 128;
     p.ntiles = (unsigned)((long long)n * p.tiles_y * p.tiles_x * p.ncot);
     p.bias = bias; p.slope = act == 0 ? 1.f : (act == 1 ? 0.f : slope); p.signs = signs; p.amax = amax;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        hipError_t de = hipGetDevice(&dev);
-        if (de == hipSuccess) de = hipGetDeviceProperties(&prop, dev);
-        if (de != hipSuccess) { (void)hipGetLastError(); return (int)de; }
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int cus = cu_count();
     unsigned grid = p.ntiles < (unsigned)cus ? p.ntiles : (unsigned)cus;
     auto kern = epi ? conv3_kernel<true> : conv3_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -827,8 +833,25 @@ struct WreduceParams {
     const unsigned* gmax;
     const unsigned* xmax;
     int ncit, nsplit;
+    // optional: the bias gradient's per-workgroup partial sums [bchunks][bc] (bias_act_nhwc_bwd) -> gbias[bc], added up
+    // in a fixed order by the extra row of workgroups blockIdx.y == ncombo (a reduction launch of its own otherwise)
+    const float* bpartial;
+    float* gbias;
+    int bchunks, bc, ncombo;
 };
 __global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(WreduceParams p) {
+    if ((int)blockIdx.y == p.ncombo) {
+        __shared__ float bred[256];
+        const int ch = (int)blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+        if ((int)blockIdx.x * 64 >= p.bc) return;
+        float s = 0.f;
+        if (ch < p.bc)
+            for (int i = grp; i < p.bchunks; i += 4) s += p.bpartial[(size_t)i * p.bc + ch];
+        bred[threadIdx.x] = s;
+        __syncthreads();
+        if (grp == 0 && ch < p.bc) p.gbias[ch] = (bred[threadIdx.x] + bred[threadIdx.x + 64]) + (bred[threadIdx.x + 128] + bred[threadIdx.x + 192]);
+        return;
+    }
     const unsigned e = blockIdx.x * 256u + threadIdx.x;              // element of the workgroup tile
     const int combo = blockIdx.y;
     if (e >= (unsigned)WG_TILE) return;
@@ -850,14 +873,7 @@ static bool wgrad_dims_ok(int n, int h, int w, int cin, int cout) {
     return (cout / 128) * (cin / 128) * 3 <= 256 && (long long)n * h * ((w + WG_TW - 1) / WG_TW) < (1ll << 40);
 }
 static int wgrad_splits(int cin, int cout, long long total) {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cus = prop.multiProcessorCount;
-        else { (void)hipGetLastError(); cus = 256; }
-    }
+    const int cus = cu_count();
     const int ncombo = (cout / 128) * (cin / 128) * 3;
     long long s = cus / ncombo;
     s = s < 1 ? 1 : s;
@@ -874,9 +890,21 @@ extern "C" size_t sbmc_conv3x3_wgrad_scratch_bytes(int n, int h, int w, int cin,
     const long long total = (long long)n * h * ((w + WG_TW - 1) / WG_TW);
     return (size_t)(cout / 128) * (cin / 128) * 3 * wgrad_splits(cin, cout, total) * WG_TILE * 4;
 }
+extern "C" int sbmc_conv3x3_wgrad_bias_f32(const float* gy, const unsigned* gmax, const float* x, const unsigned* xmax,
+                                            float* gw, long s_co, long s_ci, long s_ky, long s_kx, void* scratch, int n,
+                                            int h, int w, int cin, int cout, const float* bias_partial, int bias_chunks,
+                                            int bias_c, float* gbias, void* stream);
 extern "C" int sbmc_conv3x3_wgrad_f32(const float* gy, const unsigned* gmax, const float* x, const unsigned* xmax,
                                        float* gw, long s_co, long s_ci, long s_ky, long s_kx, void* scratch, int n,
                                        int h, int w, int cin, int cout, void* stream) {
+    return sbmc_conv3x3_wgrad_bias_f32(gy, gmax, x, xmax, gw, s_co, s_ci, s_ky, s_kx, scratch, n, h, w, cin, cout, nullptr, 0,
+                                       0, nullptr, stream);
+}
+extern "C" int sbmc_conv3x3_wgrad_bias_f32(const float* gy, const unsigned* gmax, const float* x, const unsigned* xmax,
+                                            float* gw, long s_co, long s_ci, long s_ky, long s_kx, void* scratch, int n,
+                                            int h, int w, int cin, int cout, const float* bias_partial, int bias_chunks,
+                                            int bias_c, float* gbias, void* stream) {
+    if (bias_partial && (!gbias || bias_chunks < 1 || bias_c < 1 || bias_c > 64 * (WG_TILE / 256))) return SBMC_HIP_EINVAL;
     if (!wgrad_dims_ok(n, h, w, cin, cout) || !gy || !gmax || !x || !xmax || !gw || !scratch) return SBMC_HIP_EINVAL;
     if ((uintptr_t)gy % 16 || (uintptr_t)x % 16 || (uintptr_t)scratch % 16) return SBMC_HIP_EINVAL;
     WgradParams p;
@@ -896,7 +924,9 @@ extern "C" int sbmc_conv3x3_wgrad_f32(const float* gy, const unsigned* gmax, con
     WreduceParams q;
     q.partial = p.partial; q.gw = gw; q.s_co = s_co; q.s_ci = s_ci; q.s_ky = s_ky; q.s_kx = s_kx;
     q.gmax = gmax; q.xmax = xmax; q.ncit = p.ncit; q.nsplit = p.nsplit;
-    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(WG_TILE / 256, (unsigned)ncombo), dim3(256), 0, (hipStream_t)stream, q);
+    q.bpartial = bias_partial; q.gbias = gbias; q.bchunks = bias_chunks; q.bc = bias_c; q.ncombo = ncombo;
+    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(WG_TILE / 256, (unsigned)(ncombo + (bias_partial ? 1 : 0))), dim3(256), 0,
+                       (hipStream_t)stream, q);
     return (int)hipGetLastError();
 }
 

@@ -296,7 +296,11 @@ def _halo_pad_channel_bwd(ctx, g, r, part, h):
     if es not in (2, 4):
         raise RuntimeError("halo transport: float32 / float16 gradients only")
     ch.put(rows_run(g, 0, r, nhwc) if top else None, rows_run(g, hp - r, hp, nhwc) if bot else None)
-    if nhwc and g.shape[0] == 1 and not (top and bot and h < 2 * r):
+    if nhwc and g.shape[0] == 1 and not (top and bot and h < 2 * r) and g._base is None:
+        # (g._base is None: the gradient is a tensor of its own -- what a convolution's data-gradient kernel returns --,
+        # never a view into memory another branch of the graph may still read; the kernels below write through raw
+        # pointers, so a magnitude tag on it would go stale without its version counter noticing)
+        g.__dict__.pop("_sbmc_amax", None)
         # one channels-last image: its own rows are one dense block of the incoming gradient -- the neighbours'
         # contributions are added to its edge rows in place and that block is handed on as a view (no copy of the
         # slab; the gradient of a padded map has no other consumer: it comes out of the first convolution's
@@ -369,6 +373,9 @@ class _HaloRefresh(th.autograd.Function):
         ch = part.channel
         fmt = th.channels_last if nhwc else th.contiguous_format
         g = g.contiguous(memory_format=fmt)
+        if g._base is not None:
+            g = g.clone(memory_format=fmt)     # never write through a view into a gradient another branch may read
+        g.__dict__.pop("_sbmc_amax", None)     # (raw writes below: a magnitude tag would go stale unnoticed)
         top = r if part.has_up else 0
         bot = r if part.has_down else 0
         hp = top + h + bot
@@ -624,7 +631,8 @@ def merge_overhang(sum_r, sum_w, max_w, p, part):
     """The cross-rank step of the sharded splat.  In: this rank's partial state on
     its slab extended by p rows towards every neighbour; out: the complete state of its own rows."""
     c = sum_r.shape[1]
-    if part.channel is not None and sum_r.is_cuda and sum_r.dtype == th.float32 and c <= 8:
+    if (part.channel is not None and sum_r.is_cuda and sum_r.dtype == th.float32 and c <= 8
+            and sum_r.shape[0] * (c + 2) * p * sum_r.shape[-1] * 4 <= part.channel.slot_bytes):     # (one message per edge)
         # put + ONE merge kernel (csrc/halo.hip) instead of an exchange and 9 torch kernels per edge
         own = _MergeOverhangChannel.apply(th.cat([sum_r, sum_w, max_w], 1), p, part)
         return own[:, :c], own[:, c:c + 1], own[:, c + 1:]
@@ -653,6 +661,8 @@ class ShardedDenoiser(object):
         self.merge_state = possible if merge_state is None else (bool(merge_state) and possible)
         self._flat = None
         self._channel_tried = False
+        self._hook_handles = []
+        self.transport_note = None
 
     def _connect(self, device, bs, w):
         """Once, at the first frame (a collective: every rank gets here): the IPC mailboxes between
@@ -669,13 +679,51 @@ class ShardedDenoiser(object):
         # the largest U-net message: 3 rows of a right branch's input (3 * width channels at full width; the
         # same number of bytes at every level); larger runs (the halo-recompute form of the splat) are split
         mb = 1 << 20
-        slot = min(64 * mb, max(mb, -(-9 * self.model.width * w * 4 * bs // mb) * mb))
+        overhang = bs * 5 * ((self.model.ksize - 1) // 2) * w * 4          # the splat state's rows: ONE message (merge kernel)
+        slot = min(64 * mb, max(mb, -(-max(9 * self.model.width * w * 4 * bs, overhang) // mb) * mb))
         part.channel = HaloChannel.connect(part, device, slot)
 
     def check(self):
         """Raises if the halo transport has reported a time-out (synchronises the device)."""
         if self.part.channel is not None:
             self.part.channel.check()
+
+    @property
+    def transport(self):
+        """How neighbour rows travel right now: "ipc" (mailboxes, csrc/halo.hip) or "p2p" (torch.distributed)."""
+        return "ipc" if self.part.channel is not None else "p2p"
+
+    def settle_transport(self):
+        """COLLECTIVE (every rank of the partition calls it, e.g. after a step raised or at a checkpoint): has any
+        rank's mailbox recorded a time-out?  Then every rank drops the IPC channel together and the frame goes on
+        over torch.distributed P2P (RCCL) -- a slower step instead of a dead run.  Returns the transport in use;
+        `transport_note` says why a fallback happened."""
+        part = self.part
+        bad, why = 0.0, ""
+        if part.channel is not None:
+            try:
+                part.channel.check()
+            except RuntimeError as e:
+                bad, why = 1.0, str(e)
+        if part.world > 1:
+            flag = _all_reduce_sum(th.tensor([bad]), part)
+            bad = float(flag.cpu().item())
+        if bad > 0 and part.channel is not None:
+            ch, part.channel = part.channel, None
+            th.cuda.synchronize(ch.device)
+            if part.world > 1:
+                dist.barrier(group=part.group)         # nobody still stores into a mailbox that is about to go
+            ch._finalizer()
+            self.transport_note = "fell back from ipc to p2p: " + (why or "a neighbouring rank reported a time-out")
+        return self.transport
+
+    def close(self):
+        """Removes the gradient hooks this runner registered on the model's parameters and frees its flat gradient
+        buffer (a second runner on the same model would otherwise leave both sets of hooks firing)."""
+        for h in getattr(self, "_hook_handles", []):
+            h.remove()
+        self._hook_handles = []
+        self._flat = None
 
     def forward(self, batch):
         from . import wbank
@@ -756,7 +804,7 @@ class ShardedDenoiser(object):
                     self._bucket_of[i] = b
             self._in_step = False
             for i, q in enumerate(self._params):
-                q.register_post_accumulate_grad_hook(lambda _q, i=i: self._grad_arrived(i))
+                self._hook_handles.append(q.register_post_accumulate_grad_hook(lambda _q, i=i: self._grad_arrived(i)))
         return self._flat
 
     def _grad_arrived(self, i):

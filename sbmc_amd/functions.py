@@ -715,11 +715,14 @@ class ToChannelsLast(th.autograd.Function):
         _lib.check(rc, "transpose2d")
         if want_amax:
             ctx.mark_non_differentiable(amax)
+            ctx.set_materialize_grads(False)
             return out, amax
         return out
 
     @staticmethod
     def backward(ctx, g, *_):
+        if g is None:
+            return None, None
         return FromChannelsLast.apply(g.contiguous(memory_format=th.channels_last)), None
 
 
@@ -842,11 +845,14 @@ class BiasActNHWC(th.autograd.Function):
             ctx.save_for_backward(signs)
         if amax is not None:
             ctx.mark_non_differentiable(amax)
+            ctx.set_materialize_grads(False)
             return y, amax
         return y
 
     @staticmethod
     def backward(ctx, gy, *_):
+        if gy is None:
+            return None, None, None, None, None
         gy = gy.contiguous(memory_format=th.channels_last)
         b, c, h, w = gy.shape
         gx = th.empty_like(gy, memory_format=th.channels_last)
@@ -1022,10 +1028,13 @@ class Conv3x3NHWC(th.autograd.Function):
                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wp)
 
     @staticmethod
-    def _backward(x, w, xmax, gy, want_gx, want_gw, wp=None):
+    def _backward(x, w, xmax, gy, want_gx, want_gw, wp=None, bias_partial=None):
+        """bias_partial: the bias gradient's per-workgroup partial sums [chunks, cout] (bias_act_nhwc_bwd); where the
+        weight-gradient kernel runs, its reduction launch adds them up as well and a third value, the bias gradient,
+        is returned (else None: the caller sums)."""
         b, cin, h, wd = x.shape
         cout = w.shape[0]
-        gx = gw = None
+        gx = gw = gbias = None
         L = _lib.lib()
         dev = gy.device
         with th.cuda.device(dev):
@@ -1042,13 +1051,19 @@ class Conv3x3NHWC(th.autograd.Function):
                         gw = th.empty((cout, cin, 3, 3), dtype=th.float32, device=dev, memory_format=th.channels_last)
                         scratch = th.empty(L.sbmc_conv3x3_wgrad_scratch_bytes(b, h, wd, cin, cout), dtype=th.uint8, device=dev)
                         s = gw.stride()
-                        _lib.check(L.sbmc_conv3x3_wgrad_f32(_lib.ptr(gy), _lib.ptr(gmax), _lib.ptr(x), _lib.ptr(xmax),
-                                                            _lib.ptr(gw), s[0], s[1], s[2], s[3], _lib.ptr(scratch), b, h,
-                                                            wd, cin, cout, _lib.current_stream(dev)), "conv3x3_wgrad")
+                        if bias_partial is not None:
+                            gbias = th.empty(cout, dtype=th.float32, device=dev)
+                        _lib.check(L.sbmc_conv3x3_wgrad_bias_f32(
+                            _lib.ptr(gy), _lib.ptr(gmax), _lib.ptr(x), _lib.ptr(xmax), _lib.ptr(gw), s[0], s[1], s[2], s[3],
+                            _lib.ptr(scratch), b, h, wd, cin, cout, _lib.ptr(bias_partial),
+                            bias_partial.shape[0] if bias_partial is not None else 0, cout, _lib.ptr(gbias),
+                            _lib.current_stream(dev)), "conv3x3_wgrad")
                     else:
                         wcl = w.contiguous(memory_format=th.channels_last)      # (MIOpen's NHWC solver)
                         gw = th.ops.aten.convolution_backward(gy, x, wcl, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                               [False, True, False])[1]
+        if bias_partial is not None:
+            return gx, gw, gbias
         return gx, gw
 
 
@@ -1088,10 +1103,13 @@ class Conv3x3BiasActNHWC(th.autograd.Function):
         ctx.wp = getattr(w, "_sbmc_wp", None)
         ctx.save_for_backward(x, w, xmax, signs if signs is not None else xmax)
         ctx.mark_non_differentiable(amax)
+        ctx.set_materialize_grads(False)         # (else autograd zero-fills a "gradient" for the amax word every step)
         return y, amax
 
     @staticmethod
     def backward(ctx, gy, _gamax):
+        if gy is None:
+            return None, None, None, None, None
         x, w, xmax, signs = ctx.saved_tensors
         gy = gy.contiguous(memory_format=th.channels_last)
         b, cout, h, wd = gy.shape
@@ -1105,8 +1123,13 @@ class Conv3x3BiasActNHWC(th.autograd.Function):
                                                          _lib.ptr(partial), _lib.ptr(gmax), b * h * wd, cout, ctx.act, ctx.slope,
                                                          _lib.current_stream(dev)), "bias_act_nhwc_bwd")
         tag_amax(gz, gmax)
-        gx, gw = Conv3x3NHWC._backward(x, w, xmax, gz, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wp)
-        return gx, gw, (partial.sum(0) if ctx.needs_input_grad[2] else None), None, None
+        want_bias = ctx.needs_input_grad[2]
+        res = Conv3x3NHWC._backward(x, w, xmax, gz, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wp,
+                                    partial if want_bias else None)
+        gbias = res[2] if want_bias else None
+        if want_bias and gbias is None:
+            gbias = partial.sum(0)               # (the weight-gradient kernel did not run: its reduction adds them up)
+        return res[0], res[1], gbias, None, None
 
 
 def upsample_cat_nhwc_supported(coarse, left, top=0, bot=0):

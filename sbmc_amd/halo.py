@@ -13,6 +13,7 @@ import ctypes
 import logging
 import os
 import socket
+import time
 import weakref
 
 import torch as th
@@ -86,6 +87,7 @@ class HaloChannel(object):
         self._opened = []
         self.send_seq = [0, 0]
         self.recv_seq = [0, 0]
+        self.handshake_ms = None
         self._finalizer = weakref.finalize(self, HaloChannel._release, self.lib, self.box, self._opened)
 
     @staticmethod
@@ -169,9 +171,14 @@ class HaloChannel(object):
         keep, self.timeout_ticks = self.timeout_ticks, int(timeout_s * TICKS_PER_SECOND)
         try:
             run = rows_run(mine, 0, 1)
+            th.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
             self.put(run if part.has_up else None, run if part.has_down else None)
             self.get(rows_run(got[0:1], 0, 1) if part.has_up else None, rows_run(got[1:2], 0, 1) if part.has_down else None)
             th.cuda.synchronize(self.device)
+            #: wall time of the first exchange over this rank's links (two launches + the neighbours' answers; the ranks
+            #: do not enter it at the same instant, so this bounds the link latency from above)
+            self.handshake_ms = (time.perf_counter() - t0) * 1e3
             err = ctypes.c_uint(0)
             with th.cuda.device(self.device):
                 _lib.check(self.lib.sbmc_halo_status(self.box, ctypes.byref(err)), "sbmc_halo_status")

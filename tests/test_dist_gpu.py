@@ -82,9 +82,11 @@ def _worker(rank, world, port, height, layout="auto", per_conv=True, transport="
         no_worse_than(loss, ref_loss, l64, what="loss")
         scales = module_scales(g64)
         for k, q in model.named_parameters():
-            # (slack 3: the yardstick is ONE sample of fp32 rounding -- the single-process gradient's own error --,
-            # and the smallest modules' gradients, 1e-8 here, sit at 0.6e-5 of their scale in either evaluation)
-            no_worse_than(q.grad, ref_grads[k], g64[k], what="grad " + k, scale=scales[k], slack=3.0)
+            # (2e-5 / slack 3: a bias gradient here is an fp32 sum over ~9000 pixel-samples of mixed sign; both the
+            # single-process and the sharded evaluation sit at 0.3-1.2e-5 of the module's gradient scale from the
+            # float64 one, and which side of 1e-5 a given parameter lands on changes with any last-bit change upstream
+            # (round 4: the weight bank's weight norm differs from torch's in the last bit))
+            no_worse_than(q.grad, ref_grads[k], g64[k], rtol=2e-5, what="grad " + k, scale=scales[k], slack=3.0)
         assert (part.channel is not None) == (transport == "ipc")
     finally:
         dist.destroy_process_group()
@@ -99,3 +101,57 @@ def test_sharded_denoiser_on_device_kernels(layout, per_conv, transport):
     before every chain of three.  transport: neighbour rows through the IPC mailboxes (csrc/halo.hip; the splat
     state then merges in ONE kernel) or through torch.distributed P2P (gloo here: staged through the host)."""
     mp.spawn(_worker, args=(2, _free_port(), 64, layout, per_conv, transport), nprocs=2, join=True)
+
+
+def _fallback_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sbmc_amd import Multisteps, losses
+        from sbmc_amd import dist as sdist
+        from sbmc_amd.halo import TICKS_PER_SECOND, rows_run
+        dev = th.device("cuda", 0)
+        height, nf, ks, spp, w = 64, 6, 5, 2, 72
+        th.manual_seed(3)
+        model = Multisteps(nf, 3, width=8, embedding_width=8, ksize=ks, nsteps=2).to(dev).train()
+        g = th.Generator().manual_seed(4)
+        full = {"radiance": th.empty(1, spp, 3, height, w).exponential_(1.0, generator=g).to(dev),
+                "features": th.rand(1, spp, nf, height, w, generator=g).to(dev),
+                "global_features": th.rand(1, 3, 1, 1, generator=g).to(dev),
+                "target_image": th.empty(1, 3, height, w).exponential_(1.0, generator=g).to(dev)}
+        part = sdist.SlabPartition(height, world, rank)
+        slab = {k: (v if k == "global_features" else v[..., part.y0:part.y1, :].contiguous()) for k, v in full.items()}
+        runner = sdist.ShardedDenoiser(model, part)
+        loss_fn = losses.TonemappedRelativeMSE()
+        opt = th.optim.SGD(model.parameters(), lr=0.0)
+        first = float(runner.train_step(opt, loss_fn, slab))
+        assert runner.transport == "ipc" and runner.settle_transport() == "ipc"      # nothing to fall back from
+        grads = {k: q.grad.clone() for k, q in model.named_parameters()}
+        if rank == 1:
+            # rows that nobody ever sends: this rank's mailbox records a time-out (0.3 s) -- what a dead or
+            # desynchronised neighbour looks like from here
+            ch = part.channel
+            ch.timeout_ticks = int(0.3 * TICKS_PER_SECOND)
+            junk = th.empty(1, 1, 1, 64, device=dev)
+            ch.get(rows_run(junk, 0, 1), None)
+            th.cuda.synchronize(dev)
+            with pytest.raises(RuntimeError):
+                runner.check()
+        assert runner.settle_transport() == "p2p"               # BOTH ranks drop the mailboxes together
+        assert part.channel is None and "fell back" in runner.transport_note
+        second = float(runner.train_step(opt, loss_fn, slab))    # ... and the frame goes on over torch.distributed
+        assert abs(second - first) <= 1e-6 * abs(first)
+        for k, q in model.named_parameters():
+            assert (q.grad - grads[k]).abs().max().item() <= 2e-5 * max(grads[k].abs().max().item(), 1e-30), k
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_mailbox_time_out_mid_run_falls_back_to_p2p_on_every_rank():
+    """The defence around the first real multi-GPU run (bench.validate_sharded does the same): a rank whose halo wait
+    timed out makes ALL ranks leave the IPC mailboxes at the next `settle_transport` and continue over
+    torch.distributed P2P with the same results."""
+    mp.spawn(_fallback_worker, args=(2, _free_port()), nprocs=2, join=True)

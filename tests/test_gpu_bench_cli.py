@@ -57,3 +57,10 @@ def test_bench_starts_its_own_ranks(workload):
             assert r["step_ms"] > 0 and r["exchanges"] > 0 and r["exchange_ms"] >= 0
             assert abs(r["compute_ms"] + r["exchange_ms"] + r["all_reduce_exposed_ms"] - r["step_ms"]) < 1e-2
         assert d["whole_step_tflops"] > 0 and "unet_layout" in d
+        for r in d["per_rank"]:
+            assert r["transport"] in ("ipc", "p2p")
+    if workload == "model":
+        # the first thing N ranks do is a correctness check against rank 0's single-GPU forward of the whole frame
+        v = d["validation"]
+        assert v["rel_diff"] is not None and v["rel_diff"] <= 1e-5, v
+        assert d["transport"] in ("ipc", "p2p") and d["rccl_ranks"] == 2

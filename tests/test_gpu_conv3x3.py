@@ -240,8 +240,13 @@ def test_fused_epilogue_equals_the_two_passes(act, slope):
         assert amax.view(th.float32).item() == y.abs().max().item()
         return (y.detach().clone(),) + th.autograd.grad(y, (xs, ws, bs), gy)
 
-    for a, b in zip(two_passes(), fused()):
-        assert th.equal(a, b)
+    for i, (a, b) in enumerate(zip(two_passes(), fused())):
+        if i == 3:
+            # the bias gradient: the same per-workgroup partial sums, added up by torch's `sum` in the two-pass form and
+            # by the weight gradient's reduction launch in the fused one (round 4) -- two fixed orders of one fp32 sum
+            assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()
+        else:
+            assert th.equal(a, b)
 
 
 @pytest.mark.parametrize("shape", [(1, 128, 48, 80), (2, 64, 31, 44), (1, 128, 720, 1280)])
