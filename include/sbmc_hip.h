@@ -394,6 +394,15 @@ SBMC_API int sbmc_pointwise_fwd_f16(const void *x, int x_is_half, const float *w
  */
 SBMC_API int sbmc_pointwise_bwd_supported(int cin, int cout, long hw);
 SBMC_API int sbmc_pointwise_bwd_groups(int b, int s, int t_mode, long hw);
+/* Weight and bias gradient of a WIDE linear 1x1 layer, 128 < cout <= 512 (the 441-channel kernel regressor output,
+ * reference sbmc/models.py:98-102; the fused backward above takes cout <= 128): gw[co][k] = sum_{b, px} gz[b][co][px]
+ * x[b][k][px] at fp32 accuracy on the bf16 matrix pipe, gbias[co] = sum gz, in ONE pass over gz and x.
+ * gw_partial [groups, cout, cin] and gb_partial [groups, cout] (groups = ..._groups(b, hw)) are written completely;
+ * the caller adds the groups up.  cin <= 128, hw % 4 == 0. */
+SBMC_API int sbmc_pointwise_gw_wide_supported(int cin, int cout, long hw);
+SBMC_API int sbmc_pointwise_gw_wide_groups(int b, long hw);
+SBMC_API int sbmc_pointwise_gw_wide_f32(const float *gz, const float *x, float *gw_partial, float *gb_partial, int b,
+                               int cin, int cout, long hw, void *stream);
 SBMC_API int sbmc_pointwise_bwd_f32(const float *gy, const float *y, const float *x, const float *w,
                            float *gx, float *gw_partial, float *gb_partial, float *gt,
                            const float *gmean, int s_mean, int b, int s, int cin, int cout, long hw,
@@ -588,8 +597,14 @@ SBMC_API size_t sbmc_conv3x3_weights_bytes(int cin, int cout);
 SBMC_API int sbmc_conv3x3_absmax_f32(const float *x, long n, unsigned *out, void *stream);
 SBMC_API int sbmc_conv3x3_prepare_weights_f32(const float *w, long s_co, long s_ci, long s_ky, long s_kx,
                                      long storage_elems, int cin, int cout, int flip, void *wp, void *stream);
+/* Stream-K workspace (optional, `ws` below; NULL: whole tiles are dealt round-robin to the compute units): a launch whose
+ * tile count is no multiple of the CU count then cuts its (tile, 32-channel chunk) units into equal ranges over ALL
+ * compute units; partial tiles meet in `ws` (workspace_bytes of device memory, 16-byte aligned, used by one launch at
+ * a time) and a second, small launch adds them in a fixed order and runs their epilogues: the result does not depend on
+ * the run. */
+SBMC_API size_t sbmc_conv3x3_workspace_bytes(void);
 SBMC_API int sbmc_conv3x3_nhwc_f32(const float *x, const unsigned *xmax, const void *wp, float *y, int n, int h,
-                          int w, int cin, int cout, void *stream);
+                          int w, int cin, int cout, void *ws, void *stream);
 /* The same convolution with the bias + activation pass behind it (reference sbmc/modules.py:154-175) in its
  * epilogue: y = act(conv(x) + bias[cout]), act 0 linear / 1 ReLU / 2 LeakyReLU(slope).  signs (or NULL): one bit
  * per output (pre-activation > 0), bit e % 32 of word e / 32 of the channels-last element index e -- what
@@ -597,7 +612,22 @@ SBMC_API int sbmc_conv3x3_nhwc_f32(const float *x, const unsigned *xmax, const v
  * word the caller zeroed). */
 SBMC_API int sbmc_conv3x3_bias_act_nhwc_f32(const float *x, const unsigned *xmax, const void *wp, const float *bias,
                                    float *y, unsigned *signs, unsigned *amax, int n, int h, int w, int cin,
-                                   int cout, int act, float slope, void *stream);
+                                   int cout, int act, float slope, void *ws, void *stream);
+/* Half activations (torch.autocast(float16) semantics: half inputs, weights rounded to half once, fp32 accumulation,
+ * half outputs): x, y _Float16 channels-last; wp the prepared weights of prepare_weights_f32 / the weight bank (their
+ * high plane is f16 of the power-of-two-scaled weight, the scale is divided out); bias fp32; no magnitude words. */
+SBMC_API int sbmc_conv3x3_nhwc_f16(const void *x, const void *wp, void *y, int n, int h, int w, int cin, int cout,
+                          void *ws, void *stream);
+SBMC_API int sbmc_conv3x3_bias_act_nhwc_f16(const void *x, const void *wp, const float *bias, void *y, unsigned *signs,
+                                   int n, int h, int w, int cin, int cout, int act, float slope, void *ws,
+                                   void *stream);
+/* ... its weight gradient (gy, x _Float16; gw and gbias fp32) and the activation adjoint + bias partial sums on half
+ * gradients (signs NULL <=> act 0; gx may alias gy) */
+SBMC_API int sbmc_conv3x3_wgrad_bias_f16(const void *gy, const void *x, float *gw, long s_co, long s_ci, long s_ky,
+                                long s_kx, void *scratch, int n, int h, int w, int cin, int cout,
+                                const float *bias_partial, int bias_chunks, int bias_c, float *gbias, void *stream);
+SBMC_API int sbmc_bias_act_nhwc_bwd_signs_f16(const void *gy, const unsigned *signs, void *gx, float *partial,
+                                     long pixels, int c, int act, float slope, void *stream);
 /* Weight gradient of the same convolution: gw[co][ci][ky][kx] (element strides s_*) = sum over the pixels of
  * gy[n][y][x][co] x[n][y + ky - 1][x + kx - 1][ci]; gmax / xmax: the tensors' largest magnitudes as written by
  * sbmc_conv3x3_absmax_f32; scratch: wgrad_scratch_bytes of device memory (partial sums of the pixel ranges,

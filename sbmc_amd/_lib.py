@@ -55,6 +55,9 @@ SYMBOLS = (
     "sbmc_pointwise_bwd_supported",
     "sbmc_pointwise_bwd_groups",
     "sbmc_pointwise_bwd_f32",
+    "sbmc_pointwise_gw_wide_supported",
+    "sbmc_pointwise_gw_wide_groups",
+    "sbmc_pointwise_gw_wide_f32",
     "sbmc_pointwise_bwd_f16",
     "sbmc_pointwise_fwd_signs_f32",
     "sbmc_pointwise_bwd_signs_f32",
@@ -95,12 +98,17 @@ SYMBOLS = (
     "sbmc_conv3x3_weights_bytes",
     "sbmc_conv3x3_absmax_f32",
     "sbmc_conv3x3_prepare_weights_f32",
+    "sbmc_conv3x3_workspace_bytes",
     "sbmc_conv3x3_nhwc_f32",
     "sbmc_conv3x3_bias_act_nhwc_f32",
     "sbmc_conv3x3_wgrad_supported",
     "sbmc_conv3x3_wgrad_scratch_bytes",
     "sbmc_conv3x3_wgrad_f32",
     "sbmc_conv3x3_wgrad_bias_f32",
+    "sbmc_conv3x3_nhwc_f16",
+    "sbmc_conv3x3_bias_act_nhwc_f16",
+    "sbmc_conv3x3_wgrad_bias_f16",
+    "sbmc_bias_act_nhwc_bwd_signs_f16",
     "sbmc_wbank_forward_f32",
     "sbmc_wbank_backward_f32",
 )
@@ -202,6 +210,9 @@ def lib():
     handle.sbmc_pointwise_fwd_f16.argtypes = [p, i, p, p, p, p, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_supported.argtypes = [i, i, ctypes.c_long]
     handle.sbmc_pointwise_bwd_groups.argtypes = [i, i, i, ctypes.c_long]
+    handle.sbmc_pointwise_gw_wide_supported.argtypes = [i, i, ctypes.c_long]
+    handle.sbmc_pointwise_gw_wide_groups.argtypes = [i, ctypes.c_long]
+    handle.sbmc_pointwise_gw_wide_f32.argtypes = [p, p, p, p, i, i, i, ctypes.c_long, p]
     handle.sbmc_pointwise_bwd_f32.argtypes = [p] * 9 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_fwd_signs_f32.argtypes = [p] * 6 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_signs_f32.argtypes = handle.sbmc_pointwise_bwd_f32.argtypes
@@ -248,16 +259,22 @@ def lib():
     handle.sbmc_conv3x3_weights_bytes.argtypes = [i, i]
     handle.sbmc_conv3x3_absmax_f32.argtypes = [p, lg, p, p]
     handle.sbmc_conv3x3_prepare_weights_f32.argtypes = [p, lg, lg, lg, lg, lg, i, i, i, p, p]
-    handle.sbmc_conv3x3_nhwc_f32.argtypes = [p, p, p, p, i, i, i, i, i, p]
-    handle.sbmc_conv3x3_bias_act_nhwc_f32.argtypes = [p] * 7 + [i] * 6 + [ctypes.c_float, p]
+    handle.sbmc_conv3x3_workspace_bytes.argtypes = []
+    handle.sbmc_conv3x3_nhwc_f32.argtypes = [p, p, p, p, i, i, i, i, i, p, p]
+    handle.sbmc_conv3x3_bias_act_nhwc_f32.argtypes = [p] * 7 + [i] * 6 + [ctypes.c_float, p, p]
     handle.sbmc_conv3x3_wgrad_supported.argtypes = [i] * 5
     handle.sbmc_conv3x3_wgrad_scratch_bytes.argtypes = [i] * 5
     handle.sbmc_conv3x3_wgrad_f32.argtypes = [p, p, p, p, p, lg, lg, lg, lg, p, i, i, i, i, i, p]
     handle.sbmc_conv3x3_wgrad_bias_f32.argtypes = [p, p, p, p, p, lg, lg, lg, lg, p, i, i, i, i, i, p, i, i, p, p]
+    handle.sbmc_conv3x3_nhwc_f16.argtypes = [p, p, p, i, i, i, i, i, p, p]
+    handle.sbmc_conv3x3_bias_act_nhwc_f16.argtypes = [p, p, p, p, p, i, i, i, i, i, i, ctypes.c_float, p, p]
+    handle.sbmc_conv3x3_wgrad_bias_f16.argtypes = [p, p, p, lg, lg, lg, lg, p, i, i, i, i, i, p, i, i, p, p]
+    handle.sbmc_bias_act_nhwc_bwd_signs_f16.argtypes = [p, p, p, p, lg, i, i, ctypes.c_float, p]
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_halo_bytes.restype = ctypes.c_size_t
     handle.sbmc_conv3x3_weights_bytes.restype = ctypes.c_size_t
+    handle.sbmc_conv3x3_workspace_bytes.restype = ctypes.c_size_t
     handle.sbmc_conv3x3_wgrad_scratch_bytes.restype = ctypes.c_size_t
     handle.sbmc_splat_update_bwd_scratch_bytes.restype = ctypes.c_size_t
     if handle.sbmc_hip_abi_version() != ABI_VERSION:

@@ -41,6 +41,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 using h2 = __attribute__((ext_vector_type(2))) _Float16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using f2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int CV_TS = 16;                    // tile side (pixels)
@@ -95,10 +96,10 @@ __device__ __forceinline__ f32x16 cv_mfma(u32x4 a, u32x4 b, f32x16 c) {
 }
 
 struct Conv3Params {
-    const float* x;          // [N, H, W, Cin]
+    const void* x;           // [N, H, W, Cin] float (HF: _Float16)
     const u32x4* wp;         // prepared weights: [cout tile][Cin / 16][ky][kx][plane][k half][128] entries of 8 halves
-    float* y;                // [N, H, W, Cout]
-    const unsigned* xmax;    // bit pattern of max |x|
+    void* y;                 // [N, H, W, Cout] float (HF: _Float16)
+    const unsigned* xmax;    // bit pattern of max |x| (HF: unused)
     const float* wscale;     // the weights' scale
     int N, H, W, Cin, Cout;
     int tiles_x, tiles_y, ncot;
@@ -109,10 +110,159 @@ struct Conv3Params {
     float slope;             // 1: linear, 0: ReLU, else LeakyReLU
     unsigned* signs;         // one bit per output (pre-activation > 0), bit e % 32 of word e / 32 of the NHWC element index e; or nullptr
     unsigned* amax;          // raised to the bit pattern of max |y| (a word zeroed by the caller); or nullptr
+    // stream-K (or nullptr: whole tiles dealt round-robin): [4 KB unused][partial slabs: gridDim.x x 32768 floats][parked
+    // slabs: the same]
+    void* ws;
 };
+constexpr int CV_SLAB = 256 * 128;           // floats of one workgroup's accumulators
+constexpr int CV_WS_HDR = 4096;
 
-template <bool EPI>
+// ---- a tile is complete: scale back (+ bias, activation, sign bits, largest magnitude), store, clear.  One code for the
+// main kernel and for the stream-K fix-up kernel (same thread -> (pixel, channel) map).  park (stream-K): the accumulators
+// go to this workgroup's slab RAW instead -- same stores, other descriptor and offsets, selected, not branched to: a
+// branch around the epilogue (or a second copy of it) costs the main loop 140 spilled registers. ----
+struct CvTile { int n, y0, x0, ct; };
+template <bool EPI, bool HF>
+__device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4][2], const CvTile& t, const bool park,
+                                          float* park_slab, const float oscale, unsigned& amax_run) {
+    constexpr unsigned ES = HF ? 2u : 4u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int mh = wave & 1, nh = wave >> 1;
+    const bool sign_lane = l31 == 0;
+    const rsrc_t rpark = cv_rsrc(park ? park_slab : static_cast<float*>(p.ws), park ? (unsigned)CV_SLAB * 4u : 0u);
+    char* yb = static_cast<char*>(p.y) + ((((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)p.Cout + t.ct * 128) * ES;
+    const rsrc_t ry = cv_rsrc(yb, 0x7FFFFFF0u);
+    float bv[2] = {0.f, 0.f};
+    rsrc_t rs = ry;
+    if constexpr (EPI) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bv[ni] = p.bias[t.ct * 128 + nh * 64 + ni * 32 + l31];
+        // sign words of this tile's first pixel and output-channel tile: word = pixel (Cout / 32) + channel / 32
+        rs = cv_rsrc(p.signs + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)(p.Cout / 32) + t.ct * 4,
+                     p.signs ? 0x7FFFFFF0u : 0u);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // accumulator register r of a 32 x 32 block: pixel (r & 3) + 8 (r >> 2) + 4 (lane / 32) of the
+            // block's 2 rows x 16 columns; output channel lane % 32
+            const int row = mh * 8 + mi * 2 + (r >> 3);
+            const int col = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi + 14 * (r >> 3)) & 15;     // (the rotation above)
+            const bool ok = t.y0 + row < p.H && t.x0 + col < p.W;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const unsigned voff = (ok && !park) ? (unsigned)((row * p.W + col) * p.Cout + nh * 64 + ni * 32 + l31) * ES : CV_OOB;
+                buf_store(acc[mi][ni][r], rpark, (unsigned)tid * 4u, (unsigned)(((mi * 2 + ni) * 16 + r) * 1024));   // (empty descriptor unless parking)
+                float v = acc[mi][ni][r] * oscale;
+                if constexpr (EPI) {
+                    v += bv[ni];
+                    const bool pos = v > 0.f;
+                    {
+                        // lanes 0-31 are the 32 channels of one sign word (pixel of the lower half), 32-63 the next
+                        // pixel's; no branch on `signs`: without them every lane's offset is out of range
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(pos);
+                        const unsigned word = lhi ? (unsigned)(bal >> 32) : (unsigned)bal;
+                        const unsigned so = (ok && sign_lane && !park) ? (unsigned)((row * p.W + col) * (p.Cout / 32) + nh * 2 + ni) * 4u : CV_OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(word, rs, so, 0, 0);
+                    }
+                    v = pos ? v : v * p.slope;
+                    if (ok && !park) {
+                        const unsigned a = abits(v);
+                        amax_run = amax_run > a ? amax_run : a;
+                    }
+                }
+                if constexpr (HF)
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), ry, voff, 0, 0);
+                else
+                    buf_store(v, ry, voff, 0);
+                acc[mi][ni][r] = 0.f;
+            }
+            if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);      // (one register's ballots and stores at a time)
+        }
+    }
+}
+
+// a workgroup's accumulators <-> a slab of the stream-K workspace (element e of thread t at e * 256 + t; buffer
+// addressing: one lane-offset register and immediate element offsets)
+__device__ __forceinline__ void cv_slab_store(const f32x16 (&acc)[4][2], float* base) {
+    const rsrc_t rb = cv_rsrc(base, (unsigned)CV_SLAB * 4u);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                buf_store(acc[mi][ni][r], rb, threadIdx.x * 4u, (unsigned)(((mi * 2 + ni) * 16 + r) * 1024));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+template <bool ADD, bool PACE = true>
+__device__ __forceinline__ void cv_slab_load(f32x16 (&acc)[4][2], const float* base) {
+    const rsrc_t rb = cv_rsrc(base, (unsigned)CV_SLAB * 4u);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = buf_load(rb, threadIdx.x * 4u, (unsigned)(((mi * 2 + ni) * 16 + r) * 1024));
+                acc[mi][ni][r] = ADD ? acc[mi][ni][r] + v : v;
+            }
+            if (PACE) __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+// Stream-K fix-up (the launch behind a conv3_kernel that ran with a workspace): workgroup g of that launch parked the
+// tail of its first tile if its range of (tile, chunk) units began inside that tile and reached the tile's end; the
+// workgroups before it left the tile's head (and middle) in their partial slabs.  Tail + partials in a FIXED order
+// (g - 1, g - 2, ... back to the workgroup whose range holds the tile's first unit), then the tile's epilogue.
+template <bool EPI, bool HF>
+__global__ __launch_bounds__(256) void conv3_fixup_kernel(Conv3Params p, unsigned G) {
+    const unsigned g = blockIdx.x, nchunks = (unsigned)p.Cin / 32u;
+    const unsigned long long U = (unsigned long long)p.ntiles * nchunks;
+    const unsigned long long u0 = U * g / G, u1 = U * (g + 1) / G;
+    const unsigned first = (unsigned)(u0 / nchunks), c0 = (unsigned)(u0 % nchunks);
+    if (c0 == 0 || u0 + (nchunks - c0) > u1) return;      // began on a tile boundary, or never reached its tile's end
+    float* const slabs = reinterpret_cast<float*>(static_cast<char*>(p.ws) + CV_WS_HDR);
+    // (a slab's 128 loads per thread all in flight -- this kernel has the registers --: issued 16 at a time it took 20 us,
+    // on latency alone, where the convolution it completes takes 120)
+    f32x16 acc[4][2], part[4][2];
+    cv_slab_load<false, false>(acc, slabs + (size_t)(G + g) * CV_SLAB);
+    const unsigned long long head = (unsigned long long)first * nchunks;
+    for (unsigned gp = g; gp-- > 0;) {
+        cv_slab_load<false, false>(part, slabs + (size_t)gp * CV_SLAB);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] += part[mi][ni];
+        if (U * gp / G <= head) break;
+    }
+    CvTile t;
+    t.ct = (int)(first % (unsigned)p.ncot);
+    const unsigned pt = first / (unsigned)p.ncot;
+    t.x0 = (int)(pt % (unsigned)p.tiles_x) * CV_TS;
+    const unsigned rest = pt / (unsigned)p.tiles_x;
+    t.y0 = (int)(rest % (unsigned)p.tiles_y) * CV_TS;
+    t.n = (int)(rest / (unsigned)p.tiles_y);
+    const float cx = HF ? 1.f : cv_scale_of(*p.xmax);
+    const float oscale = (1.f / cx) * (1.f / *p.wscale);
+    unsigned amax_run = 0;
+    cv_finish<EPI, HF>(p, acc, t, false, nullptr, oscale, amax_run);
+    if constexpr (EPI) {
+        if (p.amax) amax_publish(amax_run, p.amax);
+    }
+}
+
+// HF: half activations ("fp16 activations", BASELINE configs[4]; torch.autocast(float16) semantics: half inputs, the
+// weights rounded to half once, fp32 accumulation, half output): x and y are _Float16 tensors, the patch goes to LDS
+// as it is (one plane, no split, no scale), the weights are the prepared weights' HIGH plane (f16 of the scaled
+// weight: the rounding autocast applies, with a power-of-two scale that is divided out again), ONE matrix product per
+// term instead of three.
+template <bool EPI, bool HF = false>
 __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
+    constexpr unsigned ES = HF ? 2u : 4u;              // bytes of an activation element
     extern __shared__ float4 cv_lds[];
     u32x4* As = reinterpret_cast<u32x4*>(cv_lds);
     u32x4* Ws = As + 2 * CV_ABUF;
@@ -124,15 +274,39 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     // lanes must be rotated by 18 mod 16 = 2 columns for every such group to cover 16 different 16-byte slots of
     // the 256-byte bank row: lane 16 + j reads column (j + 14) mod 16.
     const int pcol = (l31 + 14 * (l31 >> 4)) & 15;
-    const float cx = cv_scale_of(*p.xmax);
+    const float cx = HF ? 1.f : cv_scale_of(*p.xmax);
     const float oscale = (1.f / cx) * (1.f / *p.wscale);
     const unsigned nchunks = (unsigned)p.Cin / 32u;
 
-    // the chunks of this workgroup, in order: chunk h is channels 32 (h % nchunks) .. of tile first + (h / nchunks) stride
-    const unsigned first = blockIdx.x, stride = gridDim.x;
-    const unsigned my_tiles = first < p.ntiles ? (p.ntiles - first + stride - 1) / stride : 0;
-    const unsigned total = my_tiles * nchunks;
-    struct Tile { int n, y0, x0, ct; };
+    // The work of this workgroup, in (tile, 32-channel chunk) units.
+    //   whole tiles, round-robin (p.ws == nullptr): tiles blockIdx.x, + gridDim.x, ...: a launch whose tile count is not a
+    //     multiple of the CU count idles part of the chip in its last round -- 320 tiles on 256 CUs run at 62 %, which is
+    //     what the slabs of a frame sharded over 8 GPUs look like at the U-net's coarser levels;
+    //   stream-K (p.ws): the units of all tiles, tile after tile, are cut into gridDim.x EQUAL contiguous ranges.  A range
+    //     that starts inside a tile holds that tile's TAIL: the workgroup parks those accumulators in its slab when the
+    //     tile's last chunk is through and goes on with whole tiles; a range that ends inside a tile leaves that tile's
+    //     head in the workgroup's other slab.  conv3_fixup_kernel, the next launch, adds heads to tails in a fixed
+    //     order and runs those tiles' epilogues: no flags, no waiting between workgroups, nothing that depends on which
+    //     of them the dispatcher started first (a first version that combined inside the launch needed both).
+    const bool sk = p.ws != nullptr;
+    const unsigned G = gridDim.x, g = blockIdx.x;
+    const unsigned long long U = (unsigned long long)p.ntiles * nchunks;
+    unsigned first, stride, total, cc;
+    if (sk) {
+        const unsigned long long u0 = U * g / G, u1 = U * (g + 1) / G;
+        first = (unsigned)(u0 / nchunks);
+        cc = (unsigned)(u0 % nchunks);
+        stride = 1;
+        total = (unsigned)(u1 - u0);
+    } else {
+        first = g;
+        stride = G;
+        cc = 0;
+        const unsigned my_tiles = first < p.ntiles ? (p.ntiles - first + stride - 1) / stride : 0;
+        total = my_tiles * nchunks;
+    }
+    const unsigned c0 = cc;                             // chunk the first tile starts at (stream-K: may be inside it)
+    using Tile = CvTile;
     auto tile_at = [&](unsigned i) -> Tile {
         // output-channel tiles of one pixel tile are neighbours in the walk (they read the same patch)
         const unsigned t = first + i * stride;
@@ -147,32 +321,26 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     };
     // the tile of the current chunk and the one after it (the divisions above: once per tile, not per stage)
     Tile tcur = tile_at(0), tnext = tile_at(1);
-    unsigned cc = 0;                                    // chunk of the current tile
+    unsigned ti = 0;                                    // tiles this workgroup has completed
 
     // ---- staging of a patch: unit u = (pixel u / 2, channels 16 (u % 2) ..), 64 contiguous bytes ----
-    float areg[CV_AROUNDS][16];
+    u32x4 areg[CV_AROUNDS][HF ? 2 : 4];                // 16 channels of one pixel: 64 bytes of float, 32 of _Float16
     // (valid = false: a request beyond the workgroup's last chunk -- an empty descriptor, every lane reads zero.  NO
     // load of the main loop sits under a branch: at a control-flow join the compiler can no longer count which
     // loads are outstanding and waits for ALL of them, i.e. for the request it has just made.)
     auto issue_a = [&](const Tile& t, unsigned cc, bool valid) {
-        const float* xb = p.x + (((long)t.n * p.H + (t.y0 - 1)) * (long)p.W + (t.x0 - 1)) * (long)p.Cin;
-        const rsrc_t rx = cv_rsrc(valid ? xb : p.x, valid ? 0x7FFFFFF0u : 0u);
+        const char* xb = static_cast<const char*>(p.x) + (((long)t.n * p.H + (t.y0 - 1)) * (long)p.W + (t.x0 - 1)) * (long)p.Cin * ES;
+        const rsrc_t rx = cv_rsrc(valid ? (const void*)xb : p.x, valid ? 0x7FFFFFF0u : 0u);
 #pragma unroll
         for (int j = 0; j < CV_AROUNDS; ++j) {
             const int u = tid + 256 * j, q = u >> 1, half = u & 1;
             const int qr = q / CV_PS, qc = q - qr * CV_PS;
             const int gy = t.y0 - 1 + qr, gx = t.x0 - 1 + qc;
             const bool in = u < 2 * CV_PP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const unsigned voff = in ? (unsigned)((qr * p.W + qc) * p.Cin + half * 16) * 4u : CV_OOB;
+            const unsigned voff = in ? (unsigned)((qr * p.W + qc) * p.Cin + half * 16) * ES : CV_OOB;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, cc * 128u + 16u * i, 0);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const unsigned word = v[c];      // (a copy: bit_cast of the element expression itself reads element 0)
-                    areg[j][4 * i + c] = __builtin_bit_cast(float, word);
-                }
-            }
+            for (int i = 0; i < (HF ? 2 : 4); ++i)
+                areg[j][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff, cc * 32u * ES + 16u * i, 0);
         }
     };
     auto commit_a_round = [&](int abuf, int j) {
@@ -180,14 +348,21 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         if (u < 2 * CV_PP) {
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
-                float v[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = areg[j][8 * o + c] * cx;
-                u32x4 hh, ll;
-                cv_split(v, hh, ll);
                 u32x4* d = As + abuf * CV_ABUF + (2 * half + o) * CV_PR + q;
-                d[0] = hh;
-                d[4 * CV_PR] = ll;
+                if constexpr (HF) {
+                    d[0] = areg[j][o];               // 8 channels of the pixel: an operand entry as it is
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const unsigned word = areg[j][2 * o + c / 4][c % 4];   // (a copy: bit_cast of the element expression itself reads element 0)
+                        v[c] = __builtin_bit_cast(float, word) * cx;
+                    }
+                    u32x4 hh, ll;
+                    cv_split(v, hh, ll);
+                    d[0] = hh;
+                    d[4 * CV_PR] = ll;
+                }
             }
         }
     };
@@ -231,12 +406,12 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             o.ah[mi] = Ab[mi * 2 * CV_PS + kx];
-            o.al[mi] = Ab[4 * CV_PR + mi * 2 * CV_PS + kx];
+            if constexpr (!HF) o.al[mi] = Ab[4 * CV_PR + mi * 2 * CV_PS + kx];
         }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             o.bh[ni] = Wb[kx * 512 + ni * 32];
-            o.bl[ni] = Wb[kx * 512 + 256 + ni * 32];
+            if constexpr (!HF) o.bl[ni] = Wb[kx * 512 + 256 + ni * 32];
         }
     };
     auto mfmas = [&](const Ops& o) {
@@ -244,22 +419,24 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.ah[mi], o.bh[ni], acc[mi][ni]);
+        if constexpr (!HF) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.ah[mi], o.bl[ni], acc[mi][ni]);
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.ah[mi], o.bl[ni], acc[mi][ni]);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.al[mi], o.bh[ni], acc[mi][ni]);
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.al[mi], o.bh[ni], acc[mi][ni]);
+        }
     };
     // The next tap's 12 operand fetches go BETWEEN the current tap's 24 MFMAs (2 MFMAs, 1 fetch, ...): left to
     // itself the compiler sinks them to just before their first use and the matrix pipe waits for LDS every tap.
     auto interleave = [&]() {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);       // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
+        for (int i = 0; i < (HF ? 6 : 12); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, HF ? 1 : 2, 0);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // DS read
         }
     };
     // LDS addresses of stage st of chunk h for this lane (tap kx adds kx / 512 kx entries)
@@ -268,20 +445,22 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     };
     auto w_ptr = [&](int st) -> const u32x4* { return Ws + (st % 3) * CV_WSTAGE + lhi * 128 + nh * 64 + l31; };
 
+    float* const slabs = sk ? reinterpret_cast<float*>(static_cast<char*>(p.ws) + CV_WS_HDR) : nullptr;
+
     // Pipeline.  Stage s = 6 h + st reads weight buffer s % 3 (= st % 3: a chunk has 6 stages).  The weights of
     // stage s + 3 are REQUESTED at the start of stage s (register set (s + 1) % 2), those of stage s + 2 are
     // WRITTEN to LDS at its end (set s % 2; buffer (s + 2) % 3, last read in stage s - 1, i.e. before the previous
     // barrier), so every stage finds its weights -- and its patch: written in stage 3 of the previous chunk --
     // in LDS one whole stage early, and the operands of its first tap are fetched during the last tap of the
     // stage before: after a barrier the matrix pipe continues at once.
-    issue_a(tcur, 0, true);
-    issue_w(wregA, tcur, 0, 0, true);
-    issue_w(wregB, tcur, 0, 1, true);
+    issue_a(tcur, cc, true);
+    issue_w(wregA, tcur, cc, 0, true);
+    issue_w(wregB, tcur, cc, 1, true);
     commit_a(0);
     commit_w(wregA, 0);
     commit_w(wregB, 1);
     __syncthreads();
-    issue_w(wregA, tcur, 0, 2, true);
+    issue_w(wregA, tcur, cc, 2, true);
     Ops o0, o1;
     load_ops(o0, a_ptr(0, 0), w_ptr(0), 0);
 
@@ -324,63 +503,23 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         stage(o0, o1, wregB, wregA, 4);
         stage(o1, o0, wregA, wregB, 5);
         if (last) {
-            // ---- the tile is complete: scale back (+ bias, activation, sign bits, largest magnitude), store, clear ----
-            const Tile t = tcur;
-            float* yb = p.y + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)p.Cout + t.ct * 128;
-            const rsrc_t ry = cv_rsrc(yb, 0x7FFFFFF0u);
-            float bv[2] = {0.f, 0.f};
-            rsrc_t rs = ry;
-            if constexpr (EPI) {
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) bv[ni] = p.bias[t.ct * 128 + nh * 64 + ni * 32 + l31];
-                // sign words of this tile's first pixel and output-channel tile: word = pixel (Cout / 32) + channel / 32
-                rs = cv_rsrc(p.signs + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)(p.Cout / 32) + t.ct * 4,
-                             p.signs ? 0x7FFFFFF0u : 0u);
-            }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // accumulator register r of a 32 x 32 block: pixel (r & 3) + 8 (r >> 2) + 4 (lane / 32) of the
-                    // block's 2 rows x 16 columns; output channel lane % 32
-                    const int row = mh * 8 + mi * 2 + (r >> 3);
-                    const int col = ((r & 3) + 8 * ((r >> 2) & 1) + 4 * lhi + 14 * (r >> 3)) & 15;     // (the rotation above)
-                    const bool ok = t.y0 + row < p.H && t.x0 + col < p.W;
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const unsigned voff = ok ? (unsigned)((row * p.W + col) * p.Cout + nh * 64 + ni * 32 + l31) * 4u : CV_OOB;
-                        float v = acc[mi][ni][r] * oscale;
-                        if constexpr (EPI) {
-                            v += bv[ni];
-                            const bool pos = v > 0.f;
-                            {
-                                // lanes 0-31 are the 32 channels of one sign word (pixel of the lower half), 32-63 the next
-                                // pixel's; no branch on `signs`: without them every lane's offset is out of range
-                                const unsigned long long bal = __builtin_amdgcn_ballot_w64(pos);
-                                const unsigned word = lhi ? (unsigned)(bal >> 32) : (unsigned)bal;
-                                const unsigned so = (ok && sign_lane) ? (unsigned)((row * p.W + col) * (p.Cout / 32) + nh * 2 + ni) * 4u : CV_OOB;
-                                __builtin_amdgcn_raw_buffer_store_b32(word, rs, so, 0, 0);
-                            }
-                            v = pos ? v : v * p.slope;
-                            if (ok) {
-                                const unsigned a = abits(v);
-                                amax_run = amax_run > a ? amax_run : a;
-                            }
-                        }
-                        buf_store(v, ry, voff, 0);
-                        acc[mi][ni][r] = 0.f;
-                    }
-                    if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);      // (one register's ballots and stores at a time)
-                }
-            }
+            // (stream-K: the tail of a tile whose head other workgroups hold is parked until this one's range is through)
+            const bool park = sk && ti == 0 && c0 > 0;
+            cv_finish<EPI, HF>(p, acc, tcur, park, park ? slabs + (size_t)(G + g) * CV_SLAB : nullptr, oscale, amax_run);
         }
         if (last) {
             tcur = tnext;
-            tnext = tile_at(h / nchunks + 2);
+            ++ti;
+            tnext = tile_at(ti + 1);
             cc = 0;
         } else {
             ++cc;
         }
+    }
+    if (sk && cc != 0) {
+        // the range ended inside a tile: its head (or middle) goes to this workgroup's "partial" slab; the fix-up kernel
+        // (the next launch: no flags, no waiting) adds it to the tail its neighbour parked and runs that tile's epilogue
+        cv_slab_store(acc, slabs + (size_t)g * CV_SLAB);
     }
     if constexpr (EPI) {
         if (p.amax) amax_publish(amax_run, p.amax);
@@ -515,10 +654,10 @@ extern "C" int sbmc_conv3x3_prepare_weights_f32(const float* w, long s_co, long 
     return (int)hipGetLastError();
 }
 
-static int conv3_launch(const float* x, const unsigned* xmax, const void* wp, float* y, int n, int h, int w, int cin,
+static int conv3_launch(const void* x, const unsigned* xmax, const void* wp, void* y, int n, int h, int w, int cin,
                         int cout, const float* bias, int act, float slope, unsigned* signs, unsigned* amax, bool epi,
-                        void* stream) {
-    if (!conv3_dims_ok(n, h, w, cin, cout) || !x || !xmax || !wp || !y) return SBMC_HIP_EINVAL;
+                        void* ws, void* stream, bool hf = false) {
+    if (!conv3_dims_ok(n, h, w, cin, cout) || !x || (!xmax && !hf) || !wp || !y) return SBMC_HIP_EINVAL;
     if ((uintptr_t)x % 16 || (uintptr_t)wp % 16) return SBMC_HIP_EINVAL;
     Conv3Params p;
     p.x = x; p.wp = static_cast<const u32x4*>(wp); p.y = y; p.xmax = xmax;
@@ -529,26 +668,61 @@ static int conv3_launch(const float* x, const unsigned* xmax, const void* wp, fl
     p.bias = bias; p.slope = act == 0 ? 1.f : (act == 1 ? 0.f : slope); p.signs = signs; p.amax = amax;
     const int cus = cu_count();
     unsigned grid = p.ntiles < (unsigned)cus ? p.ntiles : (unsigned)cus;
-    auto kern = epi ? conv3_kernel<true> : conv3_kernel<false>;
+    p.ws = nullptr;
+    const unsigned rounds = (p.ntiles + (unsigned)cus - 1) / (unsigned)cus;
+    if (ws != nullptr && (unsigned long long)p.ntiles * 100 < (unsigned long long)rounds * (unsigned)cus * 85) {
+        // stream-K: (tile, chunk) units in equal ranges over ALL compute units -- where whole tiles dealt round-robin
+        // would leave more than 15 % of the chip idle in their last round (320 or 160 tiles on 256 CUs: the slabs of a
+        // sharded frame at the U-net's coarser levels).  Nearly every workgroup then holds a split tile, and the slabs
+        // they meet in are as many bytes as a small convolution's own tensors: not worth it for a few per cent.
+        if ((uintptr_t)ws % 16) return SBMC_HIP_EINVAL;
+        const unsigned long long units = (unsigned long long)p.ntiles * (unsigned)(cin / 32);
+        grid = units < (unsigned long long)cus ? (unsigned)units : (unsigned)cus;
+        p.ws = ws;
+    }
+    auto kern = hf ? (epi ? conv3_kernel<true, true> : conv3_kernel<false, true>)
+                   : (epi ? conv3_kernel<true, false> : conv3_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess || p.ws == nullptr) return (int)e;
+    auto fix = hf ? (epi ? conv3_fixup_kernel<true, true> : conv3_fixup_kernel<false, true>)
+                  : (epi ? conv3_fixup_kernel<true, false> : conv3_fixup_kernel<false, false>);
+    hipLaunchKernelGGL(fix, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, grid);
     return (int)hipGetLastError();
 }
 
+extern "C" size_t sbmc_conv3x3_workspace_bytes(void) {
+    return (size_t)CV_WS_HDR + (size_t)2 * cu_count() * CV_SLAB * sizeof(float);
+}
+
 extern "C" int sbmc_conv3x3_nhwc_f32(const float* x, const unsigned* xmax, const void* wp, float* y, int n, int h,
-                                      int w, int cin, int cout, void* stream) {
-    return conv3_launch(x, xmax, wp, y, n, h, w, cin, cout, nullptr, 0, 1.f, nullptr, nullptr, false, stream);
+                                      int w, int cin, int cout, void* ws, void* stream) {
+    return conv3_launch(x, xmax, wp, y, n, h, w, cin, cout, nullptr, 0, 1.f, nullptr, nullptr, false, ws, stream);
 }
 
 extern "C" int sbmc_conv3x3_bias_act_nhwc_f32(const float* x, const unsigned* xmax, const void* wp, const float* bias,
                                                float* y, unsigned* signs, unsigned* amax, int n, int h, int w, int cin,
-                                               int cout, int act, float slope, void* stream) {
+                                               int cout, int act, float slope, void* ws, void* stream) {
     if (!bias || act < 0 || act > 2 || (uintptr_t)signs % 4) return SBMC_HIP_EINVAL;
     // (*amax is RAISED to max |y|: the caller hands in a zeroed word -- one memset launch per convolution was a
     // cost that does not shrink with the slab of a sharded frame)
-    return conv3_launch(x, xmax, wp, y, n, h, w, cin, cout, bias, act, slope, signs, amax, true, stream);
+    return conv3_launch(x, xmax, wp, y, n, h, w, cin, cout, bias, act, slope, signs, amax, true, ws, stream);
+}
+
+// Half activations (torch.autocast(float16) semantics): x, y _Float16 channels-last; wp: the SAME prepared weights
+// (their high plane is f16 of the scaled weight); bias fp32; fp32 accumulation, one rounding to half on the store.
+extern "C" int sbmc_conv3x3_nhwc_f16(const void* x, const void* wp, void* y, int n, int h, int w, int cin, int cout,
+                                      void* ws, void* stream) {
+    return conv3_launch(x, nullptr, wp, y, n, h, w, cin, cout, nullptr, 0, 1.f, nullptr, nullptr, false, ws, stream, true);
+}
+extern "C" int sbmc_conv3x3_bias_act_nhwc_f16(const void* x, const void* wp, const float* bias, void* y, unsigned* signs,
+                                               int n, int h, int w, int cin, int cout, int act, float slope, void* ws,
+                                               void* stream) {
+    if (!bias || act < 0 || act > 2 || (uintptr_t)signs % 4) return SBMC_HIP_EINVAL;
+    return conv3_launch(x, nullptr, wp, y, n, h, w, cin, cout, bias, act, slope, signs, nullptr, true, ws, stream, true);
 }
 
 // =============================================================================================================
@@ -580,8 +754,8 @@ constexpr unsigned WG_LDS_BYTES = (2 * WG_G + 4 * WG_XR) * 16;     // 98304: two
 constexpr int WG_TILE = 128 * 128 * 3;          // outputs of a workgroup
 
 struct WgradParams {
-    const float* gy;         // [N, H, W, Cout]
-    const float* x;          // [N, H, W, Cin]
+    const void* gy;          // [N, H, W, Cout] float (HF: _Float16)
+    const void* x;           // [N, H, W, Cin]
     float* partial;          // [combo][split][WG_TILE]
     const unsigned* gmax;    // bit patterns of max |gy|, max |x|
     const unsigned* xmax;
@@ -597,14 +771,18 @@ __device__ __forceinline__ unsigned cv_pack_hh(_Float16 a, _Float16 b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// HF: half activations -- gy and x are _Float16 tensors: the staging is a pure 8 x 4 transposition (no split, no scale,
+// one plane), one matrix product per term; gw stays fp32.
+template <bool HF>
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
+    constexpr unsigned ES = HF ? 2u : 4u;
     extern __shared__ float4 cv_lds[];
     u32x4* Gs = reinterpret_cast<u32x4*>(cv_lds);       // [2][WG_G]
     u32x4* Xs = Gs + 2 * WG_G;                          // [4][WG_XR]: ring of x rows
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int l31 = lane & 31, lhi = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
-    const float cg = cv_scale_of(*p.gmax), cx = cv_scale_of(*p.xmax);
+    const float cg = HF ? 1.f : cv_scale_of(*p.gmax), cx = HF ? 1.f : cv_scale_of(*p.xmax);
 
     const unsigned logical = logical_block_id();
     const int ncombo = p.ncot * p.ncit * 3;
@@ -627,7 +805,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     const int shift = xrole ? kx - 1 : 0;               // first pixel of the stage's 32, relative to x0
     unsigned lvoff[8];                                  // byte offsets of the thread's pixels from that pixel
 #pragma unroll
-    for (int j = 0; j < 8; ++j) lvoff[j] = (unsigned)(uq * 16 + (8 * uo + j) * C * 4);
+    for (int j = 0; j < 8; ++j) lvoff[j] = (unsigned)(uq * 4 + (8 * uo + j) * C) * ES;
     struct Rows { u32x4 v[8]; };
     // the stage the next request is for: walks down the rows of a strip, then to the next strip, the next image
     int qy, qx0, qn;
@@ -645,13 +823,20 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         // (xs >= W: the last strip's single column shifted right -- nothing of the row is left, and the byte count
         // below must not wrap)
         const bool rowin = valid && row >= 0 && row < p.H && xs < p.W;
-        const float* base = (xrole ? p.x : p.gy) + (((long)n * p.H + (rowin ? row : 0)) * (long)p.W + xs) * (long)C +
-                            (xrole ? cit : cot) * 128;
-        const rsrc_t r = cv_rsrc(rowin ? base : p.x, rowin ? (unsigned)((p.W - xs) * C - (xrole ? cit : cot) * 128) * 4u : 0u);
+        const char* base = static_cast<const char*>(xrole ? p.x : p.gy) +
+                           ((((long)n * p.H + (rowin ? row : 0)) * (long)p.W + xs) * (long)C + (xrole ? cit : cot) * 128) * ES;
+        const rsrc_t r = cv_rsrc(rowin ? (const void*)base : p.x,
+                                 rowin ? (unsigned)((p.W - xs) * C - (xrole ? cit : cot) * 128) * ES : 0u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool off = j == 0 && xs < 0 && uo == 0;
-            rr.v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, off ? CV_OOB : lvoff[j], 0, 0);
+            if constexpr (HF) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off ? CV_OOB : lvoff[j], 0, 0);
+                rr.v[j][0] = v[0];
+                rr.v[j][1] = v[1];
+            } else {
+                rr.v[j] = __builtin_amdgcn_raw_buffer_load_b128(r, off ? CV_OOB : lvoff[j], 0, 0);
+            }
         }
     };
     // One request = what stage (qn, qx0, qy) still lacks in the steady state: its gy row, and x row qy + 1 (rows
@@ -685,15 +870,21 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
             u32x4 hh, ll;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const unsigned a = rr.v[2 * i][ch], b = rr.v[2 * i + 1][ch];
-                unsigned hp, lp;
-                pair(a, b, c, hp, lp);
-                hh[i] = hp;
-                ll[i] = lp;
+                if constexpr (HF) {
+                    // channel ch of pixels 2 i, 2 i + 1: halves of dword ch / 2 of their two loads
+                    const unsigned a = rr.v[2 * i][ch >> 1], b = rr.v[2 * i + 1][ch >> 1];
+                    hh[i] = (ch & 1) ? ((a >> 16) | (b & 0xFFFF0000u)) : ((a & 0xFFFFu) | (b << 16));
+                } else {
+                    const unsigned a = rr.v[2 * i][ch], b = rr.v[2 * i + 1][ch];
+                    unsigned hp, lp;
+                    pair(a, b, c, hp, lp);
+                    hh[i] = hp;
+                    ll[i] = lp;
+                }
             }
             u32x4* e = d + (ch ^ usw);
             e[0] = hh;
-            e[WG_OCT * 128] = ll;
+            if constexpr (!HF) e[WG_OCT * 128] = ll;
         }
     };
     // stage k's rows: gy -> Gs[k % 2]; x row (y + 1) -> ring slot (k + 1) % 4 (y - 1, y: slots (k - 1) % 4, k % 4)
@@ -721,7 +912,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             o.h[mi] = Gb[mi * 32];
-            o.l[mi] = Gb[WG_OCT * 128 + mi * 32];
+            if constexpr (!HF) o.l[mi] = Gb[WG_OCT * 128 + mi * 32];
         }
     };
     auto load_b = [&](OpB& o, unsigned k, int ks, int ky) {
@@ -729,7 +920,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             o.h[ni] = Xb[ni * 32];
-            o.l[ni] = Xb[WG_OCT * 128 + ni * 32];
+            if constexpr (!HF) o.l[ni] = Xb[WG_OCT * 128 + ni * 32];
         }
     };
     auto mfmas = [&](const OpA& a, const OpB& b, int ky) {
@@ -737,14 +928,16 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.h[mi], b.h[ni], acc[mi][ni][ky]);
+        if constexpr (!HF) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.h[mi], b.l[ni], acc[mi][ni][ky]);
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.h[mi], b.l[ni], acc[mi][ni][ky]);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.l[mi], b.h[ni], acc[mi][ni][ky]);
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.l[mi], b.h[ni], acc[mi][ni][ky]);
+        }
     };
 
     // Pipeline.  Stage k (= t - t0): its gy row and its last x row are REQUESTED in the middle of stage k - 3
@@ -841,15 +1034,29 @@ struct WreduceParams {
 };
 __global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(WreduceParams p) {
     if ((int)blockIdx.y == p.ncombo) {
+        // 16 channels x 16 groups of chunks per workgroup, eight loads in flight per thread (a first version with 4
+        // groups and one load at a time took 200 us for 2048 chunks -- 9 ms of a 240 ms step -- on latency alone)
         __shared__ float bred[256];
-        const int ch = (int)blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-        if ((int)blockIdx.x * 64 >= p.bc) return;
-        float s = 0.f;
-        if (ch < p.bc)
-            for (int i = grp; i < p.bchunks; i += 4) s += p.bpartial[(size_t)i * p.bc + ch];
-        bred[threadIdx.x] = s;
+        const int c0 = (int)blockIdx.x * 16;
+        if (c0 >= p.bc) return;
+        const int ch = c0 + (threadIdx.x & 15), grp = threadIdx.x >> 4;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ch < p.bc) {
+            int i = grp;
+            for (; i + 16 * 7 < p.bchunks; i += 16 * 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += p.bpartial[(size_t)(i + 16 * u) * p.bc + ch];
+            }
+            for (; i < p.bchunks; i += 16) a[0] += p.bpartial[(size_t)i * p.bc + ch];
+        }
+        bred[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         __syncthreads();
-        if (grp == 0 && ch < p.bc) p.gbias[ch] = (bred[threadIdx.x] + bred[threadIdx.x + 64]) + (bred[threadIdx.x + 128] + bred[threadIdx.x + 192]);
+        if (grp == 0 && ch < p.bc) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += bred[g * 16 + (threadIdx.x & 15)];
+            p.gbias[ch] = s;
+        }
         return;
     }
     const unsigned e = blockIdx.x * 256u + threadIdx.x;              // element of the workgroup tile
@@ -858,7 +1065,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(WreduceParams p
     const float* src = p.partial + (size_t)combo * p.nsplit * WG_TILE + e;
     float s = 0.f;
     for (int i = 0; i < p.nsplit; ++i) s += src[(size_t)i * WG_TILE];
-    const float oscale = (1.f / cv_scale_of(*p.gmax)) * (1.f / cv_scale_of(*p.xmax));
+    const float oscale = p.gmax ? (1.f / cv_scale_of(*p.gmax)) * (1.f / cv_scale_of(*p.xmax)) : 1.f;    // (half inputs: unscaled)
     const int lane = e & 63, r = (e >> 6) & 15;
     const int rest = e >> 10, ky = rest % 3, ni = (rest / 3) & 1, mi = (rest / 6) & 1, wave = rest / 12;
     const int kx = combo % 3, cit = (combo / 3) % p.ncit, cot = combo / (3 * p.ncit);
@@ -900,12 +1107,31 @@ extern "C" int sbmc_conv3x3_wgrad_f32(const float* gy, const unsigned* gmax, con
     return sbmc_conv3x3_wgrad_bias_f32(gy, gmax, x, xmax, gw, s_co, s_ci, s_ky, s_kx, scratch, n, h, w, cin, cout, nullptr, 0,
                                        0, nullptr, stream);
 }
+static int wgrad_launch(const void* gy, const unsigned* gmax, const void* x, const unsigned* xmax,
+                        float* gw, long s_co, long s_ci, long s_ky, long s_kx, void* scratch, int n,
+                        int h, int w, int cin, int cout, const float* bias_partial, int bias_chunks,
+                        int bias_c, float* gbias, void* stream, bool hf);
 extern "C" int sbmc_conv3x3_wgrad_bias_f32(const float* gy, const unsigned* gmax, const float* x, const unsigned* xmax,
                                             float* gw, long s_co, long s_ci, long s_ky, long s_kx, void* scratch, int n,
                                             int h, int w, int cin, int cout, const float* bias_partial, int bias_chunks,
                                             int bias_c, float* gbias, void* stream) {
-    if (bias_partial && (!gbias || bias_chunks < 1 || bias_c < 1 || bias_c > 64 * (WG_TILE / 256))) return SBMC_HIP_EINVAL;
-    if (!wgrad_dims_ok(n, h, w, cin, cout) || !gy || !gmax || !x || !xmax || !gw || !scratch) return SBMC_HIP_EINVAL;
+    return wgrad_launch(gy, gmax, x, xmax, gw, s_co, s_ci, s_ky, s_kx, scratch, n, h, w, cin, cout, bias_partial, bias_chunks,
+                        bias_c, gbias, stream, false);
+}
+// half activations: gy, x _Float16; gw (and the bias gradient) fp32
+extern "C" int sbmc_conv3x3_wgrad_bias_f16(const void* gy, const void* x, float* gw, long s_co, long s_ci, long s_ky,
+                                            long s_kx, void* scratch, int n, int h, int w, int cin, int cout,
+                                            const float* bias_partial, int bias_chunks, int bias_c, float* gbias,
+                                            void* stream) {
+    return wgrad_launch(gy, nullptr, x, nullptr, gw, s_co, s_ci, s_ky, s_kx, scratch, n, h, w, cin, cout, bias_partial,
+                        bias_chunks, bias_c, gbias, stream, true);
+}
+static int wgrad_launch(const void* gy, const unsigned* gmax, const void* x, const unsigned* xmax,
+                        float* gw, long s_co, long s_ci, long s_ky, long s_kx, void* scratch, int n,
+                        int h, int w, int cin, int cout, const float* bias_partial, int bias_chunks,
+                        int bias_c, float* gbias, void* stream, bool hf) {
+    if (bias_partial && (!gbias || bias_chunks < 1 || bias_c < 1 || bias_c > 16 * (WG_TILE / 256))) return SBMC_HIP_EINVAL;
+    if (!wgrad_dims_ok(n, h, w, cin, cout) || !gy || (!hf && (!gmax || !xmax)) || !x || !gw || !scratch) return SBMC_HIP_EINVAL;
     if ((uintptr_t)gy % 16 || (uintptr_t)x % 16 || (uintptr_t)scratch % 16) return SBMC_HIP_EINVAL;
     WgradParams p;
     p.gy = gy; p.x = x; p.partial = static_cast<float*>(scratch); p.gmax = gmax; p.xmax = xmax;
@@ -914,7 +1140,7 @@ extern "C" int sbmc_conv3x3_wgrad_bias_f32(const float* gy, const unsigned* gmax
     p.total = (unsigned long long)n * h * p.nstrips;
     p.nsplit = wgrad_splits(cin, cout, (long long)p.total);
     const int ncombo = p.ncot * p.ncit * 3;
-    auto kern = conv3_wgrad_kernel;
+    auto kern = hf ? conv3_wgrad_kernel<true> : conv3_wgrad_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }

@@ -90,9 +90,10 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_fwd_signs_kernel(float* __r
 // gx = gy * act'(y); partial[chunk, C] = this workgroup's sums of gx per channel.
 // 256 threads = (256 / c4n) pixel lanes x c4n channel quads; c4n must divide 256.
 // SG: `y` holds the forward's sign bits (bias_act_nhwc_fwd_signs_kernel) instead of its output.
-template <bool SG>
-__global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
-                                                               float* __restrict__ gx, float* __restrict__ partial,
+// T: storage type of gy / gx (float, or _Float16 for half activations: fp32 arithmetic and sums, one rounding)
+template <bool SG, typename T = float>
+__global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const T* __restrict__ gy, const float* __restrict__ y,
+                                                               T* __restrict__ gx, float* __restrict__ partial,
                                                                size_t pixels, int c4n, float slope, int linear,
                                                                unsigned* __restrict__ amax) {
     __shared__ float4 red[256];
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __r
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (size_t px = p0 + pl; px < p1; px += npl) {
         const size_t i = px * c4n + cq;
-        float4 g = reinterpret_cast<const float4*>(gy)[i];
+        float4 g = Quad<T>::load(gy, i);
         if (!linear) {
             if constexpr (SG) {
                 const unsigned bits = reinterpret_cast<const unsigned*>(y)[i >> 3] >> (4 * (unsigned)(i & 7));
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __r
                 g.z = v.z > 0.f ? g.z : g.z * slope; g.w = v.w > 0.f ? g.w : g.w * slope;
             }
         }
-        if (store) reinterpret_cast<float4*>(gx)[i] = g;
+        if (store) Quad<T>::store(gx, i, g);
         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
         m = amax4(m, g);
     }
@@ -353,6 +354,25 @@ extern "C" int sbmc_bias_act_nhwc_fwd_amax_f32(float* y, const float* bias, unsi
     else
         hipLaunchKernelGGL(bias_act_nhwc_fwd_kernel, dim3(grid_for(total4 / 4 + 1)), dim3(256), 0, (hipStream_t)stream, y,
                            bias, total4, c / 4, act == 1 ? 0.f : slope, act == 0, amax);
+    return (int)hipGetLastError();
+}
+
+// half activations: gy, gx _Float16 (gx may alias gy), sign bits as written by the convolution's epilogue, fp32 partial sums
+extern "C" int sbmc_bias_act_nhwc_bwd_signs_f16(const void* gy, const unsigned* signs, void* gx, float* partial,
+                                                long pixels, int c, int act, float slope, void* stream) {
+    if (pixels < 0 || c < 0 || act < 0 || act > 2 || ((signs == nullptr) != (act == 0))) return SBMC_HIP_EINVAL;
+    if (pixels == 0 || c == 0) return 0;
+    if (!gy || !gx || !partial || !sbmc_bias_act_nhwc_supported(c)) return SBMC_HIP_EINVAL;
+    if ((uintptr_t)gy % 8 || (uintptr_t)signs % 4 || (uintptr_t)gx % 8 || (uintptr_t)partial % 16) return SBMC_HIP_EINVAL;
+    const unsigned grid = (unsigned)sbmc_bias_act_nhwc_chunks(pixels, c);
+    if (signs)
+        hipLaunchKernelGGL((bias_act_nhwc_bwd_kernel<true, _Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const _Float16*>(gy), reinterpret_cast<const float*>(signs), static_cast<_Float16*>(gx),
+                           partial, (size_t)pixels, c / 4, act == 1 ? 0.f : slope, 0, (unsigned*)nullptr);
+    else
+        hipLaunchKernelGGL((bias_act_nhwc_bwd_kernel<false, _Float16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const _Float16*>(gy), (const float*)nullptr, static_cast<_Float16*>(gx), partial,
+                           (size_t)pixels, c / 4, 0.f, 1, (unsigned*)nullptr);
     return (int)hipGetLastError();
 }
 

@@ -16,6 +16,8 @@
 // fp32 MFMA is exact fp32 (an fmaf chain over k): results differ from a library GEMM by
 // summation order only.
 #include "common.hpp"
+#include <cstring>
+#include <type_traits>
 #include "../../include/sbmc_hip.h"
 #include <stdlib.h>
 
@@ -1226,6 +1228,202 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weight and bias gradient of a WIDE linear 1x1 layer (128 < Cout <= 512: the 441-channel kernel regressor output,
+// reference sbmc/models.py:98-102): gw[co][k] = sum over images and pixels of gz[co][px] x[k][px], gbias[co] = sum gz.
+// Until round 4 a library GEMM (8.4 ms per step on the fp32 matrix pipe) behind a read-only pass over the 13 GB logit
+// gradient for the bias sums (2.2 ms).  Here: pw_bwd_kernel's split-precision weight-gradient product (three bf16 planes
+// of both operands, six products, fp32 accumulation; both operands want 8 consecutive PIXELS per lane -- the natural
+// planar order) with the x tile staged ONCE per pixel tile and the gz tile four times, 128 output channels at a time,
+// into four sets of accumulators (128 registers); the row sums for the bias are taken while staging.  One pass over
+// gz and x: 16.8 GB at 720p x 8 spp.
+template <int KP>
+__global__ __launch_bounds__(PW_THREADS) void pw_gw_wide_kernel(PwBwdParams p) {
+    const float* gz_g = static_cast<const float*>(p.gy);
+    const float* x_g = static_cast<const float*>(p.x);
+    extern __shared__ float4 pw_lds[];
+    _Float16* gzn = reinterpret_cast<_Float16*>(pw_lds);              // [3][128][PBS_PITCH]
+    _Float16* xn = gzn + 3 * 128 * PBS_PITCH;                         // [3][KP][PBS_PITCH]
+    constexpr int NB = KP / 32, NX = KP / 32;
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int rb = wave & 3, ph = wave >> 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const unsigned hw = p.hw;
+    const unsigned g = blockIdx.x, G = gridDim.x;
+    const unsigned c4 = (threadIdx.x & 15) * 4, srow = threadIdx.x >> 4;
+    const int nct = (p.Cout + 127) / 128;                             // output-channel tiles in use (<= 4)
+
+    u32x4 pg[4], px[NX];
+    auto coords = [&](unsigned unit, unsigned& b, unsigned& p0) {
+        b = unit / p.tiles_per_plane;
+        p0 = (unit % p.tiles_per_plane) * PB_NT;
+    };
+    auto issue_g = [&](unsigned unit, int ct) {
+        unsigned b, p0;
+        coords(unit, b, p0);
+        const rsrc_t rg = make_rsrc_n(gz_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
+        const bool colok = p0 + c4 < hw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned r = 128u * ct + srow + 32u * i;
+            pg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB, 0, 0);
+        }
+    };
+    auto issue_x = [&](unsigned unit) {
+        unsigned b, p0;
+        coords(unit, b, p0);
+        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
+        const bool colok = p0 + c4 < hw;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const unsigned r = srow + 32u * i;
+            px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * 4u : PW_OOB, 0, 0);
+        }
+    };
+    float bsum[4][4];                                                 // row sums of gz: [cout tile][rows srow + 32 i]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bsum[a][i] = 0.f;
+    auto commit_g = [&](auto ctc) __attribute__((always_inline)) {
+        constexpr int CT = decltype(ctc)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 gv = __builtin_bit_cast(float4, pg[i]);
+            bsum[CT][i] += (gv.x + gv.y) + (gv.z + gv.w);
+            u32x2 h, m, l;
+            split3_4(gv, h, m, l);
+            _Float16* e = gzn + (srow + 32 * i) * PBS_PITCH + c4;
+            *reinterpret_cast<u32x2*>(e) = h;
+            *reinterpret_cast<u32x2*>(e + 128 * PBS_PITCH) = m;
+            *reinterpret_cast<u32x2*>(e + 2 * 128 * PBS_PITCH) = l;
+        }
+    };
+    auto commit_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const float4 xv = __builtin_bit_cast(float4, px[i]);
+            u32x2 h, m, l;
+            split3_4(xv, h, m, l);
+            _Float16* e = xn + (srow + 32 * i) * PBS_PITCH + c4;
+            *reinterpret_cast<u32x2*>(e) = h;
+            *reinterpret_cast<u32x2*>(e + KP * PBS_PITCH) = m;
+            *reinterpret_cast<u32x2*>(e + 2 * KP * PBS_PITCH) = l;
+        }
+    };
+
+    f32x16 acc_w[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc_w[a][n][j] = 0.f;
+
+    unsigned unit = g;
+    bool valid = unit < p.nunits;
+    if (valid) {
+        issue_g(unit, 0);
+        issue_x(unit);
+        commit_g(std::integral_constant<int, 0>{});
+        commit_x();
+    }
+    __syncthreads();
+    const bool two = 2 * ph + 1 < NB;
+    // one (pixel tile, output-channel tile) step: the next step's gz rows (and, for a new pixel tile, its x rows) are in
+    // flight during the products; one LDS stage, two barriers per step
+    auto step = [&](auto ctc) __attribute__((always_inline)) {
+        constexpr int CT = decltype(ctc)::value;
+        const bool last_ct = CT + 1 >= nct;
+        const unsigned nunit = last_ct ? unit + G : unit;
+        const bool nvalid = nunit < p.nunits;
+        if (nvalid) {
+            if (last_ct) { issue_g(nunit, 0); issue_x(nunit); }
+            else issue_g(nunit, CT + 1);
+        }
+        if (2 * ph < NB) {
+            const _Float16* ga = gzn + (rb * 32 + l31) * PBS_PITCH + 8 * lhi;
+            const _Float16* xb0 = xn + ((2 * ph) * 32 + l31) * PBS_PITCH + 8 * lhi;
+            const _Float16* xb1 = xn + ((2 * ph + 1) * 32 + l31) * PBS_PITCH + 8 * lhi;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {               // 16 pixels per step
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(ga + 16 * s);
+                const u32x4 am = *reinterpret_cast<const u32x4*>(ga + 16 * s + 128 * PBS_PITCH);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(ga + 16 * s + 2 * 128 * PBS_PITCH);
+                {
+                    const u32x4 bh = *reinterpret_cast<const u32x4*>(xb0 + 16 * s);
+                    const u32x4 bm = *reinterpret_cast<const u32x4*>(xb0 + 16 * s + KP * PBS_PITCH);
+                    const u32x4 bl = *reinterpret_cast<const u32x4*>(xb0 + 16 * s + 2 * KP * PBS_PITCH);
+                    acc_w[CT][0] = mfma_bf16(ah, bl, acc_w[CT][0]);
+                    acc_w[CT][0] = mfma_bf16(al, bh, acc_w[CT][0]);
+                    acc_w[CT][0] = mfma_bf16(am, bm, acc_w[CT][0]);
+                    acc_w[CT][0] = mfma_bf16(ah, bm, acc_w[CT][0]);
+                    acc_w[CT][0] = mfma_bf16(am, bh, acc_w[CT][0]);
+                    acc_w[CT][0] = mfma_bf16(ah, bh, acc_w[CT][0]);
+                }
+                if (two) {
+                    const u32x4 bh = *reinterpret_cast<const u32x4*>(xb1 + 16 * s);
+                    const u32x4 bm = *reinterpret_cast<const u32x4*>(xb1 + 16 * s + KP * PBS_PITCH);
+                    const u32x4 bl = *reinterpret_cast<const u32x4*>(xb1 + 16 * s + 2 * KP * PBS_PITCH);
+                    acc_w[CT][1] = mfma_bf16(ah, bl, acc_w[CT][1]);
+                    acc_w[CT][1] = mfma_bf16(al, bh, acc_w[CT][1]);
+                    acc_w[CT][1] = mfma_bf16(am, bm, acc_w[CT][1]);
+                    acc_w[CT][1] = mfma_bf16(ah, bm, acc_w[CT][1]);
+                    acc_w[CT][1] = mfma_bf16(am, bh, acc_w[CT][1]);
+                    acc_w[CT][1] = mfma_bf16(ah, bh, acc_w[CT][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        lds_barrier();                                  // every wave is through with the stage before it is refilled
+        if (nvalid) {
+            if (last_ct) { commit_g(std::integral_constant<int, 0>{}); commit_x(); }
+            else commit_g(std::integral_constant<int, (CT + 1) % 4>{});
+        }
+        __syncthreads();
+        if (last_ct) {
+            unit = nunit;
+            valid = nvalid;
+        }
+    };
+    while (valid) {
+        step(std::integral_constant<int, 0>{});
+        if (nct > 1) step(std::integral_constant<int, 1>{});
+        if (nct > 2) step(std::integral_constant<int, 2>{});
+        if (nct > 3) step(std::integral_constant<int, 3>{});
+    }
+
+    // ---- this workgroup's partial sums: gbias (rows reduced over the 16 threads of a staging row), gw
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = bsum[a][i];
+            v += __shfl_xor(v, 8, 16);
+            v += __shfl_xor(v, 4, 16);
+            v += __shfl_xor(v, 2, 16);
+            v += __shfl_xor(v, 1, 16);
+            const unsigned r = 128u * a + srow + 32u * i;
+            if ((threadIdx.x & 15) == 0 && r < (unsigned)p.Cout) p.gbp[(size_t)g * p.Cout + r] = v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int r0 = a * 128 + rb * 32;
+        const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
+        const rsrc_t rgw = make_rsrc_n(p.gwp + ((size_t)g * p.Cout + r0) * p.K, (unsigned)(nrows * p.K) * 4u);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = (2 * ph + n) * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rl = (j & 3) + 8 * (j >> 2) + 4 * lhi;
+                buf_store(acc_w[a][n][j], rgw, (col < p.K && nrows > 0 && rl < nrows) ? (unsigned)(rl * p.K + col) * 4u : PW_OOB, 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // The backward for half activations on the f16 matrix pipe (training under torch.autocast(float16)): gy, y, x
 // and gx are _Float16 in HBM, gz = gy * act'(y) is formed in fp32 and rounded to half once (what autocast's
 // activation backward hands to its convolution backward), the weights are rounded to half, every product is
@@ -1787,6 +1985,50 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
 #undef SBMC_PWB_LAUNCH
 #undef SBMC_PWB_LAUNCH2
     if (e != hipSuccess) return (int)e;
+    return (int)hipGetLastError();
+}
+
+// gw / gbias partial sums of a wide linear layer (pw_gw_wide_kernel): gw_partial [groups, cout, cin], gb_partial
+// [groups, cout], every element written; groups = sbmc_pointwise_gw_wide_groups(b, hw)
+extern "C" int sbmc_pointwise_gw_wide_supported(int cin, int cout, long hw) {
+    return (cin >= 1 && cin <= 128 && cout > 128 && cout <= 512 && hw > 0 && hw % 4 == 0 &&
+            (double)cout * (double)hw * 4.0 < 4294967000.0) ? 1 : 0;
+}
+extern "C" int sbmc_pointwise_gw_wide_groups(int b, long hw) {
+    if (b <= 0 || hw <= 0) return 1;
+    return (int)pw_bwd_grid(b, 1, hw, nullptr);
+}
+extern "C" int sbmc_pointwise_gw_wide_f32(const float* gz, const float* x, float* gw_partial, float* gb_partial, int b,
+                                          int cin, int cout, long hw, void* stream) {
+    if (b < 0) return SBMC_HIP_EINVAL;
+    if (b == 0) return 0;
+    if (!sbmc_pointwise_gw_wide_supported(cin, cout, hw) || !gz || !x || !gw_partial || !gb_partial) return SBMC_HIP_EINVAL;
+    if ((uintptr_t)gz % 16 || (uintptr_t)x % 16) return SBMC_HIP_EINVAL;
+    PwBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.gy = gz; p.x = x; p.gwp = gw_partial; p.gbp = gb_partial;
+    p.B = b; p.S = 1; p.K = cin; p.Cout = cout; p.Bq = 1;
+    p.hw = (unsigned)hw;
+    p.tiles_per_plane = (unsigned)((hw + PB_NT - 1) / PB_NT);
+    p.slope = 1.f;
+    const unsigned grid = pw_bwd_grid(b, 1, hw, &p.nunits);
+    const int kp = (cin + 31) / 32 * 32;
+    const size_t lds = (size_t)3 * (128 + kp) * PBS_PITCH * 2;
+    hipError_t e = hipSuccess;
+#define SBMC_GWW(KPV)                                                                                    \
+    do {                                                                                                 \
+        auto kern = pw_gw_wide_kernel<KPV>;                                                              \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(grid), dim3(PW_THREADS), lds, (hipStream_t)stream, p); \
+    } while (0)
+    switch (kp) {
+        case 32: SBMC_GWW(32); break;
+        case 64: SBMC_GWW(64); break;
+        case 96: SBMC_GWW(96); break;
+        default: SBMC_GWW(128); break;
+    }
+#undef SBMC_GWW
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     return (int)hipGetLastError();
 }
 

@@ -604,6 +604,24 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
             if ctx.needs_input_grad[1]:
                 gw = th.bmm(gz, x.half().transpose(1, 2)).float().sum(0)
         return gx, gw, gbias, gt
+    if (act == 0 and t_mode == 0 and not half and gy.dtype == th.float32 and x.dtype == th.float32
+            and os.environ.get("SBMC_HIP_PW_GW_WIDE", "1") != "0" and L.sbmc_pointwise_gw_wide_supported(cin, cout, hw)):
+        # the 441-channel logits layer (linear): weight and bias gradient in ONE pass over the logit gradient on the
+        # bf16 matrix pipe at fp32 accuracy (csrc/pointwise.hip pw_gw_wide_kernel) instead of a read-only pass for the
+        # bias sums + a library GEMM on the fp32 pipe; the data gradient (its reduction runs over the 441 channels: the
+        # weights do not fit a CU in split form) stays a library GEMM
+        gx = gw = gbias = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            groups = L.sbmc_pointwise_gw_wide_groups(B, hw)
+            gwp = w.new_empty(groups, cout, cin)
+            gbp = w.new_empty(groups, cout)
+            with th.cuda.device(dev), _timed("pointwise_gw_wide %dx%d" % (cout, cin), dev):
+                _lib.check(L.sbmc_pointwise_gw_wide_f32(_lib.ptr(gy), _lib.ptr(x.contiguous()), _lib.ptr(gwp), _lib.ptr(gbp), B,
+                                                        cin, cout, hw, _lib.current_stream(dev)), "pointwise_gw_wide")
+            gw, gbias = gwp.sum(0), gbp.sum(0)
+        if ctx.needs_input_grad[0]:
+            gx = th.bmm(w.t().unsqueeze(0).expand(B, -1, -1), gy)
+        return gx, gw, gbias, None
     gz = gy if (act == 0 and t_mode == 0) else th.empty_like(gy)   # linear: gz is gy, only sums needed
     gt = None
     with th.cuda.device(dev):
@@ -870,6 +888,30 @@ class BiasActNHWC(th.autograd.Function):
         return gx, partial.sum(0), None, None, None
 
 
+class _StreamK(object):
+    """The stream-K workspace of csrc/conv3x3.hip (partial tiles of a launch whose tile count is no multiple of the CU
+    count meet there), one per (device, stream): launches on one stream run one after the other.
+    SBMC_CONV3X3_STREAMK=0: whole tiles round-robin, as in round 3."""
+
+    def __init__(self):
+        self._ws = {}
+
+    def take(self, device):
+        """-> workspace pointer, or None"""
+        if os.environ.get("SBMC_CONV3X3_STREAMK", "1") in ("0", "off", "no"):
+            return None
+        key = (device.index, th.cuda.current_stream(device).cuda_stream)
+        ent = self._ws.get(key)
+        if ent is None:
+            with th.cuda.device(device):
+                nbytes = _lib.lib().sbmc_conv3x3_workspace_bytes()
+            ent = self._ws[key] = th.empty(nbytes, dtype=th.uint8, device=device)
+        return _lib.ptr(ent)
+
+
+_STREAMK = _StreamK()
+
+
 class _AmaxArena(object):
     """Zeroed device words for the passes that RAISE a word to the largest magnitude of what they write (ABI 5: they no
     longer zero it themselves -- that was one memset launch per pass, ~230 per training step, none of which shrinks
@@ -1004,8 +1046,9 @@ class Conv3x3NHWC(th.autograd.Function):
         """x [b, cin, h, w] in channels-last memory order -> [b, cout, h, w], the same order."""
         b, cin, h, w = x.shape
         y = th.empty((b, cout, h, w), dtype=th.float32, device=x.device, memory_format=th.channels_last)
+        ws = _STREAMK.take(x.device)
         _lib.check(_lib.lib().sbmc_conv3x3_nhwc_f32(_lib.ptr(x), _lib.ptr(xmax), _lib.ptr(wp), _lib.ptr(y), b, h, w, cin,
-                                                    cout, _lib.current_stream(x.device)), "conv3x3_nhwc")
+                                                    cout, ws, _lib.current_stream(x.device)), "conv3x3_nhwc")
         return y
 
     @staticmethod
@@ -1096,9 +1139,10 @@ class Conv3x3BiasActNHWC(th.autograd.Function):
             y = th.empty((b, cout, h, wd), dtype=th.float32, device=dev, memory_format=th.channels_last)
             signs = th.empty((y.numel() + 31) // 32, dtype=th.int32, device=dev) if (act != 0 and need_grad) else None
             amax = amax_word(dev)
+            ws = _STREAMK.take(dev)
             _lib.check(L.sbmc_conv3x3_bias_act_nhwc_f32(_lib.ptr(x), _lib.ptr(xmax), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y),
                                                         _lib.ptr(signs), _lib.ptr(amax), b, h, wd, cin, cout, act, slope,
-                                                        _lib.current_stream(dev)), "conv3x3_bias_act_nhwc")
+                                                        ws, _lib.current_stream(dev)), "conv3x3_bias_act_nhwc")
         ctx.act, ctx.slope = act, slope
         ctx.wp = getattr(w, "_sbmc_wp", None)
         ctx.save_for_backward(x, w, xmax, signs if signs is not None else xmax)
@@ -1130,6 +1174,101 @@ class Conv3x3BiasActNHWC(th.autograd.Function):
         if want_bias and gbias is None:
             gbias = partial.sum(0)               # (the weight-gradient kernel did not run: its reduction adds them up)
         return res[0], res[1], gbias, None, None
+
+
+class Conv3x3BiasActHalfNHWC(th.autograd.Function):
+    """The U-nets' 3 x 3 convolution + bias + ReLU / LeakyReLU on HALF activations ("fp16 activations", BASELINE
+    configs[4]; reference sbmc/modules.py:154-175 under torch.autocast(float16) semantics: half inputs, the fp32 weight
+    rounded to half once, fp32 accumulation, half output) on csrc/conv3x3.hip's kernels in their one-plane form: ONE f16
+    matrix product per term where the fp32 form issues three, no scales, no absmax.  x [b, cin, h, w] float16
+    channels-last, w fp32 (a weight bank's weight carries its prepared forms), bias fp32 -> y float16 channels-last.
+    Backward: activation adjoint + bias partial sums in one pass over the half gradient, data gradient by the same
+    kernel on the mirrored weights, weight gradient (fp32) by the one-plane weight-gradient kernel."""
+
+    @staticmethod
+    def supported(x, conv):
+        if os.environ.get("SBMC_CONV3X3", "1") in ("0", "off", "no") or os.environ.get("SBMC_CONV3X3_HALF", "1") in ("0", "off", "no"):
+            return False
+        if not (isinstance(conv, th.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+                and conv.padding_mode == "zeros" and conv.bias is not None):
+            return False
+        if not (x.is_cuda and x.dtype == th.float16 and x.numel() > 0 and _is_channels_last(x)
+                and x.data_ptr() % 16 == 0 and x.shape[1] == conv.in_channels):
+            return False
+        b, c, h, w = x.shape
+        L = _lib.lib()
+        return bool(L.sbmc_conv3x3_supported(b, h, w, c, conv.out_channels)
+                    and L.sbmc_conv3x3_supported(b, h, w, conv.out_channels, c)
+                    and L.sbmc_bias_act_nhwc_supported(int(conv.out_channels)))
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act, slope):
+        L = _lib.lib()
+        b, cin, h, wd = x.shape
+        cout = w.shape[0]
+        dev = x.device
+        wf = w if w.dtype == th.float32 else w.float()
+        bias = bias.float().contiguous()
+        need_grad = any(ctx.needs_input_grad[:3])
+        with th.cuda.device(dev), _timed("conv3x3_f16_fwd %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
+            wp = Conv3x3NHWC._prepare(wf, False)
+            y = th.empty((b, cout, h, wd), dtype=th.float16, device=dev, memory_format=th.channels_last)
+            signs = th.empty((y.numel() + 31) // 32, dtype=th.int32, device=dev) if (act != 0 and need_grad) else None
+            ws = _STREAMK.take(dev)
+            _lib.check(L.sbmc_conv3x3_bias_act_nhwc_f16(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(signs),
+                                                        b, h, wd, cin, cout, act, slope, ws, _lib.current_stream(dev)),
+                       "conv3x3_bias_act_nhwc_f16")
+        ctx.act, ctx.slope = act, slope
+        ctx.wp = getattr(wf, "_sbmc_wp", None)
+        ctx.save_for_backward(x, wf, signs if signs is not None else x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, signs = ctx.saved_tensors
+        if gy.dtype != th.float16:
+            gy = gy.half()
+        gy = gy.contiguous(memory_format=th.channels_last)
+        b, cout, h, wd = gy.shape
+        cin = x.shape[1]
+        L = _lib.lib()
+        dev = gy.device
+        want_gx, want_gw, want_gb = ctx.needs_input_grad[:3]
+        gx = gw = gbias = None
+        with th.cuda.device(dev):
+            st = _lib.current_stream(dev)
+            gz = th.empty_like(gy, memory_format=th.channels_last)
+            partial = th.empty(L.sbmc_bias_act_nhwc_chunks(b * h * wd, cout), cout, dtype=th.float32, device=dev)
+            _lib.check(L.sbmc_bias_act_nhwc_bwd_signs_f16(_lib.ptr(gy), _lib.ptr(signs) if ctx.act != 0 else None, _lib.ptr(gz),
+                                                          _lib.ptr(partial), b * h * wd, cout, ctx.act, ctx.slope, st),
+                       "bias_act_nhwc_bwd_f16")
+            if want_gx:
+                with _timed("conv3x3_f16_bwd_data %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
+                    wpb = ctx.wp[1] if ctx.wp is not None else Conv3x3NHWC._prepare(w, True)
+                    gx = th.empty((b, cin, h, wd), dtype=th.float16, device=dev, memory_format=th.channels_last)
+                    ws = _STREAMK.take(dev)
+                    _lib.check(L.sbmc_conv3x3_nhwc_f16(_lib.ptr(gz), _lib.ptr(wpb), _lib.ptr(gx), b, h, wd, cout, cin, ws, st),
+                               "conv3x3_nhwc_f16 (data gradient)")
+            if want_gw:
+                with _timed("conv3x3_f16_bwd_weight %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
+                    if L.sbmc_conv3x3_wgrad_supported(b, h, wd, cin, cout):
+                        gw = th.empty((cout, cin, 3, 3), dtype=th.float32, device=dev, memory_format=th.channels_last)
+                        scratch = th.empty(L.sbmc_conv3x3_wgrad_scratch_bytes(b, h, wd, cin, cout), dtype=th.uint8, device=dev)
+                        s = gw.stride()
+                        if want_gb:
+                            gbias = th.empty(cout, dtype=th.float32, device=dev)
+                        _lib.check(L.sbmc_conv3x3_wgrad_bias_f16(
+                            _lib.ptr(gz), _lib.ptr(x), _lib.ptr(gw), s[0], s[1], s[2], s[3], _lib.ptr(scratch), b, h, wd, cin,
+                            cout, _lib.ptr(partial) if want_gb else None, partial.shape[0] if want_gb else 0, cout,
+                            _lib.ptr(gbias), st), "conv3x3_wgrad_f16")
+                    else:
+                        wcl = w.half().contiguous(memory_format=th.channels_last)      # (MIOpen's half NHWC solver)
+                        gw = th.ops.aten.convolution_backward(gz, x, wcl, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                              [False, True, False])[1].float()
+        if want_gb and gbias is None:
+            gbias = partial.sum(0)
+        return gx, gw, gbias, None, None
 
 
 def upsample_cat_nhwc_supported(coarse, left, top=0, bot=0):

@@ -223,6 +223,10 @@ def unet_channels_last(net, x, rows=None):
         # ~2-3x MIOpen's fp32 solvers in either layout): nothing to measure, no dependence on MIOpen's find-db
         _LAYOUT_DECISIONS.setdefault((x.device.index, "own 3x3 kernel"), True)
         return True
+    if x.dtype == th.float16 and _convs_on_own_kernel(net, x) and os.environ.get("SBMC_CONV3X3_HALF", "1") not in ("0", "off", "no"):
+        # half activations: the same kernels in their one-plane form (functions.Conv3x3BiasActHalfNHWC)
+        _LAYOUT_DECISIONS.setdefault((x.device.index, "own 3x3 kernel"), True)
+        return True
     grad = th.is_grad_enabled() and any(q.requires_grad for q in net.parameters())
     shape = (x.shape[0], x.shape[1], int(rows) if rows else x.shape[2], x.shape[3])
     dtype = th.float16 if (half or x.dtype == th.float16) else th.float32     # what MIOpen will convolve in
@@ -342,15 +346,22 @@ class ConvChain(nn.Module):
     def _conv_bias_act(conv, x, activation):
         """conv(x) without bias, then bias + activation by the fused pass.  Returns (y, activation
         was applied), or (None, False) when the fused pass does not apply."""
-        if (conv.bias is None or conv.padding_mode != "zeros" or not isinstance(conv.padding, tuple)
-                or th.is_autocast_enabled()):
+        if conv.bias is None or conv.padding_mode != "zeros" or not isinstance(conv.padding, tuple):
             return None, False
-        w = conv_weight(conv)
         act, slope = 0, 0.0
         if isinstance(activation, nn.ReLU):
             act = 1
         elif isinstance(activation, nn.LeakyReLU):
             act, slope = 2, float(activation.negative_slope)
+        if x.dtype == th.float16:
+            # fp16 activations (torch.autocast(float16)): the one-plane form of csrc/conv3x3.hip, bias + activation in
+            # its epilogue; anything it does not take runs the module (MIOpen's half solvers) as before
+            if (activation is None or act != 0) and funcs.Conv3x3BiasActHalfNHWC.supported(x, conv):
+                return funcs.Conv3x3BiasActHalfNHWC.apply(x, conv_weight(conv), conv.bias, act, slope), act != 0
+            return None, False
+        if th.is_autocast_enabled():
+            return None, False
+        w = conv_weight(conv)
         if funcs._is_channels_last(x):
             # the U-net runs channels-last (Autoencoder.forward): MIOpen's NHWC solvers without any layout
             # change around them, bias + activation by the NHWC pass
@@ -413,12 +424,12 @@ class ConvChain(nn.Module):
                     i += 1
                 elif nxt is not None and mean_out:
                     mean_out.clear()                              # an activation is still to come
-            elif (self.fuse_bias_act and x.is_cuda and x.dtype == th.float32
+            elif (self.fuse_bias_act and x.is_cuda and x.dtype in (th.float32, th.float16)
                   and isinstance(m, ConvChain._ConvBNRelu) and len(m.layer) == 2
                   and isinstance(m.layer[0], nn.Conv2d)):
                 y, fused = ConvChain._conv_bias_act(m.layer[0], x, m.layer[1])
                 x = m(x) if y is None else (y if fused else m.layer[1](y))
-            elif self.fuse_bias_act and x.is_cuda and x.dtype == th.float32 and isinstance(m, nn.Conv2d):
+            elif self.fuse_bias_act and x.is_cuda and x.dtype in (th.float32, th.float16) and isinstance(m, nn.Conv2d):
                 nxt = mods[i] if i < len(mods) else None
                 y, fused = ConvChain._conv_bias_act(m, x, nxt)
                 if y is None:

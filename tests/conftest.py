@@ -14,6 +14,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: CPU tests of more than ~10 s (hipcc resource reports, the exhaustive gradcheck): "
+                                       "`-m 'not gpu and not slow'` is the pre-commit gate (~1 min), `-m 'not gpu'` the full CPU suite")
 
 
 @pytest.fixture

@@ -134,7 +134,7 @@ def test_abi_rejects_unsupported_shapes():
     assert L.sbmc_conv3x3_weights_bytes(48, 128) == 0
     assert L.sbmc_conv3x3_wgrad_supported(1, 8, 8, 64, 128) == 0
     assert L.sbmc_conv3x3_wgrad_supported(1, 8, 8, 256, 128) == 1
-    assert L.sbmc_conv3x3_nhwc_f32(None, None, None, None, 1, 8, 8, 128, 128, None) == -1
+    assert L.sbmc_conv3x3_nhwc_f32(None, None, None, None, 1, 8, 8, 128, 128, None, None) == -1
 
 
 @pytest.mark.parametrize("activation", ["tanh", "leaky_relu"])
@@ -264,3 +264,30 @@ def test_every_pass_that_leaves_a_scale_leaves_the_largest_magnitude(shape):
         g = _cl(th.randn(*shape, device=dev))
         (gz,) = th.autograd.grad(z, y, g)
     # the adjoint's word rides on the gradient it returns (checked where it is consumed: the tag test above)
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 128, 94, 1280), (1, 256, 256, 49, 640), (1, 512, 512, 26, 320), (2, 768, 256, 33, 70),
+                                   (1, 128, 128, 16, 16), (1, 512, 128, 5, 7)])
+def test_stream_k_equals_whole_tiles(shape, monkeypatch):
+    """Stream-K (round 4): a launch whose tile count is no multiple of the CU count cuts its (tile, chunk) units into equal
+    ranges over all compute units; split tiles are completed by the fix-up launch.  Same values as the whole-tile walk
+    up to the order of ONE addition per split tile, the same to the bit from run to run; shapes: the slabs of a rank of
+    8 at the three U-net levels (480 / 320 / 160 tiles), more chunks than tiles, a single tile over 4 and 16 chunks."""
+    dev = _dev()
+    b, cin, cout, h, w = shape
+    g = th.Generator(device="cpu").manual_seed(5 + cin + h)
+    x = _cl(th.randn(b, cin, h, w, generator=g).to(dev))
+    wt = (th.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev)
+    bias = th.randn(cout, generator=g).to(dev)
+    ys = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("SBMC_CONV3X3_STREAMK", mode)
+        y, amax = funcs.Conv3x3BiasActNHWC.apply(x, wt, bias, 2, 0.01)
+        assert amax.view(th.float32).item() == y.abs().max().item()
+        if mode in ys:
+            assert th.equal(ys[mode], y)                    # reproducible to the bit
+        ys[mode] = y.clone()
+    scale = ys["0"].abs().max().item()
+    assert (ys["1"] - ys["0"]).abs().max().item() <= 2e-6 * scale
+    ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), bias.double(), padding=1), 0.01)
+    assert _err(ys["1"], ref) <= 1e-5

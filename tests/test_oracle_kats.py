@@ -79,6 +79,7 @@ def test_scatter2gather_delta(oracle, ksize):
                     assert gather.sum().item() == 0.5
 
 
+@pytest.mark.slow
 def test_scatter2gather_gradcheck_and_involution(oracle):
     """reference tests/test_functions.py:187-208; for odd k the op is an involution"""
     th.manual_seed(0)

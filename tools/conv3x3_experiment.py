@@ -38,7 +38,7 @@ def conv(x_nhwc, wp, cout, xmax=None):
         _lib.check(lib.sbmc_conv3x3_absmax_f32(_lib.ptr(x_nhwc), x_nhwc.numel(), _lib.ptr(xmax), _lib.current_stream(th.device("cuda"))), "absmax")
     y = th.empty(n, h, w, cout, dtype=th.float32, device=x_nhwc.device)
     _lib.check(lib.sbmc_conv3x3_nhwc_f32(_lib.ptr(x_nhwc), _lib.ptr(xmax), _lib.ptr(wp), _lib.ptr(y), n, h, w, cin, cout,
-                                         _lib.current_stream(th.device("cuda"))), "conv3x3")
+                                         None, _lib.current_stream(th.device("cuda"))), "conv3x3")
     return y, xmax
 
 

@@ -6,7 +6,7 @@
 # Raw output goes to gpurun_out/prof_<tag>/, condensed summaries to gpurun_out/profiles_<tag>/
 # (copy those into profiles/ to commit them).
 tag=$1; shift
-root=/root/repo
+root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/prof_$tag
 sum=$root/gpurun_out/profiles_$tag
 mkdir -p $out $sum

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summary of the model workload only (top kernels by total time)
-root=/root/repo
+root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/prof_model
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp

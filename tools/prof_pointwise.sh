@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counters of the fused 1x1-layer kernels (one counter group per run, kernel-trace only):
 # HBM traffic, MFMA busy cycles, LDS bank conflicts.  Summary -> gpurun_out/profiles_pw/r02_pointwise_pmc.txt
-root=/root/repo
+root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/prof_pw
 sum=$root/gpurun_out/profiles_pw
 mkdir -p $out $sum

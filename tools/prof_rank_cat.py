@@ -4,11 +4,11 @@ import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 5.0
 CATS = [
-    ("conv3x3 fwd/dgrad", r"sbmc::conv3_kernel"),
+    ("conv3x3 fwd/dgrad", r"sbmc::conv3_kernel|conv3_fixup"),
     ("conv3x3 wgrad", r"conv3_wgrad"),
     ("conv3x3 weight prep / absmax", r"prep_weights|absmax"),
     ("1x1 fwd", r"pw_fwd"),
-    ("1x1 bwd", r"pw_bwd"),
+    ("1x1 bwd", r"pw_bwd|pw_gw_wide"),
     ("hipBLASLt / rocBLAS", r"Cijk_|rocblas|gemm"),
     ("MIOpen", r"igemm|miopen|naive_conv|batched_transpose"),
     ("splat", r"splat_|gather_|s2g_|kw_"),
