@@ -475,6 +475,8 @@ SBMC_API int sbmc_upsample2x_cat_slab_bwd_f32(const float *gout, float *gcoarse,
 /* Batched 2-d transpose dst[b][cols][rows] = src[b][rows][cols] (rows, cols multiples of 4): the planar <->
  * channels-last conversion at the U-net's entry, (rows, cols) = (c, h*w) one way and (h*w, c) the other. */
 SBMC_API int sbmc_transpose2d_f32(const float *src, float *dst, int b, int rows, int cols, void *stream);
+/* the same batched 2-d transpose of _Float16 tensors (rows, cols multiples of 4; 8-byte aligned) */
+SBMC_API int sbmc_transpose2d_f16(const void *src, void *dst, int b, int rows, int cols, void *stream);
 /* ... and *amax raised to the bit pattern of the largest magnitude of the tensor (see sbmc_bias_act_nhwc_fwd_amax_f32). */
 SBMC_API int sbmc_transpose2d_amax_f32(const float *src, float *dst, unsigned *amax, int b, int rows, int cols,
                               void *stream);

@@ -68,6 +68,7 @@ SYMBOLS = (
     "sbmc_upsample2x_cat_slab_fwd_f32",
     "sbmc_upsample2x_cat_slab_bwd_f32",
     "sbmc_transpose2d_f32",
+    "sbmc_transpose2d_f16",
     "sbmc_bias_act_nhwc_supported",
     "sbmc_bias_act_nhwc_chunks",
     "sbmc_bias_act_nhwc_fwd_f32",
@@ -225,6 +226,7 @@ def lib():
     handle.sbmc_upsample2x_cat_slab_fwd_f32.argtypes = [p, p, p, i, i, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_slab_bwd_f32.argtypes = [p, p, i, i, i, i, i, i, i, p]
     handle.sbmc_transpose2d_f32.argtypes = [p, p, i, i, i, p]
+    handle.sbmc_transpose2d_f16.argtypes = [p, p, i, i, i, p]
     handle.sbmc_bias_act_nhwc_supported.argtypes = [i]
     handle.sbmc_bias_act_nhwc_chunks.argtypes = [ctypes.c_long, i]
     handle.sbmc_bias_act_nhwc_fwd_f32.argtypes = [p, p, ctypes.c_long, i, i, ctypes.c_float, p]

@@ -463,6 +463,52 @@ extern "C" int sbmc_upsample2x_cat_nhwc_slab_bwd_f16(const void* gout, void* gco
                                static_cast<_Float16*>(gleft), b, cu, cl, hc, w, top, bot, stream);
 }
 
+// the same transpose of _Float16 tensors (the U-nets' entry / exit layout change under torch.autocast(float16): torch's
+// strided copy takes 0.96 ms for a [128, 720, 1280] half map, ~10 per training step)
+__global__ __launch_bounds__(256) void transpose2d_h_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst,
+                                                           int R, int Cn, int tiles_r, int tiles_c) {
+    using h4 = __attribute__((ext_vector_type(4))) _Float16;
+    __shared__ _Float16 tile[TT][TT + 2];
+    unsigned blk = blockIdx.x;
+    const int tc = blk % tiles_c; blk /= tiles_c;
+    const int tr = blk % tiles_r;
+    const size_t b = blk / tiles_r;
+    const int r0 = tr * TT, c0 = tc * TT;
+    const _Float16* s = src + b * (size_t)R * Cn;
+    _Float16* d = dst + b * (size_t)R * Cn;
+    const int q = threadIdx.x % 16, line = threadIdx.x / 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + line + 16 * i, c = c0 + 4 * q;
+        h4 v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (r < R && c < Cn) v = *reinterpret_cast<const h4*>(s + (size_t)r * Cn + c);
+        _Float16* t = &tile[line + 16 * i][4 * q];
+        t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + line + 16 * i, r = r0 + 4 * q;
+        if (c < Cn && r < R) {
+            h4 v;
+            v[0] = tile[4 * q + 0][line + 16 * i]; v[1] = tile[4 * q + 1][line + 16 * i];
+            v[2] = tile[4 * q + 2][line + 16 * i]; v[3] = tile[4 * q + 3][line + 16 * i];
+            *reinterpret_cast<h4*>(d + (size_t)c * R + r) = v;
+        }
+    }
+}
+extern "C" int sbmc_transpose2d_f16(const void* src, void* dst, int b, int rows, int cols, void* stream) {
+    if (b < 0 || rows < 0 || cols < 0) return SBMC_HIP_EINVAL;
+    if (b == 0 || rows == 0 || cols == 0) return 0;
+    if (!src || !dst || rows % 4 || cols % 4 || (uintptr_t)src % 8 || (uintptr_t)dst % 8) return SBMC_HIP_EINVAL;
+    const int tr = (rows + TT - 1) / TT, tc = (cols + TT - 1) / TT;
+    const unsigned long long blocks = (unsigned long long)b * tr * tc;
+    if (blocks > 0x7fffffffull) return SBMC_HIP_EINVAL;
+    hipLaunchKernelGGL(transpose2d_h_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const _Float16*>(src), static_cast<_Float16*>(dst), rows, cols, tr, tc);
+    return (int)hipGetLastError();
+}
+
 extern "C" int sbmc_transpose2d_f32(const float* src, float* dst, int b, int rows, int cols, void* stream) {
     if (b < 0 || rows < 0 || cols < 0) return SBMC_HIP_EINVAL;
     if (b == 0 || rows == 0 || cols == 0) return 0;

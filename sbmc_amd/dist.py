@@ -540,9 +540,11 @@ def sharded_autoencoder(autoencoder, x, part):
     # (the key holds nothing rank-specific: every rank meets a new key at the same call)
     if _all_agree(mine, part, (part.world, part.height, x.shape[0], x.shape[1], x.shape[-1], x.dtype, grad,
                                th.is_autocast_enabled())):
-        if funcs.ToChannelsLast.supported(x):
+        if funcs.ToChannelsLast.supported(x) and x.dtype == th.float32:
             xin, amax = funcs.ToChannelsLast.apply(x, True)       # (the first convolution's scale, found on the way)
             funcs.tag_amax(xin, amax)
+        elif funcs.ToChannelsLast.supported(x):
+            xin = funcs.ToChannelsLast.apply(x)                   # (half activations: no scales)
         else:
             xin = x.contiguous(memory_format=th.channels_last)
         y = _level(autoencoder.net, xin, part, nhwc=True)

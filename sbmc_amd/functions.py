@@ -714,7 +714,8 @@ class ToChannelsLast(th.autograd.Function):
 
     @staticmethod
     def supported(x):
-        return (x.is_cuda and x.dtype == th.float32 and x.dim() == 4 and x.is_contiguous() and x.numel() > 0
+        """fp32, or fp16 (the U-nets under torch.autocast(float16); no magnitude word there: want_amax must be False)"""
+        return (x.is_cuda and x.dtype in (th.float32, th.float16) and x.dim() == 4 and x.is_contiguous() and x.numel() > 0
                 and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0)
 
     @staticmethod
@@ -723,6 +724,13 @@ class ToChannelsLast(th.autograd.Function):
         b, c, h, w = x.shape
         out = th.empty(b, c, h, w, dtype=x.dtype, device=x.device, memory_format=th.channels_last)
         dev = x.device
+        if x.dtype == th.float16:
+            if want_amax:
+                raise TypeError("ToChannelsLast: no magnitude word for half tensors")
+            with th.cuda.device(dev):
+                _lib.check(_lib.lib().sbmc_transpose2d_f16(_lib.ptr(x), _lib.ptr(out), b, c, h * w, _lib.current_stream(dev)),
+                           "transpose2d_f16")
+            return out
         amax = amax_word(dev) if want_amax else None
         with th.cuda.device(dev):
             if want_amax:
@@ -749,7 +757,7 @@ class FromChannelsLast(th.autograd.Function):
 
     @staticmethod
     def supported(x):
-        return (x.is_cuda and x.dtype == th.float32 and _is_channels_last(x) and x.numel() > 0
+        return (x.is_cuda and x.dtype in (th.float32, th.float16) and _is_channels_last(x) and x.numel() > 0
                 and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0)
 
     @staticmethod
@@ -757,8 +765,9 @@ class FromChannelsLast(th.autograd.Function):
         b, c, h, w = x.shape
         out = th.empty(b, c, h, w, dtype=x.dtype, device=x.device)
         dev = x.device
+        fn = _lib.lib().sbmc_transpose2d_f16 if x.dtype == th.float16 else _lib.lib().sbmc_transpose2d_f32
         with th.cuda.device(dev):
-            rc = _lib.lib().sbmc_transpose2d_f32(_lib.ptr(x), _lib.ptr(out), b, h * w, c, _lib.current_stream(dev))
+            rc = fn(_lib.ptr(x), _lib.ptr(out), b, h * w, c, _lib.current_stream(dev))
         _lib.check(rc, "transpose2d")
         return out
 

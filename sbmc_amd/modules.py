@@ -145,14 +145,15 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     wt = wt.view(wt.shape[0], cs + cp)
     cout = wt.shape[0]
     xs = per_sample.reshape(bs * S, cs, h * w)
-    nhwc_ctx = funcs._is_channels_last(context) and context.dtype == th.float32 and h * w > 1
+    nhwc_ctx = funcs._is_channels_last(context) and context.dtype in (th.float32, th.float16) and h * w > 1
     ctx3 = None if nhwc_ctx else context.reshape(bs, cp, -1)
 
     def context_term(wc):
         # the U-net may hand its result over channels-last: the product then reads it in place and returns
-        # the context gradient channels-last as well (functions.ContextProductNHWC)
+        # the context gradient channels-last as well (functions.ContextProductNHWC).  A half context (fp16
+        # activations) is widened in its own memory order first: an elementwise pass instead of a strided copy
         if nhwc_ctx:
-            return funcs.ContextProductNHWC.apply(context, wc.contiguous())
+            return funcs.ContextProductNHWC.apply(context.float(), wc.float().contiguous())
         return th.bmm(wc.unsqueeze(0).expand(bs, -1, -1), ctx3.to(wc.dtype))
     if funcs.pointwise_half_supported(xs, cout):             # fp16 activations, inference
         with th.autocast("cuda", enabled=False):
@@ -516,9 +517,11 @@ class Autoencoder(nn.Module):
     def forward(self, x):
         if unet_channels_last(self, x):
             # channels-last between the convolutions: MIOpen's NHWC-native solvers need no transposes then
-            if funcs.ToChannelsLast.supported(x):
+            if funcs.ToChannelsLast.supported(x) and x.dtype == th.float32:
                 xin, amax = funcs.ToChannelsLast.apply(x, True)       # (the first convolution's scale, found on the way)
                 funcs.tag_amax(xin, amax)
+            elif funcs.ToChannelsLast.supported(x):
+                xin = funcs.ToChannelsLast.apply(x)                   # (half activations: no scales)
             else:
                 xin = x.contiguous(memory_format=th.channels_last)
             y = self.net(xin)

@@ -111,3 +111,19 @@ def test_unet_under_autocast_runs_on_the_half_kernels(monkeypatch):
     num = sum(((gh[k] - p.grad) ** 2).sum().item() for k, p in net.named_parameters())
     den = sum((p.grad ** 2).sum().item() for k, p in net.named_parameters())
     assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 36, 52), (2, 8, 12, 20), (1, 132, 7, 8)])
+def test_half_layout_changes_are_exact(shape):
+    """planar <-> channels-last of half tensors by the LDS-tile transpose (csrc/nhwc_ops.hip transpose2d_h_kernel):
+    a permutation, equal to torch's copy bit for bit, forward and backward."""
+    from sbmc_amd import functions as funcs
+    x = th.randn(*shape, device=DEV).half().requires_grad_()
+    assert funcs.ToChannelsLast.supported(x)
+    y = funcs.ToChannelsLast.apply(x)
+    assert y.is_contiguous(memory_format=th.channels_last) and th.equal(y, x.detach())
+    z = funcs.FromChannelsLast.apply(y)
+    assert z.is_contiguous() and th.equal(z, x.detach())
+    g = th.randn(*shape, device=DEV).half()
+    z.backward(g)
+    assert th.equal(x.grad, g)
