@@ -403,6 +403,9 @@ SBMC_API int sbmc_pointwise_gw_wide_supported(int cin, int cout, long hw);
 SBMC_API int sbmc_pointwise_gw_wide_groups(int b, long hw);
 SBMC_API int sbmc_pointwise_gw_wide_f32(const float *gz, const float *x, float *gw_partial, float *gb_partial, int b,
                                int cin, int cout, long hw, void *stream);
+/* ... with gz and x _Float16 (fp16 activations); the partial sums stay fp32 */
+SBMC_API int sbmc_pointwise_gw_wide_f16(const void *gz, const void *x, float *gw_partial, float *gb_partial, int b,
+                               int cin, int cout, long hw, void *stream);
 SBMC_API int sbmc_pointwise_bwd_f32(const float *gy, const float *y, const float *x, const float *w,
                            float *gx, float *gw_partial, float *gb_partial, float *gt,
                            const float *gmean, int s_mean, int b, int s, int cin, int cout, long hw,
@@ -475,6 +478,13 @@ SBMC_API int sbmc_upsample2x_cat_slab_bwd_f32(const float *gout, float *gcoarse,
 /* Batched 2-d transpose dst[b][cols][rows] = src[b][rows][cols] (rows, cols multiples of 4): the planar <->
  * channels-last conversion at the U-net's entry, (rows, cols) = (c, h*w) one way and (h*w, c) the other. */
 SBMC_API int sbmc_transpose2d_f32(const float *src, float *dst, int b, int rows, int cols, void *stream);
+/* 2 x 2 / stride 2 max-pooling of a channels-last map x [b, 2 hc, 2 wc, c] -> y [b, hc, wc, c] (the U-nets' pooling,
+ * reference sbmc/modules.py:262-263) and its adjoint fused with the addition of the skip connection's gradient:
+ * gx = gskip (NULL: 0) + gpool routed to the FIRST maximum of each window (the element torch's max_pool2d records; the
+ * arg-max is recomputed from x).  elem: 4 = float, 2 = _Float16; c % 4 == 0. */
+SBMC_API int sbmc_maxpool2_nhwc_fwd(const void *x, void *y, int b, int hc, int wc, int c, int elem, void *stream);
+SBMC_API int sbmc_maxpool2_nhwc_bwd_add(const void *x, const void *gpool, const void *gskip, void *gx, int b, int hc,
+                               int wc, int c, int elem, void *stream);
 /* the same batched 2-d transpose of _Float16 tensors (rows, cols multiples of 4; 8-byte aligned) */
 SBMC_API int sbmc_transpose2d_f16(const void *src, void *dst, int b, int rows, int cols, void *stream);
 /* ... and *amax raised to the bit pattern of the largest magnitude of the tensor (see sbmc_bias_act_nhwc_fwd_amax_f32). */

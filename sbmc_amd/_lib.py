@@ -58,6 +58,7 @@ SYMBOLS = (
     "sbmc_pointwise_gw_wide_supported",
     "sbmc_pointwise_gw_wide_groups",
     "sbmc_pointwise_gw_wide_f32",
+    "sbmc_pointwise_gw_wide_f16",
     "sbmc_pointwise_bwd_f16",
     "sbmc_pointwise_fwd_signs_f32",
     "sbmc_pointwise_bwd_signs_f32",
@@ -69,6 +70,8 @@ SYMBOLS = (
     "sbmc_upsample2x_cat_slab_bwd_f32",
     "sbmc_transpose2d_f32",
     "sbmc_transpose2d_f16",
+    "sbmc_maxpool2_nhwc_fwd",
+    "sbmc_maxpool2_nhwc_bwd_add",
     "sbmc_bias_act_nhwc_supported",
     "sbmc_bias_act_nhwc_chunks",
     "sbmc_bias_act_nhwc_fwd_f32",
@@ -214,6 +217,7 @@ def lib():
     handle.sbmc_pointwise_gw_wide_supported.argtypes = [i, i, ctypes.c_long]
     handle.sbmc_pointwise_gw_wide_groups.argtypes = [i, ctypes.c_long]
     handle.sbmc_pointwise_gw_wide_f32.argtypes = [p, p, p, p, i, i, i, ctypes.c_long, p]
+    handle.sbmc_pointwise_gw_wide_f16.argtypes = [p, p, p, p, i, i, i, ctypes.c_long, p]
     handle.sbmc_pointwise_bwd_f32.argtypes = [p] * 9 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_fwd_signs_f32.argtypes = [p] * 6 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_signs_f32.argtypes = handle.sbmc_pointwise_bwd_f32.argtypes
@@ -227,6 +231,8 @@ def lib():
     handle.sbmc_upsample2x_cat_slab_bwd_f32.argtypes = [p, p, i, i, i, i, i, i, i, p]
     handle.sbmc_transpose2d_f32.argtypes = [p, p, i, i, i, p]
     handle.sbmc_transpose2d_f16.argtypes = [p, p, i, i, i, p]
+    handle.sbmc_maxpool2_nhwc_fwd.argtypes = [p, p, i, i, i, i, i, p]
+    handle.sbmc_maxpool2_nhwc_bwd_add.argtypes = [p, p, p, p, i, i, i, i, i, p]
     handle.sbmc_bias_act_nhwc_supported.argtypes = [i]
     handle.sbmc_bias_act_nhwc_chunks.argtypes = [ctypes.c_long, i]
     handle.sbmc_bias_act_nhwc_fwd_f32.argtypes = [p, p, ctypes.c_long, i, i, ctypes.c_float, p]

@@ -378,14 +378,15 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         const rsrc_t rw = cv_rsrc(p.wp, valid ? wbytes : 0u);
         const unsigned k16 = cc * 2u + (unsigned)(st / 3), ky = (unsigned)(st % 3);
         const unsigned block = valid ? ((unsigned)t.ct * ((unsigned)p.Cin / 16u) + k16) * 3u + ky : 0u;
+        // (HF: the high plane only -- entries kx 512 + 0..255 of the stage: half the L2 and LDS traffic of the weights)
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(tid + 256 * i) * 16u,
+        for (int i = 0; i < (HF ? 3 : 6); ++i)
+            wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(HF ? tid + 512 * i : tid + 256 * i) * 16u,
                                                             block * (unsigned)(CV_WSTAGE * 16), 0);
     };
     auto commit_w = [&](const u32x4 (&wreg)[6], int wbuf) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) Ws[wbuf * CV_WSTAGE + tid + 256 * i] = wreg[i];
+        for (int i = 0; i < (HF ? 3 : 6); ++i) Ws[wbuf * CV_WSTAGE + (HF ? tid + 512 * i : tid + 256 * i)] = wreg[i];
     };
 
     f32x16 acc[4][2];

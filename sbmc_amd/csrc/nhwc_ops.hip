@@ -217,6 +217,68 @@ __global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const T* __restrict
     }
 }
 
+// 2 x 2 / stride 2 max-pooling of a channels-last map (the U-nets' `pooling="max"`, reference sbmc/modules.py:262-263,
+// 300-302) and its adjoint FUSED with the addition of the skip connection's gradient: the pooled map's input also feeds
+// the up path's concatenation, so autograd ran max_pool_backward, wrote a full-size gradient, and added the skip's to it
+// in a third pass.  Here gx = gskip + (this pixel is the FIRST maximum of its window, the element torch's kernel records
+// ? gpool : 0) in one pass; the arg-max is recomputed from the saved input instead of an int64 index tensor.
+// One thread = one float4 of channels of one COARSE pixel (its four fine pixels).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_nhwc_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int c4n, int hc,
+                                                               int wc, size_t total4) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % c4n);
+        size_t rest = idx / c4n;
+        const int j = (int)(rest % wc);
+        rest /= wc;
+        const int i = (int)(rest % hc);
+        const size_t b = rest / hc;
+        const size_t f = ((b * 2 * hc + 2 * i) * (size_t)(2 * wc) + 2 * j) * c4n + q;     // fine pixel (2i, 2j)
+        const size_t row = (size_t)(2 * wc) * c4n;
+        const float4 a = Quad<T>::load(x, f), bq = Quad<T>::load(x, f + c4n), c = Quad<T>::load(x, f + row),
+                     d = Quad<T>::load(x, f + row + c4n);
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, bq.x), fmaxf(c.x, d.x)); m.y = fmaxf(fmaxf(a.y, bq.y), fmaxf(c.y, d.y));
+        m.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(c.z, d.z)); m.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(c.w, d.w));
+        Quad<T>::store(y, idx, m);
+    }
+}
+__device__ __forceinline__ int first_max4(float a, float b, float c, float d) {
+    int k = 0;
+    float m = a;
+    if (b > m) { m = b; k = 1; }
+    if (c > m) { m = c; k = 2; }
+    if (d > m) { k = 3; }
+    return k;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_nhwc_bwd_add_kernel(const T* __restrict__ x, const T* __restrict__ gpool,
+                                                                   const T* __restrict__ gskip, T* __restrict__ gx, int c4n,
+                                                                   int hc, int wc, size_t total4) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % c4n);
+        size_t rest = idx / c4n;
+        const int j = (int)(rest % wc);
+        rest /= wc;
+        const int i = (int)(rest % hc);
+        const size_t b = rest / hc;
+        const size_t f = ((b * 2 * hc + 2 * i) * (size_t)(2 * wc) + 2 * j) * c4n + q;
+        const size_t row = (size_t)(2 * wc) * c4n;
+        const size_t at[4] = {f, f + c4n, f + row, f + row + c4n};
+        const float4 a = Quad<T>::load(x, at[0]), bq = Quad<T>::load(x, at[1]), c = Quad<T>::load(x, at[2]),
+                     d = Quad<T>::load(x, at[3]);
+        const float4 g = Quad<T>::load(gpool, idx);
+        const int kx = first_max4(a.x, bq.x, c.x, d.x), ky = first_max4(a.y, bq.y, c.y, d.y);
+        const int kz = first_max4(a.z, bq.z, c.z, d.z), kw = first_max4(a.w, bq.w, c.w, d.w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 o = gskip ? Quad<T>::load(gskip, at[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            o.x += kx == k ? g.x : 0.f; o.y += ky == k ? g.y : 0.f; o.z += kz == k ? g.z : 0.f; o.w += kw == k ? g.w : 0.f;
+            Quad<T>::store(gx, at[k], o);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void slice_channels_nhwc_kernel(const T* __restrict__ src, T* __restrict__ dst,
                                                                  int ct4, int c0_4, int cn4, size_t total4) {
@@ -497,6 +559,40 @@ __global__ __launch_bounds__(256) void transpose2d_h_kernel(const _Float16* __re
         }
     }
 }
+// x [b, 2 hc, 2 wc, c] -> y [b, hc, wc, c]; elem: 4 (float) or 2 (_Float16); c % 4 == 0
+extern "C" int sbmc_maxpool2_nhwc_fwd(const void* x, void* y, int b, int hc, int wc, int c, int elem, void* stream) {
+    if (b < 0 || hc < 0 || wc < 0 || c < 0 || (elem != 2 && elem != 4)) return SBMC_HIP_EINVAL;
+    if (b == 0 || hc == 0 || wc == 0 || c == 0) return 0;
+    if (!x || !y || c % 4 || (uintptr_t)x % (4 * elem) || (uintptr_t)y % (4 * elem)) return SBMC_HIP_EINVAL;
+    const size_t total4 = (size_t)b * hc * wc * (c / 4);
+    if (elem == 4)
+        hipLaunchKernelGGL(maxpool2_nhwc_fwd_kernel<float>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const float*>(x), static_cast<float*>(y), c / 4, hc, wc, total4);
+    else
+        hipLaunchKernelGGL(maxpool2_nhwc_fwd_kernel<_Float16>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const _Float16*>(x), static_cast<_Float16*>(y), c / 4, hc, wc, total4);
+    return (int)hipGetLastError();
+}
+// gx [b, 2 hc, 2 wc, c] = gskip (or 0 if NULL) + the pooled map's gradient gpool [b, hc, wc, c] routed to the first maximum
+// of each window of x
+extern "C" int sbmc_maxpool2_nhwc_bwd_add(const void* x, const void* gpool, const void* gskip, void* gx, int b, int hc,
+                                          int wc, int c, int elem, void* stream) {
+    if (b < 0 || hc < 0 || wc < 0 || c < 0 || (elem != 2 && elem != 4)) return SBMC_HIP_EINVAL;
+    if (b == 0 || hc == 0 || wc == 0 || c == 0) return 0;
+    if (!x || !gpool || !gx || c % 4 || (uintptr_t)x % (4 * elem) || (uintptr_t)gpool % (4 * elem) ||
+        (uintptr_t)gskip % (4 * elem) || (uintptr_t)gx % (4 * elem)) return SBMC_HIP_EINVAL;
+    const size_t total4 = (size_t)b * hc * wc * (c / 4);
+    if (elem == 4)
+        hipLaunchKernelGGL(maxpool2_nhwc_bwd_add_kernel<float>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const float*>(x), static_cast<const float*>(gpool), static_cast<const float*>(gskip),
+                           static_cast<float*>(gx), c / 4, hc, wc, total4);
+    else
+        hipLaunchKernelGGL(maxpool2_nhwc_bwd_add_kernel<_Float16>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const _Float16*>(x), static_cast<const _Float16*>(gpool),
+                           static_cast<const _Float16*>(gskip), static_cast<_Float16*>(gx), c / 4, hc, wc, total4);
+    return (int)hipGetLastError();
+}
+
 extern "C" int sbmc_transpose2d_f16(const void* src, void* dst, int b, int rows, int cols, void* stream) {
     if (b < 0 || rows < 0 || cols < 0) return SBMC_HIP_EINVAL;
     if (b == 0 || rows == 0 || cols == 0) return 0;

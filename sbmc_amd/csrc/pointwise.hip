@@ -1236,10 +1236,13 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 // planar order) with the x tile staged ONCE per pixel tile and the gz tile four times, 128 output channels at a time,
 // into four sets of accumulators (128 registers); the row sums for the bias are taken while staging.  One pass over
 // gz and x: 16.8 GB at 720p x 8 spp.
-template <int KP>
+// T: storage type of gz and x (float, or _Float16 for training under torch.autocast(float16): the same products, the
+// values widened on the way into the split -- their low planes are zero).
+template <int KP, typename T = float>
 __global__ __launch_bounds__(PW_THREADS) void pw_gw_wide_kernel(PwBwdParams p) {
-    const float* gz_g = static_cast<const float*>(p.gy);
-    const float* x_g = static_cast<const float*>(p.x);
+    constexpr unsigned ST = (unsigned)sizeof(T);
+    const T* gz_g = static_cast<const T*>(p.gy);
+    const T* x_g = static_cast<const T*>(p.x);
     extern __shared__ float4 pw_lds[];
     _Float16* gzn = reinterpret_cast<_Float16*>(pw_lds);              // [3][128][PBS_PITCH]
     _Float16* xn = gzn + 3 * 128 * PBS_PITCH;                         // [3][KP][PBS_PITCH]
@@ -1252,7 +1255,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_gw_wide_kernel(PwBwdParams p) {
     const unsigned c4 = (threadIdx.x & 15) * 4, srow = threadIdx.x >> 4;
     const int nct = (p.Cout + 127) / 128;                             // output-channel tiles in use (<= 4)
 
-    u32x4 pg[4], px[NX];
+    typename Pack4<T>::type pg[4], px[NX];
     auto coords = [&](unsigned unit, unsigned& b, unsigned& p0) {
         b = unit / p.tiles_per_plane;
         p0 = (unit % p.tiles_per_plane) * PB_NT;
@@ -1260,23 +1263,23 @@ __global__ __launch_bounds__(PW_THREADS) void pw_gw_wide_kernel(PwBwdParams p) {
     auto issue_g = [&](unsigned unit, int ct) {
         unsigned b, p0;
         coords(unit, b, p0);
-        const rsrc_t rg = make_rsrc_n(gz_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
+        const rsrc_t rg = make_rsrc_n(gz_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * ST);
         const bool colok = p0 + c4 < hw;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned r = 128u * ct + srow + 32u * i;
-            pg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB, 0, 0);
+            pg[i] = load4<T>(rg, (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * ST : PW_OOB);
         }
     };
     auto issue_x = [&](unsigned unit) {
         unsigned b, p0;
         coords(unit, b, p0);
-        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
+        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * ST);
         const bool colok = p0 + c4 < hw;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const unsigned r = srow + 32u * i;
-            px[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * 4u : PW_OOB, 0, 0);
+            px[i] = load4<T>(rx, (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * ST : PW_OOB);
         }
     };
     float bsum[4][4];                                                 // row sums of gz: [cout tile][rows srow + 32 i]
@@ -1288,7 +1291,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_gw_wide_kernel(PwBwdParams p) {
         constexpr int CT = decltype(ctc)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float4 gv = __builtin_bit_cast(float4, pg[i]);
+            const float4 gv = unpack4<T>(pg[i]);
             bsum[CT][i] += (gv.x + gv.y) + (gv.z + gv.w);
             u32x2 h, m, l;
             split3_4(gv, h, m, l);
@@ -1301,7 +1304,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_gw_wide_kernel(PwBwdParams p) {
     auto commit_x = [&]() {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const float4 xv = __builtin_bit_cast(float4, px[i]);
+            const float4 xv = unpack4<T>(px[i]);
             u32x2 h, m, l;
             split3_4(xv, h, m, l);
             _Float16* e = xn + (srow + 32 * i) * PBS_PITCH + c4;
@@ -1998,8 +2001,21 @@ extern "C" int sbmc_pointwise_gw_wide_groups(int b, long hw) {
     if (b <= 0 || hw <= 0) return 1;
     return (int)pw_bwd_grid(b, 1, hw, nullptr);
 }
+template <typename T>
+static int pw_gw_wide_launch(const void* gz, const void* x, float* gw_partial, float* gb_partial, int b, int cin, int cout,
+                             long hw, void* stream);
 extern "C" int sbmc_pointwise_gw_wide_f32(const float* gz, const float* x, float* gw_partial, float* gb_partial, int b,
                                           int cin, int cout, long hw, void* stream) {
+    return pw_gw_wide_launch<float>(gz, x, gw_partial, gb_partial, b, cin, cout, hw, stream);
+}
+// gz and x _Float16 (training under torch.autocast(float16)); the partial sums stay fp32
+extern "C" int sbmc_pointwise_gw_wide_f16(const void* gz, const void* x, float* gw_partial, float* gb_partial, int b,
+                                          int cin, int cout, long hw, void* stream) {
+    return pw_gw_wide_launch<_Float16>(gz, x, gw_partial, gb_partial, b, cin, cout, hw, stream);
+}
+template <typename T>
+static int pw_gw_wide_launch(const void* gz, const void* x, float* gw_partial, float* gb_partial, int b, int cin, int cout,
+                             long hw, void* stream) {
     if (b < 0) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!sbmc_pointwise_gw_wide_supported(cin, cout, hw) || !gz || !x || !gw_partial || !gb_partial) return SBMC_HIP_EINVAL;
@@ -2017,7 +2033,7 @@ extern "C" int sbmc_pointwise_gw_wide_f32(const float* gz, const float* x, float
     hipError_t e = hipSuccess;
 #define SBMC_GWW(KPV)                                                                                    \
     do {                                                                                                 \
-        auto kern = pw_gw_wide_kernel<KPV>;                                                              \
+        auto kern = pw_gw_wide_kernel<KPV, T>;                                                           \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(grid), dim3(PW_THREADS), lds, (hipStream_t)stream, p); \
     } while (0)

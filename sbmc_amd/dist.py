@@ -504,7 +504,13 @@ def _level(level, x, part, nhwc=False):
         return left
     if left.shape[-2] % 2:
         raise RuntimeError("sharded path needs an even number of rows at every U-net level")
-    pooled = level.downsample(left)
+    if funcs.PoolSkip.supported(left, level.downsample):
+        known = funcs.known_amax(left)
+        pooled, left = funcs.PoolSkip.apply(left)        # (down path + skip connection: one node, one gradient pass)
+        if known is not None:
+            funcs.tag_amax(left, known)
+    else:
+        pooled = level.downsample(left)
     if isinstance(level.downsample, (th.nn.MaxPool2d, th.nn.AvgPool2d)) and funcs.known_amax(left) is not None:
         funcs.tag_amax(pooled, funcs.known_amax(left))            # pooling grows no magnitude
     coarse = _level(level.next_level, pooled, part, nhwc)

@@ -586,6 +586,24 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
         if t_mode == 1:
             gt = per_image.view(tshape)
         return gx, gwp.sum(0), per_image.sum(0), gt
+    if (half and act == 0 and t_mode == 0 and x.dtype == th.float16 and os.environ.get("SBMC_HIP_PW_GW_WIDE", "1") != "0"
+            and L.sbmc_pointwise_gw_wide_supported(cin, cout, hw)):
+        # the 441-channel logits layer with half activations: weight + bias gradient in ONE pass over the half logit
+        # gradient (pw_gw_wide_kernel; before: a cast of the 6.6 GB gradient to fp32 for the bias sums, a reduction
+        # over the 13 GB copy and a half GEMM); the data gradient stays a half GEMM
+        gx = gw = gbias = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            groups = L.sbmc_pointwise_gw_wide_groups(B, hw)
+            gwp = th.empty(groups, cout, cin, dtype=th.float32, device=dev)
+            gbp = th.empty(groups, cout, dtype=th.float32, device=dev)
+            with th.cuda.device(dev), _timed("pointwise_gw_wide_f16 %dx%d" % (cout, cin), dev):
+                _lib.check(L.sbmc_pointwise_gw_wide_f16(_lib.ptr(gy), _lib.ptr(x.contiguous()), _lib.ptr(gwp), _lib.ptr(gbp), B,
+                                                        cin, cout, hw, _lib.current_stream(dev)), "pointwise_gw_wide_f16")
+            gw, gbias = gwp.sum(0), gbp.sum(0)
+        if ctx.needs_input_grad[0]:
+            with th.autocast("cuda", enabled=False):
+                gx = th.bmm(w.half().t().unsqueeze(0).expand(B, -1, -1), gy).to(x.dtype)
+        return gx, gw, gbias, None
     if half:
         # wider than the fused backward takes (the 441-channel logits): activation adjoint and the sums in
         # torch, the two products as half GEMMs with fp32 accumulation (rocBLAS / hipBLASLt)
@@ -775,6 +793,54 @@ class FromChannelsLast(th.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         return ToChannelsLast.apply(g) if ToChannelsLast.supported(g) else g.contiguous(memory_format=th.channels_last)
+
+
+class PoolSkip(th.autograd.Function):
+    """left [b, c, h, w] channels-last -> (max_pool2d(left, 2, 2), left): a U-net level's down path AND its skip
+    connection as ONE node (reference sbmc/modules.py:300-320: `self.downsample(left)` ... `th.cat([up, left], 1)`), so that
+    both gradients of `left` reach one backward: gx = g_skip + g_pooled routed to each window's first maximum, in one
+    pass (csrc/nhwc_ops.hip) instead of max_pool_backward + a full-size accumulation pass.  Same values as
+    torch's max_pool2d and its backward; no int64 index tensor (the arg-max is recomputed from `left`)."""
+
+    @staticmethod
+    def supported(left, pool):
+        return (isinstance(pool, th.nn.MaxPool2d) and pool.kernel_size in (2, (2, 2)) and pool.stride in (2, (2, 2))
+                and pool.padding in (0, (0, 0)) and pool.dilation in (1, (1, 1)) and not pool.ceil_mode
+                and not pool.return_indices and left.is_cuda and left.dtype in (th.float32, th.float16) and left.dim() == 4
+                and _is_channels_last(left) and left.shape[1] % 4 == 0 and left.shape[2] % 2 == 0 and left.shape[3] % 2 == 0
+                and left.numel() > 0 and left.data_ptr() % 16 == 0
+                and os.environ.get("SBMC_POOL_SKIP", "1") not in ("0", "off", "no"))
+
+    @staticmethod
+    def forward(ctx, left):
+        b, c, h, w = left.shape
+        pooled = th.empty((b, c, h // 2, w // 2), dtype=left.dtype, device=left.device, memory_format=th.channels_last)
+        dev = left.device
+        with th.cuda.device(dev):
+            _lib.check(_lib.lib().sbmc_maxpool2_nhwc_fwd(_lib.ptr(left), _lib.ptr(pooled), b, h // 2, w // 2, c,
+                                                         left.element_size(), _lib.current_stream(dev)), "maxpool2_nhwc_fwd")
+        ctx.save_for_backward(left)
+        ctx.set_materialize_grads(False)
+        # (a second handle on the same memory with the same strides: returning `left` itself would make autograd re-view
+        # it, which loses the channels-last strides of a one-image batch)
+        return pooled, left.detach()
+
+    @staticmethod
+    def backward(ctx, g_pooled, g_skip):
+        (left,) = ctx.saved_tensors
+        if g_pooled is None:
+            return g_skip
+        b, c, h, w = left.shape
+        g_pooled = g_pooled.to(left.dtype).contiguous(memory_format=th.channels_last)
+        if g_skip is not None:
+            g_skip = g_skip.to(left.dtype).contiguous(memory_format=th.channels_last)
+        gx = th.empty_like(left, memory_format=th.channels_last)
+        dev = left.device
+        with th.cuda.device(dev):
+            _lib.check(_lib.lib().sbmc_maxpool2_nhwc_bwd_add(_lib.ptr(left), _lib.ptr(g_pooled), _lib.ptr(g_skip), _lib.ptr(gx),
+                                                             b, h // 2, w // 2, c, left.element_size(),
+                                                             _lib.current_stream(dev)), "maxpool2_nhwc_bwd_add")
+        return gx
 
 
 class ContextProductNHWC(th.autograd.Function):

@@ -563,7 +563,14 @@ class Autoencoder(nn.Module):
             left = self.left(x)
             if self.is_last:
                 return left
-            pooled = self.downsample(left)
+            if funcs.PoolSkip.supported(left, self.downsample):
+                # down path and skip connection as one autograd node: their gradients meet in ONE pass
+                known = funcs.known_amax(left)
+                pooled, left = funcs.PoolSkip.apply(left)
+                if known is not None:
+                    funcs.tag_amax(left, known)
+            else:
+                pooled = self.downsample(left)
             if isinstance(self.downsample, (nn.MaxPool2d, nn.AvgPool2d)) and funcs.known_amax(left) is not None:
                 funcs.tag_amax(pooled, funcs.known_amax(left))        # pooling grows no magnitude
             coarse = self.next_level(pooled)
