@@ -494,6 +494,7 @@ def main():
         else:
             batch = make_model_inputs(H, W, S, device, seed=1234, rows=(part.y0, part.y1))
             runner = sdist.ShardedDenoiser(model, part)
+            sync()      # (the ranks finish building their slabs seconds apart: the first exchange must not wait for that)
             validation = validate_sharded(model, runner, loss_fn, batch, part, H, W, S, device)
             if rank == 0 and validation["rel_diff"] is not None and validation["rel_diff"] > 1e-3:
                 # (1e-5 is the bar and is reported; beyond 1e-3 the sharded step is WRONG: no number is printed)

@@ -426,6 +426,10 @@ SBMC_API int sbmc_pointwise_fwd_signs_f32(const float *x, const float *w, const 
 SBMC_API int sbmc_pointwise_fwd_mean_f32(const float *x, const float *w, const float *bias, const float *t, float *y,
                                 unsigned *signs, float *ymean, int s_mean, int b, int s, int cin, int cout,
                                 long hw, int t_mode, int act, float slope, void *stream);
+/* the all-half layer (x, y _Float16) with the mean as a _Float16 tensor: the mean of the half values as stored */
+SBMC_API int sbmc_pointwise_fwd_mean_f16(const void *x, const float *w, const float *bias, const float *t, void *y,
+                                void *ymean, int s_mean, int b, int s, int cin, int cout, long hw, int t_mode,
+                                int act, float slope, void *stream);
 SBMC_API int sbmc_pointwise_bwd_signs_f32(const float *gy, const unsigned *signs, const float *x, const float *w,
                                  float *gx, float *gw_partial, float *gb_partial, float *gt,
                                  const float *gmean, int s_mean, int b, int s, int cin, int cout, long hw,

@@ -317,8 +317,11 @@ constexpr int PS_NT = 64;           // pixels per tile of the split-precision ke
 // SIMD with the whole 512-entry register file -- accumulators in AccVGPRs --; a wave owns 32 channels x 64
 // pixels): the second form leaves the compiler room to keep LDS reads and the split of the next tile in
 // flight between the MFMAs instead of waiting for each operand.
-template <int KP, int TMODE, int WAVES>
+// TO: storage type of y (float; _Float16 for a chain's FIRST layer under fp16 activations -- fp32 network input in, half
+// out: until round 4 that layer ran on the fp32-MFMA kernel; no sign bits or mean in that form).
+template <int KP, int TMODE, int WAVES, typename TO = float>
 __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
+    constexpr unsigned SO = (unsigned)sizeof(TO);
     constexpr int KO = KP / 8;                         // channel octets
     constexpr int KS = KP / 16;                        // MFMA k-steps
     constexpr int NOCT = (KO + WAVES - 1) / WAVES;     // octets a staging thread owns
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     // where a per-pixel context term needs the 16 registers at 128 channels
     constexpr bool TWO = !(TMODE == 2 && KP == 128 && WAVES == 8);
     const float* xg = static_cast<const float*>(p.x);
-    float* yg = static_cast<float*>(p.y);
+    TO* yg = static_cast<TO*>(p.y);
     extern __shared__ float4 pw_lds[];
     u32x4* xs = reinterpret_cast<u32x4*>(pw_lds);      // [2][3][KO][PS_NT]
     const int lane = threadIdx.x & 63, wave = wave_id();
@@ -546,8 +549,8 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
         }
 
         // bias, context term, sign bits, activation, store
-        const rsrc_t ry = make_rsrc_n(yg + ((size_t)b * p.Cout + r0) * hw, (unsigned)nrows * hw * 4u);
-        const rsrc_t rm = make_rsrc_n(p.ymean != nullptr ? p.ymean + ((size_t)bq * p.Cout + r0) * hw : yg,
+        const rsrc_t ry = make_rsrc_n(yg + ((size_t)b * p.Cout + r0) * hw, (unsigned)nrows * hw * SO);
+        const rsrc_t rm = make_rsrc_n(p.ymean != nullptr ? (const void*)(p.ymean + ((size_t)bq * p.Cout + r0) * hw) : (const void*)yg,
                                       (unsigned)nrows * hw * 4u);
         const unsigned s_in = tile % S;                // which of the pixel's samples this tile is
 #pragma unroll
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
                 myword = l31 == j ? word : myword;     // lane j (j + 32) keeps the word of register j's row (+ 4)
                 v = v > 0.f ? v : v * p.slope;
                 const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
-                buf_store(v, ry, o0[h] != PW_OOB ? o0[h] + ro : PW_OOB, 0);
+                logit_store<TO>(v, ry, o0[h] != PW_OOB ? (o0[h] + ro) / (4u / SO) : PW_OOB, 0);
                 if (p.ymean != nullptr) {
                     float* mp = macc + (rb * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * PS_NT + (ph0 + h) * 32 + l31;
                     const float m = s_in == 0 ? v : *mp + v;
@@ -602,7 +605,11 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
 // Same persistent tile walk and software pipeline as pw_fwd_kernel.
 using h4 = __attribute__((ext_vector_type(4))) _Float16;
 
-template <int KP, int TMODE>
+// MEAN: also the mean of y over the S samples of a pixel (p.ymean, here _Float16: what feeds the U-net, reference
+// sbmc/models.py:179) -- the walk is then unit-major (a workgroup takes the S samples of a pixel tile one after the other)
+// and every wave keeps the running sum of its own 32 x 64 block in registers: no pass over y for the mean (three
+// reductions over 7.5 GB per frame at 32 spp otherwise).
+template <int KP, int TMODE, bool MEAN = false>
 __global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
     constexpr int NT = 128;                            // pixels per tile
     constexpr int KQ = KP / 4;                         // channel quads
@@ -690,17 +697,26 @@ __global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
             bias[j] = buf_load(rbias, (unsigned)(r0 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * 4u, 0);
     }
 
+    // step v of this workgroup: sample v % S of unit first + (v / S) stride (S = 1 unless MEAN: plain tile order)
+    const unsigned S = MEAN ? (unsigned)p.S : 1u;
+    const unsigned nunits = p.ntiles / S;
+    auto tile_at = [&](unsigned v) -> unsigned {
+        const unsigned unit = first + (v / S) * stride;
+        return unit < nunits ? unit * S + v % S : 0xFFFFFFFFu;
+    };
     u32x2 pre[NPASS][4];
-    unsigned tile = first;
+    unsigned v = 0;
+    unsigned tile = tile_at(0);
     if (tile < p.ntiles) {
         issue_loads(tile, pre);
         commit(0, pre);
     }
     __syncthreads();
 
-    f32x16 out0, out1;
+    f32x16 out0, out1, m0, m1;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) out0[j] = out1[j] = 0.f;
+    for (int j = 0; j < 16; ++j) out0[j] = out1[j] = m0[j] = m1[j] = 0.f;
+    const float inv_s = 1.f / (float)S;
     unsigned b_prev = 0;
     unsigned o_prev0 = PW_OOB, o_prev1 = PW_OOB;       // byte offsets for 4-byte elements; halves sit at half of them
     auto store_prev = [&](int j) {
@@ -711,8 +727,8 @@ __global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
     };
 
     int buf = 0;
-    for (; tile < p.ntiles; tile += stride, buf ^= 1) {
-        const unsigned next = tile + stride;
+    for (; tile < p.ntiles; tile = tile_at(++v), buf ^= 1) {
+        const unsigned next = tile_at(v + 1);
         if (next < p.ntiles) issue_loads(next, pre);
 
         unsigned b, bq, p0;
@@ -764,6 +780,26 @@ __global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
             }
             out0[j] = v0 > 0.f ? v0 : v0 * p.slope;
             out1[j] = v1 > 0.f ? v1 : v1 * p.slope;
+        }
+        if constexpr (MEAN) {
+            const unsigned s_in = tile % S;
+            // (the mean is taken of the values as stored: rounded to half, like torch's mean over the half tensor)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float h0 = (float)(_Float16)out0[j], h1 = (float)(_Float16)out1[j];
+                m0[j] = s_in == 0 ? h0 : m0[j] + h0;
+                m1[j] = s_in == 0 ? h1 : m1[j] + h1;
+            }
+            if (s_in + 1 == S) {
+                _Float16* ymh = reinterpret_cast<_Float16*>(p.ymean);
+                const rsrc_t rm = make_rsrc_n(ymh + ((size_t)bq * p.Cout + r0) * hw, (unsigned)nrows * hw * 2u);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
+                    logit_store<_Float16>(m0[j] * inv_s, rm, o0 != PW_OOB ? (o0 + ro) / 2u : PW_OOB, 0);
+                    logit_store<_Float16>(m1[j] * inv_s, rm, o1 != PW_OOB ? (o1 + ro) / 2u : PW_OOB, 0);
+                }
+            }
         }
         b_prev = __builtin_amdgcn_readfirstlane(b);
         o_prev0 = o0;
@@ -1702,6 +1738,16 @@ using namespace sbmc;
 
 extern "C" int sbmc_pointwise_supported(int cin, int cout, long hw) { return pw_dims_ok(cin, cout, hw) ? 1 : 0; }
 
+// (half output: no per-pixel context form -- a chain's first layer with fp32 input has none in Multisteps, and it spills)
+template <int KPV, int WV, typename TO>
+static auto pws_pick(int t_mode) -> void (*)(PwFwdParams) {
+    if constexpr (sizeof(TO) == 4) {
+        return t_mode == 2 ? pw_fwd_s_kernel<KPV, 2, WV, TO> : (t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV, TO> : pw_fwd_s_kernel<KPV, 0, WV, TO>);
+    } else {
+        return t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV, TO> : pw_fwd_s_kernel<KPV, 0, WV, TO>;
+    }
+}
+
 template <typename TI, typename TO>
 static int pw_fwd_launch(const void* x, const float* w, const float* bias, const float* t, void* y, int b, int s,
                          int cin, int cout, long hw, int t_mode, int act, float slope, void* stream,
@@ -1714,15 +1760,17 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
     p.x = x; p.w = w; p.bias = bias; p.t = t; p.y = y;
     p.signs = signs;
     p.ymean = ymean;
+    // (the mean: the fp32 split-precision kernel, or the all-half kernel -- there ymean is a _Float16 tensor)
     if (ymean != nullptr && (s_mean < 1 || b % s_mean || cout > 128 || (t_mode && s != s_mean) ||
-                             sizeof(TI) != 4 || sizeof(TO) != 4)) return SBMC_HIP_EINVAL;
+                             !((sizeof(TI) == 4 && sizeof(TO) == 4) || (sizeof(TI) == 2 && sizeof(TO) == 2))))
+        return SBMC_HIP_EINVAL;
     p.B = b; p.S = t_mode ? s : (ymean != nullptr ? s_mean : 1); p.K = cin; p.Cout = cout;
     p.hw = (unsigned)hw;
-    if constexpr (sizeof(TI) == 4 && sizeof(TO) == 4) {
-        // fp32 in, fp32 out: the split-precision kernel on the bf16 matrix pipe (SBMC_HIP_PW_SPLIT=0 keeps the
+    if constexpr (sizeof(TI) == 4) {
+        // fp32 in (fp32 or half out): the split-precision kernel on the bf16 matrix pipe (SBMC_HIP_PW_SPLIT=0 keeps the
         // fp32-MFMA kernel: development knob, not part of the ABI)
         const char* knob = getenv("SBMC_HIP_PW_SPLIT");
-        if (!knob || atoi(knob) != 0) {
+        if ((!knob || atoi(knob) != 0) && (sizeof(TO) == 4 || (signs == nullptr && ymean == nullptr && t_mode != 2))) {
             p.tiles_per_plane = (unsigned)((hw + PS_NT - 1) / PS_NT);
             const unsigned long long nts = (unsigned long long)p.tiles_per_plane * (unsigned)b;
             if (nts > 0xFFFFFFFFull - 4096) return SBMC_HIP_EINVAL;
@@ -1744,8 +1792,7 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
             hipError_t se = hipSuccess;
 #define SBMC_PWS_LAUNCH2(KPV, WV)                                                                        \
     do {                                                                                                 \
-        auto kern = t_mode == 2 ? pw_fwd_s_kernel<KPV, 2, WV>                                             \
-                                : (t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV> : pw_fwd_s_kernel<KPV, 0, WV>); \
+        auto kern = pws_pick<KPV, WV, TO>(t_mode);                                                        \
         se = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);                 \
         if (se == hipSuccess)                                                                            \
@@ -1793,6 +1840,7 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
         // half in, half out: the f16 matrix pipe (weights rounded to half); SBMC_HIP_PW_F16MFMA=0 keeps
         // the fp32-MFMA kernel (development knob, not part of the ABI)
         const char* knob = getenv("SBMC_HIP_PW_F16MFMA");
+        if (ymean != nullptr && knob && atoi(knob) == 0) return SBMC_HIP_EINVAL;      // (the fp32-MFMA kernel writes no mean)
         if (!knob || atoi(knob) != 0) {
             const size_t hlds = (size_t)2 * (kp / 4) * 128 * 8;
             unsigned hgrid = (unsigned)(2 * cus) / unit * unit;      // two workgroups per CU when they fit
@@ -1800,7 +1848,9 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
             if (hgrid < unit) hgrid = unit;
 #define SBMC_PWH_LAUNCH(KPV)                                                                             \
     do {                                                                                                 \
-        auto kern = t_mode == 2 ? pw_fwd_h_kernel<KPV, 2> : (t_mode == 1 ? pw_fwd_h_kernel<KPV, 1> : pw_fwd_h_kernel<KPV, 0>); \
+        auto kern = ymean != nullptr                                                                      \
+            ? (t_mode == 2 ? pw_fwd_h_kernel<KPV, 2, true> : (t_mode == 1 ? pw_fwd_h_kernel<KPV, 1, true> : pw_fwd_h_kernel<KPV, 0, true>)) \
+            : (t_mode == 2 ? pw_fwd_h_kernel<KPV, 2> : (t_mode == 1 ? pw_fwd_h_kernel<KPV, 1> : pw_fwd_h_kernel<KPV, 0>)); \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds);                  \
         if (e == hipSuccess)                                                                             \
@@ -1864,6 +1914,15 @@ extern "C" int sbmc_pointwise_fwd_f16(const void* x, int x_is_half, const float*
     if (x_is_half)
         return pw_fwd_launch<_Float16, _Float16>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream);
     return pw_fwd_launch<float, _Float16>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream);
+}
+
+// all-half layer that also writes ymean [b / s_mean, cout, hw] (_Float16): the mean of y over groups of s_mean images
+extern "C" int sbmc_pointwise_fwd_mean_f16(const void* x, const float* w, const float* bias, const float* t, void* y,
+                                           void* ymean, int s_mean, int b, int s, int cin, int cout, long hw, int t_mode,
+                                           int act, float slope, void* stream) {
+    if (!ymean) return SBMC_HIP_EINVAL;
+    return pw_fwd_launch<_Float16, _Float16>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream, nullptr,
+                                             static_cast<float*>(ymean), s_mean);
 }
 
 static unsigned pw_bwd_grid(int b, int s, long hw, unsigned* nunits_out) {

@@ -506,8 +506,17 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False, mean_s=0):
     if (mean_s and mean_s >= 1 and not half and _pw_split_enabled() and cout <= 128 and B % mean_s == 0
             and (t_mode == 0 or s == mean_s) and os.environ.get("SBMC_PW_FUSED_MEAN", "1") != "0"):
         ymean = th.empty(B // mean_s, cout, hw, dtype=th.float32, device=dev)
+    half_mean = (mean_s and mean_s >= 1 and half and x.dtype == th.float16 and cout <= 128 and B % mean_s == 0
+                 and (t_mode == 0 or s == mean_s) and os.environ.get("SBMC_PW_FUSED_MEAN", "1") != "0"
+                 and os.environ.get("SBMC_HIP_PW_F16MFMA", "1") != "0")
+    if half_mean:
+        ymean = th.empty(B // mean_s, cout, hw, dtype=th.float16, device=dev)
     with th.cuda.device(dev), _timed("pointwise_fwd%s %dx%d" % ("_f16" if half else "", cout, cin), dev):
-        if ymean is not None:
+        if half_mean:
+            rc = L.sbmc_pointwise_fwd_mean_f16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(t) if t is not None else None,
+                                               _lib.ptr(y), _lib.ptr(ymean), mean_s, B, s, cin, cout, hw, t_mode, act, slope,
+                                               _lib.current_stream(dev))
+        elif ymean is not None:
             rc = L.sbmc_pointwise_fwd_mean_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias),
                                                _lib.ptr(t) if t is not None else None, _lib.ptr(y),
                                                _lib.ptr(signs) if signs is not None else None, _lib.ptr(ymean), mean_s,

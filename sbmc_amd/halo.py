@@ -74,7 +74,7 @@ class HaloChannel(object):
         if timeout_s is None:
             # (a wait that runs into it poisons the mailbox: every later wait of the step returns at once, the host
             # raises at its next status read -- csrc/halo.hip wait_reached)
-            timeout_s = float(os.environ.get("SBMC_HALO_TIMEOUT_S", "30"))
+            timeout_s = float(os.environ.get("SBMC_HALO_TIMEOUT_S", "120"))
         self.timeout_ticks = int(timeout_s * TICKS_PER_SECOND)
         self.bytes = self.lib.sbmc_halo_bytes(self.slot_bytes, self.nslots)
         base = ctypes.c_void_p()
