@@ -234,14 +234,11 @@ def validate_sharded(model, runner, loss_fn, batch, part, H, W, S, device):
     from sbmc_amd import dist as sdist
     from sbmc_amd.utils import crop_like
     sgd = th.optim.SGD(model.parameters(), lr=0.0)
-    failed, loss = 0.0, None
+    loss = None
     try:
         loss = float(runner.train_step(sgd, loss_fn, batch))
-    except RuntimeError as e:
-        failed = 1.0
-        runner.transport_note = "first sharded step failed: %s" % e
-    if float(sdist._all_reduce_sum(th.tensor([failed]), part).cpu().item()) > 0:
-        runner.settle_transport()
+    except sdist.HaloTimeout as e:              # (every rank gets it together and has settled the transport already)
+        runner.transport_note = (runner.transport_note or "") + " [first sharded step: %s]" % e
         loss = float(runner.train_step(sgd, loss_fn, batch))
     out = {"sharded_loss": loss, "single_gpu_loss": None, "rel_diff": None, "bound": 1e-5}
     if S * H * W > 30e6:
@@ -502,7 +499,12 @@ def main():
                 raise SystemExit(3)
 
             def step():
-                runner.train_step(opt, loss_fn, batch)
+                try:
+                    runner.train_step(opt, loss_fn, batch)
+                except sdist.HaloTimeout:
+                    # (raised on every rank together; the ranks have left the IPC transport: the step is repeated
+                    # over torch.distributed P2P and the line says so in `transport` / `transport_note`)
+                    runner.train_step(opt, loss_fn, batch)
         dt = timed(step, warmup, steps, timings if world == 1 else None, events_inside=False)
         med_s, spread = timed.median, timed.spread
         model_timings = timings

@@ -560,6 +560,9 @@ SBMC_API int sbmc_halo_open(const unsigned char *handle, void **base);
 SBMC_API int sbmc_halo_close(void *peer_base);
 /* reads the time-out word of a mailbox (synchronous 4-byte copy: call at a synchronisation point) */
 SBMC_API int sbmc_halo_status(void *box, unsigned *err);
+/* the same word as a float (1: some wait has timed out, 0: none) written to device memory ON THE STREAM: the flag can
+ * ride in a collective, so that every rank learns of a time-out at the same point of its step */
+SBMC_API int sbmc_halo_status_to(void *box, float *dst, void *stream);
 /* sends src_up to the mailbox up_box and src_down to down_box (a NULL box: no such neighbour).  amax (or NULL):
  * the device word with the bit pattern of the largest magnitude of the tensor the rows are cut from (what
  * sbmc_conv3x3_* scale by); it travels with the message. */

@@ -92,6 +92,7 @@ SYMBOLS = (
     "sbmc_halo_open",
     "sbmc_halo_close",
     "sbmc_halo_status",
+    "sbmc_halo_status_to",
     "sbmc_halo_put",
     "sbmc_halo_get",
     "sbmc_halo_merge_state_fwd_f32",
@@ -255,6 +256,7 @@ def lib():
     handle.sbmc_halo_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(p)]
     handle.sbmc_halo_close.argtypes = [p]
     handle.sbmc_halo_status.argtypes = [p, ctypes.POINTER(u)]
+    handle.sbmc_halo_status_to.argtypes = [p, p, p]
     handle.sbmc_halo_put.argtypes = [p] * 5 + [ll, ll, ll, u, u, i, ll, ll, p, p]
     handle.sbmc_halo_get.argtypes = [p] * 7 + [i, ll, ll, ll, ll, p, p, ll, ll, ll, ll, u, u, i, ll, ll, p, p]
     handle.sbmc_wbank_forward_f32.argtypes = [p, i, p]

@@ -328,6 +328,11 @@ __global__ void __launch_bounds__(THREADS) merge_bwd_kernel(MergeBwdArgs a) {
     for (int j = 0; j < C + 2; ++j) a.gext[(((size_t)n * (C + 2) + j) * hd + a.top + row) * a.w + x] = gs.v[j];
 }
 
+// *dst = 1 if a wait of this mailbox has timed out, else 0 (on the stream: the flag can ride in a collective)
+__global__ void status_to_kernel(char* box, float* dst) {
+    *dst = __hip_atomic_load(word(box, OFF_ERR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 ? 1.f : 0.f;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static inline unsigned blocks_for(unsigned units) {
@@ -397,6 +402,12 @@ int sbmc_halo_status(void* box, unsigned* err) {
     const hipError_t e = hipMemcpy(err, static_cast<char*>(box) + OFF_ERR, 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) (void)hipGetLastError();
     return (int)e;
+}
+
+int sbmc_halo_status_to(void* box, float* dst, void* stream) {
+    if (box == nullptr || dst == nullptr) return SBMC_HIP_EINVAL;
+    hipLaunchKernelGGL(status_to_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), static_cast<char*>(box), dst);
+    return (int)hipGetLastError();
 }
 
 int sbmc_halo_put(void* box, void* up_box, void* down_box, const void* src_up, const void* src_down,
@@ -501,7 +512,12 @@ int sbmc_halo_get(void* box, void* up_box, void* down_box, void* dst_up, void* d
     a.body_total_units = body_dst ? (unsigned)(body_chunks * body_chunk_bytes / unit) : 0;
     // one grid: parts 0 / 1 = the two directions (halo_blocks blocks each: a few rows), 2 = the body (a plain
     // copy of the whole slab: enough blocks to stream at the HBM rate)
+    // (at most 16 workgroups per direction wait for a flag: a waiting workgroup holds its CU slot, and where several
+    // ranks share ONE device -- the 8-ranks-on-one-GPU dry runs -- waiting workgroups on every CU keep the other ranks'
+    // whole-CU convolution workgroups from ever starting: a resource deadlock no real node can have, but a cheap one to
+    // make unlikely)
     a.halo_blocks = blocks_for(a.total_units);
+    if (a.halo_blocks > 16) a.halo_blocks = 16;
     unsigned bx = (a.body_total_units + THREADS * 8 - 1) / (THREADS * 8);
     bx = bx > 2048 ? 2048 : bx;
     if (bx < a.halo_blocks) bx = a.halo_blocks;

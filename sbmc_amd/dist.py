@@ -34,10 +34,18 @@ import torch as th
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import _lib
 from . import functions as funcs
 from .utils import crop_like
 
-__all__ = ["SlabPartition", "halo_pad", "sharded_autoencoder", "ShardedDenoiser"]
+__all__ = ["SlabPartition", "halo_pad", "sharded_autoencoder", "ShardedDenoiser", "HaloTimeout"]
+
+
+class HaloTimeout(RuntimeError):
+    """Raised by `ShardedDenoiser.train_step` on EVERY rank of the partition, at the same point of the step, when any
+    rank's halo mailbox recorded a time-out during it (the flag rides in the last gradient bucket's all-reduce).  The
+    step's results are void, nothing was applied; the ranks have already left the IPC transport together
+    (`settle_transport`), so the caller may simply repeat the step -- it then runs over torch.distributed P2P."""
 
 
 class SlabPartition(object):
@@ -789,15 +797,17 @@ class ShardedDenoiser(object):
     BUCKET_BYTES = 48 << 20
 
     def _flat_grads(self):
-        """One flat fp32 buffer with a slot per parameter gradient plus one for the loss.  It is cut into
+        """One flat fp32 buffer: [halo status | a slot per parameter gradient | the loss].  It is cut into
         contiguous buckets at parameter boundaries (registration order: the backward fills the buffer from its
         end); a bucket's cross-rank sum starts when its last gradient arrives (post-accumulate hooks), so only
-        the last bucket's all-reduce is not hidden behind the rest of the backward."""
+        the last bucket's all-reduce is not hidden behind the rest of the backward.  The loss rides with the bucket
+        the backward completes first, the halo transport's time-out flag with the one it completes LAST (every
+        exchange of the step is behind it by then): all ranks learn of a time-out together."""
         if self._flat is None:
             self._params = [q for q in self.model.parameters() if q.requires_grad]
-            n = sum(q.numel() for q in self._params)
+            n = sum(q.numel() for q in self._params) + 1
             self._flat = th.zeros(n + 1, dtype=th.float32, device=self._params[0].device)
-            self._views, off = [], 0
+            self._views, off = [], 1
             self._buckets = []                       # [first param, last param + 1, first element, last element + 1]
             for i, q in enumerate(self._params):
                 self._views.append(self._flat[off:off + q.numel()].view_as(q))
@@ -805,6 +815,7 @@ class ShardedDenoiser(object):
                     self._buckets.append([i, i, off, off])
                 off += q.numel()
                 self._buckets[-1][1], self._buckets[-1][3] = i + 1, off
+            self._buckets[0][2] = 0                  # the halo status rides with the bucket the backward completes last
             self._buckets[-1][3] = n + 1             # the loss rides with the bucket the backward completes first
             self._bucket_of = {}
             for b, (i0, i1, _, _) in enumerate(self._buckets):
@@ -838,6 +849,11 @@ class ShardedDenoiser(object):
                 v.zero_()
             q.grad = v
         self._missing[b] = -1
+        if b == 0 and self.part.channel is not None and self._flat.is_cuda:
+            ch = self.part.channel
+            with th.cuda.device(ch.device):
+                _lib.check(ch.lib.sbmc_halo_status_to(ch.box, _lib.ptr(self._flat), _lib.current_stream(ch.device)),
+                           "sbmc_halo_status_to")
         work = _all_reduce_sum_start(self._flat[e0:e1], self.part)
         if work is not None:
             self._works.append(work)
@@ -872,9 +888,15 @@ class ShardedDenoiser(object):
             for work in self._works:
                 work.wait()
         total = flat[-1]
-        finite = th.isfinite(total).item()             # the step's one host synchronisation (reference guard)
-        self.check()                                   # (a 4-byte read right after it: did a halo wait time out?)
-        if not finite:
+        status, value = th.stack([flat[0], total]).tolist()     # the step's one host synchronisation
+        if status != 0:
+            # some rank's mailbox timed out during this step (its neighbour gone, or -- several ranks sharing ONE
+            # device in a dry run -- starved): every rank is here with the same flag.  Leave the transport together.
+            flat[0] = 0.0
+            self.settle_transport()
+            raise HaloTimeout("a halo mailbox wait timed out on %d rank(s) during this step; the ranks now exchange over "
+                              "torch.distributed P2P -- repeat the step" % int(round(status)))
+        if not (value == value and abs(value) != float("inf")):  # (reference guard, sbmc/interfaces.py:95-99)
             raise RuntimeError("non-finite loss")
         th.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
         optimizer.step()

@@ -140,8 +140,12 @@ def _fallback_worker(rank, world, port):
             th.cuda.synchronize(dev)
             with pytest.raises(RuntimeError):
                 runner.check()
-        assert runner.settle_transport() == "p2p"               # BOTH ranks drop the mailboxes together
-        assert part.channel is None and "fell back" in runner.transport_note
+        dist.barrier()          # (rank 0 must not start the next step -- and answer that wait -- before it has timed out)
+        # the next step: rank 1's waits return at once (its mailbox is poisoned), the flag rides in the last gradient
+        # bucket's all-reduce, and BOTH ranks raise at the same point, having left the mailboxes together
+        with pytest.raises(sdist.HaloTimeout):
+            runner.train_step(opt, loss_fn, slab)
+        assert runner.transport == "p2p" and part.channel is None and "fell back" in runner.transport_note
         second = float(runner.train_step(opt, loss_fn, slab))    # ... and the frame goes on over torch.distributed
         assert abs(second - first) <= 1e-6 * abs(first)
         for k, q in model.named_parameters():
