@@ -614,6 +614,8 @@ SBMC_API int sbmc_halo_merge_state_bwd_f32(const float *ext, const float *recv_u
 SBMC_API int sbmc_conv3x3_supported(int n, int h, int w, int cin, int cout);
 SBMC_API size_t sbmc_conv3x3_weights_bytes(int cin, int cout);
 SBMC_API int sbmc_conv3x3_absmax_f32(const float *x, long n, unsigned *out, void *stream);
+/* ... RAISING *out instead of setting it (atomic maximum with what it holds) */
+SBMC_API int sbmc_conv3x3_absmax_raise_f32(const float *x, long n, unsigned *out, void *stream);
 SBMC_API int sbmc_conv3x3_prepare_weights_f32(const float *w, long s_co, long s_ci, long s_ky, long s_kx,
                                      long storage_elems, int cin, int cout, int flip, void *wp, void *stream);
 /* Stream-K workspace (optional, `ws` below; NULL: whole tiles are dealt round-robin to the compute units): a launch whose

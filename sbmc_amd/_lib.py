@@ -103,6 +103,7 @@ SYMBOLS = (
     "sbmc_conv3x3_supported",
     "sbmc_conv3x3_weights_bytes",
     "sbmc_conv3x3_absmax_f32",
+    "sbmc_conv3x3_absmax_raise_f32",
     "sbmc_conv3x3_prepare_weights_f32",
     "sbmc_conv3x3_workspace_bytes",
     "sbmc_conv3x3_nhwc_f32",
@@ -270,6 +271,7 @@ def lib():
     handle.sbmc_conv3x3_supported.argtypes = [i] * 5
     handle.sbmc_conv3x3_weights_bytes.argtypes = [i, i]
     handle.sbmc_conv3x3_absmax_f32.argtypes = [p, lg, p, p]
+    handle.sbmc_conv3x3_absmax_raise_f32.argtypes = [p, lg, p, p]
     handle.sbmc_conv3x3_prepare_weights_f32.argtypes = [p, lg, lg, lg, lg, lg, i, i, i, p, p]
     handle.sbmc_conv3x3_workspace_bytes.argtypes = []
     handle.sbmc_conv3x3_nhwc_f32.argtypes = [p, p, p, p, i, i, i, i, i, p, p]

@@ -636,6 +636,17 @@ extern "C" int sbmc_conv3x3_absmax_f32(const float* x, long n, unsigned* out, vo
     return (int)hipGetLastError();
 }
 
+// the same, RAISING *out (an atomic maximum: *out keeps what it held if that is larger) -- the rows a neighbour sent
+// folded into the word of the slab they pad (sbmc_amd/dist.py, torch.distributed transport)
+extern "C" int sbmc_conv3x3_absmax_raise_f32(const float* x, long n, unsigned* out, void* stream) {
+    if (n < 0 || (n && !x) || !out || (uintptr_t)x % 16) return SBMC_HIP_EINVAL;
+    if (n == 0) return 0;
+    long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return (int)hipGetLastError();
+}
+
 extern "C" int sbmc_conv3x3_prepare_weights_f32(const float* w, long s_co, long s_ci, long s_ky, long s_kx,
                                                  long storage_elems, int cin, int cout, int flip, void* wp,
                                                  void* stream) {

@@ -218,6 +218,14 @@ class _HaloPad(th.autograd.Function):
             _exchange_into(part, _rows_nhwc(x, 0, r), _rows_nhwc(x, h - r, h),
                            _rows_nhwc(out, 0, top), _rows_nhwc(out, top + h, top + h + bot),
                            between=lambda: out[..., top:top + h, :].copy_(x))
+            if amax is not None:
+                # the padded map's scale for the 3 x 3 kernels: this slab's word raised to the received rows' magnitudes
+                # (two launches over a few rows instead of an absmax pass over the whole padded map)
+                with th.cuda.device(x.device):
+                    if top:
+                        funcs.raise_amax(amax, _rows_nhwc(out, 0, top))
+                    if bot:
+                        funcs.raise_amax(amax, _rows_nhwc(out, top + h, top + h + bot))
             return out
         from_up, from_down = _exchange(part, x[..., :r, :], x[..., -r:, :])
         if funcs._is_channels_last(x):
@@ -338,9 +346,11 @@ def halo_pad(x, r, part, nhwc_wire=False):
     travel in memory order and land in place."""
     if r == 0 or part.world == 1:
         return x
-    if part.channel is not None and nhwc_wire and funcs.wants_amax(x):
+    if nhwc_wire and x.dim() == 4 and funcs.wants_amax(x) and (
+            part.channel is not None or (x.shape[0] == 1 and dist.get_backend(part.group) == "nccl")):
         # the scale of the 3 x 3 convolution that reads the padded map: this slab's word, raised in place to the
-        # neighbours' by the exchange itself (a larger bound stays a bound for everyone else who holds the word)
+        # neighbours' -- by the exchange itself through the mailboxes, by two launches over the received rows through
+        # torch.distributed -- (a larger bound stays a bound for everyone else who holds the word)
         amax = funcs.ensure_amax(x)
         return funcs.tag_amax(_HaloPad.apply(x, r, part, nhwc_wire, amax), amax)
     return _HaloPad.apply(x, r, part, nhwc_wire)

@@ -1052,6 +1052,13 @@ def ensure_amax(t):
     return a
 
 
+def raise_amax(word, block):
+    """word := max(word, largest magnitude of `block`), on the device: `block` a dense run of fp32 values (a few halo
+    rows), `word` the magnitude word of the map they are attached to."""
+    _lib.check(_lib.lib().sbmc_conv3x3_absmax_raise_f32(_lib.ptr(block), block.numel(), _lib.ptr(word),
+                                                        _lib.current_stream(block.device)), "conv3x3_absmax_raise")
+
+
 def wants_amax(t):
     """Will a 3 x 3 convolution of csrc/conv3x3.hip scale this tensor by its largest magnitude?  (fp32,
     channels-last, the kernels not switched off.)"""
