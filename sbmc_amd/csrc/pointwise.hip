@@ -813,6 +813,143 @@ __global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The all-half forward for WIDE layers without a context term (128 < Cout <= 512: the 441-channel logits, reference
+// sbmc/models.py:98-102): pw_fwd_h_kernel gives every 128-row tile of the output a workgroup of its own, so the input
+// tile is fetched (through L2), transposed and written to LDS four times over, and the layer ran at 45 % of the rate
+// its bytes allow (3.76 ms at 720p x 8 spp, 15 ms at 32 spp).  Here ONE workgroup stages the tile once and walks the
+// row tiles: the weights of all of them stay in registers (half: 32 registers per tile), the B operands are re-read
+// from LDS per row tile, the outputs of one (tile, row tile) unit are stored between the MFMAs of the next.
+template <int KP>
+__global__ __launch_bounds__(512) void pw_fwd_hw_kernel(PwFwdParams p) {
+    constexpr int NT = 128;
+    constexpr int KQ = KP / 4;
+    constexpr int KS = KP / 8;
+    constexpr int NPASS = (KQ + 15) / 16;
+    constexpr int NR = 4;                              // row tiles of 128 output channels
+    const _Float16* xg = static_cast<const _Float16*>(p.x);
+    _Float16* yg = static_cast<_Float16*>(p.y);
+    extern __shared__ float4 pw_lds[];
+    u32x2* xs = reinterpret_cast<u32x2*>(pw_lds);      // [2][KQ][NT] entries of 4 halves
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int rb = wave & 3, ph = wave >> 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const unsigned hw = p.hw;
+    const unsigned first = blockIdx.x, stride = gridDim.x;
+    const int nr = (p.Cout + 127) / 128;               // row tiles in use
+    const unsigned pg = threadIdx.x & 31, sq = threadIdx.x >> 5;
+
+    auto issue_loads = [&](unsigned tile, u32x2 (&regs)[NPASS][4]) {
+        const unsigned b = tile / p.tiles_per_plane, p0 = (tile % p.tiles_per_plane) * NT;
+        const rsrc_t rx = make_rsrc_n(xg + (size_t)b * p.K * hw, (unsigned)p.K * hw * 2u);
+        const bool colok = p0 + 4 * pg < hw;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned k = 4u * (sq + 16u * i) + r;
+                regs[i][r] = __builtin_amdgcn_raw_buffer_load_b64(rx, (colok && k < (unsigned)p.K) ? (k * hw + p0 + 4 * pg) * 2u : PW_OOB, 0, 0);
+            }
+        }
+    };
+    auto commit = [&](int buf, const u32x2 (&regs)[NPASS][4]) {
+        u32x2* dst = xs + buf * (KQ * NT);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const unsigned q = sq + 16u * i;
+            if (q < (unsigned)KQ) {
+                const h4 a0 = __builtin_bit_cast(h4, regs[i][0]), a1 = __builtin_bit_cast(h4, regs[i][1]);
+                const h4 a2 = __builtin_bit_cast(h4, regs[i][2]), a3 = __builtin_bit_cast(h4, regs[i][3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h4 o;
+                    o[0] = a0[j]; o[1] = a1[j]; o[2] = a2[j]; o[3] = a3[j];
+                    dst[q * NT + 4 * pg + j] = __builtin_bit_cast(u32x2, o);
+                }
+            }
+        }
+    };
+
+    // weight rows of this wave for every row tile: a[rt][kk][i] = W[128 rt + 32 rb + lane % 32][8 kk + 4 (lane / 32) + i]
+    // (kept as packed words: as _Float16 vectors the compiler holds one half per register)
+    u32x2 a[NR][KS];
+    {
+        const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) {
+            const int row = rt * 128 + rb * 32 + l31;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                h4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 8 * kk + 4 * lhi + i;
+                    v[i] = (_Float16)buf_load(rw, (row < p.Cout && k < p.K) ? (unsigned)(row * p.K + k) * 4u : PW_OOB, 0);
+                }
+                a[rt][kk] = __builtin_bit_cast(u32x2, v);
+            }
+        }
+    }
+    const rsrc_t rbias = make_rsrc_n(p.bias, (unsigned)p.Cout * 4u);
+
+    u32x2 pre[NPASS][4];
+    unsigned tile = first;
+    if (tile < p.ntiles) {
+        issue_loads(tile, pre);
+        commit(0, pre);
+    }
+    __syncthreads();
+
+    int buf = 0;
+    for (; tile < p.ntiles; tile += stride, buf ^= 1) {
+        const unsigned next = tile + stride;
+        if (next < p.ntiles) issue_loads(next, pre);
+        const unsigned b = tile / p.tiles_per_plane, p0 = (tile % p.tiles_per_plane) * NT;
+        const unsigned col = p0 + ph * 64 + l31;
+        const u32x2* xb = xs + buf * (KQ * NT) + lhi * NT + ph * 64 + l31;
+#pragma unroll
+        for (int rt = 0; rt < NR; ++rt) {
+            if (rt < nr) {
+                const int r0 = rt * 128 + rb * 32;
+                const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
+                const unsigned o0 = (col < hw && nrows > 0) ? (4u * lhi * hw + col) * 4u : PW_OOB;
+                const unsigned o1 = (col + 32 < hw && nrows > 0) ? (4u * lhi * hw + col + 32) * 4u : PW_OOB;
+                f32x16 acc0, acc1;
+                // (an opaque zero in the scalar offset: the bias values are the same for every pixel tile, and hoisted out of
+                // the tile loop they would be 64 live registers -- 39 spilled; reloaded per unit they are cache hits)
+                unsigned z;
+                asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float v = buf_load(rbias, (unsigned)(r0 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * 4u, z);   // (rows >= Cout: 0)
+                    acc0[j] = v;
+                    acc1[j] = v;
+                }
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const h4 b0 = __builtin_bit_cast(h4, xb[(2 * kk) * NT]);
+                    const h4 b1 = __builtin_bit_cast(h4, xb[(2 * kk) * NT + 32]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(h4, a[rt][kk]), b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(h4, a[rt][kk]), b1, acc1, 0, 0, 0);
+                }
+                // (stored right away: the workgroup's other waves and the CU's second wave per SIMD keep the matrix pipe
+                // busy meanwhile; holding a unit's outputs back for the next unit's MFMAs costs 32 registers = spills here)
+                const rsrc_t ry = make_rsrc_n(yg + ((size_t)b * p.Cout + r0) * hw, (unsigned)nrows * hw * 2u);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
+                    const float v0 = acc0[j] > 0.f ? acc0[j] : acc0[j] * p.slope;
+                    const float v1 = acc1[j] > 0.f ? acc1[j] : acc1[j] * p.slope;
+                    logit_store<_Float16>(v0, ry, o0 != PW_OOB ? (o0 + ro) / 2u : PW_OOB, 0);
+                    logit_store<_Float16>(v1, ry, o1 != PW_OOB ? (o1 + ro) / 2u : PW_OOB, 0);
+                }
+            }
+        }
+        if (next < p.ntiles) commit(buf ^ 1, pre);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of the layer in ONE pass over gy, y and x (cout <= 128):
 //   gz = gy * act'(y)                      (never written to HBM)
 //   gx[b]  = w^T @ gz[b]                    (MFMA, reduction over cout)
@@ -1843,6 +1980,29 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
         if (ymean != nullptr && knob && atoi(knob) == 0) return SBMC_HIP_EINVAL;      // (the fp32-MFMA kernel writes no mean)
         if (!knob || atoi(knob) != 0) {
             const size_t hlds = (size_t)2 * (kp / 4) * 128 * 8;
+            const char* wknob = getenv("SBMC_HIP_PW_FWD_WIDE");
+            if (cout > 128 && cout <= 512 && t_mode == 0 && ymean == nullptr && (!wknob || atoi(wknob) != 0)) {
+                // wide layer (the 441-channel logits): one workgroup per pixel tile walks all row tiles
+                unsigned wgrid = (unsigned)cus;
+                if ((unsigned long long)wgrid > nt) wgrid = (unsigned)nt;
+#define SBMC_PWHW_LAUNCH(KPV)                                                                            \
+    do {                                                                                                 \
+        auto kern = pw_fwd_hw_kernel<KPV>;                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)hlds);                  \
+        if (e == hipSuccess)                                                                             \
+            hipLaunchKernelGGL(kern, dim3(wgrid), dim3(512), hlds, (hipStream_t)stream, p);              \
+    } while (0)
+                switch (kp) {
+                    case 32: SBMC_PWHW_LAUNCH(32); break;
+                    case 64: SBMC_PWHW_LAUNCH(64); break;
+                    case 96: SBMC_PWHW_LAUNCH(96); break;
+                    default: SBMC_PWHW_LAUNCH(128); break;
+                }
+#undef SBMC_PWHW_LAUNCH
+                if (e != hipSuccess) return (int)e;
+                return (int)hipGetLastError();
+            }
             unsigned hgrid = (unsigned)(2 * cus) / unit * unit;      // two workgroups per CU when they fit
             if (hgrid > need) hgrid = (unsigned)need;
             if (hgrid < unit) hgrid = unit;
