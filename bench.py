@@ -493,6 +493,7 @@ def main():
             runner = sdist.ShardedDenoiser(model, part)
             sync()      # (the ranks finish building their slabs seconds apart: the first exchange must not wait for that)
             validation = validate_sharded(model, runner, loss_fn, batch, part, H, W, S, device)
+            sync()      # (rank 0 has just drawn and denoised the whole frame alone: nobody's exchange waits through that)
             if rank == 0 and validation["rel_diff"] is not None and validation["rel_diff"] > 1e-3:
                 # (1e-5 is the bar and is reported; beyond 1e-3 the sharded step is WRONG: no number is printed)
                 print(json.dumps({"error": "sharded step disagrees with the single-GPU step", "validation": validation}))
