@@ -24,6 +24,7 @@
 namespace sbmc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
@@ -966,6 +967,7 @@ __global__ __launch_bounds__(512) void pw_fwd_hw_kernel(PwFwdParams p) {
 #endif
 constexpr int PB_NT = 64;
 constexpr int PB_PITCH = 66;
+constexpr int PB_PITCH_N = 82;      // gz tile of pw_bwd_kernel's NARROW form
 
 // 4 consecutive pixels of one row as they sit in HBM: 16 bytes of float or 8 bytes of _Float16
 template <typename T> struct Pack4 { using type = u32x4; };
@@ -1042,11 +1044,18 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     // gx of a tile is stored right away.  (PW_BWD_PIPE = 1 holds it back and stores it between the MFMAs of
     // the next tile, as the forward does with y: here that costs spills, see the knob.)
     constexpr bool PIPE = PW_BWD_PIPE && !TPIX && !GM;
+    // NARROW (split gw with a context or mean gradient, which keep 16 more registers alive): the gx product as
+    // 16 x 16 x 4 MFMAs, a wave owning 16 rows of K over all 64 pixels -- w^T is then spread over the 8 waves
+    // without a copy (32 instead of 64 registers; same matrix-pipe cycles, twice the 4-byte LDS reads).  Its
+    // B operand (4 rows x 16 pixels per read) wants the rows 16 or 18 banks apart; 18 keeps the staging's
+    // 8-byte stores conflict-free as well.
+    constexpr bool NARROW = GWS && DX && (TPIX || GM);
+    constexpr int GP = NARROW ? PB_PITCH_N : PB_PITCH;   // floats per row of the fp32 gz tile
     extern __shared__ float4 pw_lds[];
     float* lds = reinterpret_cast<float*>(pw_lds);
     constexpr int BUF = (128 + KP) * PB_PITCH;          // floats per pipeline stage: gz tile, then x tile
     // GWS: one stage -- fp32 gz tile, then the bf16 images of gz and x ([3][128][PBS_PITCH], [3][KP][PBS_PITCH] halves)
-    _Float16* gzn = reinterpret_cast<_Float16*>(lds + 128 * PB_PITCH);
+    _Float16* gzn = reinterpret_cast<_Float16*>(lds + 128 * GP);
     _Float16* xn = gzn + 3 * 128 * PBS_PITCH;
     constexpr int NB = KP / 32;                         // 32-column blocks of gw
     constexpr int NX = KP / 32;                         // staging passes of the x tile
@@ -1061,8 +1070,17 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     const unsigned c4 = (threadIdx.x & 15) * 4, srow = threadIdx.x >> 4;
 
     // w^T rows of this wave as MFMA A-operands for gx: a2[kk] = w[2 kk + lane / 32][32 rb + lane % 32]
-    float a2[DX ? 64 : 1];
-    if (DX) {
+    // (NARROW: a2[kk] = w[4 kk + lane / 16][16 wave + lane % 16])
+    float a2[DX ? (NARROW ? 32 : 64) : 1];
+    if constexpr (NARROW) {
+        const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
+        const int k = wave * 16 + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const int co = 4 * kk + (lane >> 4);
+            a2[kk] = buf_load(rw, (co < p.Cout && k < p.K) ? (unsigned)(co * p.K + k) * 4u : PW_OOB, 0);
+        }
+    } else if (DX) {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
         const int k = rb * 32 + l31;
 #pragma unroll
@@ -1193,7 +1211,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             if (TPIX) {
                 gts[i].x += gv.x; gts[i].y += gv.y; gts[i].z += gv.z; gts[i].w += gv.w;
             }
-            float2* d = reinterpret_cast<float2*>(gzs + (srow + 32 * i) * PB_PITCH + c4);
+            float2* d = reinterpret_cast<float2*>(gzs + (srow + 32 * i) * GP + c4);
             d[0] = make_float2(gv.x, gv.y);
             d[1] = make_float2(gv.z, gv.w);
             if constexpr (GWS) {
@@ -1278,7 +1296,24 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 
         // ---- gx tile: rows 32 rb .. of K, pixels 32 ph ..; reduction over cout
         f32x16 acc_x;
-        if (DX) {
+        f32x4 acc_n[NARROW ? 4 : 1];                    // NARROW: rows 16 wave .. of K, pixel blocks of 16
+        if constexpr (NARROW) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) acc_n[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* gb = gzs + (lane >> 4) * GP + (lane & 15);
+#pragma unroll
+            for (int grp = 0; grp < 8; ++grp) {
+#pragma unroll
+                for (int kk = grp * 4; kk < grp * 4 + 4; ++kk) {
+#pragma unroll
+                    for (int pb = 0; pb < 4; ++pb)
+                        acc_n[pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kk], gb[(4 * kk) * GP + 16 * pb],
+                                                                         acc_n[pb], 0, 0, 0);
+                }
+                if (grp == 3 && nvalid) issue_x(nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (DX) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc_x[j] = 0.f;
             const float* gb = gzs + lhi * PB_PITCH + ph * 32 + l31;
@@ -1298,7 +1333,20 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             }
         }
         auto store_gx = [&]() {
-            if (DX) {
+            if constexpr (NARROW) {
+                const int r0 = wave * 16;
+                const int nr = p.K - r0 < 16 ? (p.K - r0 > 0 ? p.K - r0 : 0) : 16;
+                const rsrc_t rgx = make_rsrc_n(gx_g + ((size_t)b * p.K + r0) * hw, (unsigned)nr * hw * SX);
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) {
+                    const unsigned col = p0 + 16 * pb + (lane & 15);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned row = 4 * (lane >> 4) + j;
+                        logit_store<TXT>(acc_n[pb][j], rgx, (col < hw && nr > 0) ? (row * hw + col) * SX : PW_OOB, 0);
+                    }
+                }
+            } else if (DX) {
                 const unsigned col = p0 + ph * 32 + l31;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) out[j] = acc_x[j];
@@ -2188,26 +2236,33 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
     size_t lds = (size_t)2 * (128 + kp) * PB_PITCH * sizeof(float);
     // fp32 tensors: the weight-gradient product on the bf16 matrix pipe (split precision); SBMC_HIP_PW_GWS=0 keeps
     // the all-fp32-MFMA kernel (development knob)
-    // (not with a per-pixel context gradient or a mean gradient: 16 more live registers make that form spill
-    // 15-17 VGPRs and measure 8 % slower than the fp32-MFMA kernel; plain layers: 4.41 -> 3.96 ms at 720p x 8 spp)
+    // (plain layers: 4.41 -> 3.96 ms at 720p x 8 spp.  With a per-pixel context gradient or a mean gradient -- 16
+    // more live registers -- the kernel's NARROW gx product makes the room; SBMC_HIP_PW_GWS=1 keeps those on the
+    // all-fp32-MFMA kernel, 2 = default splits them too)
     bool gws = false;
     if constexpr (sizeof(TA) == 4 && sizeof(TXT) == 4) {
         const char* gknob = getenv("SBMC_HIP_PW_GWS");
-        gws = (!gknob || atoi(gknob) != 0) && t_mode != 2 && !gmean;
-        if (gws) lds = (size_t)128 * PB_PITCH * sizeof(float) + (size_t)3 * (128 + kp) * PBS_PITCH * 2;
+        const int gmode = gknob ? atoi(gknob) : 2;
+        const bool side = t_mode == 2 || gmean;
+        gws = gmode != 0 && (!side || gmode >= 2);
+        if (gws)
+            lds = (size_t)128 * ((side && gx) ? PB_PITCH_N : PB_PITCH) * sizeof(float) +
+                  (size_t)3 * (128 + kp) * PBS_PITCH * 2;
     }
+#define SBMC_PWB_PICK(KPV, DXV, TPV, SGV, GWSV)                                                          \
+    ((gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, float, float, SGV, GWSV>                     \
+                     : pw_bwd_kernel<KPV, DXV, TPV, false, float, float, SGV, GWSV>)
 #define SBMC_PWB_LAUNCH2(KPV, DXV, TPV)                                                                  \
     do {                                                                                                 \
         auto kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, TA, TXT>                       \
                                     : pw_bwd_kernel<KPV, DXV, TPV, false, TA, TXT>;                       \
         if constexpr (sizeof(TA) == 4 && sizeof(TXT) == 4) {                                             \
-            if (y_is_signs && gws && !TPV && !gmean)                                                     \
-                kern = pw_bwd_kernel<KPV, DXV, false, false, float, float, true, true>;                  \
-            else if (y_is_signs)                                                                         \
-                kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, float, float, true>         \
-                                       : pw_bwd_kernel<KPV, DXV, TPV, false, float, float, true>;         \
-            else if (gws && !TPV && !gmean)                                                              \
-                kern = pw_bwd_kernel<KPV, DXV, false, false, float, float, false, true>;                 \
+            if (y_is_signs) {                                                                            \
+                if (gws) kern = SBMC_PWB_PICK(KPV, DXV, TPV, true, true);                                \
+                else     kern = SBMC_PWB_PICK(KPV, DXV, TPV, true, false);                               \
+            } else if (gws) {                                                                            \
+                kern = SBMC_PWB_PICK(KPV, DXV, TPV, false, true);                                        \
+            }                                                                                            \
         }                                                                                                \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
@@ -2227,6 +2282,7 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
     }
 #undef SBMC_PWB_LAUNCH
 #undef SBMC_PWB_LAUNCH2
+#undef SBMC_PWB_PICK
     if (e != hipSuccess) return (int)e;
     return (int)hipGetLastError();
 }
