@@ -49,6 +49,12 @@ H, W, S, K = 720, 1280, 8, 21
 if "--4k" in sys.argv:                      # BASELINE configs[3]: 3840x2160 (one rank of 8 fits one GPU)
     sys.argv.remove("--4k")
     H, W = 2160, 3840
+if "--quarter" in sys.argv:                 # 640x360: the GPU's share shrinks 4x, the host's does not
+    sys.argv.remove("--quarter")
+    H, W = 368, 640
+HOST_TIME = "--host-time" in sys.argv
+if HOST_TIME:
+    sys.argv.remove("--host-time")
 full = bench.make_model_inputs(H, W, S, dev, seed=1234)
 for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     th.manual_seed(0)
@@ -75,11 +81,40 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         step = lambda: runner.train_step(opt, loss_fn, batch)
     for _ in range(2):
         step()
+    # (--host-time: how long the HOST takes to enqueue a step, up to its one synchronisation -- `th.stack` of the status
+    # and the loss in ShardedDenoiser.train_step: a step cannot be shorter than that)
+    host = []
+    if HOST_TIME and world > 1:
+        orig_stack = th.stack
+        begun = [0.0]
+
+        def stack_mark(*a, **k):
+            host.append(time.time() - begun[0])
+            return orig_stack(*a, **k)
+        th.stack = stack_mark
+        inner = step
+        step = lambda: (begun.__setitem__(0, time.time()), inner())[1]
+    if "SBMC_RANK_COST_CPROFILE" in os.environ:       # where the host's time goes: cProfile of 3 steps
+        import cProfile, pstats
+        th.cuda.synchronize()
+        prof = cProfile.Profile()
+        prof.enable()
+        for _ in range(3):
+            step()
+        th.cuda.synchronize()
+        prof.disable()
+        st = pstats.Stats(prof, stream=open(os.environ["SBMC_RANK_COST_CPROFILE"], "w"))
+        st.sort_stats("tottime").print_stats(70)
+        st.sort_stats("cumulative").print_stats(90)
     th.cuda.synchronize(); t0 = time.time()
     for _ in range(3):
         step()
     th.cuda.synchronize()
     ms = (time.time() - t0) / 3 * 1e3
+    if host:
+        th.stack = orig_stack
+        # (two calls per step: the step's own, then one inside clip_grad_norm_ -- after the synchronisation)
+        print("host enqueue up to the step's synchronisation: %s ms" % ", ".join("%.1f" % (1e3 * h) for h in host[-6::2]), flush=True)
     print("world %d rank %d rows %d%s: %.1f ms/step" % (world, rank, part.rows,
                                                          " (exchanges through IPC mailboxes to self)" if IPC_SELF else " (exchanges over RCCL to self)" if RCCL_SELF else "", ms), flush=True)
     del model, opt, runner, batch
