@@ -30,6 +30,7 @@
 // delivers 128 B / cycle to the whole CU, so operands must be re-used from registers -- 12 operand reads per 24
 // MFMAs here (0.5 of the LDS bandwidth at full matrix rate).
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/sbmc_hip.h"
@@ -122,7 +123,31 @@ constexpr int CV_WS_HDR = 4096;
 // go to this workgroup's slab RAW instead -- same stores, other descriptor and offsets, selected, not branched to: a
 // branch around the epilogue (or a second copy of it) costs the main loop 140 spilled registers. ----
 struct CvTile { int n, y0, x0, ct; };
-template <bool EPI, bool HF>
+
+// lanes LANE and LANE + 32 of v = the halves of a ballot (v_writelane_b32 with an inline-constant lane; the s_nop: a VALU
+// reading a scalar register a VALU has just written needs two wait states on gfx940+, and the compiler's hazard
+// recognizer does not look into inline assembly)
+template <int LANE>
+__device__ __forceinline__ void cv_write_lanes(unsigned& v, unsigned long long ballot) {
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+        : "+v"(v) : "s"((unsigned)ballot), "s"((unsigned)(ballot >> 32)), "n"(LANE), "n"(LANE + 32));
+}
+template <class F, int... J>
+__device__ __forceinline__ void cv_unrolled_impl(F&& f, std::integer_sequence<int, J...>) {
+    (f(std::integral_constant<int, J>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in its body
+template <int N, class F>
+__device__ __forceinline__ void cv_unrolled(F&& f) { cv_unrolled_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// SK: the launch may park (stream-K): only then is the parking store in the code at all.
+// The epilogue runs with the matrix pipe idle and one wave per SIMD: its time is its instruction count.  Tiles whose 16
+// columns are all inside the image (every tile of the model's power-of-two widths) take the lean form: one lane offset
+// (two: registers 8 and 9 wrap around the tile's 16 columns in the upper half-wave), a scalar offset per (row, column)
+// and an immediate per channel block; rows beyond the image select an empty descriptor per row pair; the sign words
+// of 16 registers are gathered in a register (lane r / r + 32 <- the ballot's halves) and leave in ONE store; the
+// largest magnitude is a masked max.  ~12 instructions per accumulator register instead of ~35.
+template <bool EPI, bool HF, bool SK>
 __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4][2], const CvTile& t, const bool park,
                                           float* park_slab, const float oscale, unsigned& amax_run) {
     constexpr unsigned ES = HF ? 2u : 4u;
@@ -130,9 +155,11 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
     const int l31 = lane & 31, lhi = lane >> 5;
     const int mh = wave & 1, nh = wave >> 1;
     const bool sign_lane = l31 == 0;
-    const rsrc_t rpark = cv_rsrc(park ? park_slab : static_cast<float*>(p.ws), park ? (unsigned)CV_SLAB * 4u : 0u);
+    (void)sign_lane;
+    const bool parking = SK && park;
+    const rsrc_t rpark = cv_rsrc(parking ? park_slab : static_cast<float*>(p.ws), parking ? (unsigned)CV_SLAB * 4u : 0u);
     char* yb = static_cast<char*>(p.y) + ((((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)p.Cout + t.ct * 128) * ES;
-    const rsrc_t ry = cv_rsrc(yb, 0x7FFFFFF0u);
+    const rsrc_t ry = cv_rsrc(yb, parking ? 0u : 0x7FFFFFF0u);
     float bv[2] = {0.f, 0.f};
     rsrc_t rs = ry;
     if constexpr (EPI) {
@@ -140,7 +167,74 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
         for (int ni = 0; ni < 2; ++ni) bv[ni] = p.bias[t.ct * 128 + nh * 64 + ni * 32 + l31];
         // sign words of this tile's first pixel and output-channel tile: word = pixel (Cout / 32) + channel / 32
         rs = cv_rsrc(p.signs + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)(p.Cout / 32) + t.ct * 4,
-                     p.signs ? 0x7FFFFFF0u : 0u);
+                     (p.signs && !parking) ? 0x7FFFFFF0u : 0u);
+    }
+    if (t.x0 + CV_TS <= p.W) {
+        // ---- every column inside ----
+        const rsrc_t rnone = cv_rsrc(yb, 0u);
+        const unsigned lb = (unsigned)((4 * lhi) * p.Cout + nh * 64 + l31) * ES;
+        // registers 8, 9: columns 14 | 15 in the lower half-wave, (14 | 15) + 4 - 16 = 2 | 3 in the upper: based at 2 | 3
+        // (a lane offset must not go negative: it is range-checked BEFORE the scalar offset is added)
+        const unsigned lbw = (unsigned)((lhi ? 0 : 12) * p.Cout + nh * 64 + l31) * ES;
+        const int rows_in = p.H - t.y0 - mh * 8;                               // rows of this wave's 8 inside the image
+        // sign words: lane j (j < 16) / 32 + j holds register j's word: pixel (j / 8, column of register j)
+        unsigned sgl = CV_OOB;
+        if constexpr (EPI) {
+            const int cj = (l31 & 3) + 8 * ((l31 >> 2) & 1) + 14 * ((l31 >> 3) & 1);
+            const int colj = (cj + 4 * lhi) & 15;
+            sgl = (unsigned)(((((l31 >> 3) & 1) * p.W + colj) * (p.Cout / 32) + nh * 2) * 4);
+        }
+        const unsigned amask_in = parking ? 0u : 0x7FFFFFFFu;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            unsigned sw[2] = {0u, 0u};
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                const bool gok = mi * 2 + rh < rows_in;                       // wave-uniform
+                const rsrc_t rg = gok ? ry : rnone;
+                const unsigned amask = gok ? amask_in : 0u;
+                const int row = mh * 8 + mi * 2 + rh;
+                cv_unrolled<8>([&](auto rc) {
+                    constexpr int r8 = decltype(rc)::value;
+                    const int r = rh * 8 + r8;
+                    const bool wraps = rh == 1 && r8 < 2;
+                    const int col0 = (((r8 & 3) + 8 * ((r8 >> 2) & 1) + 14 * rh) & 15) - (wraps ? 12 : 0);
+                    const unsigned vb = wraps ? lbw : lb;
+                    const unsigned so = (unsigned)((row * p.W + col0) * p.Cout) * ES;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        if constexpr (SK)
+                            buf_store(acc[mi][ni][r], rpark, (unsigned)tid * 4u, (unsigned)(((mi * 2 + ni) * 16 + r) * 1024));
+                        float v = acc[mi][ni][r] * oscale;
+                        if constexpr (EPI) {
+                            v += bv[ni];
+                            const bool pos = v > 0.f;
+                            const unsigned long long bal = __builtin_amdgcn_ballot_w64(pos);
+                            if (rh == 0) cv_write_lanes<r8>(sw[ni], bal);
+                            else cv_write_lanes<r8 + 8>(sw[ni], bal);
+                            v = pos ? v : v * p.slope;
+                            const unsigned a = __builtin_bit_cast(unsigned, v) & amask;
+                            amax_run = amax_run > a ? amax_run : a;
+                        }
+                        if constexpr (HF)
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rg,
+                                                                  vb + (unsigned)(ni * 32) * ES, so, 0);
+                        else
+                            buf_store(v, rg, vb + (unsigned)(ni * 32) * ES, so);
+                        acc[mi][ni][r] = 0.f;
+                    }
+                });
+            }
+            if constexpr (EPI) {
+                // lanes 0-15 / 32-47: the words of registers 0-15; row pair mi, row (l31 / 8) of it
+                const bool ok = l31 < 16 && mi * 2 + ((l31 >> 3) & 1) < rows_in;
+                const unsigned so = (unsigned)(((mh * 8 + mi * 2) * p.W) * (p.Cout / 32)) * 4u;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    __builtin_amdgcn_raw_buffer_store_b32(sw[ni], rs, ok ? sgl + (unsigned)ni * 4u : CV_OOB, so, 0);
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
@@ -153,8 +247,9 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
             const bool ok = t.y0 + row < p.H && t.x0 + col < p.W;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                const unsigned voff = (ok && !park) ? (unsigned)((row * p.W + col) * p.Cout + nh * 64 + ni * 32 + l31) * ES : CV_OOB;
-                buf_store(acc[mi][ni][r], rpark, (unsigned)tid * 4u, (unsigned)(((mi * 2 + ni) * 16 + r) * 1024));   // (empty descriptor unless parking)
+                const unsigned voff = ok ? (unsigned)((row * p.W + col) * p.Cout + nh * 64 + ni * 32 + l31) * ES : CV_OOB;
+                if constexpr (SK)
+                    buf_store(acc[mi][ni][r], rpark, (unsigned)tid * 4u, (unsigned)(((mi * 2 + ni) * 16 + r) * 1024));   // (empty descriptor unless parking)
                 float v = acc[mi][ni][r] * oscale;
                 if constexpr (EPI) {
                     v += bv[ni];
@@ -164,11 +259,11 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
                         // pixel's; no branch on `signs`: without them every lane's offset is out of range
                         const unsigned long long bal = __builtin_amdgcn_ballot_w64(pos);
                         const unsigned word = lhi ? (unsigned)(bal >> 32) : (unsigned)bal;
-                        const unsigned so = (ok && sign_lane && !park) ? (unsigned)((row * p.W + col) * (p.Cout / 32) + nh * 2 + ni) * 4u : CV_OOB;
+                        const unsigned so = (ok && sign_lane) ? (unsigned)((row * p.W + col) * (p.Cout / 32) + nh * 2 + ni) * 4u : CV_OOB;
                         __builtin_amdgcn_raw_buffer_store_b32(word, rs, so, 0, 0);
                     }
                     v = pos ? v : v * p.slope;
-                    if (ok && !park) {
+                    if (ok && !parking) {
                         const unsigned a = abits(v);
                         amax_run = amax_run > a ? amax_run : a;
                     }
@@ -249,7 +344,7 @@ __global__ __launch_bounds__(256) void conv3_fixup_kernel(Conv3Params p, unsigne
     const float cx = HF ? 1.f : cv_scale_of(*p.xmax);
     const float oscale = (1.f / cx) * (1.f / *p.wscale);
     unsigned amax_run = 0;
-    cv_finish<EPI, HF>(p, acc, t, false, nullptr, oscale, amax_run);
+    cv_finish<EPI, HF, false>(p, acc, t, false, nullptr, oscale, amax_run);
     if constexpr (EPI) {
         if (p.amax) amax_publish(amax_run, p.amax);
     }
@@ -260,7 +355,7 @@ __global__ __launch_bounds__(256) void conv3_fixup_kernel(Conv3Params p, unsigne
 // as it is (one plane, no split, no scale), the weights are the prepared weights' HIGH plane (f16 of the scaled
 // weight: the rounding autocast applies, with a power-of-two scale that is divided out again), ONE matrix product per
 // term instead of three.
-template <bool EPI, bool HF = false>
+template <bool EPI, bool HF = false, bool SK = false>
 __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     constexpr unsigned ES = HF ? 2u : 4u;              // bytes of an activation element
     extern __shared__ float4 cv_lds[];
@@ -288,7 +383,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     //     head in the workgroup's other slab.  conv3_fixup_kernel, the next launch, adds heads to tails in a fixed
     //     order and runs those tiles' epilogues: no flags, no waiting between workgroups, nothing that depends on which
     //     of them the dispatcher started first (a first version that combined inside the launch needed both).
-    const bool sk = p.ws != nullptr;
+    constexpr bool sk = SK;                              // (the launcher: SK <=> p.ws != nullptr)
     const unsigned G = gridDim.x, g = blockIdx.x;
     const unsigned long long U = (unsigned long long)p.ntiles * nchunks;
     unsigned first, stride, total, cc;
@@ -398,7 +493,6 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     unsigned amax_run = 0;
-    const bool sign_lane = l31 == 0;
     if (total == 0) return;
 
     // operands of one tap: A 4 m-blocks x 2 planes, B 2 n-blocks x 2 planes
@@ -506,7 +600,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         if (last) {
             // (stream-K: the tail of a tile whose head other workgroups hold is parked until this one's range is through)
             const bool park = sk && ti == 0 && c0 > 0;
-            cv_finish<EPI, HF>(p, acc, tcur, park, park ? slabs + (size_t)(G + g) * CV_SLAB : nullptr, oscale, amax_run);
+            cv_finish<EPI, HF, SK>(p, acc, tcur, park, park ? slabs + (size_t)(G + g) * CV_SLAB : nullptr, oscale, amax_run);
         }
         if (last) {
             tcur = tnext;
@@ -694,6 +788,9 @@ static int conv3_launch(const void* x, const unsigned* xmax, const void* wp, voi
     }
     auto kern = hf ? (epi ? conv3_kernel<true, true> : conv3_kernel<false, true>)
                    : (epi ? conv3_kernel<true, false> : conv3_kernel<false, false>);
+    if (p.ws != nullptr)
+        kern = hf ? (epi ? conv3_kernel<true, true, true> : conv3_kernel<false, true, true>)
+                  : (epi ? conv3_kernel<true, false, true> : conv3_kernel<false, false, true>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }

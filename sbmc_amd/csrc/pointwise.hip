@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include <cstring>
 #include <type_traits>
+#include <utility>
 #include "../../include/sbmc_hip.h"
 #include <stdlib.h>
 
@@ -308,11 +309,31 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// lanes LANE and LANE + 32 of v = the halves of a ballot (v_writelane_b32: this compiler has the readlane builtin only; the
+// lane is an inline constant -- the instruction reads one scalar register).  The s_nop: on gfx940+ a VALU that reads
+// a scalar register a VALU (the compare) has just written needs two wait states, and the compiler's hazard recognizer
+// does not look into inline assembly (without it the low word of some rows came out stale).
+template <int LANE>
+__device__ __forceinline__ void write_lanes(unsigned& v, unsigned long long ballot) {
+    asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+        : "+v"(v) : "s"((unsigned)ballot), "s"((unsigned)(ballot >> 32)), "n"(LANE), "n"(LANE + 32));
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in its body
+template <class F, int... J>
+__device__ __forceinline__ void unrolled_impl(F&& f, std::integer_sequence<int, J...>) {
+    (f(std::integral_constant<int, J>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void unrolled(F&& f) { unrolled_impl(f, std::make_integer_sequence<int, N>{}); }
+
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
 }
 
 constexpr int PS_NT = 64;           // pixels per tile of the split-precision kernels
+#ifndef PW_ABL
+#define PW_ABL 0                    // development: 1 = pw_fwd_s without its y stores, 2 = without its MFMAs, 3 = without the split
+#endif
 
 // WAVES: 8 (two waves per SIMD, 256 registers each; a wave owns 32 channels x 32 pixels) or 4 (one wave per
 // SIMD with the whole 512-entry register file -- accumulators in AccVGPRs --; a wave owns 32 channels x 64
@@ -320,7 +341,8 @@ constexpr int PS_NT = 64;           // pixels per tile of the split-precision ke
 // flight between the MFMAs instead of waiting for each operand.
 // TO: storage type of y (float; _Float16 for a chain's FIRST layer under fp16 activations -- fp32 network input in, half
 // out: until round 4 that layer ran on the fp32-MFMA kernel; no sign bits or mean in that form).
-template <int KP, int TMODE, int WAVES, typename TO = float>
+// MEAN: p.ymean is written (compile time: the epilogue has no branch on it).
+template <int KP, int TMODE, int WAVES, typename TO = float, bool MEAN = false>
 __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     constexpr unsigned SO = (unsigned)sizeof(TO);
     constexpr int KO = KP / 8;                         // channel octets
@@ -348,23 +370,38 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     const unsigned first = (slot / (unsigned)p.nrt) * NUM_XCD + g % NUM_XCD;
     const unsigned stride = gridDim.x / (unsigned)p.nrt;
     const unsigned S = (unsigned)p.S, nunits = p.ntiles / S;
-    auto tile_at = [&](unsigned v) -> unsigned {
-        const unsigned unit = first + (v / S) * stride;
-        return unit < nunits ? unit * S + v % S : 0xFFFFFFFFu;
+    // The walk is kept as a cursor that ADVANCES (sample, unit, the unit's pixel tile and image group): decoding
+    // step numbers by division cost ~450 scalar instructions and 96 SGPR spill moves per tile -- half of the
+    // loop's instructions, in a loop whose time is its instruction count.  The divisions left: four, before the loop.
+    struct Cur { unsigned s, unit, pt, bq; };
+    const unsigned tpp = p.tiles_per_plane;
+    const unsigned st_bq = stride / tpp, st_pt = stride % tpp;
+    auto advance = [&](Cur c) -> Cur {
+        c.s += 1;
+        if (c.s == S) {
+            c.s = 0;
+            c.unit += stride;
+            c.pt += st_pt;
+            c.bq += st_bq;
+            if (c.pt >= tpp) {
+                c.pt -= tpp;
+                c.bq += 1;
+            }
+        }
+        return c;
     };
+    auto live = [&](const Cur& c) -> bool { return c.unit < nunits; };
     const int r0 = rt * 128 + rb * 32;
     const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
 
-    auto tile_coords = [&](unsigned tile, unsigned& b, unsigned& bq, unsigned& p0) {
-        const unsigned s = tile % (unsigned)p.S, rest = tile / (unsigned)p.S;
-        const unsigned pt = rest % p.tiles_per_plane;
-        bq = rest / p.tiles_per_plane;
-        b = bq * (unsigned)p.S + s;
-        p0 = pt * PS_NT;
+    auto tile_coords = [&](const Cur& c, unsigned& b, unsigned& bq, unsigned& p0) {
+        bq = c.bq;
+        b = c.bq * S + c.s;
+        p0 = c.pt * PS_NT;
     };
     // staging role: pixel `lane` of the tile, channel octets wave + WAVES i.  One lane offset per tile, the row
     // offsets are scalar (the octet is the wave's); rows beyond K (padding up to KP) are zeros.
-    auto issue_loads = [&](unsigned tile, float (&regs)[NOCT][8]) {
+    auto issue_loads = [&](const Cur& tile, float (&regs)[NOCT][8]) {
         unsigned b, bq, p0;
         tile_coords(tile, b, bq, p0);
         const rsrc_t rx = make_rsrc_n(xg + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
@@ -418,12 +455,16 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     // load is never copied: a copy would wait for it), and the barrier orders LDS traffic only.  The split of
     // the next tile (registers -> LDS) is dealt out between the MFMAs of the k-steps.
     float preA[NOCT][8], preB[NOCT][8];
-    unsigned v = 0;
-    unsigned tile = tile_at(0);
-    if (tile < p.ntiles) {
+    Cur tile;
+    tile.s = 0;
+    tile.unit = first;
+    tile.pt = first % tpp;
+    tile.bq = first / tpp;
+    Cur next = advance(tile), next2 = advance(next);
+    if (live(tile)) {
         issue_loads(tile, preA);
         commit(0, preA);
-        if (tile_at(1) < p.ntiles) issue_loads(tile_at(1), preA);
+        if (live(next)) issue_loads(next, preA);
     }
     __syncthreads();
     // the mean over a pixel's samples: every wave accumulates its own 32 x 32 block of outputs in LDS
@@ -454,9 +495,7 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     // one tile; `cur` holds the NEXT tile's values (split and written to LDS stage buf ^ 1 during this one),
     // `fill` receives the loads of the tile after that
     auto step = [&](const float (&cur)[NOCT][8], float (&fill)[NOCT][8], const int buf) {
-        const unsigned next = tile_at(v + 1), next2 = tile_at(v + 2);
-        if (next2 < p.ntiles) issue_loads(next2, fill);
-        const bool more = next < p.ntiles;
+        if (live(next2)) issue_loads(next2, fill);
 
         unsigned b, bq, p0;
         tile_coords(tile, b, bq, p0);
@@ -513,6 +552,10 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
                     bm = xb[(KO + 2 * s) * PS_NT + 32 * h];
                     bl = xb[(2 * KO + 2 * s) * PS_NT + 32 * h];
                 }
+#if PW_ABL == 2
+                asm volatile("" :: "v"(bh), "v"(bm), "v"(bl));
+                continue;
+#endif
                 if constexpr (TWO) {
                     acc[h] = mfma_bf16(ah[s], bh, acc[h]);
                     small[h] = mfma_bf16(ah[s], bl, small[h]);
@@ -542,52 +585,76 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
                     if (TMODE == 1) add[j] += buf_load(rt1, ro, 0);
                 }
             }
-            if (more) {
+#if PW_ABL == 3
+            if (live(next) && s == KS - 1) {
 #pragma unroll
-                for (int u = 4 * NOCT * s / KS; u < 4 * NOCT * (s + 1) / KS; ++u) commit_unit(cur, u, buf ^ 1);   // in order
+                for (int i = 0; i < NOCT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) asm volatile("" :: "v"(cur[i][r]));
             }
+#else
+            // (no branch on `more`: behind the last tile this stages stale registers into the stage nobody reads)
+#pragma unroll
+            for (int u = 4 * NOCT * s / KS; u < 4 * NOCT * (s + 1) / KS; ++u) commit_unit(cur, u, buf ^ 1);   // in order
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
 
-        // bias, context term, sign bits, activation, store
+        // bias, context term, sign bits, activation, store.  Branch-free: a store that is not wanted gets an offset
+        // beyond its descriptor (dropped by the hardware), the mean's running sum is a select.
         const rsrc_t ry = make_rsrc_n(yg + ((size_t)b * p.Cout + r0) * hw, (unsigned)nrows * hw * SO);
-        const rsrc_t rm = make_rsrc_n(p.ymean != nullptr ? (const void*)(p.ymean + ((size_t)bq * p.Cout + r0) * hw) : (const void*)yg,
-                                      (unsigned)nrows * hw * 4u);
-        const unsigned s_in = tile % S;                // which of the pixel's samples this tile is
+        const rsrc_t rm = make_rsrc_n(MEAN ? (const void*)(p.ymean + ((size_t)bq * p.Cout + r0) * hw) : (const void*)yg,
+                                      MEAN ? (unsigned)nrows * hw * 4u : 0u);
+        const rsrc_t rsg = make_rsrc_n(p.signs != nullptr ? p.signs + ((size_t)b * p.Cout + r0) * wpr : (const unsigned*)yg,
+                                       p.signs != nullptr ? (unsigned)nrows * wpr * 4u : 0u);
+        const unsigned s_in = tile.s;                  // which of the pixel's samples this tile is
+        const bool first_s = s_in == 0, last_s = s_in + 1 == S;
 #pragma unroll
         for (int h = 0; h < NPH; ++h) {
             unsigned myword = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            unrolled<16>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
                 float v = TWO ? acc[h][j] + (small[h][j] + add[j]) : acc[h][j] + add[j];
                 if (TMODE == 2) v += t0[h][j];
+                // lane j (j + 32) keeps the sign word of register j's row (+ 4): the ballot's halves, written
+                // straight from the scalar registers into those lanes
                 const unsigned long long pos = __ballot(v > 0.f);
-                const unsigned word = lhi ? (unsigned)(pos >> 32) : (unsigned)pos;
-                myword = l31 == j ? word : myword;     // lane j (j + 32) keeps the word of register j's row (+ 4)
+                write_lanes<j>(myword, pos);
                 v = v > 0.f ? v : v * p.slope;
                 const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
+#if PW_ABL == 1
+                asm volatile("" :: "v"(v));
+#else
                 logit_store<TO>(v, ry, o0[h] != PW_OOB ? (o0[h] + ro) / (4u / SO) : PW_OOB, 0);
-                if (p.ymean != nullptr) {
+#endif
+                if constexpr (MEAN) {
                     float* mp = macc + (rb * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * PS_NT + (ph0 + h) * 32 + l31;
-                    const float m = s_in == 0 ? v : *mp + v;
-                    if (s_in + 1 == S) buf_store(m * inv_s, rm, o0[h] != PW_OOB ? o0[h] + ro : PW_OOB, 0);
-                    else *mp = m;
+                    const float m = (first_s ? 0.f : *mp) + v;
+                    *mp = m;
+                    buf_store(m * inv_s, rm, (last_s && o0[h] != PW_OOB) ? o0[h] + ro : PW_OOB, 0);
                 }
-            }
-            if (p.signs != nullptr && l31 < 16) {
-                const int row = r0 + (l31 & 3) + 8 * (l31 >> 2) + 4 * lhi;
+            });
+            {
+                // lanes 0-15 / 32-47: row (l31 & 3) + 8 (l31 >> 2) + 4 lhi of the wave's 32, word of this 32-pixel block
+                const unsigned row = (unsigned)((l31 & 3) + 8 * (l31 >> 2) + 4 * lhi);
                 const unsigned c0 = p0 + (ph0 + h) * 32;
-                if (row < p.Cout && c0 < hw) p.signs[((size_t)b * p.Cout + row) * wpr + c0 / 32] = myword;
+                const bool ok = l31 < 16 && (int)row < nrows && c0 < hw;
+                __builtin_amdgcn_raw_buffer_store_b32(myword, rsg, ok ? (row * wpr + c0 / 32) * 4u : PW_OOB, 0, 0);
             }
         }
         lds_barrier();
     };
-    while (tile < p.ntiles) {
+    auto roll = [&]() {
+        tile = next;
+        next = next2;
+        next2 = advance(next2);
+    };
+    while (live(tile)) {
         step(preA, preB, 0);
-        tile = tile_at(++v);
-        if (!(tile < p.ntiles)) break;
+        roll();
+        if (!live(tile)) break;
         step(preB, preA, 1);
-        tile = tile_at(++v);
+        roll();
     }
 }
 
@@ -1946,8 +2013,11 @@ extern "C" int sbmc_pointwise_supported(int cin, int cout, long hw) { return pw_
 
 // (half output: no per-pixel context form -- a chain's first layer with fp32 input has none in Multisteps, and it spills)
 template <int KPV, int WV, typename TO>
-static auto pws_pick(int t_mode) -> void (*)(PwFwdParams) {
+static auto pws_pick(int t_mode, bool mean) -> void (*)(PwFwdParams) {
     if constexpr (sizeof(TO) == 4) {
+        if (mean)
+            return t_mode == 2 ? pw_fwd_s_kernel<KPV, 2, WV, TO, true>
+                               : (t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV, TO, true> : pw_fwd_s_kernel<KPV, 0, WV, TO, true>);
         return t_mode == 2 ? pw_fwd_s_kernel<KPV, 2, WV, TO> : (t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV, TO> : pw_fwd_s_kernel<KPV, 0, WV, TO>);
     } else {
         return t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV, TO> : pw_fwd_s_kernel<KPV, 0, WV, TO>;
@@ -1998,7 +2068,7 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
             hipError_t se = hipSuccess;
 #define SBMC_PWS_LAUNCH2(KPV, WV)                                                                        \
     do {                                                                                                 \
-        auto kern = pws_pick<KPV, WV, TO>(t_mode);                                                        \
+        auto kern = pws_pick<KPV, WV, TO>(t_mode, ymean != nullptr);                                                        \
         se = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);                 \
         if (se == hipSuccess)                                                                            \

@@ -39,6 +39,28 @@ else:
 for _ in range(2):
     step()
 th.cuda.synchronize()
+if "SBMC_SMALL_KERNELS" in os.environ:
+    # which operator (and Python frame) launches the step's fill / memset / copy KERNELS -- what the dispatch-mode
+    # listing below cannot see: composite C++ operators (constant_pad_nd = fill + copy), memsets inside libraries
+    pat = tuple(os.environ["SBMC_SMALL_KERNELS"].split(",")) if os.environ["SBMC_SMALL_KERNELS"] else (
+        "fill", "Fill", "copyBuffer", "copy_kernel", "Memset", "Memcpy")
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        step()
+        th.cuda.synchronize()
+    by = collections.Counter()
+    dur = collections.Counter()
+    for ev in prof.events():
+        for k in getattr(ev, "kernels", []) or []:
+            if any(q in k.name for q in pat):
+                frames = [f for f in (ev.stack or []) if "sbmc_amd/" in f or "bench.py" in f or "clip_grad" in f or "/optim/" in f]
+                where = frames[0].split("/")[-1] if frames else "(no python frame)"
+                key = (k.name[:48], ev.name[:40], where[:70])
+                by[key] += 1
+                dur[key] += k.duration
+    print("world %d: small kernels of one step by launching operator" % world)
+    for key, n in sorted(by.items(), key=lambda kv: -kv[1])[:80]:
+        print("%5d %8.1f us  %-48s %-40s %s" % (n, dur[key], key[0], key[1], key[2]))
+    sys.exit(0)
 import traceback
 from torch.utils._python_dispatch import TorchDispatchMode
 sites = collections.Counter()
