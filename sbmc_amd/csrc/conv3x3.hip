@@ -882,6 +882,9 @@ __device__ __forceinline__ unsigned cv_pack_hh(_Float16 a, _Float16 b) {
 
 // HF: half activations -- gy and x are _Float16 tensors: the staging is a pure 8 x 4 transposition (no split, no scale,
 // one plane), one matrix product per term; gw stays fp32.
+#ifndef WG_INTERLEAVE
+#define WG_INTERLEAVE 1      // development: 0 = leave the order of a stage's instructions to the compiler
+#endif
 template <bool HF>
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     constexpr unsigned ES = HF ? 2u : 4u;
@@ -972,10 +975,11 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         lp = cv_pack(fa - (float)hv[0], fb - (float)hv[1]);
     };
     // the thread's 8 pixels x 4 channels -> entries of row buffer `dst` ([plane][octet][128])
-    auto write_row = [&](const Rows& rr, u32x4* dst, float c) {
+    // (channels ch0 .. ch1 - 1 of the thread's four: the steady state deals them out between its MFMA groups)
+    auto write_row = [&](const Rows& rr, u32x4* dst, float c, const int ch0 = 0, const int ch1 = 4) {
         u32x4* d = dst + uo * 128 + 4 * uq;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
+        for (int ch = ch0; ch < ch1; ++ch) {
             u32x4 hh, ll;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -997,8 +1001,8 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         }
     };
     // stage k's rows: gy -> Gs[k % 2]; x row (y + 1) -> ring slot (k + 1) % 4 (y - 1, y: slots (k - 1) % 4, k % 4)
-    auto commit = [&](const Rows& rr, unsigned k) {
-        write_row(rr, xrole ? Xs + ((k + 1) & 3u) * WG_XR : Gs + (k & 1u) * WG_G, xrole ? cx : cg);
+    auto commit = [&](const Rows& rr, unsigned k, const int ch0 = 0, const int ch1 = 4) {
+        write_row(rr, xrole ? Xs + ((k + 1) & 3u) * WG_XR : Gs + (k & 1u) * WG_G, xrole ? cx : cg, ch0, ch1);
     };
     // where this lane's channel of a [128] row sits (the swizzle above), as a reader: channel w 64 + 32 i + l31
     const int rsw = (l31 & ~3) + ((l31 & 3) ^ ((l31 >> 3) & 3));
@@ -1091,16 +1095,42 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
                 ++sn;
             }
         }
+        // One wave per SIMD issues in order: a block of MFMAs followed by a block of conversions runs the two pipes one
+        // after the other (measured: 53 % matrix-pipe busy = 2304 of 4224 cycles per stage).  The staging of the next
+        // stage's rows (the split: ~6 vector instructions per MFMA, 8 LDS stores) and the operand fetches are therefore
+        // DEALT OUT between this half's MFMAs; what it writes was last read before the previous stage's middle barrier.
+        // (a channel's two LDS stores come BEFORE the next group's operand fetches in program order: LDS reads are
+        // not moved above LDS stores, so a commit in one piece would hold back the fetches -- and the MFMAs behind
+        // them -- until all of its conversions were through)
+        auto deal = [&](auto nv) {
+#if WG_INTERLEAVE
+            constexpr int nvalu = decltype(nv)::value;
+#pragma unroll
+            for (int i = 0; i < (HF ? 4 : 12); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, nvalu, 0);         // VALU
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);             // DS write
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
+            }
+#endif
+        };
         load_b(b1, k, 0, 1);
+        commit(done, k + 1, 0, 1);
         mfmas(a0, b0, 0);
+        deal(std::integral_constant<int, 4>{});
         load_b(b0, k, 0, 2);
+        commit(done, k + 1, 1, 2);
         mfmas(a0, b1, 1);
+        deal(std::integral_constant<int, 4>{});
         load_a(a1, k, 1);
         load_b(b1, k, 1, 0);
+        commit(done, k + 1, 2, 4);
         mfmas(a0, b0, 2);
-        commit(done, k + 1);
-        issue(done, t + 3 < t1);
+        deal(std::integral_constant<int, HF ? 8 : 7>{});
         cv_lds_barrier();
+        // (the next request's address arithmetic -- ~60 scalar instructions -- and its loads: behind the barrier, between
+        // the second half's MFMAs)
+        issue(done, t + 3 < t1);
         load_b(b0, k, 1, 1);
         mfmas(a1, b1, 0);
         load_b(b1, k, 1, 2);
@@ -1108,6 +1138,20 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         load_a(a0, k + 1, 0);
         load_b(b0, k + 1, 0, 0);
         mfmas(a1, b1, 2);
+#if WG_INTERLEAVE
+#pragma unroll
+        for (int i = 0; i < (HF ? 6 : 18); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x004, HF ? 12 : 4, 0);       // SALU (the request's descriptor first)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // DS read
+        }
+#pragma unroll
+        for (int i = 0; i < (HF ? 6 : 18); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, HF ? 2 : 1, 0);        // VMEM read (its loads)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // DS read
+        }
+#endif
         cv_lds_barrier();
     };
     unsigned k = 0;
