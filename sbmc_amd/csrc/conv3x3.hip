@@ -169,7 +169,9 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
         rs = cv_rsrc(p.signs + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)(p.Cout / 32) + t.ct * 4,
                      (p.signs && !parking) ? 0x7FFFFFF0u : 0u);
     }
-    if (t.x0 + CV_TS <= p.W) {
+    // (not in the stream-K instantiations: with the parking store as well the lean form spills ~40 registers there; their
+    // split tiles finish in the fix-up kernel, which has it)
+    if (!SK && t.x0 + CV_TS <= p.W) {
         // ---- every column inside ----
         const rsrc_t rnone = cv_rsrc(yb, 0u);
         const unsigned lb = (unsigned)((4 * lhi) * p.Cout + nh * 64 + l31) * ES;

@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-o=gpurun_out/r04t; mkdir -p $o
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $o/tests_all.txt; cat $o/tests_all.txt
+mkdir -p gpurun_out/r04x
+( time timeout 2400 python -m pytest tests -x -q -m gpu ) > gpurun_out/r04x/gpu_suite.txt 2>&1; tail -5 gpurun_out/r04x/gpu_suite.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
