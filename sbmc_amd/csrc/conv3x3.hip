@@ -123,6 +123,7 @@ constexpr int CV_WS_HDR = 4096;
 // go to this workgroup's slab RAW instead -- same stores, other descriptor and offsets, selected, not branched to: a
 // branch around the epilogue (or a second copy of it) costs the main loop 140 spilled registers. ----
 struct CvTile { int n, y0, x0, ct; };
+__device__ __forceinline__ void cv_slab_store(const f32x16 (&acc)[4][2], float* base);
 
 // lanes LANE and LANE + 32 of v = the halves of a ballot (v_writelane_b32 with an inline-constant lane; the s_nop: a VALU
 // reading a scalar register a VALU has just written needs two wait states on gfx940+, and the compiler's hazard
@@ -156,8 +157,7 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
     const int mh = wave & 1, nh = wave >> 1;
     const bool sign_lane = l31 == 0;
     (void)sign_lane;
-    const bool parking = SK && park;
-    const rsrc_t rpark = cv_rsrc(parking ? park_slab : static_cast<float*>(p.ws), parking ? (unsigned)CV_SLAB * 4u : 0u);
+    constexpr bool parking = false;                     // (a parked tile has left above)
     char* yb = static_cast<char*>(p.y) + ((((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)p.Cout + t.ct * 128) * ES;
     const rsrc_t ry = cv_rsrc(yb, parking ? 0u : 0x7FFFFFF0u);
     float bv[2] = {0.f, 0.f};
@@ -169,9 +169,20 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
         rs = cv_rsrc(p.signs + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)(p.Cout / 32) + t.ct * 4,
                      (p.signs && !parking) ? 0x7FFFFFF0u : 0u);
     }
-    // (not in the stream-K instantiations: with the parking store as well the lean form spills ~40 registers there; their
-    // split tiles finish in the fix-up kernel, which has it)
-    if (!SK && t.x0 + CV_TS <= p.W) {
+    if constexpr (SK) {
+        // stream-K: a parked tile's accumulators go to the slab raw (its epilogue runs in the fix-up kernel)
+        if (park) {
+            cv_slab_store(acc, park_slab);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            return;
+        }
+    }
+    if (t.x0 + CV_TS <= p.W) {
         // ---- every column inside ----
         const rsrc_t rnone = cv_rsrc(yb, 0u);
         const unsigned lb = (unsigned)((4 * lhi) * p.Cout + nh * 64 + l31) * ES;
@@ -205,8 +216,6 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
                     const unsigned so = (unsigned)((row * p.W + col0) * p.Cout) * ES;
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
-                        if constexpr (SK)
-                            buf_store(acc[mi][ni][r], rpark, (unsigned)tid * 4u, (unsigned)(((mi * 2 + ni) * 16 + r) * 1024));
                         float v = acc[mi][ni][r] * oscale;
                         if constexpr (EPI) {
                             v += bv[ni];
@@ -250,8 +259,6 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const unsigned voff = ok ? (unsigned)((row * p.W + col) * p.Cout + nh * 64 + ni * 32 + l31) * ES : CV_OOB;
-                if constexpr (SK)
-                    buf_store(acc[mi][ni][r], rpark, (unsigned)tid * 4u, (unsigned)(((mi * 2 + ni) * 16 + r) * 1024));   // (empty descriptor unless parking)
                 float v = acc[mi][ni][r] * oscale;
                 if constexpr (EPI) {
                     v += bv[ni];
