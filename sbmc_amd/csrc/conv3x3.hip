@@ -224,8 +224,10 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
                             if (rh == 0) cv_write_lanes<r8>(sw[ni], bal);
                             else cv_write_lanes<r8 + 8>(sw[ni], bal);
                             v = pos ? v : v * p.slope;
-                            const unsigned a = __builtin_bit_cast(unsigned, v) & amask;
-                            amax_run = amax_run > a ? amax_run : a;
+                            if constexpr (!HF) {                               // (half outputs carry no scale word)
+                                const unsigned a = __builtin_bit_cast(unsigned, v) & amask;
+                                amax_run = amax_run > a ? amax_run : a;
+                            }
                         }
                         if constexpr (HF)
                             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rg,
