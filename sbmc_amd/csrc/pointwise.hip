@@ -492,6 +492,15 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
         }
     };
 
+    // the bias of this wave's 16 accumulator rows: without a context term it is the same for every tile -- loaded once
+    // (16 of a tile's 48 vector-memory instructions per wave)
+    float bias_rows[TMODE == 0 ? 16 : 1];
+    if constexpr (TMODE == 0) {
+        const rsrc_t rbias = make_rsrc_n(p.bias, (unsigned)p.Cout * 4u);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) bias_rows[j] = buf_load(rbias, (unsigned)(r0 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * 4u, 0);
+    }
+
     // one tile; `cur` holds the NEXT tile's values (split and written to LDS stage buf ^ 1 during this one),
     // `fill` receives the loads of the tile after that
     auto step = [&](const float (&cur)[NOCT][8], float (&fill)[NOCT][8], const int buf) {
@@ -508,6 +517,10 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
 
         f32x16 acc[NPH], small[NPH], t0[NPH];
         float add[16];                                 // bias (+ the per-image context term) of the 16 accumulator rows
+        if constexpr (TMODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) add[j] = bias_rows[j];     // (loaded once: they are live through a tile anyway)
+        }
 #pragma unroll
         for (int h = 0; h < NPH; ++h) {
 #pragma unroll
@@ -573,7 +586,7 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
                 }
             }
             // fillers of this k-step
-            if (s == ((TMODE == 2 && WAVES == 8 && KS > 2) ? KS - 2 : 0)) {
+            if (TMODE != 0 && s == ((TMODE == 2 && WAVES == 8 && KS > 2) ? KS - 2 : 0)) {
                 // bias and per-image context term (cache hits), behind the first MFMAs; at 256 registers with a
                 // per-pixel term as well (16 more live registers) late in the loop, just in time for the epilogue
                 const rsrc_t rbias = make_rsrc_n(p.bias, (unsigned)p.Cout * 4u);
