@@ -326,6 +326,9 @@ __device__ __forceinline__ void unrolled_impl(F&& f, std::integer_sequence<int, 
 template <int N, class F>
 __device__ __forceinline__ void unrolled(F&& f) { unrolled_impl(f, std::make_integer_sequence<int, N>{}); }
 
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
 }
@@ -1045,6 +1048,9 @@ __global__ __launch_bounds__(512) void pw_fwd_hw_kernel(PwFwdParams p) {
 #define PW_BWD_PIPE 0     // 1 = keep a tile's gx in registers and store it between the next tile's MFMAs: 16 more
                           // live registers = 10-12 spilled VGPRs at 2 waves/SIMD; measured 4.98 ms vs 4.66 ms without
 #endif
+#ifndef PW_BWD_GXS
+#define PW_BWD_GXS 1      // split-gw kernels with a data gradient: gx on the bf16 pipe too (transposing LDS reads)
+#endif
 constexpr int PB_NT = 64;
 constexpr int PB_PITCH = 66;
 constexpr int PB_PITCH_N = 82;      // gz tile of pw_bwd_kernel's NARROW form
@@ -1129,8 +1135,15 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     // without a copy (32 instead of 64 registers; same matrix-pipe cycles, twice the 4-byte LDS reads).  Its
     // B operand (4 rows x 16 pixels per read) wants the rows 16 or 18 banks apart; 18 keeps the staging's
     // 8-byte stores conflict-free as well.
-    constexpr bool NARROW = GWS && DX && (TPIX || GM);
-    constexpr int GP = NARROW ? PB_PITCH_N : PB_PITCH;   // floats per row of the fp32 gz tile
+    // GXS (split gw, with a data gradient): gx = W^T gz on the bf16 pipe as well -- the six products of the three-way
+    // split, 16 x 16 x 32 MFMAs, a wave owning 16 rows of K over all 64 pixels (w^T in three planes: 48 registers).  Its
+    // reduction runs over OUTPUT CHANNELS, the planar bf16 image of gz has 8 consecutive PIXELS per 16 bytes: the B
+    // operand comes through ds_read_b64_tr_b16 (within a 16-lane group lane i points at row i / 4, columns 4 (i % 4) ..
+    // of a 4 x 16 block and receives column i of all four rows: tools/dev/tr16_probe.hip), two reads per plane and
+    // k-step.  1536 instead of 4096 matrix-pipe cycles per wave and tile, and no fp32 gz tile in LDS.
+    constexpr bool GXS = GWS && DX && PW_BWD_GXS;
+    constexpr bool NARROW = GWS && DX && (TPIX || GM) && !GXS;
+    constexpr int GP = GXS ? 0 : (NARROW ? PB_PITCH_N : PB_PITCH);   // floats per row of the fp32 gz tile
     extern __shared__ float4 pw_lds[];
     float* lds = reinterpret_cast<float*>(pw_lds);
     constexpr int BUF = (128 + KP) * PB_PITCH;          // floats per pipeline stage: gz tile, then x tile
@@ -1151,8 +1164,23 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 
     // w^T rows of this wave as MFMA A-operands for gx: a2[kk] = w[2 kk + lane / 32][32 rb + lane % 32]
     // (NARROW: a2[kk] = w[4 kk + lane / 16][16 wave + lane % 16])
-    float a2[DX ? (NARROW ? 32 : 64) : 1];
-    if constexpr (NARROW) {
+    float a2[(DX && !GXS) ? (NARROW ? 32 : 64) : 1];
+    // GXS: aw*[s] = planes of w[32 s + 8 (lane / 16) + 0..7][16 wave + lane % 16]
+    u32x4 awh[GXS ? 4 : 1], awm[GXS ? 4 : 1], awl[GXS ? 4 : 1];
+    if constexpr (GXS) {
+        const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
+        const int kr = wave * 16 + (lane & 15);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int co = 32 * st + 8 * (lane >> 4) + e;
+                v[e] = buf_load(rw, (co < p.Cout && kr < p.K) ? (unsigned)(co * p.K + kr) * 4u : PW_OOB, 0);
+            }
+            split3(v, awh[st], awm[st], awl[st]);
+        }
+    } else if constexpr (NARROW) {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
         const int k = wave * 16 + (lane & 15);
 #pragma unroll
@@ -1291,9 +1319,11 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             if (TPIX) {
                 gts[i].x += gv.x; gts[i].y += gv.y; gts[i].z += gv.z; gts[i].w += gv.w;
             }
-            float2* d = reinterpret_cast<float2*>(gzs + (srow + 32 * i) * GP + c4);
-            d[0] = make_float2(gv.x, gv.y);
-            d[1] = make_float2(gv.z, gv.w);
+            if constexpr (!GXS) {
+                float2* d = reinterpret_cast<float2*>(gzs + (srow + 32 * i) * GP + c4);
+                d[0] = make_float2(gv.x, gv.y);
+                d[1] = make_float2(gv.z, gv.w);
+            }
             if constexpr (GWS) {
                 u32x2 h, m, l;
                 split3_4(gv, h, m, l);
@@ -1376,8 +1406,37 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 
         // ---- gx tile: rows 32 rb .. of K, pixels 32 ph ..; reduction over cout
         f32x16 acc_x;
-        f32x4 acc_n[NARROW ? 4 : 1];                    // NARROW: rows 16 wave .. of K, pixel blocks of 16
-        if constexpr (NARROW) {
+        f32x4 acc_n[(NARROW || GXS) ? 4 : 1];           // NARROW, GXS: rows 16 wave .. of K, pixel blocks of 16
+        if constexpr (GXS) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) acc_n[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // this lane's address in a 4 x 16 block: row (lane % 16) / 4, columns 4 (lane % 4) ..; blocks: rows 8 (lane / 16) ..
+            const _Float16* tb = gzn + (8 * (lane >> 4) + ((lane & 15) >> 2)) * PBS_PITCH + 4 * (lane & 3);
+            using v4s = short __attribute__((ext_vector_type(4)));
+            using v4sp = __attribute__((address_space(3))) v4s*;
+            auto tr8 = [&](const _Float16* q) -> u32x4 {          // 8 consecutive rows of this lane's column
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4sp)q);
+                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4sp)(q + 4 * PBS_PITCH));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                return u32x4{l2[0], l2[1], h2[0], h2[1]};
+            };
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) {
+                    const _Float16* q = tb + (32 * st) * PBS_PITCH + 16 * pb;
+                    const u32x4 bh = tr8(q), bm = tr8(q + 128 * PBS_PITCH), bl = tr8(q + 2 * 128 * PBS_PITCH);
+                    acc_n[pb] = mfma16_bf16(awh[st], bl, acc_n[pb]);
+                    acc_n[pb] = mfma16_bf16(awl[st], bh, acc_n[pb]);
+                    acc_n[pb] = mfma16_bf16(awm[st], bm, acc_n[pb]);
+                    acc_n[pb] = mfma16_bf16(awh[st], bm, acc_n[pb]);
+                    acc_n[pb] = mfma16_bf16(awm[st], bh, acc_n[pb]);
+                    acc_n[pb] = mfma16_bf16(awh[st], bh, acc_n[pb]);
+                }
+                if (st == 1 && nvalid) issue_x(nxt);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (NARROW) {
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) acc_n[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float* gb = gzs + (lane >> 4) * GP + (lane & 15);
@@ -1413,7 +1472,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             }
         }
         auto store_gx = [&]() {
-            if constexpr (NARROW) {
+            if constexpr (NARROW || GXS) {
                 const int r0 = wave * 16;
                 const int nr = p.K - r0 < 16 ? (p.K - r0 > 0 ? p.K - r0 : 0) : 16;
                 const rsrc_t rgx = make_rsrc_n(gx_g + ((size_t)b * p.K + r0) * hw, (unsigned)nr * hw * SX);
@@ -2329,7 +2388,7 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
         const bool side = t_mode == 2 || gmean;
         gws = gmode != 0 && (!side || gmode >= 2);
         if (gws)
-            lds = (size_t)128 * ((side && gx) ? PB_PITCH_N : PB_PITCH) * sizeof(float) +
+            lds = (size_t)128 * ((PW_BWD_GXS && gx) ? 0 : ((side && gx) ? PB_PITCH_N : PB_PITCH)) * sizeof(float) +
                   (size_t)3 * (128 + kp) * PBS_PITCH * 2;
     }
 #define SBMC_PWB_PICK(KPV, DXV, TPV, SGV, GWSV)                                                          \
