@@ -1165,7 +1165,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     // w^T rows of this wave as MFMA A-operands for gx: a2[kk] = w[2 kk + lane / 32][32 rb + lane % 32]
     // (NARROW: a2[kk] = w[4 kk + lane / 16][16 wave + lane % 16])
     float a2[(DX && !GXS) ? (NARROW ? 32 : 64) : 1];
-    // GXS: aw*[s] = planes of w[32 s + 8 (lane / 16) + 0..7][16 wave + lane % 16]
+    // GXS: aw*[s] = planes of w[32 s + row(lane / 16, 0..7)][16 wave + lane % 16].  Which output channel of a 32-step sits
+    // at which reduction index is free as long as both operands agree: row(g, e) = 16 (g / 2) + 8 (g % 2) + 2 (e % 4) + e / 4
+    // makes the 32 lanes of half a wave read EIGHT EVEN (first read) or EIGHT ODD (second) rows of 16 -- with rows 36 banks
+    // apart those tile the 64 banks exactly; consecutive rows per group (the obvious map) measured 31 % conflict cycles
     u32x4 awh[GXS ? 4 : 1], awm[GXS ? 4 : 1], awl[GXS ? 4 : 1];
     if constexpr (GXS) {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
@@ -1175,7 +1178,8 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int co = 32 * st + 8 * (lane >> 4) + e;
+                const int g4 = lane >> 4;
+                const int co = 32 * st + 16 * (g4 >> 1) + 8 * (g4 & 1) + 2 * (e & 3) + (e >> 2);
                 v[e] = buf_load(rw, (co < p.Cout && kr < p.K) ? (unsigned)(co * p.K + kr) * 4u : PW_OOB, 0);
             }
             split3(v, awh[st], awm[st], awl[st]);
@@ -1410,13 +1414,14 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         if constexpr (GXS) {
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) acc_n[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // this lane's address in a 4 x 16 block: row (lane % 16) / 4, columns 4 (lane % 4) ..; blocks: rows 8 (lane / 16) ..
-            const _Float16* tb = gzn + (8 * (lane >> 4) + ((lane & 15) >> 2)) * PBS_PITCH + 4 * (lane & 3);
+            // this lane's address for the first read: row 16 (g / 2) + 8 (g % 2) + 2 j of the 32-step, g = lane / 16,
+            // j = (lane % 16) / 4; columns 4 (lane % 4) .. of the pixel block.  The second read: the odd row below.
+            const _Float16* tb = gzn + (16 * (lane >> 5) + 8 * ((lane >> 4) & 1) + 2 * ((lane & 15) >> 2)) * PBS_PITCH + 4 * (lane & 3);
             using v4s = short __attribute__((ext_vector_type(4)));
             using v4sp = __attribute__((address_space(3))) v4s*;
-            auto tr8 = [&](const _Float16* q) -> u32x4 {          // 8 consecutive rows of this lane's column
+            auto tr8 = [&](const _Float16* q) -> u32x4 {          // this lane's 8 rows of its column
                 const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4sp)q);
-                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4sp)(q + 4 * PBS_PITCH));
+                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4sp)(q + PBS_PITCH));
                 const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
                 return u32x4{l2[0], l2[1], h2[0], h2[1]};
             };
