@@ -92,6 +92,18 @@ __device__ __forceinline__ void cv_split(const float (&v)[8], u32x4& h, u32x4& l
     }
 }
 
+// Two fp32 values and their (wave-uniform, power-of-two) scale -> the packed f16 pairs h = f16(c v), l = f16(c v - h): FOUR
+// instructions (v_fma_mix*_f16: an fp32 fused multiply-add whose addend is read as a half and whose result is rounded to
+// half once) where multiply, convert, convert back, subtract, convert take eight.  Same values: c v and c v - h are exact.
+// In the staging paths of the 3 x 3 kernels the split is most of what is not an MFMA.
+__device__ __forceinline__ void cv_split_pair(float a, float b, float c, unsigned& h, unsigned& l) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h), "=&v"(l) : "v"(a), "v"(b), "s"(c));
+}
+
 __device__ __forceinline__ f32x16 cv_mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
@@ -458,14 +470,16 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
                 if constexpr (HF) {
                     d[0] = areg[j][o];               // 8 channels of the pixel: an operand entry as it is
                 } else {
-                    float v[8];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const unsigned word = areg[j][2 * o + c / 4][c % 4];   // (a copy: bit_cast of the element expression itself reads element 0)
-                        v[c] = __builtin_bit_cast(float, word) * cx;
-                    }
                     u32x4 hh, ll;
-                    cv_split(v, hh, ll);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned w0 = areg[j][2 * o + (2 * c) / 4][(2 * c) % 4];        // (copies: bit_cast of the element expression itself reads element 0)
+                        const unsigned w1 = areg[j][2 * o + (2 * c + 1) / 4][(2 * c + 1) % 4];
+                        unsigned hp, lp;
+                        cv_split_pair(__builtin_bit_cast(float, w0), __builtin_bit_cast(float, w1), cx, hp, lp);
+                        hh[c] = hp;
+                        ll[c] = lp;
+                    }
                     d[0] = hh;
                     d[4 * CV_PR] = ll;
                 }
@@ -978,12 +992,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     };
     // two scaled values -> their h and l halves, packed (element 0 in the low half)
     auto pair = [&](unsigned a, unsigned b, float c, unsigned& hp, unsigned& lp) {
-        const float fa = __builtin_bit_cast(float, a) * c, fb = __builtin_bit_cast(float, b) * c;
-        h2 hv;
-        hv[0] = (_Float16)fa;
-        hv[1] = (_Float16)fb;
-        hp = __builtin_bit_cast(unsigned, hv);
-        lp = cv_pack(fa - (float)hv[0], fb - (float)hv[1]);
+        cv_split_pair(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), c, hp, lp);
     };
     // the thread's 8 pixels x 4 channels -> entries of row buffer `dst` ([plane][octet][128])
     // (channels ch0 .. ch1 - 1 of the thread's four: the steady state deals them out between its MFMA groups)
