@@ -15,7 +15,6 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libsbmc_hip.so")
 SOURCES = ["plain_ops.hip", "splat_fused.hip", "bias_act.hip", "pointwise.hip", "resample.hip", "nhwc_ops.hip", "halo.hip", "conv3x3.hip"]
-DEPS = SOURCES + ["common.hpp", os.path.join(ROOT, "include", "sbmc_hip.h")]
 ARCH = "gfx950"
 
 
@@ -33,8 +32,7 @@ def _source_hash():
     """Hash of everything the library is built from (sources, headers, flags)."""
     import hashlib
     h = hashlib.sha256((ARCH + " -O3 -std=c++17").encode())
-    for d in DEPS:
-        path = d if os.path.isabs(d) else os.path.join(CSRC, d)
+    for path in [os.path.join(CSRC, src) for src in SOURCES] + _headers():
         with open(path, "rb") as f:
             h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()
@@ -58,11 +56,31 @@ OBJ_DIR = os.path.join(HERE, ".obj")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
+_COMPILER_ID = None
+
+
+def _compiler_id():
+    """`hipcc --version` (a compiler upgrade must not link objects of the old one)."""
+    global _COMPILER_ID
+    if _COMPILER_ID is None:
+        try:
+            _COMPILER_ID = subprocess.check_output([_hipcc(), "--version"], stderr=subprocess.STDOUT).decode("utf-8", "replace")
+        except (OSError, subprocess.CalledProcessError):
+            _COMPILER_ID = "unknown"
+    return _COMPILER_ID
+
+
+def _headers():
+    """Every header a source may include: all of csrc/*.hpp|*.h and the ABI header."""
+    own = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".inc")))
+    return own + [os.path.join(ROOT, "include", "sbmc_hip.h")]
+
+
 def _object_hash(src):
-    """Hash of what ONE object file is built from: its source, the shared headers, the flags."""
+    """Hash of what ONE object file is built from: its source, every header of csrc/, the flags, the compiler."""
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
-    for path in (os.path.join(CSRC, src), os.path.join(CSRC, "common.hpp"), os.path.join(ROOT, "include", "sbmc_hip.h")):
+    h = hashlib.sha256((" ".join(FLAGS) + "\0" + _compiler_id()).encode())
+    for path in [os.path.join(CSRC, src)] + _headers():
         with open(path, "rb") as f:
             h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()
@@ -102,8 +120,12 @@ def build(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
     if force:
-        for f in os.listdir(OBJ_DIR):
-            os.remove(os.path.join(OBJ_DIR, f))
+        for f in os.listdir(OBJ_DIR):          # the cached objects and their stamps only: another rank that is
+            if f.endswith((".o", ".hash")):    # building right now owns the "<obj>.<pid>.tmp" files
+                try:
+                    os.remove(os.path.join(OBJ_DIR, f))
+                except OSError:
+                    pass
     digest = _source_hash()
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as pool:    # one hipcc per source
         objs = list(pool.map(lambda s: _compile(s, verbose), SOURCES))

@@ -15,6 +15,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <strings.h>
 
 namespace sbmc {
 
@@ -171,6 +173,16 @@ __device__ __forceinline__ void amax_publish(unsigned m, unsigned* amax) {
         for (unsigned w = 1; w < (blockDim.x + 63) / 64; ++w) m = m > wave_max[w] ? m : wave_max[w];
         if (m > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, m);
     }
+}
+
+// An integer development knob from the environment (never part of the ABI), read by the same rule as the host
+// side's sbmc_amd/utils.py `knob`: unset -> fallback; "on" / "yes" / "true" -> 1; else atoi ("off", "no" -> 0).
+static inline int env_knob(const char* name, int fallback) {
+    const char* v = getenv(name);
+    if (!v) return fallback;
+    while (*v == ' ' || *v == '\t') ++v;
+    if (!strncasecmp(v, "on", 2) || !strncasecmp(v, "yes", 3) || !strncasecmp(v, "true", 4)) return 1;
+    return atoi(v);
 }
 
 }  // namespace sbmc

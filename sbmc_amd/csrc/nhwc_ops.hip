@@ -222,6 +222,13 @@ __global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const T* __restrict
 // the up path's concatenation, so autograd ran max_pool_backward, wrote a full-size gradient, and added the skip's to it
 // in a third pass.  Here gx = gskip + (this pixel is the FIRST maximum of its window, the element torch's kernel records
 // ? gpool : 0) in one pass; the arg-max is recomputed from the saved input instead of an int64 index tensor.
+__device__ __forceinline__ float pool_max4(float a, float b, float c, float d) {     // NaN-propagating, as torch
+    float m = a;
+    m = (b > m || b != b) ? b : m;
+    m = (c > m || c != c) ? c : m;
+    m = (d > m || d != d) ? d : m;
+    return m;
+}
 // One thread = one float4 of channels of one COARSE pixel (its four fine pixels).
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_nhwc_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int c4n, int hc,
@@ -238,17 +245,20 @@ __global__ __launch_bounds__(256) void maxpool2_nhwc_fwd_kernel(const T* __restr
         const float4 a = Quad<T>::load(x, f), bq = Quad<T>::load(x, f + c4n), c = Quad<T>::load(x, f + row),
                      d = Quad<T>::load(x, f + row + c4n);
         float4 m;
-        m.x = fmaxf(fmaxf(a.x, bq.x), fmaxf(c.x, d.x)); m.y = fmaxf(fmaxf(a.y, bq.y), fmaxf(c.y, d.y));
-        m.z = fmaxf(fmaxf(a.z, bq.z), fmaxf(c.z, d.z)); m.w = fmaxf(fmaxf(a.w, bq.w), fmaxf(c.w, d.w));
+        m.x = pool_max4(a.x, bq.x, c.x, d.x); m.y = pool_max4(a.y, bq.y, c.y, d.y);
+        m.z = pool_max4(a.z, bq.z, c.z, d.z); m.w = pool_max4(a.w, bq.w, c.w, d.w);
         Quad<T>::store(y, idx, m);
     }
 }
+// The window's winner as torch's max_pool2d picks it: the FIRST maximum, and a NaN beats everything (the last NaN of
+// the window takes the gradient) -- so that a non-finite activation reaches the loss's non-finite guard through the
+// pooled branch as well.
 __device__ __forceinline__ int first_max4(float a, float b, float c, float d) {
     int k = 0;
     float m = a;
-    if (b > m) { m = b; k = 1; }
-    if (c > m) { m = c; k = 2; }
-    if (d > m) { k = 3; }
+    if (b > m || b != b) { m = b; k = 1; }
+    if (c > m || c != c) { m = c; k = 2; }
+    if (d > m || d != d) { k = 3; }
     return k;
 }
 template <typename T>

@@ -2122,8 +2122,7 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
     if constexpr (sizeof(TI) == 4) {
         // fp32 in (fp32 or half out): the split-precision kernel on the bf16 matrix pipe (SBMC_HIP_PW_SPLIT=0 keeps the
         // fp32-MFMA kernel: development knob, not part of the ABI)
-        const char* knob = getenv("SBMC_HIP_PW_SPLIT");
-        if ((!knob || atoi(knob) != 0) && (sizeof(TO) == 4 || (signs == nullptr && ymean == nullptr && t_mode != 2))) {
+        if (env_knob("SBMC_HIP_PW_SPLIT", 1) != 0 && (sizeof(TO) == 4 || (signs == nullptr && ymean == nullptr && t_mode != 2))) {
             p.tiles_per_plane = (unsigned)((hw + PS_NT - 1) / PS_NT);
             const unsigned long long nts = (unsigned long long)p.tiles_per_plane * (unsigned)b;
             if (nts > 0xFFFFFFFFull - 4096) return SBMC_HIP_EINVAL;
@@ -2192,12 +2191,11 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
     if constexpr (sizeof(TI) == 2 && sizeof(TO) == 2) {
         // half in, half out: the f16 matrix pipe (weights rounded to half); SBMC_HIP_PW_F16MFMA=0 keeps
         // the fp32-MFMA kernel (development knob, not part of the ABI)
-        const char* knob = getenv("SBMC_HIP_PW_F16MFMA");
-        if (ymean != nullptr && knob && atoi(knob) == 0) return SBMC_HIP_EINVAL;      // (the fp32-MFMA kernel writes no mean)
-        if (!knob || atoi(knob) != 0) {
+        const bool f16mfma = env_knob("SBMC_HIP_PW_F16MFMA", 1) != 0;
+        if (ymean != nullptr && !f16mfma) return SBMC_HIP_EINVAL;      // (the fp32-MFMA kernel writes no mean)
+        if (f16mfma) {
             const size_t hlds = (size_t)2 * (kp / 4) * 128 * 8;
-            const char* wknob = getenv("SBMC_HIP_PW_FWD_WIDE");
-            if (cout > 128 && cout <= 512 && t_mode == 0 && ymean == nullptr && (!wknob || atoi(wknob) != 0)) {
+            if (cout > 128 && cout <= 512 && t_mode == 0 && ymean == nullptr && env_knob("SBMC_HIP_PW_FWD_WIDE", 1) != 0) {
                 // wide layer (the 441-channel logits): one workgroup per pixel tile walks all row tiles
                 unsigned wgrid = (unsigned)cus;
                 if ((unsigned long long)wgrid > nt) wgrid = (unsigned)nt;
@@ -2351,8 +2349,7 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
     const int kp = (cin + 31) / 32 * 32;
     if constexpr (sizeof(TA) == 2 && sizeof(TXT) == 2) {
         // all-half layer: the f16 matrix pipe (SBMC_HIP_PW_F16MFMA=0 keeps the fp32-MFMA kernel: development knob)
-        const char* knob = getenv("SBMC_HIP_PW_F16MFMA");
-        if (!knob || atoi(knob) != 0) {
+        if (env_knob("SBMC_HIP_PW_F16MFMA", 1) != 0) {
             const size_t hlds = (size_t)2 * ((128 + kp) * PBH_PITCH + 32 * PB_NT * 4) * 2;
 #define SBMC_PWBH_LAUNCH2(KPV, DXV, TPV)                                                                 \
     do {                                                                                                 \
@@ -2388,8 +2385,7 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
     // all-fp32-MFMA kernel, 2 = default splits them too)
     bool gws = false;
     if constexpr (sizeof(TA) == 4 && sizeof(TXT) == 4) {
-        const char* gknob = getenv("SBMC_HIP_PW_GWS");
-        const int gmode = gknob ? atoi(gknob) : 2;
+        const int gmode = env_knob("SBMC_HIP_PW_GWS", 2);
         const bool side = t_mode == 2 || gmean;
         gws = gmode != 0 && (!side || gmode >= 2);
         if (gws)

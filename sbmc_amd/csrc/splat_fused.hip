@@ -973,8 +973,7 @@ static inline bool strip_ok(int c, int k, int h, int w, bool half = false) {
 // Development knob (not part of the ABI): SBMC_HIP_SPLAT_VARIANT=0 forces the generic tile
 // kernels even where the strip kernels apply (used by the tests to cover both at k = 21).
 static int splat_variant() {
-    const char* e = getenv("SBMC_HIP_SPLAT_VARIANT");
-    return e ? atoi(e) : 1;
+    return env_knob("SBMC_HIP_SPLAT_VARIANT", 1);
 }
 
 }  // namespace sbmc

@@ -13,6 +13,7 @@ import torch as th
 
 from . import _lib
 from . import halide_ops as ops
+from .utils import knob
 
 __all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_supported",
            "SplatAll", "splat_all_supported", "splat_all_supported_dims", "splat_slab_supported", "gather_update_supported", "BiasAct", "CtxAct"]
@@ -504,11 +505,11 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False, mean_s=0):
         signs = th.empty(B, cout, (hw + 31) // 32, dtype=th.int32, device=dev)
     ymean = None
     if (mean_s and mean_s >= 1 and not half and _pw_split_enabled() and cout <= 128 and B % mean_s == 0
-            and (t_mode == 0 or s == mean_s) and os.environ.get("SBMC_PW_FUSED_MEAN", "1") != "0"):
+            and (t_mode == 0 or s == mean_s) and knob("SBMC_PW_FUSED_MEAN") != 0):
         ymean = th.empty(B // mean_s, cout, hw, dtype=th.float32, device=dev)
     half_mean = (mean_s and mean_s >= 1 and half and x.dtype == th.float16 and cout <= 128 and B % mean_s == 0
-                 and (t_mode == 0 or s == mean_s) and os.environ.get("SBMC_PW_FUSED_MEAN", "1") != "0"
-                 and os.environ.get("SBMC_HIP_PW_F16MFMA", "1") != "0")
+                 and (t_mode == 0 or s == mean_s) and knob("SBMC_PW_FUSED_MEAN") != 0
+                 and knob("SBMC_HIP_PW_F16MFMA") != 0)
     if half_mean:
         ymean = th.empty(B // mean_s, cout, hw, dtype=th.float16, device=dev)
     with th.cuda.device(dev), _timed("pointwise_fwd%s %dx%d" % ("_f16" if half else "", cout, cin), dev):
@@ -545,7 +546,7 @@ def _pw_split_enabled():
     """SBMC_HIP_PW_SPLIT=0 (development knob, read by the library as well) keeps the fp32-MFMA forward kernel,
     which writes no sign bits."""
     import os
-    return os.environ.get("SBMC_HIP_PW_SPLIT", "1") != "0"
+    return knob("SBMC_HIP_PW_SPLIT") != 0
 
 
 def _pointwise_backward(ctx, gy, gmean, mean_s):
@@ -595,7 +596,7 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
         if t_mode == 1:
             gt = per_image.view(tshape)
         return gx, gwp.sum(0), per_image.sum(0), gt
-    if (half and act == 0 and t_mode == 0 and x.dtype == th.float16 and os.environ.get("SBMC_HIP_PW_GW_WIDE", "1") != "0"
+    if (half and act == 0 and t_mode == 0 and x.dtype == th.float16 and knob("SBMC_HIP_PW_GW_WIDE") != 0
             and L.sbmc_pointwise_gw_wide_supported(cin, cout, hw)):
         # the 441-channel logits layer with half activations: weight + bias gradient in ONE pass over the half logit
         # gradient (pw_gw_wide_kernel; before: a cast of the 6.6 GB gradient to fp32 for the bias sums, a reduction
@@ -632,7 +633,7 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
                 gw = th.bmm(gz, x.half().transpose(1, 2)).float().sum(0)
         return gx, gw, gbias, gt
     if (act == 0 and t_mode == 0 and not half and gy.dtype == th.float32 and x.dtype == th.float32
-            and os.environ.get("SBMC_HIP_PW_GW_WIDE", "1") != "0" and L.sbmc_pointwise_gw_wide_supported(cin, cout, hw)):
+            and knob("SBMC_HIP_PW_GW_WIDE") != 0 and L.sbmc_pointwise_gw_wide_supported(cin, cout, hw)):
         # the 441-channel logits layer (linear): weight and bias gradient in ONE pass over the logit gradient on the
         # bf16 matrix pipe at fp32 accuracy (csrc/pointwise.hip pw_gw_wide_kernel) instead of a read-only pass for the
         # bias sums + a library GEMM on the fp32 pipe; the data gradient (its reduction runs over the 441 channels: the
@@ -818,7 +819,7 @@ class PoolSkip(th.autograd.Function):
                 and not pool.return_indices and left.is_cuda and left.dtype in (th.float32, th.float16) and left.dim() == 4
                 and _is_channels_last(left) and left.shape[1] % 4 == 0 and left.shape[2] % 2 == 0 and left.shape[3] % 2 == 0
                 and left.numel() > 0 and left.data_ptr() % 16 == 0
-                and os.environ.get("SBMC_POOL_SKIP", "1") not in ("0", "off", "no"))
+                and knob("SBMC_POOL_SKIP") != 0)
 
     @staticmethod
     def forward(ctx, left):
@@ -982,7 +983,7 @@ class _StreamK(object):
 
     def take(self, device):
         """-> workspace pointer, or None"""
-        if os.environ.get("SBMC_CONV3X3_STREAMK", "1") in ("0", "off", "no"):
+        if knob("SBMC_CONV3X3_STREAMK") == 0:
             return None
         key = (device.index, th.cuda.current_stream(device).cuda_stream)
         ent = self._ws.get(key)
@@ -1034,7 +1035,7 @@ def tag_amax(t, amax):
 
 
 def known_amax(t):
-    if os.environ.get("SBMC_AMAX_TAGS", "1") in ("0", "off", "no"):
+    if knob("SBMC_AMAX_TAGS") == 0:
         return None
     tag = getattr(t, "_sbmc_amax", None)
     if tag is not None and tag[1] == t._version and tag[2] == t.data_ptr() and tag[0].device == t.device:
@@ -1063,8 +1064,8 @@ def wants_amax(t):
     """Will a 3 x 3 convolution of csrc/conv3x3.hip scale this tensor by its largest magnitude?  (fp32,
     channels-last, the kernels not switched off.)"""
     return (t.is_cuda and t.dtype == th.float32 and t.dim() == 4 and _is_channels_last(t) and t.data_ptr() % 16 == 0
-            and os.environ.get("SBMC_CONV3X3", "1") not in ("0", "off", "no")
-            and os.environ.get("SBMC_AMAX_TAGS", "1") not in ("0", "off", "no"))
+            and knob("SBMC_CONV3X3") != 0
+            and knob("SBMC_AMAX_TAGS") != 0)
 
 
 def bound_amax(*amaxes):
@@ -1089,7 +1090,7 @@ class Conv3x3NHWC(th.autograd.Function):
 
     @staticmethod
     def supported(x, conv):
-        if os.environ.get("SBMC_CONV3X3", "1") in ("0", "off", "no"):
+        if knob("SBMC_CONV3X3") == 0:
             return False
         if not (isinstance(conv, th.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
                 and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
@@ -1180,7 +1181,7 @@ class Conv3x3NHWC(th.autograd.Function):
                     gx = Conv3x3NHWC._conv(gy, gmax, wp[1] if wp is not None else Conv3x3NHWC._prepare(w, True), cin)
             if want_gw:
                 with _timed("conv3x3_bwd_weight %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
-                    if (os.environ.get("SBMC_CONV3X3_WGRAD", "1") not in ("0", "off", "no")
+                    if (knob("SBMC_CONV3X3_WGRAD") != 0
                             and L.sbmc_conv3x3_wgrad_supported(b, h, wd, cin, cout)):
                         gw = th.empty((cout, cin, 3, 3), dtype=th.float32, device=dev, memory_format=th.channels_last)
                         scratch = th.empty(L.sbmc_conv3x3_wgrad_scratch_bytes(b, h, wd, cin, cout), dtype=th.uint8, device=dev)
@@ -1278,7 +1279,7 @@ class Conv3x3BiasActHalfNHWC(th.autograd.Function):
 
     @staticmethod
     def supported(x, conv):
-        if os.environ.get("SBMC_CONV3X3", "1") in ("0", "off", "no") or os.environ.get("SBMC_CONV3X3_HALF", "1") in ("0", "off", "no"):
+        if knob("SBMC_CONV3X3") == 0 or knob("SBMC_CONV3X3_HALF") == 0:
             return False
         if not (isinstance(conv, th.nn.Conv2d) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
                 and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1

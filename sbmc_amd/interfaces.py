@@ -163,7 +163,8 @@ class Checkpointer(object):
 
 
 def train(interface, dataloader, num_epochs=1, val_dataloader=None, checkpointer=None,
-          start_epoch=0, log_every=10):
+          start_epoch=0, log_every=10, validation_log=None):
+    """-> the per-step statistics.  validation_log: a list that receives each epoch's validation means."""
     history = []
     frozen = False
     for epoch in range(start_epoch, num_epochs):
@@ -189,6 +190,8 @@ def train(interface, dataloader, num_epochs=1, val_dataloader=None, checkpointer
                 for batch in val_dataloader:
                     running = interface.update_validation(batch, interface.forward(batch), running)
             LOG.info("epoch %d validation loss %.5f rmse %.5f", epoch, running["loss"], running["rmse"])
+            if validation_log is not None:
+                validation_log.append(dict(running, epoch=epoch))
         if checkpointer is not None:
             checkpointer.save("epoch_%04d" % epoch, epoch + 1)
     if checkpointer is not None:

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import functions as funcs
 from . import modules as ops
-from .utils import crop_like
+from .utils import crop_like, knob
 
 __all__ = ["Multisteps", "KPCN"]
 
@@ -122,7 +122,7 @@ class Multisteps(nn.Module):
         SBMC_WBANK=0): the modules then run torch's weight norm layer by layer."""
         import os
         from . import wbank
-        if not like.is_cuda or os.environ.get("SBMC_WBANK", "1") in ("0", "off", "no"):
+        if not like.is_cuda or knob("SBMC_WBANK") == 0:
             return []
         groups = [[getattr(self, "embedding_{:02d}".format(s)), getattr(self, "propagation_{:02d}".format(s))]
                   for s in range(self.nsteps)] + [[self.kernel_regressor]]

@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functions as funcs
+from .utils import knob
 
 __all__ = ["ConvChain", "Autoencoder", "KernelApply", "ProgressiveKernelApply"]
 
@@ -187,7 +188,7 @@ def _convs_on_own_kernel(net, x):
     """True if all spatial convolutions of `net` are 3 x 3 / stride 1 / padding 1 with channel counts the
     split-precision kernel takes (functions.Conv3x3NHWC), at x's resolution or coarser."""
     import os
-    if os.environ.get("SBMC_CONV3X3", "1") in ("0", "off", "no") or x.shape[2] * x.shape[3] < 2:
+    if knob("SBMC_CONV3X3") == 0 or x.shape[2] * x.shape[3] < 2:
         return False
     convs = [m for m in net.modules() if isinstance(m, nn.Conv2d) and m.kernel_size != (1, 1)]
     if not convs:
@@ -224,7 +225,7 @@ def unet_channels_last(net, x, rows=None):
         # ~2-3x MIOpen's fp32 solvers in either layout): nothing to measure, no dependence on MIOpen's find-db
         _LAYOUT_DECISIONS.setdefault((x.device.index, "own 3x3 kernel"), True)
         return True
-    if x.dtype == th.float16 and _convs_on_own_kernel(net, x) and os.environ.get("SBMC_CONV3X3_HALF", "1") not in ("0", "off", "no"):
+    if x.dtype == th.float16 and _convs_on_own_kernel(net, x) and knob("SBMC_CONV3X3_HALF") != 0:
         # half activations: the same kernels in their one-plane form (functions.Conv3x3BiasActHalfNHWC)
         _LAYOUT_DECISIONS.setdefault((x.device.index, "own 3x3 kernel"), True)
         return True

@@ -1,5 +1,6 @@
 """Small host-side helpers (stand-ins for the two torch-tools symbols the hot path uses)."""
 import logging
+import os
 
 
 def get_logger(name):
@@ -21,3 +22,22 @@ def crop_like(src, tgt):
     if dy < 0 or dx < 0:
         raise ValueError("crop_like: source is smaller than the target")
     return src[..., dy:dy + th_, dx:dx + tw]
+
+
+def knob(name, default=1):
+    """An integer development knob from the environment, read by ONE rule on both sides of the C ABI
+    (csrc/common.hpp `env_knob`): unset -> default; "on" / "yes" / "true" -> 1; otherwise the leading integer as C's
+    atoi reads it, i.e. "off" / "no" / "false" / anything else -> 0."""
+    v = os.environ.get(name)
+    if v is None:
+        return default
+    v = v.strip().lower()
+    if v in ("on", "yes", "true"):
+        return 1
+    i, n = 0, len(v)
+    if i < n and v[i] in "+-":
+        i += 1
+    j = i
+    while j < n and v[j].isdigit():
+        j += 1
+    return int(v[:j]) if j > i else 0

@@ -21,10 +21,11 @@ import os
 import torch as th
 
 from . import _lib
+from .utils import knob
 
 
 def _conv3x3_enabled():
-    return os.environ.get("SBMC_CONV3X3", "1") not in ("0", "off", "no")
+    return knob("SBMC_CONV3X3") != 0
 
 
 class _BankFn(th.autograd.Function):

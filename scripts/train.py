@@ -19,10 +19,18 @@ from sbmc_amd import KPCN, Multisteps, interfaces  # noqa: E402
 
 
 def main(args):
-    np.random.seed(0)
-    th.manual_seed(0)
+    """-> the run's record: {"history": per-step {"loss", "rmse"}, "validation": per-epoch running means,
+    "start_epoch": the epoch a found checkpoint resumed from}."""
     if not th.cuda.is_available():
         raise SystemExit("sbmc_amd runs its operators on MI355X only; no GPU is visible")
+    return run(args, cuda=True)
+
+
+def run(args, cuda=True):
+    """The body of main().  cuda=False exists for the host tests only: the `*_cpu_float32` operators raise unless a
+    test has installed an implementation behind them (sbmc_amd/halide_ops.py)."""
+    np.random.seed(0)
+    th.manual_seed(0)
     mode = "kpcn" if args.kpcn_mode else "sbmc"          # reference scripts/train.py:39-43
     data_args = dict(spp=args.spp, mode=mode, load_coords=args.load_coords, load_gbuffer=args.load_gbuffer,
                      load_p=args.load_p, load_ld=args.load_ld, load_bt=args.load_bt)
@@ -44,15 +52,17 @@ def main(args):
                                 batch_size=args.bs, num_workers=1, shuffle=False)
     meta = dict(model_params=dict(ksize=args.ksize, gather=args.gather, pixel=args.pixel),
                 kpcn_mode=args.kpcn_mode, data_params=data_args)   # (the reference stores them all: train.py:85-87)
-    interface = interfaces.SampleBasedDenoiserInterface(model, lr=args.lr, cuda=True)
+    interface = interfaces.SampleBasedDenoiserInterface(model, lr=args.lr, cuda=cuda)
     ckpt = interfaces.Checkpointer(args.checkpoint_dir, model, interface.optimizer, meta=meta)
     extras, _ = ckpt.load_latest()
     start = extras["epoch"] if extras else 0
-    interfaces.train(interface, loader, num_epochs=args.num_epochs, val_dataloader=val_loader,
-                     checkpointer=ckpt, start_epoch=start)
+    validation = []
+    history = interfaces.train(interface, loader, num_epochs=args.num_epochs, val_dataloader=val_loader,
+                               checkpointer=ckpt, start_epoch=start, validation_log=validation)
+    return {"history": history, "validation": validation, "start_epoch": start}
 
 
-if __name__ == "__main__":
+def parser():
     p = argparse.ArgumentParser()
     p.add_argument("--data", required=True)
     p.add_argument("--val_data", default=None)
@@ -73,5 +83,9 @@ if __name__ == "__main__":
     p.add_argument("--bs", type=int, default=1)
     p.add_argument("--num_epochs", type=int, default=1)
     p.add_argument("--num_worker_threads", type=int, default=0)
+    return p
+
+
+if __name__ == "__main__":
     logging.basicConfig(level=logging.INFO)
-    main(p.parse_args())
+    main(parser().parse_args())

@@ -363,7 +363,95 @@ def gen_bin_groups(ref_root):
     save("bin_scene_groups_expected.npz", out)
 
 
+WIDE_CASES = {"k5": dict(ksize=5, seed=31, h=48, w=64, spp=2), "k21": dict(ksize=21, seed=32, h=48, w=64, spp=2)}
+
+
+def wide_inputs(case):
+    """The seeded batch of a `multisteps_wide.npz` case (shared by the generator and the tests: the fixture stores
+    float64 checksums of these tensors instead of 2.3 MB of incompressible uniform floats per case)."""
+    c = WIDE_CASES[case]
+    g = th.Generator().manual_seed(c["seed"] + 100)
+    rad = th.empty(1, c["spp"], 3, c["h"], c["w"]).exponential_(1.0, generator=g)
+    feat = th.rand(1, c["spp"], 93, c["h"], c["w"], generator=g)
+    feat[:, :, 5:8] = th.log(1 + rad) / 10            # the radiance channels as _preprocess_standard leaves them
+    feat[:, :, 8:11] = th.log(1 + rad) / 10           # (datasets.py:760-768; SURVEY 8d "synthetic inputs")
+    batch = {"radiance": rad, "features": feat, "global_features": th.rand(1, 3, 1, 1, generator=g)}
+    target = th.empty(1, 3, c["h"], c["w"]).exponential_(1.0, generator=g)
+    return batch, target
+
+
+def wide_sample_index(numel, name):
+    """64 seeded positions of a parameter's gradient (fixture digests)."""
+    import zlib
+    g = th.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7fffffff)
+    return th.randint(0, numel, (min(64, numel),), generator=g)
+
+
+def gen_multisteps_wide(ref):
+    """The reference's Multisteps at the PRODUCTION widths (93 features, width 128, embedding 128, 3 steps, k = 5 and
+    21: every channel count the 3x3 / split 1x1 kernels of csrc/ take) on a 48x64 frame at 2 spp.  34.8 M parameters
+    are not committed: the model is built under torch.manual_seed(seed) -- the fixture holds float64 checksums of
+    every parameter so that the test can tell a changed initialisation from a wrong kernel -- and the batch comes
+    from `wide_inputs`.  Outputs (eval + train), loss, and per parameter: the gradient itself where it has at most
+    1024 entries (biases, weight_g), else 64 seeded entries; its largest magnitude and L2 norm; and `gerr64`, the
+    distance of the REFERENCE's fp32 gradient from a float64 evaluation of the same graph (tests/helpers.py
+    multisteps_fp64), in units of the module's gradient scale.  That last number is what any fp32 evaluation can be
+    asked for: at this width a forward pass decides ~1e7 activation signs and pooling winners, a handful of which
+    sit within fp32 rounding of the kink, and one flipped decision moves a coarse-level bias gradient by ~1e-2 of
+    its scale -- in the reference's own evaluation (gerr64 up to 1.6e-2 for k5) as in anybody's."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import module_scales, multisteps_fp64
+    from sbmc_amd import halide_ops
+    from oracle import sbmc_oracle
+    out = {}
+    for case, c in WIDE_CASES.items():
+        th.manual_seed(c["seed"])
+        model = ref.models.Multisteps(93, 3, width=128, embedding_width=128, ksize=c["ksize"], nsteps=3)
+        for k, v in model.state_dict().items():
+            out["%s.sdsum.%s" % (case, k)] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+        batch, target = wide_inputs(case)
+        for k, v in batch.items():
+            out["%s.insum.%s" % (case, k)] = np.float64(v.double().sum().item())
+        out[case + ".insum.target_image"] = np.float64(target.double().sum().item())
+        model.train(False)
+        with th.no_grad():
+            out[case + ".eval.radiance"] = npy(model({k: v.clone() for k, v in batch.items()})["radiance"])
+        model.train(True)
+        res = model({k: v.clone() for k, v in batch.items()})["radiance"]
+        out[case + ".train.radiance"] = npy(res)
+        crop = (target.shape[-1] - res.shape[-1]) // 2
+        tgt = target[..., crop:-crop, crop:-crop]
+        loss = ref.losses.TonemappedRelativeMSE()(res, tgt)
+        loss.backward()
+        out[case + ".train.loss"] = npy(loss)
+        # the float64 yardstick of the same graph (this build's module tree with torch float64 ops only)
+        halide_ops.register_cpu_ops_for_testing(sbmc_oracle)
+        m64 = multisteps_fp64(model, (93, 3), dict(width=128, embedding_width=128, ksize=c["ksize"], nsteps=3)).train(True)
+        o64 = m64({k: v.double() for k, v in batch.items()})["radiance"]
+        ref.losses.TonemappedRelativeMSE()(o64, tgt.double()).backward()
+        halide_ops.register_cpu_ops_for_testing(None)
+        g64 = {k: q.grad for k, q in m64.named_parameters()}
+        scales = module_scales(g64)
+        out[case + ".out_err64"] = np.float64((res.detach().double() - o64.detach()).abs().max().item() / o64.abs().max().item())
+        for k, p in model.named_parameters():
+            gflat = p.grad.reshape(-1)
+            out["%s.gmax.%s" % (case, k)] = np.float64(gflat.abs().max().item())
+            out["%s.gl2.%s" % (case, k)] = np.float64(gflat.double().norm().item())
+            if gflat.numel() <= 1024:
+                out["%s.gfull.%s" % (case, k)] = npy(gflat)
+            else:
+                out["%s.gsample.%s" % (case, k)] = npy(gflat[wide_sample_index(gflat.numel(), k)])
+            out["%s.gerr64.%s" % (case, k)] = np.float64((p.grad.double() - g64[k]).abs().max().item() / scales[k])
+        errs = sorted(float(out["%s.gerr64.%s" % (case, k)]) for k, _ in model.named_parameters())
+        print(case, "loss", float(loss.detach()), "out", tuple(res.shape), "reference vs float64: output %.2e, gradients median %.2e, worst %.2e"
+              % (float(out[case + ".out_err64"]), errs[len(errs) // 2], errs[-1]))
+    save("multisteps_wide.npz", out)
+
+
 def main():
+    if "--round5" in sys.argv:        # the production-width fixture (round 5)
+        gen_multisteps_wide(refload.load_reference())
+        return
     if "--round3" in sys.argv:        # the fixture added in round 3 only
         refload.load_reference()      # (installs the stand-in for the absent `ttools` logger)
         gen_bin_groups(refload.REFERENCE_ROOT)
@@ -388,6 +476,7 @@ def main():
     gen_interface(ref)
     gen_bin_kpcn(refload.REFERENCE_ROOT)
     gen_bin_groups(refload.REFERENCE_ROOT)
+    gen_multisteps_wide(ref)
 
 
 if __name__ == "__main__":

@@ -1,9 +1,12 @@
 import os
+import sys
 
 import numpy as np
 import torch as th
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)      # make_golden.py: the seeded inputs the generator and the tests share
 
 
 def golden(name):
@@ -193,3 +196,55 @@ def close_or_yardstick(a, ref32, truth_fn, rtol=1e-5, slack=2.0, what=""):
         no_worse_than(a, ref32, truth, rtol=rtol, slack=slack, what=what + " (vs float64)")
         t = truth.detach().cpu().double()
         return ((a.detach().cpu().double() - t).abs().max().item(), (ref32.detach().cpu().double() - t).abs().max().item())
+
+
+def multisteps_wide(case, device="cpu"):
+    """The production-width fixture (tests/golden/make_golden.py:gen_multisteps_wide): Multisteps(93, 3, width 128,
+    embedding 128, 3 steps) under the fixture's seed, the seeded batch, and the check that BOTH reproduce what the
+    reference saw (float64 checksums of every parameter and input) -- so that a failing comparison below means a
+    wrong kernel, never a changed initialisation.  -> (fixture, model, batch, target)"""
+    from make_golden import WIDE_CASES, wide_inputs
+    from sbmc_amd import Multisteps
+    g = golden("multisteps_wide.npz")
+    c = WIDE_CASES[case]
+    th.manual_seed(c["seed"])
+    model = Multisteps(93, 3, width=128, embedding_width=128, ksize=c["ksize"], nsteps=3)
+    sd = model.state_dict()
+    keys = [k[len(case) + 7:] for k in g.files if k.startswith(case + ".sdsum.")]
+    assert sorted(keys) == sorted(sd.keys())
+    for k in keys:
+        want = g["%s.sdsum.%s" % (case, k)]
+        got = (sd[k].double().sum().item(), sd[k].double().abs().sum().item())
+        assert got[0] == want[0] and got[1] == want[1], "seeded init differs from the reference's: " + k
+    batch, target = wide_inputs(case)
+    for k, v in batch.items():
+        assert v.double().sum().item() == float(g["%s.insum.%s" % (case, k)]), k
+    assert target.double().sum().item() == float(g[case + ".insum.target_image"])
+    return g, model.to(device), {k: v.to(device) for k, v in batch.items()}, target.to(device)
+
+
+def rel_close(a, b, rtol=1e-5, what=""):
+    """Plain elementwise relative bound |a - b| <= rtol * |b| (+ 1e-30): for quantities that are sums of
+    non-negative terms (splat outputs, weight sums, running maxima of logits are NOT -- they are differences only
+    through their arguments), where no cancellation excuses an absolute scale."""
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double() if isinstance(b, th.Tensor) else th.from_numpy(np.asarray(b)).double()
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    err = (a - b).abs()
+    bad = err > rtol * b.abs() + 1e-30
+    assert not bad.any(), "%s: %d/%d beyond %.0e relative, worst %.3e at |b| = %.3e" % (
+        what, int(bad.sum()), b.numel(), rtol, (err / b.abs().clamp_min(1e-300))[bad].max().item(),
+        b.abs()[bad].min().item())
+
+
+def state_close(out, ref, what="", rtol=1e-5):
+    """The splat's running state (sum_r, sum_w, max_w) for NON-NEGATIVE radiance: sum_r and sum_w are sums of
+    non-negative terms -- plain elementwise 1e-5 relative, no absolute scale; max_w is a selection among the input
+    logits -- equal to the bit."""
+    for a, b, n in zip(out, ref, ("sum_r", "sum_w", "max_w")):
+        b = b if isinstance(b, th.Tensor) else th.from_numpy(np.asarray(b))
+        if n == "max_w":
+            assert th.equal(a.detach().cpu().float(), b.detach().cpu().float()), "%s max_w: not the same logit selected" % what
+        else:
+            assert (b >= 0).all(), "state_close is for non-negative radiance"
+            rel_close(a, b, rtol=rtol, what="%s %s" % (what, n))

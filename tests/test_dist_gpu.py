@@ -27,9 +27,10 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, height, layout="auto", per_conv=True, transport="ipc"):
+def _worker(rank, world, port, height, layout="auto", per_conv=True, transport="ipc", wbank=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["SBMC_WBANK"] = "1" if wbank else "0"
     os.environ["SBMC_UNET_LAYOUT"] = layout
     os.environ["SBMC_HALO_TRANSPORT"] = transport
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -82,11 +83,14 @@ def _worker(rank, world, port, height, layout="auto", per_conv=True, transport="
         no_worse_than(loss, ref_loss, l64, what="loss")
         scales = module_scales(g64)
         for k, q in model.named_parameters():
-            # (2e-5 / slack 3: a bias gradient here is an fp32 sum over ~9000 pixel-samples of mixed sign; both the
-            # single-process and the sharded evaluation sit at 0.3-1.2e-5 of the module's gradient scale from the
-            # float64 one, and which side of 1e-5 a given parameter lands on changes with any last-bit change upstream
-            # (round 4: the weight bank's weight norm differs from torch's in the last bit))
-            no_worse_than(q.grad, ref_grads[k], g64[k], rtol=2e-5, what="grad " + k, scale=scales[k], slack=3.0)
+            # weights: 1e-5 of the module's gradient scale from float64, or twice the single-process evaluation's own
+            # distance.  Biases with the weight bank on: 2e-5 / three times -- a bias gradient here is an fp32 sum over
+            # ~9000 pixel-samples of mixed sign, both evaluations sit at 0.3-1.2e-5 from the float64 one, and the bank's
+            # weight norm differs from torch's in the last bit, which moves them across 1e-5 (wbank=False below runs
+            # every parameter at the tight bound: the bank is the only source of that drift)
+            loose = wbank and k.endswith(".bias")
+            no_worse_than(q.grad, ref_grads[k], g64[k], rtol=2e-5 if loose else 1e-5, what="grad " + k, scale=scales[k],
+                          slack=3.0 if loose else 2.0)
         assert (part.channel is not None) == (transport == "ipc")
     finally:
         dist.destroy_process_group()
@@ -101,6 +105,13 @@ def test_sharded_denoiser_on_device_kernels(layout, per_conv, transport):
     before every chain of three.  transport: neighbour rows through the IPC mailboxes (csrc/halo.hip; the splat
     state then merges in ONE kernel) or through torch.distributed P2P (gloo here: staged through the host)."""
     mp.spawn(_worker, args=(2, _free_port(), 64, layout, per_conv, transport), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("transport", ["ipc", "p2p"])
+def test_sharded_denoiser_without_the_weight_bank_at_the_tight_bound(transport):
+    """SBMC_WBANK=0 (torch's weight norm layer by layer): every parameter gradient, biases included, at 1e-5 of the
+    float64 evaluation or twice the single-process evaluation's own distance from it."""
+    mp.spawn(_worker, args=(2, _free_port(), 64, "nhwc", False, transport, False), nprocs=2, join=True)
 
 
 def _fallback_worker(rank, world, port):

@@ -24,7 +24,7 @@ import sys
 import pytest
 import torch as th
 
-from helpers import close, no_worse_than
+from helpers import close, no_worse_than, state_close
 
 pytestmark = pytest.mark.gpu
 
@@ -96,8 +96,7 @@ def test_config1_forward_720p_4spp_properties(model, oracle):
     kc, rc = kernels.cpu(), rb.cpu()
     for s in range(4):
         st = oracle.progressive_kernel_apply(rc[:, s], kc[:, s], *st, splat=True)
-    for a, b, n in zip((sr, sw, mw), st, ("sum_r", "sum_w", "max_w")):
-        close(a, b, what="band " + n)
+    state_close((sr, sw, mw), st, what="band")
     close(sr / (sw + 1e-8), st[0] / (st[1] + 1e-8), what="band output")
 
 
@@ -167,8 +166,7 @@ def test_config4_fp16_logits_720p():
     with th.no_grad():
         a = F.SplatAll.apply(rad, ker)
         b = F.SplatAll.apply(rad, ker.float())
-    for x, y, n in zip(a, b, ("sum_r", "sum_w", "max_w")):
-        close(x, y, what="32 spp " + n)
+    state_close(a, b, what="32 spp ")
     del a, b
     d_out = th.randn(1, 3, H, W, device="cuda")
     r16, k16 = rad[:, :8].clone().requires_grad_(), ker[:, :8].clone().requires_grad_()
@@ -195,8 +193,7 @@ def test_config4_32spp_full_width_band_vs_oracle(oracle):
     rg, kg = rad.cuda().requires_grad_(), ker.cuda().requires_grad_()
     sr, sw, mw = F.SplatAll.apply(rg, kg)
     (sr / (sw + 1e-8)).backward(d_out.cuda())
-    for a, b, n in zip((sr, sw, mw), st, ("sum_r", "sum_w", "max_w")):
-        close(a, b, what=n)
+    state_close((sr, sw, mw), st, what="")
     close(rg.grad, ro.grad, what="d_radiance")
     # d_kernels after a 32-step chain: the element of every destination that carries the routed gradient of
     # the running max is a cancellation residual in BOTH fp32 implementations (d(out)/d(max) = 0

@@ -6,7 +6,7 @@ import pytest
 import torch as th
 
 from helpers import (close, golden, module_scales, multisteps_fp64, multisteps_from_golden, no_worse_than,
-                     run_progressive, t)
+                     run_progressive, state_close, t)
 
 pytestmark = pytest.mark.gpu
 
@@ -54,8 +54,7 @@ def test_progressive_matches_reference_fixtures(case, spp, splat, fused):
     grads = [t(g[tag + "g%d" % i]) for i in range(3)]
     mod = modules.ProgressiveKernelApply(splat=splat, fused=fused)
     out, dd, dk = run_progressive(mod, datas, kerns, grads, "cuda")
-    for a, n in zip(out, ("sum_r", "sum_w", "max_w")):
-        close(a, g[tag + n], what=n)
+    state_close(out, [t(g[tag + n]) for n in ("sum_r", "sum_w", "max_w")], what=tag)
     for i in range(spp):
         close(dd[i], g[tag + "d_data%d" % i], what="d_data")
         close(dk[i], g[tag + "d_kernels%d" % i], what="d_kernels")
@@ -120,12 +119,12 @@ def test_multisteps_on_gpu_matches_reference_fixture():
     model.train(False)
     with th.no_grad():
         out = model(batch)["radiance"]
-    close(out, g["eval.radiance"], rtol=2e-5, what="eval output")   # MIOpen conv rounding + splat
-    model.train(True)
+    close(out, g["eval.radiance"], rtol=1e-5, what="eval output")   # (width 8: MIOpen convolutions, generic 1x1 path;
+    model.train(True)                                               #  the production widths: the test below)
     res = model(batch)["radiance"]
-    close(res, g["train.radiance"], rtol=2e-5, what="train output")
+    close(res, g["train.radiance"], rtol=1e-5, what="train output")
     loss = losses.TonemappedRelativeMSE()(res, crop_like(target, res))
-    close(loss, g["train.loss"], rtol=2e-5, what="loss")
+    close(loss, g["train.loss"], rtol=1e-5, what="loss")
     loss.backward()
     # parameter gradients: sums over every pixel and sample whose fp32 value depends on the order of addition
     # (MIOpen's weight-gradient kernels, the 1x1 kernels' per-workgroup partial sums): within 1e-5 of a float64
@@ -138,6 +137,37 @@ def test_multisteps_on_gpu_matches_reference_fixture():
     scales = module_scales(g64)
     for k, p in model.named_parameters():
         no_worse_than(p.grad, t(g["grad." + k]), g64[k], what="grad " + k, scale=scales[k])
+
+
+@pytest.mark.parametrize("case", ["k5", "k21"])
+def test_multisteps_production_width_on_gpu_matches_reference_fixture(case):
+    """The kernels that carry the timed step -- split-precision 3x3 convolutions (csrc/conv3x3.hip), split 1x1 layers
+    and the wide 441-channel gradient (csrc/pointwise.hip), the fused splat -- inside the reference's
+    Multisteps(93, 3, width 128, k = 5 / 21) against what the REFERENCE computed for the same seeded model and batch
+    (tests/golden/multisteps_wide.npz): outputs and loss at 1e-5, gradients against the float64 yardstick as in
+    test_host_golden.wide_fixture_checks.  Asserts that those kernels, not a library path, ran."""
+    from test_host_golden import wide_fixture_checks
+    from sbmc_amd import functions as F
+    calls = []
+    F.enable_kernel_timing(calls)
+    try:
+        report = wide_fixture_checks(case, "cuda")
+    finally:
+        F.enable_kernel_timing(None)
+    names = [c[0] for c in calls]
+
+    def count(prefix):
+        return sum(1 for n in names if n.startswith(prefix))
+    # per forward pass: 3 U-nets x 15 convolutions, 3 embeddings x 3 + 3 regressor 1x1 layers; the fixture check
+    # runs an eval and a train forward and one backward
+    assert count("conv3x3_fwd") == 2 * 45, count("conv3x3_fwd")
+    assert count("conv3x3_bwd_weight") == 45 and count("conv3x3_bwd_data") == 45
+    assert count("pointwise_fwd ") == 2 * 12, count("pointwise_fwd ")
+    assert count("pointwise_bwd ") == 11 + (1 if case == "k5" else 0), names
+    assert count("pointwise_gw_wide") == (1 if case == "k21" else 0)
+    assert any(n.startswith("splat") for n in names), set(names)
+    worst = max(report.items(), key=lambda kv: kv[1][0])
+    print("%s: worst gradient %s at %.2e of its scale from float64 (reference %.2e)" % (case, worst[0], *worst[1]))
 
 
 def test_native_library_is_loaded():

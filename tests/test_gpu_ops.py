@@ -7,7 +7,7 @@ products are compared with an abs-scaled bound: |a - b| <= 1e-5 * max|b| + 1e-5 
 import pytest
 import torch as th
 
-from helpers import no_worse_than, progressive_fp64
+from helpers import no_worse_than, progressive_fp64, state_close
 
 pytestmark = pytest.mark.gpu
 
@@ -124,8 +124,7 @@ def test_fused_splat_update_vs_oracle(oracle, bs, c, h, w, k, spp):
         datas, kerns, grads, "cpu")
     fused = modules.ProgressiveKernelApply(splat=True)
     out, dd, dk = _progressive(fused, datas, kerns, grads, "cuda")
-    for a, b, n in zip(out, ref_out, ("sum_r", "sum_w", "max_w")):
-        close(a, b, what=n)
+    state_close(out, ref_out, what="")
     for s in range(spp):
         close(dd[s], ref_dd[s], what="d_data[%d]" % s)
         close(dk[s], ref_dk[s], what="d_kernels[%d]" % s)
@@ -200,8 +199,7 @@ def test_splat_all_vs_oracle(oracle, bs, c, h, w, spp):
     assert F.splat_all_supported(dg, kg)
     out = F.SplatAll.apply(dg, kg)
     th.autograd.backward(out, [g.cuda() for g in grads])
-    for a, b, n in zip(out, ref_out, ("sum_r", "sum_w", "max_w")):
-        close(a, b, what=n)
+    state_close(out, ref_out, what="")
     for s in range(spp):
         close(dg.grad[:, s], ref_dd[s], what="d_data[%d]" % s)
         close(kg.grad[:, s], ref_dk[s], what="d_kernels[%d]" % s)
@@ -361,8 +359,7 @@ def test_fp16_logits_vs_oracle(oracle, bs, c, h, w, spp):
     out = F.SplatAll.apply(dg, kg)
     th.autograd.backward(out, [g.cuda() for g in grads])
     assert kg.grad.dtype == th.float16
-    for a, b, n in zip(out, ref_out, ("sum_r", "sum_w", "max_w")):
-        close(a, b, what=n)
+    state_close(out, ref_out, what="")
     for s in range(spp):
         close(dg.grad[:, s], ref_dd[s], what="d_data")
         close(kg.grad[:, s].float(), ref_dk[s], rtol=1e-3, what="d_kernels (half)")
@@ -621,8 +618,7 @@ def test_fused_gather_update_vs_oracle(oracle, bs, c, h, w, k, spp):
         lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=False),
         datas, kerns, grads, "cpu")
     out, dd, dk = _progressive(modules.ProgressiveKernelApply(splat=False), datas, kerns, grads, "cuda")
-    for a, b, n in zip(out, ref_out, ("sum_r", "sum_w", "max_w")):
-        close(a, b, what=n)
+    state_close(out, ref_out, what="")
     # d_kernels: the element that receives the routed max-gradient is a difference of two k*k-term sums
     # in BOTH fp32 implementations; it is held to 1e-5 of the float64 restatement of the same graph, or to
     # twice the oracle's own fp32 error against it, whichever is larger (helpers.no_worse_than)

@@ -211,3 +211,66 @@ def test_multisteps_odd_sizes_batch2_and_gather_ablation(cpu_ops, tag):
     with th.no_grad():
         out = model(batch)["radiance"]
     close(out, g[tag + ".eval.radiance"], what=tag)
+
+
+def wide_fixture_checks(case, device):
+    """The production-width reference fixture (helpers.multisteps_wide) against this build on `device`.
+
+    eval / train outputs and the loss: 1e-5 of the reference's.  Parameter gradients, measured against a float64
+    evaluation of the same graph in units of the module's gradient scale (`err`), next to the reference's own
+    distance from it (`gerr64`, in the fixture):
+      * every parameter: err <= max(1e-5, 2 x gerr64 of that parameter) -- or, for at most a tenth of the parameters,
+        err <= 2 x the LARGEST gerr64 of the fixture: the size of a flipped activation / pooling decision, which the
+        reference's evaluation contains as well (make_golden.gen_multisteps_wide), in different places;
+      * the entries the fixture holds (whole small gradients, 64 seeded entries of the others): the same two bounds
+        against the reference's fp32 values directly, plus their L2 norms within 1e-3.
+    -> {name: (err, gerr64)}"""
+    from helpers import module_scales, multisteps_fp64, multisteps_wide
+    from make_golden import WIDE_CASES, wide_sample_index
+    from sbmc_amd import losses
+    from sbmc_amd.utils import crop_like
+    g, model, batch, target = multisteps_wide(case, device)
+    model.train(False)
+    with th.no_grad():
+        out = model({k: v.clone() for k, v in batch.items()})["radiance"]
+    close(out, g[case + ".eval.radiance"], rtol=1e-5, what="eval output")
+    model.train(True)
+    res = model({k: v.clone() for k, v in batch.items()})["radiance"]
+    close(res, g[case + ".train.radiance"], rtol=1e-5, what="train output")
+    loss = losses.TonemappedRelativeMSE()(res, crop_like(target, res))
+    assert abs(loss.item() - float(g[case + ".train.loss"])) <= 1e-5 * abs(float(g[case + ".train.loss"]))
+    loss.backward()
+    grads = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
+    m64 = multisteps_fp64(model, (93, 3), dict(width=128, embedding_width=128, ksize=WIDE_CASES[case]["ksize"],
+                                               nsteps=3)).train(True)
+    o64 = m64({k: v.cpu().double() for k, v in batch.items()})["radiance"]
+    losses.TonemappedRelativeMSE()(o64, crop_like(target.cpu().double(), o64)).backward()
+    g64 = {k: q.grad for k, q in m64.named_parameters()}
+    scales = module_scales(g64)
+    gerr = {k: float(g["%s.gerr64.%s" % (case, k)]) for k in grads}
+    kink = 2.0 * max(gerr.values())
+    report, loose = {}, []
+    for k, mine in grads.items():
+        err = (mine - g64[k]).abs().max().item() / scales[k]
+        report[k] = (err, gerr[k])
+        if err > max(1e-5, 2.0 * gerr[k]):
+            assert err <= kink, "%s: %.3e of its scale from float64 (reference %.3e; a flipped decision: %.3e)" % (
+                k, err, gerr[k], kink)
+            loose.append(k)
+        flat = mine.reshape(-1)
+        if "%s.gfull.%s" % (case, k) in g.files:
+            ref, got = t(g["%s.gfull.%s" % (case, k)]).double(), flat
+        else:
+            ref, got = t(g["%s.gsample.%s" % (case, k)]).double(), flat[wide_sample_index(flat.numel(), k)]
+        d = (got - ref).abs().max().item() / scales[k]
+        assert d <= (kink if k in loose else max(2e-5, 4.0 * gerr[k])), "%s: %.3e of its scale from the reference's entries" % (k, d)
+        n_ref = float(g["%s.gl2.%s" % (case, k)])
+        assert abs(flat.norm().item() - n_ref) <= 1e-3 * n_ref + 1e-12 * scales[k], k
+    assert len(loose) * 10 <= len(grads), "beyond their own yardstick: %s" % loose
+    return report
+
+
+@pytest.mark.parametrize("case", ["k5", "k21"])
+def test_multisteps_production_width_matches_reference_fixture(cpu_ops, case):
+    """Host composition at the production widths (torch-CPU convolutions, the oracle behind the operators)."""
+    wide_fixture_checks(case, "cpu")

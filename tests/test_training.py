@@ -2,6 +2,7 @@
 import os
 import sys
 
+import pytest
 import torch as th
 from torch.utils.data import DataLoader
 
@@ -50,6 +51,117 @@ def test_train_loop_dataset_checkpoint(cpu_ops, tmp_path):
     assert interfaces.Checkpointer.load_meta(str(tmp_path / "ckpt")) == {"a": 1}
     multi = interfaces.MultiSampleCountDataset(str(root), spp=2)
     assert len(multi) == 2 and multi[1]["features"].shape[0] == 2
-    import pytest
     with pytest.raises(RuntimeError):
         interfaces.MultiSampleCountDataset(str(root), spp=1)
+
+
+# ------------------------------------------------------------------ scripts/train.py end to end (row N3)
+def _train_cli():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_cli", os.path.join(root, "scripts", "train.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+DATA = os.path.join(GOLDEN, "bin_scene")          # root/<scene>/*.bin: four 16x16 tiles at 3 spp
+
+
+def _two_invocations(cli, ckpt_dir, cuda, extra=()):
+    """`train.py --num_epochs 1`, then `--num_epochs 2` on the same checkpoint directory (resumes after epoch 1)."""
+    recs = []
+    for epochs in (1, 2):
+        args = cli.parser().parse_args(["--data", DATA, "--val_data", DATA, "--checkpoint_dir", ckpt_dir, "--spp", "3",
+                                        "--ksize", "5", "--constant_spp", "--num_epochs", str(epochs)] + list(extra))
+        recs.append(cli.main(args) if cuda else cli.run(args, cuda=False))
+    return recs
+
+
+def _check_records(recs, ckpt_dir):
+    from sbmc_amd import interfaces
+    first, second = recs
+    assert first["start_epoch"] == 0 and second["start_epoch"] == 1          # load_latest() resumed
+    assert len(first["history"]) == 4 and len(second["history"]) == 4          # one epoch of four tiles each
+    assert len(first["validation"]) == 1 and first["validation"][0]["n"] == 4
+    assert sorted(os.listdir(ckpt_dir)) == ["epoch_0000.pth", "epoch_0001.pth", "training_end.pth"]
+    meta = interfaces.Checkpointer.load_meta(ckpt_dir)
+    assert meta["model_params"] == dict(ksize=5, gather=False, pixel=False) and meta["data_params"]["spp"] == 3
+    # the second epoch starts from the first's parameters AND optimizer state: its first steps see lower losses on
+    # the same tiles than a fresh model would (lr 1e-4, same shuffling seed -> same tile order)
+    assert all(h["loss"] == h["loss"] and h["rmse"] == h["rmse"] for r in recs for h in r["history"])
+
+
+def test_train_script_loop_checkpoint_resume_on_cpu(cpu_ops, tmp_path):
+    """scripts/train.py run(): dataset -> DataLoader -> interface -> validation -> checkpoints -> resume, on the host
+    with the oracle behind the operators (the GPU test below compares main() with exactly this run)."""
+    cli = _train_cli()
+    recs = _two_invocations(cli, str(tmp_path / "ck"), cuda=False)
+    _check_records(recs, str(tmp_path / "ck"))
+    if not th.cuda.is_available():
+        with pytest.raises(SystemExit):
+            cli.main(cli.parser().parse_args(["--data", DATA, "--checkpoint_dir", str(tmp_path / "x")]))
+
+
+
+@pytest.mark.gpu
+def test_train_script_main_on_gpu_equals_the_cpu_oracle_run(cpu_ops, tmp_path):
+    """scripts/train.py main() on the GPU (production width 128: the own 3x3 / 1x1 kernels, fused splat, fused Adam)
+    on the committed .bin scene: 2 epochs in two invocations (validation, checkpoint, resume from load_latest()),
+    loss / rmse history and validation means equal to the same run on the host with the CPU oracle behind the
+    operators.  Reference: scripts/train.py:33-115, sbmc/interfaces.py:62-132."""
+    from sbmc_amd import functions as F
+    cli = _train_cli()
+    calls = []
+    F.enable_kernel_timing(calls)
+    try:
+        gpu = _two_invocations(cli, str(tmp_path / "ck_gpu"), cuda=True)
+    finally:
+        F.enable_kernel_timing(None)
+    assert any(c[0].startswith("conv3x3_fwd") for c in calls) and any(c[0].startswith("pointwise_bwd") for c in calls)
+    _check_records(gpu, str(tmp_path / "ck_gpu"))
+    cpu = _two_invocations(cli, str(tmp_path / "ck_cpu"), cuda=False)
+    step = 0
+    for rg, rc in zip(gpu, cpu):
+        for hg, hc in zip(rg["history"], rc["history"]):
+            # Adam's first updates are lr * sign(g) wherever |g| >> eps: the parameter trajectories of two fp32
+            # evaluations stay together except where a gradient is rounding noise around zero, which by the same
+            # token does not move the loss.  Held to 1e-5 per step.
+            assert hg["loss"] == pytest.approx(hc["loss"], rel=1e-5), (step, hg, hc)
+            assert hg["rmse"] == pytest.approx(hc["rmse"], rel=2e-5), (step, hg, hc)
+            step += 1
+        for vg, vc in zip(rg["validation"], rc["validation"]):
+            assert vg["loss"] == pytest.approx(vc["loss"], rel=1e-5) and vg["n"] == vc["n"]
+    # the checkpoints hold the same model: every parameter within an Adam step's reach of the host run's
+    a = th.load(str(tmp_path / "ck_gpu" / "training_end.pth"), map_location="cpu")
+    b = th.load(str(tmp_path / "ck_cpu" / "training_end.pth"), map_location="cpu")
+    assert a["epoch"] == b["epoch"] == 2 and a["meta"] == b["meta"]
+    for k in a["model"]:
+        assert (a["model"][k] - b["model"][k]).abs().max().item() <= 8 * 2 * 1e-4 + 1e-6, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", ["--gather", "--kpcn_mode", "--pixel"])
+def test_train_script_main_variants_on_gpu(cpu_ops, tmp_path, flag):
+    """`--gather` (gather kernels, the default randomised sample count: MultiSampleCountDataset), `--kpcn_mode`
+    ([Bako2017]'s network on the "kpcn" preprocessing; its nine valid 5x5 convolutions need 64x64 tiles) and
+    `--pixel`, one epoch each through main(), against the host run."""
+    from make_golden import synthetic_scene
+    cli = _train_cli()
+    data = DATA
+    argv = ["--spp", "3", "--ksize", "5", "--num_epochs", "1", flag]
+    if flag == "--kpcn_mode":
+        data = str(tmp_path / "data")
+        synthetic_scene(os.path.join(data, "scene0"), 128, 64, 64, 2, seed=5)
+        argv = ["--spp", "2", "--ksize", "5", "--num_epochs", "1", "--constant_spp", flag]
+    elif flag == "--pixel":
+        argv.append("--constant_spp")
+    recs = {}
+    for dev in ("gpu", "cpu"):
+        args = cli.parser().parse_args(["--data", data, "--val_data", data, "--checkpoint_dir", str(tmp_path / dev)] + argv)
+        recs[dev] = cli.main(args) if dev == "gpu" else cli.run(args, cuda=False)
+    n = {"--gather": 8, "--kpcn_mode": 2, "--pixel": 4}[flag]          # --gather: 4 tiles x sample counts {2, 3}
+    assert len(recs["gpu"]["history"]) == n == len(recs["cpu"]["history"])
+    for hg, hc in zip(recs["gpu"]["history"], recs["cpu"]["history"]):
+        assert hg["loss"] == pytest.approx(hc["loss"], rel=1e-5), (hg, hc)
+    assert recs["gpu"]["validation"][0]["loss"] == pytest.approx(recs["cpu"]["validation"][0]["loss"], rel=1e-5)
