@@ -41,7 +41,7 @@ extern "C" {
 #define SBMC_API
 #endif
 
-#define SBMC_HIP_ABI_VERSION 5
+#define SBMC_HIP_ABI_VERSION 6
 #define SBMC_HIP_EINVAL (-1)
 /* largest channel count the fused/plain kernels take in one call */
 #define SBMC_HIP_MAX_CHANNELS 8
@@ -426,6 +426,29 @@ SBMC_API int sbmc_pointwise_fwd_signs_f32(const float *x, const float *w, const 
 SBMC_API int sbmc_pointwise_fwd_mean_f32(const float *x, const float *w, const float *bias, const float *t, float *y,
                                 unsigned *signs, float *ymean, int s_mean, int b, int s, int cin, int cout,
                                 long hw, int t_mode, int act, float slope, void *stream);
+/* ABI 6 -- the fp32 layer with MAGNITUDE WORDS (the scheme of the 3 x 3 kernels, sbmc_conv3x3_*: a pass leaves the bit
+ * pattern of the largest magnitude it wrote in a device word, the consumer takes its power-of-two scale from it).
+ *   xmax  a device word holding the bit pattern of a float >= max |x|, or NULL.  Not NULL: the products run in the 3 x 3
+ *         kernels' number format -- two f16 planes under the power-of-two scale, three of the four partial products
+ *         (<= 2^-22 |x w| per term dropped), fp32 accumulation -- at half the matrix-pipe work of the three-bf16-plane
+ *         form (NULL: that form, as sbmc_pointwise_fwd_signs_f32).  A word SMALLER than max |x| is the caller's error
+ *         (values beyond it overflow their f16 plane).
+ *   amax  a device word the caller zeroed (or holding a lower bound), raised to the bit pattern of max |y|; or NULL.
+ *   signs, ymean / s_mean: as above, or NULL.
+ * No reference counterpart (the reference multiplies in fp32: sbmc/modules.py:154-175 through cuDNN). */
+SBMC_API int sbmc_pointwise_fwd_scaled_f32(const float *x, const float *w, const float *bias, const float *t, float *y,
+                                  unsigned *signs, float *ymean, int s_mean, const unsigned *xmax, unsigned *amax,
+                                  int b, int s, int cin, int cout, long hw, int t_mode, int act, float slope,
+                                  void *stream);
+/* The backward with magnitude words: gmax / xmax (and gmmax when gmean is given) -- device words holding the bit patterns
+ * of floats >= max |gy| / max |x| / max |gmean| -- not NULL: both products (gw += gz x^T, gx = w^T gz) in the two-f16-plane
+ * form; both NULL: the three-bf16-plane form.  gxmax (needs gx; or NULL): a zeroed word raised to the bit pattern of
+ * max |gx| -- the scale of the backward of the layer before.  signs: the forward's sign bits (ignored when act == 0). */
+SBMC_API int sbmc_pointwise_bwd_scaled_f32(const float *gy, const unsigned *signs, const float *x, const float *w,
+                                  float *gx, float *gw_partial, float *gb_partial, float *gt, const float *gmean,
+                                  int s_mean, const unsigned *gmax, const unsigned *gmmax, const unsigned *xmax,
+                                  unsigned *gxmax, int b, int s, int cin, int cout, long hw, int t_mode, int act,
+                                  float slope, void *stream);
 /* the all-half layer (x, y _Float16) with the mean as a _Float16 tensor: the mean of the half values as stored */
 SBMC_API int sbmc_pointwise_fwd_mean_f16(const void *x, const float *w, const float *bias, const float *t, void *y,
                                 void *ymean, int s_mean, int b, int s, int cin, int cout, long hw, int t_mode,

@@ -64,6 +64,8 @@ SYMBOLS = (
     "sbmc_pointwise_bwd_signs_f32",
     "sbmc_pointwise_fwd_mean_f32",
     "sbmc_pointwise_fwd_mean_f16",
+    "sbmc_pointwise_fwd_scaled_f32",
+    "sbmc_pointwise_bwd_scaled_f32",
     "sbmc_upsample2x_cat_supported",
     "sbmc_upsample2x_cat_fwd_f32",
     "sbmc_upsample2x_cat_bwd_f32",
@@ -119,7 +121,7 @@ SYMBOLS = (
     "sbmc_wbank_forward_f32",
     "sbmc_wbank_backward_f32",
 )
-ABI_VERSION = 5
+ABI_VERSION = 6
 WBANK_MAX = 24
 
 
@@ -225,6 +227,8 @@ def lib():
     handle.sbmc_pointwise_fwd_signs_f32.argtypes = [p] * 6 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_signs_f32.argtypes = handle.sbmc_pointwise_bwd_f32.argtypes
     handle.sbmc_pointwise_fwd_mean_f32.argtypes = [p] * 7 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_pointwise_fwd_scaled_f32.argtypes = [p] * 7 + [i, p, p, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_pointwise_bwd_scaled_f32.argtypes = [p] * 9 + [i] + [p] * 4 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_fwd_mean_f16.argtypes = [p] * 6 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_f16.argtypes = [p, p, p, i, p, p, p, p, p, p, i, i, i, i, i, ctypes.c_long, i, i,
                                               ctypes.c_float, p]

@@ -175,6 +175,27 @@ __device__ __forceinline__ void amax_publish(unsigned m, unsigned* amax) {
     }
 }
 
+// ---- split precision on the f16 matrix pipe (csrc/conv3x3.hip, csrc/pointwise.hip): a tensor is scaled by a power of two
+// c that brings its largest magnitude into [2^14, 2^15), then c x = h + l + e with h = f16(c x), l = f16(c x - h),
+// |e| <= max(2^-23 |c x|, 2^-25), and x w = (hx hw + hx lw + lx hw) / (cx cw) + a term <= 2^-22 |x w|: three f16 MFMAs with
+// exact partial products, fp32 accumulation.
+// power of two that brings a tensor whose largest magnitude has the bit pattern `maxbits` into [2^14, 2^15)
+__device__ __forceinline__ float pow2_scale_of(unsigned maxbits) {
+    int e = 268 - (int)(maxbits >> 23);      // 127 + 14 - (exponent - 127)
+    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    return __builtin_bit_cast(float, (unsigned)e << 23);
+}
+// Two fp32 values and their (wave-uniform, power-of-two) scale -> the packed f16 pairs h = f16(c v), l = f16(c v - h): FOUR
+// instructions (v_fma_mix*_f16: an fp32 fused multiply-add whose addend is read as a half and whose result is rounded to
+// half once) where multiply, convert, convert back, subtract, convert take eight.  Same values: c v and c v - h are exact.
+__device__ __forceinline__ void f16_split_pair(float a, float b, float c, unsigned& h, unsigned& l) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(h), "=&v"(l) : "v"(a), "v"(b), "s"(c));
+}
+
 // An integer development knob from the environment (never part of the ABI), read by the same rule as the host
 // side's sbmc_amd/utils.py `knob`: unset -> fallback; "on" / "yes" / "true" -> 1; else atoi ("off", "no" -> 0).
 static inline int env_knob(const char* name, int fallback) {

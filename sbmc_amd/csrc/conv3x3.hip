@@ -66,12 +66,7 @@ __device__ __forceinline__ rsrc_t cv_rsrc(const void* base, unsigned bytes) {
 
 __device__ __forceinline__ void cv_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// power of two that brings a tensor whose largest magnitude has the bit pattern `maxbits` into [2^14, 2^15)
-__device__ __forceinline__ float cv_scale_of(unsigned maxbits) {
-    int e = 268 - (int)(maxbits >> 23);      // 127 + 14 - (exponent - 127)
-    e = e < 1 ? 1 : (e > 254 ? 254 : e);
-    return __builtin_bit_cast(float, (unsigned)e << 23);
-}
+__device__ __forceinline__ float cv_scale_of(unsigned maxbits) { return pow2_scale_of(maxbits); }     // (common.hpp)
 
 __device__ __forceinline__ unsigned cv_pack(float a, float b) {
     h2 v;
@@ -92,17 +87,9 @@ __device__ __forceinline__ void cv_split(const float (&v)[8], u32x4& h, u32x4& l
     }
 }
 
-// Two fp32 values and their (wave-uniform, power-of-two) scale -> the packed f16 pairs h = f16(c v), l = f16(c v - h): FOUR
-// instructions (v_fma_mix*_f16: an fp32 fused multiply-add whose addend is read as a half and whose result is rounded to
-// half once) where multiply, convert, convert back, subtract, convert take eight.  Same values: c v and c v - h are exact.
-// In the staging paths of the 3 x 3 kernels the split is most of what is not an MFMA.
-__device__ __forceinline__ void cv_split_pair(float a, float b, float c, unsigned& h, unsigned& l) {
-    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
-        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
-        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-        : "=&v"(h), "=&v"(l) : "v"(a), "v"(b), "s"(c));
-}
+// (the four-instruction f16 split of a value pair: common.hpp f16_split_pair -- in the staging paths of the 3 x 3 kernels
+// the split is most of what is not an MFMA)
+__device__ __forceinline__ void cv_split_pair(float a, float b, float c, unsigned& h, unsigned& l) { f16_split_pair(a, b, c, h, l); }
 
 __device__ __forceinline__ f32x16 cv_mfma(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);

@@ -58,6 +58,8 @@ struct PwFwdParams {
     float slope;         // 1: linear, 0: relu, else leaky relu
     unsigned* signs;     // [B, Cout, ceil(hw / 32)] one bit per output: pre-activation > 0 (nullptr: not wanted)
     float* ymean;        // [B / S, Cout, hw] mean of y over the S samples of a pixel (pw_fwd_s_kernel; nullptr: not wanted)
+    const unsigned* xmax;   // pw_fwd_s_kernel<.., F2>: device word, bit pattern of a float >= max |x| (the tensor's scale)
+    unsigned* amax;         // pw_fwd_s_kernel: raised to the bit pattern of max |y| (a word zeroed by the caller); or nullptr
 };
 
 // KP: Cin rounded up to a multiple of 32 (<= 128); TMODE: the context term (0 none, 1 per image, 2 per pixel).
@@ -332,6 +334,32 @@ __device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
 }
+using hf8 = __attribute__((ext_vector_type(8))) _Float16;
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a), __builtin_bit_cast(hf8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16_f16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hf8, a), __builtin_bit_cast(hf8, b), c, 0, 0, 0);
+}
+// 8 floats under a (wave-uniform) power-of-two scale -> their two f16 planes (common.hpp f16_split_pair)
+__device__ __forceinline__ void split2(const float (&v)[8], float c, u32x4& h, u32x4& l) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned hp, lp;
+        f16_split_pair(v[2 * q], v[2 * q + 1], c, hp, lp);
+        h[q] = hp;
+        l[q] = lp;
+    }
+}
+// the largest magnitude over a wave (bit patterns of magnitudes order like unsigned integers), in every lane
+__device__ __forceinline__ unsigned wave_umax(unsigned m) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, s, 64);
+        m = m > o ? m : o;
+    }
+    return m;
+}
 
 constexpr int PS_NT = 64;           // pixels per tile of the split-precision kernels
 #ifndef PW_ABL
@@ -345,20 +373,28 @@ constexpr int PS_NT = 64;           // pixels per tile of the split-precision ke
 // TO: storage type of y (float; _Float16 for a chain's FIRST layer under fp16 activations -- fp32 network input in, half
 // out: until round 4 that layer ran on the fp32-MFMA kernel; no sign bits or mean in that form).
 // MEAN: p.ymean is written (compile time: the epilogue has no branch on it).
-template <int KP, int TMODE, int WAVES, typename TO = float, bool MEAN = false>
+// F2 (round 5): the 3 x 3 kernels' number format -- TWO f16 planes under a power-of-two scale (x: from the device word
+// p.xmax, the producer's largest magnitude; the weights: from the largest of the wave's own 32 rows) and THREE products
+// hh + hl + lh on v_mfma_f32_32x32x16_f16 instead of three bf16 planes and six: half the matrix-pipe cycles, two thirds of
+// the LDS image, a third of the split's instructions (common.hpp).  Per product ~2 bits coarser than the bf16 form (a
+// term <= 2^-22 |x w| dropped instead of <= 2^-23), fp32 accumulation either way.
+// Both forms raise *p.amax to max |y| (where the caller asks): the next layer's scale without a pass of its own.
+template <int KP, int TMODE, int WAVES, typename TO = float, bool MEAN = false, bool F2 = false>
 __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     constexpr unsigned SO = (unsigned)sizeof(TO);
+    constexpr int NP = F2 ? 2 : 3;                     // planes of an operand
     constexpr int KO = KP / 8;                         // channel octets
     constexpr int KS = KP / 16;                        // MFMA k-steps
     constexpr int NOCT = (KO + WAVES - 1) / WAVES;     // octets a staging thread owns
     constexpr int NPH = 8 / WAVES;                     // 32-pixel blocks a wave owns
     // large and small terms in accumulators of their own (no MFMA waits for the previous one's result) -- except
     // where a per-pixel context term needs the 16 registers at 128 channels
-    constexpr bool TWO = !(TMODE == 2 && KP == 128 && WAVES == 8);
+    constexpr bool TWO = F2 || !(TMODE == 2 && KP == 128 && WAVES == 8);      // (F2: 32 weight registers fewer)
     const float* xg = static_cast<const float*>(p.x);
     TO* yg = static_cast<TO*>(p.y);
     extern __shared__ float4 pw_lds[];
-    u32x4* xs = reinterpret_cast<u32x4*>(pw_lds);      // [2][3][KO][PS_NT]
+    u32x4* xs = reinterpret_cast<u32x4*>(pw_lds);      // [2][NP][KO][PS_NT]
+    const float cx = F2 ? pow2_scale_of(*p.xmax) : 1.f;
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int rb = wave & 3, ph0 = (wave >> 2) * NPH;  // (WAVES = 4: ph0 = 0, both pixel blocks)
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -424,30 +460,59 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
         for (int i = 0; i < NOCT; ++i) {
             const int o = wave + WAVES * i;
             if (o < KO) {
-                u32x4 h, m, l;
-                split3(regs[i], h, m, l);
-                u32x4* d = xs + ((buf * 3) * KO + o) * PS_NT + lane;
-                d[0] = h;
-                d[KO * PS_NT] = m;
-                d[2 * KO * PS_NT] = l;
+                u32x4* d = xs + ((buf * NP) * KO + o) * PS_NT + lane;
+                if constexpr (F2) {
+                    u32x4 h, l;
+                    split2(regs[i], cx, h, l);
+                    d[0] = h;
+                    d[KO * PS_NT] = l;
+                } else {
+                    u32x4 h, m, l;
+                    split3(regs[i], h, m, l);
+                    d[0] = h;
+                    d[KO * PS_NT] = m;
+                    d[2 * KO * PS_NT] = l;
+                }
             }
         }
     };
 
     // weight rows of this wave as A operands, three planes: a*[s] = W[r0 + lane % 32][16 s + 8 (lane / 32) + 0..7]
-    u32x4 ah[KS], am[KS], al[KS];
+    // (F2: ah / am = the high / low f16 plane under the scale of the wave's own rows -- each accumulator row is scaled
+    // back by its own wave: no layer-wide weight maximum needed)
+    u32x4 ah[KS], am[KS], al[F2 ? 1 : KS];
+    float osc = 1.f;                                   // F2: 1 / (cx cw), applied to the accumulators
     {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
         const int row = r0 + l31;
+        if constexpr (F2) {
+            float v[KS][8];
+            unsigned wm = 0;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            float v[8];
+            for (int s = 0; s < KS; ++s) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = 16 * s + 8 * lhi + i;
-                v[i] = buf_load(rw, (row < p.Cout && k < p.K) ? (unsigned)(row * p.K + k) * 4u : PW_OOB, 0);
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 16 * s + 8 * lhi + i;
+                    v[s][i] = buf_load(rw, (row < p.Cout && k < p.K) ? (unsigned)(row * p.K + k) * 4u : PW_OOB, 0);
+                    const unsigned a = abits(v[s][i]);
+                    wm = wm > a ? wm : a;
+                }
             }
-            split3(v, ah[s], am[s], al[s]);
+            const float cw = pow2_scale_of((unsigned)__builtin_amdgcn_readfirstlane((int)wave_umax(wm)));
+            osc = (1.f / cx) * (1.f / cw);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) split2(v[s], cw, ah[s], am[s]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 16 * s + 8 * lhi + i;
+                    v[i] = buf_load(rw, (row < p.Cout && k < p.K) ? (unsigned)(row * p.K + k) * 4u : PW_OOB, 0);
+                }
+                split3(v, ah[s], am[s], al[s]);
+            }
         }
     }
     // (accumulator row of register j: r0 + (j & 3) + 8 (j >> 2) + 4 (lane / 32))
@@ -471,29 +536,38 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     }
     __syncthreads();
     // the mean over a pixel's samples: every wave accumulates its own 32 x 32 block of outputs in LDS
-    float* macc = reinterpret_cast<float*>(xs + 2 * 3 * KO * PS_NT);        // [128][PS_NT]
+    float* macc = reinterpret_cast<float*>(xs + 2 * NP * KO * PS_NT);       // [128][PS_NT]
     const float inv_s = 1.f / (float)S;
 
     // one pair of values of the next tile -> its three bf16 words; a finished octet goes to LDS
-    u32x4 ch[NOCT], cm[NOCT], cl[NOCT];
+    u32x4 ch[NOCT], cm[NOCT], cl[F2 ? 1 : NOCT];
     auto commit_unit = [&](const float (&src)[NOCT][8], int u, int buf) {     // u = 4 (octet slot) + pair
         const int i = u >> 2, q = u & 3;
-        const unsigned hp = pack_bf16(src[i][2 * q], src[i][2 * q + 1]);
-        const float r0 = src[i][2 * q] - bf16_lo(hp), r1 = src[i][2 * q + 1] - bf16_hi(hp);
-        const unsigned mp = pack_bf16(r0, r1);
-        ch[i][q] = hp;
-        cm[i][q] = mp;
-        cl[i][q] = pack_bf16(r0 - bf16_lo(mp), r1 - bf16_hi(mp));
+        if constexpr (F2) {
+            unsigned hp, lp;
+            f16_split_pair(src[i][2 * q], src[i][2 * q + 1], cx, hp, lp);
+            ch[i][q] = hp;
+            cm[i][q] = lp;
+        } else {
+            const unsigned hp = pack_bf16(src[i][2 * q], src[i][2 * q + 1]);
+            const float r0 = src[i][2 * q] - bf16_lo(hp), r1 = src[i][2 * q + 1] - bf16_hi(hp);
+            const unsigned mp = pack_bf16(r0, r1);
+            ch[i][q] = hp;
+            cm[i][q] = mp;
+            cl[i][q] = pack_bf16(r0 - bf16_lo(mp), r1 - bf16_hi(mp));
+        }
         if (q == 3) {
             const int o = wave + WAVES * i;
             if (o < KO) {
-                u32x4* d = xs + ((buf * 3) * KO + o) * PS_NT + lane;
+                u32x4* d = xs + ((buf * NP) * KO + o) * PS_NT + lane;
                 d[0] = ch[i];
                 d[KO * PS_NT] = cm[i];
-                d[2 * KO * PS_NT] = cl[i];
+                if constexpr (!F2) d[2 * KO * PS_NT] = cl[i];
             }
         }
     };
+    unsigned amax_run = 0;                              // largest |y| this thread has stored
+    const bool want_amax = p.amax != nullptr;
 
     // the bias of this wave's 16 accumulator rows: without a context term it is the same for every tile -- loaded once
     // (16 of a tile's 48 vector-memory instructions per wave)
@@ -541,15 +615,15 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
             }
         }
 
-        const u32x4* xb = xs + ((buf * 3) * KO + lhi) * PS_NT + ph0 * 32 + l31;
+        const u32x4* xb = xs + ((buf * NP) * KO + lhi) * PS_NT + ph0 * 32 + l31;
         // the B operands of the next k-step are fetched while this one's MFMAs run (where 12 registers are to
         // spare: without a context term) -- else each group of MFMAs starts by waiting for its own LDS reads
         constexpr bool AHEAD = (TMODE == 0 && NPH == 1);
-        u32x4 nbh, nbm, nbl;
+        u32x4 nbh, nbm, nbl = {};
         if constexpr (AHEAD) {
             nbh = xb[0];
             nbm = xb[KO * PS_NT];
-            nbl = xb[2 * KO * PS_NT];
+            if constexpr (!F2) nbl = xb[2 * KO * PS_NT];
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -557,22 +631,27 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
             for (int h = 0; h < NPH; ++h) {
                 u32x4 bh, bm, bl;
                 if constexpr (AHEAD) {
-                    bh = nbh; bm = nbm; bl = nbl;
+                    bh = nbh; bm = nbm;
+                    if constexpr (!F2) bl = nbl;
                     if (s + 1 < KS) {
                         nbh = xb[(2 * s + 2) * PS_NT];
                         nbm = xb[(KO + 2 * s + 2) * PS_NT];
-                        nbl = xb[(2 * KO + 2 * s + 2) * PS_NT];
+                        if constexpr (!F2) nbl = xb[(2 * KO + 2 * s + 2) * PS_NT];
                     }
                 } else {
                     bh = xb[(2 * s) * PS_NT + 32 * h];
                     bm = xb[(KO + 2 * s) * PS_NT + 32 * h];
-                    bl = xb[(2 * KO + 2 * s) * PS_NT + 32 * h];
+                    if constexpr (!F2) bl = xb[(2 * KO + 2 * s) * PS_NT + 32 * h];
                 }
 #if PW_ABL == 2
                 asm volatile("" :: "v"(bh), "v"(bm), "v"(bl));
                 continue;
 #endif
-                if constexpr (TWO) {
+                if constexpr (F2) {
+                    acc[h] = mfma_f16(ah[s], bh, acc[h]);          // (bm / am: the LOW planes)
+                    small[h] = mfma_f16(ah[s], bm, small[h]);
+                    small[h] = mfma_f16(am[s], bh, small[h]);
+                } else if constexpr (TWO) {
                     acc[h] = mfma_bf16(ah[s], bh, acc[h]);
                     small[h] = mfma_bf16(ah[s], bl, small[h]);
                     acc[h] = mfma_bf16(ah[s], bm, acc[h]);
@@ -630,13 +709,19 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
             unsigned myword = 0;
             unrolled<16>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                float v = TWO ? acc[h][j] + (small[h][j] + add[j]) : acc[h][j] + add[j];
+                float v;
+                if constexpr (F2) v = __builtin_fmaf(acc[h][j] + small[h][j], osc, add[j]);
+                else v = TWO ? acc[h][j] + (small[h][j] + add[j]) : acc[h][j] + add[j];
                 if (TMODE == 2) v += t0[h][j];
                 // lane j (j + 32) keeps the sign word of register j's row (+ 4): the ballot's halves, written
                 // straight from the scalar registers into those lanes
                 const unsigned long long pos = __ballot(v > 0.f);
                 write_lanes<j>(myword, pos);
                 v = v > 0.f ? v : v * p.slope;
+                if (want_amax) {                       // (columns beyond the plane hold bias only: not stored, not counted)
+                    const unsigned a = o0[h] != PW_OOB ? abits(v) : 0u;
+                    amax_run = amax_run > a ? amax_run : a;
+                }
                 const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
 #if PW_ABL == 1
                 asm volatile("" :: "v"(v));
@@ -672,6 +757,7 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
         step(preB, preA, 1);
         roll();
     }
+    if (want_amax) amax_publish(amax_run, p.amax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1092,6 +1178,12 @@ struct PwBwdParams {
     unsigned hw, tiles_per_plane, nunits;
     int t_mode;
     float slope;
+    // magnitude words (pw_bwd_kernel<.., F2>, pw_gw_wide_kernel<.., F2>): device words holding the bit pattern of a float
+    // >= the largest magnitude of gy / gm / x; gxmax (any form; or nullptr) is raised to the largest |gx| stored
+    const unsigned* gmax;
+    const unsigned* gmmax;
+    const unsigned* xmax;
+    unsigned* gxmax;
 };
 
 // SG: p.y holds the forward's SIGN BITS ([B, Cout, ceil(hw / 32)] words, written by pw_fwd_s_kernel) instead of
@@ -1105,6 +1197,14 @@ struct PwBwdParams {
 // transposed copy).  One LDS stage (fp32 gz 34 KB + two bf16 images 55 KB each), two barriers per tile.
 constexpr int PBS_PITCH = 72;       // halves per row of the bf16 images (64 pixels + 8)
 
+// 4 floats under a (wave-uniform) power-of-two scale -> their two f16 planes
+__device__ __forceinline__ void split2_4(float4 v, float c, u32x2& h, u32x2& l) {
+    unsigned h0, l0, h1, l1;
+    f16_split_pair(v.x, v.y, c, h0, l0);
+    f16_split_pair(v.z, v.w, c, h1, l1);
+    h[0] = h0; h[1] = h1;
+    l[0] = l0; l[1] = l1;
+}
 __device__ __forceinline__ void split3_4(float4 v, u32x2& h, u32x2& m, u32x2& l) {
     const unsigned h0 = pack_bf16(v.x, v.y), h1 = pack_bf16(v.z, v.w);
     const float r0 = v.x - bf16_lo(h0), r1 = v.y - bf16_hi(h0), r2 = v.z - bf16_lo(h1), r3 = v.w - bf16_hi(h1);
@@ -1115,10 +1215,15 @@ __device__ __forceinline__ void split3_4(float4 v, u32x2& h, u32x2& m, u32x2& l)
     l[1] = pack_bf16(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
 }
 
+// F2 (round 5, with GWS): both products in the 3 x 3 kernels' number format -- two f16 planes under power-of-two scales
+// (gz: from the words of gy and gm; x: from its word; w^T: from the largest of the wave's own rows), three products
+// instead of six: half the matrix-pipe cycles, two thirds of the LDS images, a third of the split's instructions.
 template <int KP, bool DX, bool TPIX, bool GM, typename TA = float, typename TXT = float, bool SG = false,
-          bool GWS = false>
+          bool GWS = false, bool F2 = false>
 __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     static_assert(!GWS || (sizeof(TA) == 4 && sizeof(TXT) == 4), "split gw: fp32 tensors");
+    static_assert(!F2 || (GWS && (PW_BWD_GXS || !DX)), "two-plane form: the split kernels");
+    constexpr int NP = F2 ? 2 : 3;                      // planes of an operand
     const TA* gy_g = static_cast<const TA*>(p.gy);
     const TA* y_g = static_cast<const TA*>(p.y);
     const unsigned* sg_g = static_cast<const unsigned*>(p.y);
@@ -1149,7 +1254,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     constexpr int BUF = (128 + KP) * PB_PITCH;          // floats per pipeline stage: gz tile, then x tile
     // GWS: one stage -- fp32 gz tile, then the bf16 images of gz and x ([3][128][PBS_PITCH], [3][KP][PBS_PITCH] halves)
     _Float16* gzn = reinterpret_cast<_Float16*>(lds + 128 * GP);
-    _Float16* xn = gzn + 3 * 128 * PBS_PITCH;
+    _Float16* xn = gzn + NP * 128 * PBS_PITCH;
     constexpr int NB = KP / 32;                         // 32-column blocks of gw
     constexpr int NX = KP / 32;                         // staging passes of the x tile
     const int lane = threadIdx.x & 63, wave = wave_id();
@@ -1169,20 +1274,39 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     // at which reduction index is free as long as both operands agree: row(g, e) = 16 (g / 2) + 8 (g % 2) + 2 (e % 4) + e / 4
     // makes the 32 lanes of half a wave read EIGHT EVEN (first read) or EIGHT ODD (second) rows of 16 -- with rows 36 banks
     // apart those tile the 64 banks exactly; consecutive rows per group (the obvious map) measured 31 % conflict cycles
-    u32x4 awh[GXS ? 4 : 1], awm[GXS ? 4 : 1], awl[GXS ? 4 : 1];
+    u32x4 awh[GXS ? 4 : 1], awm[GXS ? 4 : 1], awl[(GXS && !F2) ? 4 : 1];      // (F2: awm = the LOW plane)
+    // F2 scales: gz by the bound max |gy| + max |gm| / Sm, x by its word; the accumulators are scaled back on the way out
+    float cg = 1.f, cx = 1.f, osx = 1.f;               // osx: 1 / (cw cg) of this wave's gx rows
+    if constexpr (F2) {
+        float gb = __builtin_bit_cast(float, *p.gmax);
+        if constexpr (GM) gb += __builtin_bit_cast(float, *p.gmmax) / (float)p.Sm;
+        cg = pow2_scale_of(__builtin_bit_cast(unsigned, gb));
+        cx = pow2_scale_of(*p.xmax);
+    }
     if constexpr (GXS) {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
         const int kr = wave * 16 + (lane & 15);
+        float v[4][8];
+        unsigned wm = 0;
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int g4 = lane >> 4;
                 const int co = 32 * st + 16 * (g4 >> 1) + 8 * (g4 & 1) + 2 * (e & 3) + (e >> 2);
-                v[e] = buf_load(rw, (co < p.Cout && kr < p.K) ? (unsigned)(co * p.K + kr) * 4u : PW_OOB, 0);
+                v[st][e] = buf_load(rw, (co < p.Cout && kr < p.K) ? (unsigned)(co * p.K + kr) * 4u : PW_OOB, 0);
+                const unsigned a = abits(v[st][e]);
+                wm = wm > a ? wm : a;
             }
-            split3(v, awh[st], awm[st], awl[st]);
+        }
+        if constexpr (F2) {
+            const float cw = pow2_scale_of((unsigned)__builtin_amdgcn_readfirstlane((int)wave_umax(wm)));
+            osx = (1.f / cw) * (1.f / cg);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) split2(v[st], cw, awh[st], awm[st]);
+        } else {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) split3(v[st], awh[st], awm[st], awl[st]);
         }
     } else if constexpr (NARROW) {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
@@ -1328,7 +1452,13 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                 d[0] = make_float2(gv.x, gv.y);
                 d[1] = make_float2(gv.z, gv.w);
             }
-            if constexpr (GWS) {
+            if constexpr (F2) {
+                u32x2 h, l;
+                split2_4(gv, cg, h, l);
+                _Float16* e = gzn + (srow + 32 * i) * PBS_PITCH + c4;
+                *reinterpret_cast<u32x2*>(e) = h;
+                *reinterpret_cast<u32x2*>(e + 128 * PBS_PITCH) = l;
+            } else if constexpr (GWS) {
                 u32x2 h, m, l;
                 split3_4(gv, h, m, l);
                 _Float16* e = gzn + (srow + 32 * i) * PBS_PITCH + c4;
@@ -1340,7 +1470,13 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const float4 xv = unpack4<TXT>(px[i]);
-            if constexpr (GWS) {
+            if constexpr (F2) {
+                u32x2 h, l;
+                split2_4(xv, cx, h, l);
+                _Float16* e = xn + (srow + 32 * i) * PBS_PITCH + c4;
+                *reinterpret_cast<u32x2*>(e) = h;
+                *reinterpret_cast<u32x2*>(e + KP * PBS_PITCH) = l;
+            } else if constexpr (GWS) {
                 u32x2 h, m, l;
                 split3_4(xv, h, m, l);
                 _Float16* e = xn + (srow + 32 * i) * PBS_PITCH + c4;
@@ -1382,6 +1518,8 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     f32x16 acc_w[2];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc_w[0][j] = acc_w[1][j] = 0.f;
+    unsigned gxmax_run = 0;                             // largest |gx| this thread has stored (split kernels)
+    const bool want_gxmax = (NARROW || GXS) && p.gxmax != nullptr;
 
     // gx of the previous step, waiting to be stored
     f32x16 out;
@@ -1430,13 +1568,20 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 #pragma unroll
                 for (int pb = 0; pb < 4; ++pb) {
                     const _Float16* q = tb + (32 * st) * PBS_PITCH + 16 * pb;
-                    const u32x4 bh = tr8(q), bm = tr8(q + 128 * PBS_PITCH), bl = tr8(q + 2 * 128 * PBS_PITCH);
-                    acc_n[pb] = mfma16_bf16(awh[st], bl, acc_n[pb]);
-                    acc_n[pb] = mfma16_bf16(awl[st], bh, acc_n[pb]);
-                    acc_n[pb] = mfma16_bf16(awm[st], bm, acc_n[pb]);
-                    acc_n[pb] = mfma16_bf16(awh[st], bm, acc_n[pb]);
-                    acc_n[pb] = mfma16_bf16(awm[st], bh, acc_n[pb]);
-                    acc_n[pb] = mfma16_bf16(awh[st], bh, acc_n[pb]);
+                    if constexpr (F2) {
+                        const u32x4 bh = tr8(q), bl = tr8(q + 128 * PBS_PITCH);
+                        acc_n[pb] = mfma16_f16(awh[st], bl, acc_n[pb]);
+                        acc_n[pb] = mfma16_f16(awm[st], bh, acc_n[pb]);
+                        acc_n[pb] = mfma16_f16(awh[st], bh, acc_n[pb]);
+                    } else {
+                        const u32x4 bh = tr8(q), bm = tr8(q + 128 * PBS_PITCH), bl = tr8(q + 2 * 128 * PBS_PITCH);
+                        acc_n[pb] = mfma16_bf16(awh[st], bl, acc_n[pb]);
+                        acc_n[pb] = mfma16_bf16(awl[st], bh, acc_n[pb]);
+                        acc_n[pb] = mfma16_bf16(awm[st], bm, acc_n[pb]);
+                        acc_n[pb] = mfma16_bf16(awh[st], bm, acc_n[pb]);
+                        acc_n[pb] = mfma16_bf16(awm[st], bh, acc_n[pb]);
+                        acc_n[pb] = mfma16_bf16(awh[st], bh, acc_n[pb]);
+                    }
                 }
                 if (st == 1 && nvalid) issue_x(nxt);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1487,7 +1632,12 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const unsigned row = 4 * (lane >> 4) + j;
-                        logit_store<TXT>(acc_n[pb][j], rgx, (col < hw && nr > 0) ? (row * hw + col) * SX : PW_OOB, 0);
+                        const float v = F2 ? acc_n[pb][j] * osx : acc_n[pb][j];
+                        if (want_gxmax) {
+                            const unsigned a = (col < hw && nr > 0) ? abits(v) : 0u;
+                            gxmax_run = gxmax_run > a ? gxmax_run : a;
+                        }
+                        logit_store<TXT>(v, rgx, (col < hw && nr > 0) ? (row * hw + col) * SX : PW_OOB, 0);
                     }
                 }
             } else if (DX) {
@@ -1515,6 +1665,24 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                 for (int s = 0; s < 4; ++s) {           // 16 pixels per step
                     const u32x4 ah = *reinterpret_cast<const u32x4*>(ga + 16 * s);
                     const u32x4 am = *reinterpret_cast<const u32x4*>(ga + 16 * s + 128 * PBS_PITCH);
+                    if constexpr (F2) {                 // (am / bm: the LOW planes)
+                        {
+                            const u32x4 bh = *reinterpret_cast<const u32x4*>(xb0 + 16 * s);
+                            const u32x4 bm = *reinterpret_cast<const u32x4*>(xb0 + 16 * s + KP * PBS_PITCH);
+                            acc_w[0] = mfma_f16(ah, bm, acc_w[0]);
+                            acc_w[0] = mfma_f16(am, bh, acc_w[0]);
+                            acc_w[0] = mfma_f16(ah, bh, acc_w[0]);
+                        }
+                        if (two) {
+                            const u32x4 bh = *reinterpret_cast<const u32x4*>(xb1 + 16 * s);
+                            const u32x4 bm = *reinterpret_cast<const u32x4*>(xb1 + 16 * s + KP * PBS_PITCH);
+                            acc_w[1] = mfma_f16(ah, bm, acc_w[1]);
+                            acc_w[1] = mfma_f16(am, bh, acc_w[1]);
+                            acc_w[1] = mfma_f16(ah, bh, acc_w[1]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
                     const u32x4 al = *reinterpret_cast<const u32x4*>(ga + 16 * s + 2 * 128 * PBS_PITCH);
                     {
                         const u32x4 bh = *reinterpret_cast<const u32x4*>(xb0 + 16 * s);
@@ -1586,9 +1754,13 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int rl = (j & 3) + 8 * (j >> 2) + 4 * lhi;
-                buf_store(acc_w[n][j], rgw, (col < p.K && nrows > 0) ? (unsigned)(rl * p.K + col) * 4u : PW_OOB, 0);
+                const float v = F2 ? acc_w[n][j] * ((1.f / cg) * (1.f / cx)) : acc_w[n][j];
+                buf_store(v, rgw, (col < p.K && nrows > 0) ? (unsigned)(rl * p.K + col) * 4u : PW_OOB, 0);
             }
         }
+    }
+    if constexpr (NARROW || GXS) {
+        if (p.gxmax != nullptr) amax_publish(gxmax_run, p.gxmax);
     }
 }
 
@@ -2090,8 +2262,15 @@ extern "C" int sbmc_pointwise_supported(int cin, int cout, long hw) { return pw_
 
 // (half output: no per-pixel context form -- a chain's first layer with fp32 input has none in Multisteps, and it spills)
 template <int KPV, int WV, typename TO>
-static auto pws_pick(int t_mode, bool mean) -> void (*)(PwFwdParams) {
+static auto pws_pick(int t_mode, bool mean, bool f2) -> void (*)(PwFwdParams) {
     if constexpr (sizeof(TO) == 4) {
+        if (f2) {
+            if (mean)
+                return t_mode == 2 ? pw_fwd_s_kernel<KPV, 2, WV, TO, true, true>
+                                   : (t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV, TO, true, true> : pw_fwd_s_kernel<KPV, 0, WV, TO, true, true>);
+            return t_mode == 2 ? pw_fwd_s_kernel<KPV, 2, WV, TO, false, true>
+                               : (t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV, TO, false, true> : pw_fwd_s_kernel<KPV, 0, WV, TO, false, true>);
+        }
         if (mean)
             return t_mode == 2 ? pw_fwd_s_kernel<KPV, 2, WV, TO, true>
                                : (t_mode == 1 ? pw_fwd_s_kernel<KPV, 1, WV, TO, true> : pw_fwd_s_kernel<KPV, 0, WV, TO, true>);
@@ -2104,7 +2283,8 @@ static auto pws_pick(int t_mode, bool mean) -> void (*)(PwFwdParams) {
 template <typename TI, typename TO>
 static int pw_fwd_launch(const void* x, const float* w, const float* bias, const float* t, void* y, int b, int s,
                          int cin, int cout, long hw, int t_mode, int act, float slope, void* stream,
-                         unsigned* signs = nullptr, float* ymean = nullptr, int s_mean = 1) {
+                         unsigned* signs = nullptr, float* ymean = nullptr, int s_mean = 1,
+                         const unsigned* xmax = nullptr, unsigned* amax = nullptr) {
     if (b < 0 || s < 1 || act < 0 || act > 2 || t_mode < 0 || t_mode > 2) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!pw_dims_ok(cin, cout, hw) || b % s || !x || !w || !bias || !y || (t_mode && !t)) return SBMC_HIP_EINVAL;
@@ -2113,6 +2293,10 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
     p.x = x; p.w = w; p.bias = bias; p.t = t; p.y = y;
     p.signs = signs;
     p.ymean = ymean;
+    p.xmax = xmax;
+    p.amax = amax;
+    // (a scale word / a magnitude output: the fp32 split-precision kernel only)
+    if ((xmax != nullptr || amax != nullptr) && !(sizeof(TI) == 4 && sizeof(TO) == 4)) return SBMC_HIP_EINVAL;
     // (the mean: the fp32 split-precision kernel, or the all-half kernel -- there ymean is a _Float16 tensor)
     if (ymean != nullptr && (s_mean < 1 || b % s_mean || cout > 128 || (t_mode && s != s_mean) ||
                              !((sizeof(TI) == 4 && sizeof(TO) == 4) || (sizeof(TI) == 2 && sizeof(TO) == 2))))
@@ -2135,7 +2319,8 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
                 hipDeviceGetAttribute(&scus, hipDeviceAttributeMultiprocessorCount, sdev) != hipSuccess)
                 scus = 256;
             const int skp = (cin + 31) / 32 * 32;
-            const size_t slds = (size_t)2 * 3 * (skp / 8) * PS_NT * 16 + (ymean != nullptr ? (size_t)128 * PS_NT * 4 : 0);
+            const bool f2 = xmax != nullptr;
+            const size_t slds = (size_t)2 * (f2 ? 2 : 3) * (skp / 8) * PS_NT * 16 + (ymean != nullptr ? (size_t)128 * PS_NT * 4 : 0);
             const unsigned sunit = (unsigned)(NUM_XCD * p.nrt);
             unsigned sgrid = (unsigned)scus / sunit * sunit;
             const unsigned long long sneed = ((unsigned long long)(p.ntiles / (unsigned)p.S) + NUM_XCD - 1) / NUM_XCD * sunit;
@@ -2144,7 +2329,7 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
             hipError_t se = hipSuccess;
 #define SBMC_PWS_LAUNCH2(KPV, WV)                                                                        \
     do {                                                                                                 \
-        auto kern = pws_pick<KPV, WV, TO>(t_mode, ymean != nullptr);                                                        \
+        auto kern = pws_pick<KPV, WV, TO>(t_mode, ymean != nullptr, f2);                                  \
         se = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds);                 \
         if (se == hipSuccess)                                                                            \
@@ -2164,7 +2349,8 @@ static int pw_fwd_launch(const void* x, const float* w, const float* bias, const
             if (se != hipSuccess) return (int)se;
             return (int)hipGetLastError();
         }
-        if (signs != nullptr || ymean != nullptr) return SBMC_HIP_EINVAL;      // (the fp32-MFMA kernel writes neither)
+        if (signs != nullptr || ymean != nullptr || xmax != nullptr || amax != nullptr)
+            return SBMC_HIP_EINVAL;                                           // (the fp32-MFMA kernel takes / writes none of them)
     }
     const int ph = PW_FWD_PH;
     const int ntile = 64 * ph;
@@ -2290,6 +2476,19 @@ extern "C" int sbmc_pointwise_fwd_f16(const void* x, int x_is_half, const float*
     return pw_fwd_launch<float, _Float16>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream);
 }
 
+// The fp32 layer with magnitude words (ABI 6): xmax != nullptr -- a device word holding the bit pattern of a float >= max |x|
+// -- selects the two-f16-plane form of the split-precision kernel (pw_fwd_s_kernel<.., F2>), nullptr the three-bf16-plane
+// form; amax != nullptr (a word the caller zeroed, or holding a lower bound) is raised to the bit pattern of max |y|.
+// signs / ymean: as sbmc_pointwise_fwd_signs_f32 / _mean_f32, or nullptr.
+extern "C" int sbmc_pointwise_fwd_scaled_f32(const float* x, const float* w, const float* bias, const float* t, float* y,
+                                             unsigned* signs, float* ymean, int s_mean, const unsigned* xmax,
+                                             unsigned* amax, int b, int s, int cin, int cout, long hw, int t_mode, int act,
+                                             float slope, void* stream) {
+    if (env_knob("SBMC_HIP_PW_SPLIT", 1) == 0) return SBMC_HIP_EINVAL;       // (no fp32-MFMA form with magnitude words)
+    return pw_fwd_launch<float, float>(x, w, bias, t, y, b, s, cin, cout, hw, t_mode, act, slope, stream, signs, ymean,
+                                       ymean != nullptr ? s_mean : 1, xmax, amax);
+}
+
 // all-half layer that also writes ymean [b / s_mean, cout, hw] (_Float16): the mean of y over groups of s_mean images
 extern "C" int sbmc_pointwise_fwd_mean_f16(const void* x, const float* w, const float* bias, const float* t, void* y,
                                            void* ymean, int s_mean, int b, int s, int cin, int cout, long hw, int t_mode,
@@ -2323,7 +2522,8 @@ template <typename TA, typename TXT>
 static int pw_bwd_launch(const void* gy, const void* y, const void* x, const float* w, void* gx,
                          float* gw_partial, float* gb_partial, float* gt, const void* gmean,
                          int s_mean, int b, int s, int cin, int cout, long hw, int t_mode, int act,
-                         float slope, void* stream, bool y_is_signs = false) {
+                         float slope, void* stream, bool y_is_signs = false, const unsigned* gmax = nullptr,
+                         const unsigned* gmmax = nullptr, const unsigned* xmax = nullptr, unsigned* gxmax = nullptr) {
     if (b < 0 || s < 1 || act < 0 || act > 2 || t_mode < 0 || t_mode > 2) return SBMC_HIP_EINVAL;
     if (b == 0) return 0;
     if (!sbmc_pointwise_bwd_supported(cin, cout, hw) || b % s || !gy || !x || !w || !gw_partial || !gb_partial ||
@@ -2335,6 +2535,7 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
     PwBwdParams p;
     p.gy = gy; p.y = act != 0 ? y : gy; p.x = x; p.w = w; p.gx = gx; p.gwp = gw_partial; p.gbp = gb_partial; p.gt = gt;
     p.gm = gmean; p.Sm = gmean ? s_mean : 1;
+    p.gmax = gmax; p.gmmax = gmmax; p.xmax = xmax; p.gxmax = gxmax;
     // walk order: the samples of a pixel tile one after the other when something per-pixel is shared
     // between them (context term, mean gradient: its tile then stays in L2), else plain batch order
     p.B = b; p.S = t_mode ? s : (gmean ? s_mean : 1); p.K = cin; p.Cout = cout;
@@ -2383,14 +2584,21 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
     // (plain layers: 4.41 -> 3.96 ms at 720p x 8 spp.  With a per-pixel context gradient or a mean gradient -- 16
     // more live registers -- the kernel's NARROW gx product makes the room; SBMC_HIP_PW_GWS=1 keeps those on the
     // all-fp32-MFMA kernel, 2 = default splits them too)
-    bool gws = false;
+    bool gws = false, f2 = false;
     if constexpr (sizeof(TA) == 4 && sizeof(TXT) == 4) {
         const int gmode = env_knob("SBMC_HIP_PW_GWS", 2);
         const bool side = t_mode == 2 || gmean;
         gws = gmode != 0 && (!side || gmode >= 2);
+        // the two-f16-plane form: wherever the caller handed over the words it needs (a layer with an activation: with
+        // the forward's sign bits; a linear layer reads no y at all)
+        f2 = gws && gmax != nullptr && xmax != nullptr && (!gmean || gmmax != nullptr) && (y_is_signs || act == 0) &&
+             (PW_BWD_GXS || !gx);
         if (gws)
             lds = (size_t)128 * ((PW_BWD_GXS && gx) ? 0 : ((side && gx) ? PB_PITCH_N : PB_PITCH)) * sizeof(float) +
-                  (size_t)3 * (128 + kp) * PBS_PITCH * 2;
+                  (size_t)(f2 ? 2 : 3) * (128 + kp) * PBS_PITCH * 2;
+        if (gxmax != nullptr && !(gws && (PW_BWD_GXS || side))) return SBMC_HIP_EINVAL;      // (the split kernels only)
+    } else if (gmax != nullptr || gxmax != nullptr) {
+        return SBMC_HIP_EINVAL;
     }
 #define SBMC_PWB_PICK(KPV, DXV, TPV, SGV, GWSV)                                                          \
     ((gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, float, float, SGV, GWSV>                     \
@@ -2400,7 +2608,10 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
         auto kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, TA, TXT>                       \
                                     : pw_bwd_kernel<KPV, DXV, TPV, false, TA, TXT>;                       \
         if constexpr (sizeof(TA) == 4 && sizeof(TXT) == 4) {                                             \
-            if (y_is_signs) {                                                                            \
+            if (f2) {                                                                                    \
+                kern = (gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, float, float, true, true, true>   \
+                                       : pw_bwd_kernel<KPV, DXV, TPV, false, float, float, true, true, true>;   \
+            } else if (y_is_signs) {                                                                     \
                 if (gws) kern = SBMC_PWB_PICK(KPV, DXV, TPV, true, true);                                \
                 else     kern = SBMC_PWB_PICK(KPV, DXV, TPV, true, false);                               \
             } else if (gws) {                                                                            \
@@ -2493,6 +2704,19 @@ extern "C" int sbmc_pointwise_bwd_f32(const float* gy, const float* y, const flo
                                       float slope, void* stream) {
     return pw_bwd_launch<float, float>(gy, y, x, w, gx, gw_partial, gb_partial, gt, gmean, s_mean, b, s, cin, cout,
                                        hw, t_mode, act, slope, stream);
+}
+
+// The fp32 backward with magnitude words (ABI 6; see sbmc_pointwise_fwd_scaled_f32).  gmax, xmax (and gmmax with gmean)
+// not NULL: both products in the two-f16-plane form; gxmax != NULL: raised to the bit pattern of max |gx|.
+// signs: the forward's sign bits (act != 0), unused for a linear layer.
+extern "C" int sbmc_pointwise_bwd_scaled_f32(const float* gy, const unsigned* signs, const float* x, const float* w,
+                                             float* gx, float* gw_partial, float* gb_partial, float* gt,
+                                             const float* gmean, int s_mean, const unsigned* gmax, const unsigned* gmmax,
+                                             const unsigned* xmax, unsigned* gxmax, int b, int s, int cin, int cout,
+                                             long hw, int t_mode, int act, float slope, void* stream) {
+    if ((gmax == nullptr) != (xmax == nullptr) || (gxmax != nullptr && gx == nullptr)) return SBMC_HIP_EINVAL;
+    return pw_bwd_launch<float, float>(gy, signs, x, w, gx, gw_partial, gb_partial, gt, gmean, s_mean, b, s, cin, cout, hw,
+                                       t_mode, act, slope, stream, act != 0, gmax, gmmax, xmax, gxmax);
 }
 
 extern "C" int sbmc_pointwise_bwd_signs_f32(const float* gy, const unsigned* signs, const float* x, const float* w,

@@ -503,6 +503,13 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False, mean_s=0):
     if (not half and act != 0 and any(ctx.needs_input_grad[:4]) and _pw_split_enabled()
             and L.sbmc_pointwise_bwd_supported(cin, cout, hw)):
         signs = th.empty(B, cout, (hw + 31) // 32, dtype=th.int32, device=dev)
+    # magnitude words (ABI 6): the split-precision kernel leaves max |y| in a device word, and -- where the word of x
+    # is known (`known_amax`: x came out of such a pass) -- multiplies in the 3 x 3 kernels' number format (two f16
+    # planes under a power-of-two scale, three products) instead of three bf16 planes and six.  SBMC_HIP_PW_F16=0:
+    # the three-plane form everywhere, no words.
+    scaled = not half and _pw_split_enabled() and knob("SBMC_HIP_PW_F16") != 0
+    xmax = known_amax(x) if scaled else None
+    amax = amax_word(dev) if scaled else None
     ymean = None
     if (mean_s and mean_s >= 1 and not half and _pw_split_enabled() and cout <= 128 and B % mean_s == 0
             and (t_mode == 0 or s == mean_s) and knob("SBMC_PW_FUSED_MEAN") != 0):
@@ -513,7 +520,13 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False, mean_s=0):
     if half_mean:
         ymean = th.empty(B // mean_s, cout, hw, dtype=th.float16, device=dev)
     with th.cuda.device(dev), _timed("pointwise_fwd%s %dx%d" % ("_f16" if half else "", cout, cin), dev):
-        if half_mean:
+        if scaled:
+            rc = L.sbmc_pointwise_fwd_scaled_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(t) if t is not None else None,
+                                                 _lib.ptr(y), _lib.ptr(signs) if signs is not None else None,
+                                                 _lib.ptr(ymean) if ymean is not None else None, mean_s if ymean is not None else 1,
+                                                 _lib.ptr(xmax) if xmax is not None else None, _lib.ptr(amax),
+                                                 B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
+        elif half_mean:
             rc = L.sbmc_pointwise_fwd_mean_f16(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(t) if t is not None else None,
                                                _lib.ptr(y), _lib.ptr(ymean), mean_s, B, s, cin, cout, hw, t_mode, act, slope,
                                                _lib.current_stream(dev))
@@ -538,7 +551,12 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False, mean_s=0):
     ctx.cfg = (s, act, slope, t_mode, None if t is None else tuple(t.shape))
     ctx.half = half
     ctx.has_signs = signs is not None
+    ctx.xmax = xmax                  # (the backward's scale of x: the same word, the same values)
     ctx.save_for_backward(x, w, signs if signs is not None else (y if act != 0 else None))
+    if amax is not None:
+        tag_amax(y, amax)
+        if ymean is not None:
+            tag_amax(ymean, amax)    # (a mean of values of y: the bound holds)
     return y, ymean
 
 
@@ -579,6 +597,19 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
         gt = w.new_empty(tshape) if t_mode == 2 else None
         if gmean is not None:
             gmean = gmean.to(adt).contiguous()
+        # magnitude words: the two-f16-plane form wherever the words of gy (and gmean) and of x are known; the largest
+        # |gx| goes out in a word for the backward of the layer before
+        scaled = (not half and _pw_split_enabled() and knob("SBMC_HIP_PW_F16") != 0 and knob("SBMC_HIP_PW_GWS", 2) >= 2
+                  and (act == 0 or getattr(ctx, "has_signs", False)))
+        gmax = gmmax = xmax = gxmax = None
+        if scaled:
+            gmax, xmax = known_amax(gy), getattr(ctx, "xmax", None)
+            # (the mean's gradient comes out of the U-net's first convolution, 1 / S of gy's bytes: where it carries
+            # no word, the absmax pass over it costs less than the three-plane form of this layer)
+            gmmax = ensure_amax(gmean) if (gmean is not None and gmean.is_contiguous()) else None
+            if gmax is None or xmax is None or (gmean is not None and gmmax is None):
+                gmax = gmmax = xmax = None
+            gxmax = amax_word(dev) if gx is not None else None
         with th.cuda.device(dev), _timed("pointwise_bwd%s %dx%d%s" % ("_f16" if half else "", cout, cin,
                                                                       "" if gx is not None else " (no gx)"), dev):
             tail = (_lib.ptr(w), _lib.ptr(gx) if gx is not None else None, _lib.ptr(gwp),
@@ -587,6 +618,11 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
                     B, s, cin, cout, hw, t_mode, act, slope, _lib.current_stream(dev))
             if half:
                 rc = L.sbmc_pointwise_bwd_f16(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), int(x.dtype == th.float16), *tail)
+            elif scaled:
+                rc = L.sbmc_pointwise_bwd_scaled_f32(
+                    _lib.ptr(gy), _lib.ptr(y) if act != 0 else None, _lib.ptr(x), *tail[:7],
+                    _lib.ptr(gmax) if gmax is not None else None, _lib.ptr(gmmax) if gmmax is not None else None,
+                    _lib.ptr(xmax) if xmax is not None else None, _lib.ptr(gxmax) if gxmax is not None else None, *tail[7:])
             elif getattr(ctx, "has_signs", False):
                 rc = L.sbmc_pointwise_bwd_signs_f32(_lib.ptr(gy), _lib.ptr(y), _lib.ptr(x), *tail)    # y: the sign bits
             else:
@@ -595,6 +631,8 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
         per_image = gbp.sum(0)                   # [nb, cout]
         if t_mode == 1:
             gt = per_image.view(tshape)
+        if gxmax is not None:
+            tag_amax(gx, gxmax)
         return gx, gwp.sum(0), per_image.sum(0), gt
     if (half and act == 0 and t_mode == 0 and x.dtype == th.float16 and knob("SBMC_HIP_PW_GW_WIDE") != 0
             and L.sbmc_pointwise_gw_wide_supported(cin, cout, hw)):
@@ -797,7 +835,7 @@ class FromChannelsLast(th.autograd.Function):
         with th.cuda.device(dev):
             rc = fn(_lib.ptr(x), _lib.ptr(out), b, h * w, c, _lib.current_stream(dev))
         _lib.check(rc, "transpose2d")
-        return out
+        return carry_amax(out, x)            # (the same values in another order: the word holds)
 
     @staticmethod
     def backward(ctx, g):
@@ -1051,6 +1089,38 @@ def ensure_amax(t):
         a = Conv3x3NHWC._absmax(t)
         tag_amax(t, a)
     return a
+
+
+def carry_amax(dst, src):
+    """`dst` holds exactly `src`'s values (a view or reshape of the whole of it, a transposition): its word is src's."""
+    a = known_amax(src)
+    if a is not None and dst.numel() == src.numel():
+        tag_amax(dst, a)
+    return dst
+
+
+class _TaggedView(th.autograd.Function):
+    """x.view(shape) that hands the magnitude word on -- in BOTH directions: torch's own view nodes make new tensor
+    objects, the tag of `tag_amax` rides on the object, and the 1 x 1 layers either side of a reshape (models._embed:
+    [bs * spp, c, h, w] <-> [bs, spp, c, h, w] <-> [bs * spp, c, h * w]) take their scales from each other's words."""
+
+    @staticmethod
+    def forward(ctx, x, shape):
+        ctx.shape = x.shape
+        return carry_amax(x.view(shape), x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if not g.is_contiguous():
+            return g.reshape(ctx.shape), None
+        return carry_amax(g.view(ctx.shape), g), None
+
+
+def tagged_view(x, *shape):
+    """x.view(*shape); through `_TaggedView` where a magnitude word could travel (contiguous fp32 GPU tensors)."""
+    if x.is_cuda and x.dtype == th.float32 and x.is_contiguous() and knob("SBMC_AMAX_TAGS") != 0:
+        return _TaggedView.apply(x, tuple(shape))
+    return x.reshape(*shape)
 
 
 def raise_amax(word, block):

@@ -158,7 +158,7 @@ class Multisteps(nn.Module):
                     bs, n, per_pixel.shape[1], h, w)
                 flat = th.cat([part, ctx], 2).reshape(bs * n, c + per_pixel.shape[1], h, w)
                 out = module(flat)
-            outs.append(out.view(bs, n, out.shape[1], h, w))
+            outs.append(funcs.tagged_view(out, bs, n, out.shape[1], h, w))
         features = outs[0] if len(outs) == 1 else th.cat(outs, 1)
         if not want_mean:
             return features

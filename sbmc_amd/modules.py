@@ -80,7 +80,7 @@ def _pointwise_gemm(conv, x, activation=None, mean_s=0, mean_out=None):
     w = conv_weight(conv)
     b, c, h, wd = x.shape
     wmat = w.view(1, w.shape[0], c).expand(b, -1, -1)
-    x3 = x.reshape(b, c, h * wd)
+    x3 = funcs.tagged_view(x, b, c, h * wd)         # (magnitude words travel with the activations: functions.tag_amax)
     act, slope = 0, 0.0
     if isinstance(activation, nn.ReLU):
         act = 1
@@ -91,10 +91,10 @@ def _pointwise_gemm(conv, x, activation=None, mean_s=0, mean_out=None):
         wm, bias = w.view(w.shape[0], c).float(), conv.bias.float()
         if mean_s and mean_out is not None and b % mean_s == 0 and (activation is None or act != 0):
             y, m = funcs.PointwiseLayerMean.apply(x3, wm, bias, None, 1, act, slope, mean_s, half)
-            mean_out.append(m.view(b // mean_s, w.shape[0], h, wd))
+            mean_out.append(funcs.tagged_view(m, b // mean_s, w.shape[0], h, wd))
         else:
             y = funcs.PointwiseLayer.apply(x3, wm, bias, None, 1, act, slope, half)
-        return y.view(b, w.shape[0], h, wd), act != 0
+        return funcs.tagged_view(y, b, w.shape[0], h, wd), act != 0
     y = th.bmm(wmat, x3)
     if funcs.BiasAct.supported(y):
         y = funcs.BiasAct.apply(y, conv.bias, act, slope)
@@ -145,7 +145,7 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     wt = conv_weight(conv)
     wt = wt.view(wt.shape[0], cs + cp)
     cout = wt.shape[0]
-    xs = per_sample.reshape(bs * S, cs, h * w)
+    xs = funcs.tagged_view(per_sample, bs * S, cs, h * w)
     nhwc_ctx = funcs._is_channels_last(context) and context.dtype in (th.float32, th.float16) and h * w > 1
     ctx3 = None if nhwc_ctx else context.reshape(bs, cp, -1)
 
@@ -169,7 +169,7 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     if t.dtype == th.float32 and funcs.pointwise_supported(xs, cout):
         tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)
         y = funcs.PointwiseLayer.apply(xs, wt[:, :cs], conv.bias, tt, S, act[0], act[1])
-        y = y.view(bs * S, cout, h, w)
+        y = funcs.tagged_view(y, bs * S, cout, h, w)
     else:
         y = th.bmm(wt[:, :cs].unsqueeze(0).expand(bs * S, -1, -1), xs)
         if not funcs.CtxAct.supported(y, t, S):

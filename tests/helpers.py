@@ -201,9 +201,9 @@ def close_or_yardstick(a, ref32, truth_fn, rtol=1e-5, slack=2.0, what=""):
 def multisteps_wide(case, device="cpu"):
     """The production-width fixture (tests/golden/make_golden.py:gen_multisteps_wide): Multisteps(93, 3, width 128,
     embedding 128, 3 steps) under the fixture's seed, the seeded batch, and the check that BOTH reproduce what the
-    reference saw (float64 checksums of every parameter and input) -- so that a failing comparison below means a
+    reference saw (exact checksums of every parameter's and input's bit patterns) -- so that a failing comparison below means a
     wrong kernel, never a changed initialisation.  -> (fixture, model, batch, target)"""
-    from make_golden import WIDE_CASES, wide_inputs
+    from make_golden import WIDE_CASES, bits_checksum, wide_inputs
     from sbmc_amd import Multisteps
     g = golden("multisteps_wide.npz")
     c = WIDE_CASES[case]
@@ -213,13 +213,11 @@ def multisteps_wide(case, device="cpu"):
     keys = [k[len(case) + 7:] for k in g.files if k.startswith(case + ".sdsum.")]
     assert sorted(keys) == sorted(sd.keys())
     for k in keys:
-        want = g["%s.sdsum.%s" % (case, k)]
-        got = (sd[k].double().sum().item(), sd[k].double().abs().sum().item())
-        assert got[0] == want[0] and got[1] == want[1], "seeded init differs from the reference's: " + k
+        assert np.array_equal(bits_checksum(sd[k]), g["%s.sdsum.%s" % (case, k)]), "seeded init differs from the reference's: " + k
     batch, target = wide_inputs(case)
     for k, v in batch.items():
-        assert v.double().sum().item() == float(g["%s.insum.%s" % (case, k)]), k
-    assert target.double().sum().item() == float(g[case + ".insum.target_image"])
+        assert np.array_equal(bits_checksum(v), g["%s.insum.%s" % (case, k)]), k
+    assert np.array_equal(bits_checksum(target), g[case + ".insum.target_image"])
     return g, model.to(device), {k: v.to(device) for k, v in batch.items()}, target.to(device)
 
 
@@ -237,14 +235,31 @@ def rel_close(a, b, rtol=1e-5, what=""):
         b.abs()[bad].min().item())
 
 
-def state_close(out, ref, what="", rtol=1e-5):
+def state_close(out, ref, what="", rtol=1e-5, truth=None):
     """The splat's running state (sum_r, sum_w, max_w) for NON-NEGATIVE radiance: sum_r and sum_w are sums of
     non-negative terms -- plain elementwise 1e-5 relative, no absolute scale; max_w is a selection among the input
-    logits -- equal to the bit."""
-    for a, b, n in zip(out, ref, ("sum_r", "sum_w", "max_w")):
+    logits -- equal to the bit.
+    truth: a callable -> the same state in float64 (progressive_fp64).  `ref` is itself an fp32 evaluation -- a
+    sequential sum of up to 3 x 441 terms per sample, whose own rounding reaches 1e-5 of an element now and then (a
+    few elements in 10^4: measured) -- so an element that differs from it by more than rtol is held to the float64
+    value instead: within rtol of it, or no further from it than twice `ref` is."""
+    t64 = None
+    for i, (a, b, n) in enumerate(zip(out, ref, ("sum_r", "sum_w", "max_w"))):
         b = b if isinstance(b, th.Tensor) else th.from_numpy(np.asarray(b))
         if n == "max_w":
             assert th.equal(a.detach().cpu().float(), b.detach().cpu().float()), "%s max_w: not the same logit selected" % what
-        else:
-            assert (b >= 0).all(), "state_close is for non-negative radiance"
+            continue
+        assert (b >= 0).all(), "state_close is for non-negative radiance"
+        if truth is None:
             rel_close(a, b, rtol=rtol, what="%s %s" % (what, n))
+            continue
+        a64, b64 = a.detach().cpu().double(), b.detach().cpu().double()
+        bad = (a64 - b64).abs() > rtol * b64.abs() + 1e-30
+        if bad.any():
+            if t64 is None:
+                t64 = truth()
+            t = t64[i].detach().cpu().double()
+            ea, eb = (a64 - t).abs()[bad], (b64 - t).abs()[bad]
+            ok = (ea <= rtol * t.abs()[bad] + 1e-30) | (ea <= 2.0 * eb)
+            assert ok.all(), "%s %s: %d elements beyond %.0e of float64 AND beyond twice the fp32 oracle's own error" % (
+                what, n, int((~ok).sum()), rtol)

@@ -6,7 +6,7 @@ import pytest
 import torch as th
 
 from helpers import (close, golden, module_scales, multisteps_fp64, multisteps_from_golden, no_worse_than,
-                     run_progressive, state_close, t)
+                     progressive_fp64, run_progressive, state_close, t)
 
 pytestmark = pytest.mark.gpu
 
@@ -54,7 +54,8 @@ def test_progressive_matches_reference_fixtures(case, spp, splat, fused):
     grads = [t(g[tag + "g%d" % i]) for i in range(3)]
     mod = modules.ProgressiveKernelApply(splat=splat, fused=fused)
     out, dd, dk = run_progressive(mod, datas, kerns, grads, "cuda")
-    state_close(out, [t(g[tag + n]) for n in ("sum_r", "sum_w", "max_w")], what=tag)
+    state_close(out, [t(g[tag + n]) for n in ("sum_r", "sum_w", "max_w")], what=tag,
+                truth=lambda: progressive_fp64(datas, kerns, splat=splat)[0])
     for i in range(spp):
         close(dd[i], g[tag + "d_data%d" % i], what="d_data")
         close(dk[i], g[tag + "d_kernels%d" % i], what="d_kernels")

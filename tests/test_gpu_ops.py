@@ -124,7 +124,7 @@ def test_fused_splat_update_vs_oracle(oracle, bs, c, h, w, k, spp):
         datas, kerns, grads, "cpu")
     fused = modules.ProgressiveKernelApply(splat=True)
     out, dd, dk = _progressive(fused, datas, kerns, grads, "cuda")
-    state_close(out, ref_out, what="")
+    state_close(out, ref_out, truth=lambda: progressive_fp64(datas, kerns)[0])
     for s in range(spp):
         close(dd[s], ref_dd[s], what="d_data[%d]" % s)
         close(dk[s], ref_dk[s], what="d_kernels[%d]" % s)
@@ -199,7 +199,7 @@ def test_splat_all_vs_oracle(oracle, bs, c, h, w, spp):
     assert F.splat_all_supported(dg, kg)
     out = F.SplatAll.apply(dg, kg)
     th.autograd.backward(out, [g.cuda() for g in grads])
-    state_close(out, ref_out, what="")
+    state_close(out, ref_out, truth=lambda: progressive_fp64([data[:, s] for s in range(spp)], [kern[:, s] for s in range(spp)])[0])
     for s in range(spp):
         close(dg.grad[:, s], ref_dd[s], what="d_data[%d]" % s)
         close(kg.grad[:, s], ref_dk[s], what="d_kernels[%d]" % s)
@@ -359,7 +359,8 @@ def test_fp16_logits_vs_oracle(oracle, bs, c, h, w, spp):
     out = F.SplatAll.apply(dg, kg)
     th.autograd.backward(out, [g.cuda() for g in grads])
     assert kg.grad.dtype == th.float16
-    state_close(out, ref_out, what="")
+    state_close(out, ref_out, truth=lambda: progressive_fp64([data[:, s] for s in range(spp)],
+                                                             [kern_h[:, s].float() for s in range(spp)])[0])
     for s in range(spp):
         close(dg.grad[:, s], ref_dd[s], what="d_data")
         close(kg.grad[:, s].float(), ref_dk[s], rtol=1e-3, what="d_kernels (half)")
@@ -618,7 +619,7 @@ def test_fused_gather_update_vs_oracle(oracle, bs, c, h, w, k, spp):
         lambda d, kk, a, b, m: oracle.progressive_kernel_apply(d, kk, a, b, m, splat=False),
         datas, kerns, grads, "cpu")
     out, dd, dk = _progressive(modules.ProgressiveKernelApply(splat=False), datas, kerns, grads, "cuda")
-    state_close(out, ref_out, what="")
+    state_close(out, ref_out, truth=lambda: progressive_fp64(datas, kerns, splat=False)[0])
     # d_kernels: the element that receives the routed max-gradient is a difference of two k*k-term sums
     # in BOTH fp32 implementations; it is held to 1e-5 of the float64 restatement of the same graph, or to
     # twice the oracle's own fp32 error against it, whichever is larger (helpers.no_worse_than)

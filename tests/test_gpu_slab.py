@@ -84,7 +84,7 @@ def test_slab_splat_merged_equals_oracle_whole_frame(oracle, k, H, W, S, bounds)
     kg = kern.cuda().requires_grad_()
     out = sharded_state(rg, kg, bounds, p)
     th.autograd.backward(list(out), [gr.cuda(), gw.cuda(), gm.cuda()])
-    state_close(out, st, what="")
+    state_close(out, st, truth=lambda: progressive_fp64([rad[:, s] for s in range(S)], [kern[:, s] for s in range(S)])[0])
     close(rg.grad, ro.grad, what="d_radiance")
     # the routed arg-max element of d_kernels: 1e-5 of the float64 restatement, or the oracle's own fp32 error
     _, _, dk64 = progressive_fp64([rad[:, s] for s in range(S)], [kern[:, s] for s in range(S)], [gr, gw, gm])
@@ -137,7 +137,7 @@ def test_half_logit_slab(oracle):
     for s in range(S):
         st = oracle.progressive_kernel_apply(rad[:, s], kern[:, s].float(), *st, splat=True)
     out = sharded_state(rad.cuda(), kern.cuda(), [(0, 20), (20, 40)], p)
-    state_close(out, st, what="")
+    state_close(out, st, truth=lambda: progressive_fp64([rad[:, s] for s in range(S)], [kern[:, s].float() for s in range(S)])[0])
 
 
 @pytest.mark.parametrize("top,bot", [(1, 1), (1, 0), (0, 1), (0, 0)])
