@@ -443,7 +443,8 @@ SBMC_API int sbmc_pointwise_fwd_scaled_f32(const float *x, const float *w, const
 /* The backward with magnitude words: gmax / xmax (and gmmax when gmean is given) -- device words holding the bit patterns
  * of floats >= max |gy| / max |x| / max |gmean| -- not NULL: both products (gw += gz x^T, gx = w^T gz) in the two-f16-plane
  * form; both NULL: the three-bf16-plane form.  gxmax (needs gx; or NULL): a zeroed word raised to the bit pattern of
- * max |gx| -- the scale of the backward of the layer before.  signs: the forward's sign bits (ignored when act == 0). */
+ * max |gx| -- the scale of the backward of the layer before (the three-plane form keeps it only without a context or mean
+ * gradient: SBMC_HIP_EINVAL otherwise).  signs: the forward's sign bits (ignored when act == 0). */
 SBMC_API int sbmc_pointwise_bwd_scaled_f32(const float *gy, const unsigned *signs, const float *x, const float *w,
                                   float *gx, float *gw_partial, float *gb_partial, float *gt, const float *gmean,
                                   int s_mean, const unsigned *gmax, const unsigned *gmmax, const unsigned *xmax,

@@ -1286,27 +1286,37 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     if constexpr (GXS) {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
         const int kr = wave * 16 + (lane & 15);
-        float v[4][8];
-        unsigned wm = 0;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
+        auto wrow = [&](int st, float (&v)[8]) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int g4 = lane >> 4;
                 const int co = 32 * st + 16 * (g4 >> 1) + 8 * (g4 & 1) + 2 * (e & 3) + (e >> 2);
-                v[st][e] = buf_load(rw, (co < p.Cout && kr < p.K) ? (unsigned)(co * p.K + kr) * 4u : PW_OOB, 0);
-                const unsigned a = abits(v[st][e]);
-                wm = wm > a ? wm : a;
+                v[e] = buf_load(rw, (co < p.Cout && kr < p.K) ? (unsigned)(co * p.K + kr) * 4u : PW_OOB, 0);
             }
-        }
+        };
         if constexpr (F2) {
+            float v[4][8];
+            unsigned wm = 0;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                wrow(st, v[st]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned a = abits(v[st][e]);
+                    wm = wm > a ? wm : a;
+                }
+            }
             const float cw = pow2_scale_of((unsigned)__builtin_amdgcn_readfirstlane((int)wave_umax(wm)));
             osx = (1.f / cw) * (1.f / cg);
 #pragma unroll
             for (int st = 0; st < 4; ++st) split2(v[st], cw, awh[st], awm[st]);
         } else {
 #pragma unroll
-            for (int st = 0; st < 4; ++st) split3(v[st], awh[st], awm[st], awl[st]);
+            for (int st = 0; st < 4; ++st) {
+                float v[8];
+                wrow(st, v);
+                split3(v, awh[st], awm[st], awl[st]);
+            }
         }
     } else if constexpr (NARROW) {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
@@ -1519,7 +1529,10 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc_w[0][j] = acc_w[1][j] = 0.f;
     unsigned gxmax_run = 0;                             // largest |gx| this thread has stored (split kernels)
-    const bool want_gxmax = (NARROW || GXS) && p.gxmax != nullptr;
+    // (the three-plane forms with a context or mean gradient have no register to spare for it: 27-30 spilled registers
+    // and 3.3 -> 5.0 ms per launch when they kept the running maximum)
+    constexpr bool GXMAX = (NARROW || GXS) && (F2 || !(TPIX || GM));
+    const bool want_gxmax = GXMAX && p.gxmax != nullptr;
 
     // gx of the previous step, waiting to be stored
     f32x16 out;
@@ -1759,7 +1772,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             }
         }
     }
-    if constexpr (NARROW || GXS) {
+    if constexpr (GXMAX) {
         if (p.gxmax != nullptr) amax_publish(gxmax_run, p.gxmax);
     }
 }
@@ -2596,7 +2609,8 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
         if (gws)
             lds = (size_t)128 * ((PW_BWD_GXS && gx) ? 0 : ((side && gx) ? PB_PITCH_N : PB_PITCH)) * sizeof(float) +
                   (size_t)(f2 ? 2 : 3) * (128 + kp) * PBS_PITCH * 2;
-        if (gxmax != nullptr && !(gws && (PW_BWD_GXS || side))) return SBMC_HIP_EINVAL;      // (the split kernels only)
+        // (the largest |gx|: the split kernels -- the three-plane form only without a context / mean gradient)
+        if (gxmax != nullptr && !(gws && PW_BWD_GXS && (f2 || !side))) return SBMC_HIP_EINVAL;
     } else if (gmax != nullptr || gxmax != nullptr) {
         return SBMC_HIP_EINVAL;
     }

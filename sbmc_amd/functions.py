@@ -609,7 +609,9 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
             gmmax = ensure_amax(gmean) if (gmean is not None and gmean.is_contiguous()) else None
             if gmax is None or xmax is None or (gmean is not None and gmmax is None):
                 gmax = gmmax = xmax = None
-            gxmax = amax_word(dev) if gx is not None else None
+            # (the three-plane kernels with a context or mean gradient keep no running maximum: no room)
+            if gx is not None and (gmax is not None or (t_mode != 2 and gmean is None)):
+                gxmax = amax_word(dev)
         with th.cuda.device(dev), _timed("pointwise_bwd%s %dx%d%s" % ("_f16" if half else "", cout, cin,
                                                                       "" if gx is not None else " (no gx)"), dev):
             tail = (_lib.ptr(w), _lib.ptr(gx) if gx is not None else None, _lib.ptr(gwp),
