@@ -2558,6 +2558,18 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
     p.t_mode = t_mode;
     p.slope = act == 0 ? 1.f : (act == 1 ? 0.f : slope);
     const unsigned grid = pw_bwd_grid(b, p.S, hw, &p.nunits);
+    // (argument errors before anything is written: the largest |gx| comes out of the split kernels only -- of the
+    // three-plane form only without a context / mean gradient --, magnitude words go with fp32 tensors)
+    if constexpr (sizeof(TA) == 4 && sizeof(TXT) == 4) {
+        const int gmode0 = env_knob("SBMC_HIP_PW_GWS", 2);
+        const bool side0 = t_mode == 2 || gmean;
+        const bool gws0 = gmode0 != 0 && (!side0 || gmode0 >= 2);
+        const bool f20 = gws0 && gmax != nullptr && xmax != nullptr && (!gmean || gmmax != nullptr) && (y_is_signs || act == 0) &&
+                         (PW_BWD_GXS || !gx);
+        if (gxmax != nullptr && !(gws0 && PW_BWD_GXS && (f20 || !side0))) return SBMC_HIP_EINVAL;
+    } else if (gmax != nullptr || gxmax != nullptr) {
+        return SBMC_HIP_EINVAL;
+    }
     hipError_t e = hipMemsetAsync(gb_partial, 0, (size_t)grid * p.Bq * cout * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     const int kp = (cin + 31) / 32 * 32;
@@ -2609,10 +2621,6 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
         if (gws)
             lds = (size_t)128 * ((PW_BWD_GXS && gx) ? 0 : ((side && gx) ? PB_PITCH_N : PB_PITCH)) * sizeof(float) +
                   (size_t)(f2 ? 2 : 3) * (128 + kp) * PBS_PITCH * 2;
-        // (the largest |gx|: the split kernels -- the three-plane form only without a context / mean gradient)
-        if (gxmax != nullptr && !(gws && PW_BWD_GXS && (f2 || !side))) return SBMC_HIP_EINVAL;
-    } else if (gmax != nullptr || gxmax != nullptr) {
-        return SBMC_HIP_EINVAL;
     }
 #define SBMC_PWB_PICK(KPV, DXV, TPV, SGV, GWSV)                                                          \
     ((gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, float, float, SGV, GWSV>                     \
