@@ -239,6 +239,19 @@ SBMC_API int sbmc_splat_all_bwd_f32(const float *data, const float *kernels,
                            float *d_data, float *d_kernels, float *scratch,
                            int bs, int s, int c, int h, int w, int k, void *stream);
 
+/* ABI 6: sbmc_splat_all_bwd_f32 / sbmc_splat_slab_bwd_f32 (top = bot = 0: the whole frame) that also raise `bound` -- a
+ * device word the caller zeroed -- to the bit pattern of an upper bound of |d_kernels|: with every weight
+ * exp(S - M) <= 1, |dS| <= |dW| + |d_kmax| + max|data| * sum_c |dR_c| per destination, quantities the per-pixel chain
+ * holds; dmax: a device word with the bit pattern of max |data|.  The consumer of d_kernels (the wide 1 x 1 layer's
+ * backward, sbmc_pointwise_wide_bwd_f32) takes its power-of-two scale from it without a pass over 1.6 GB per sample. */
+SBMC_API int sbmc_splat_all_bwd_bound_f32(const float *data, const float *kernels,
+                                 const float *part_m, const int32_t *atap,
+                                 const float *run_r, const float *run_w, const float *run_m,
+                                 const float *d_sum_r, const float *d_sum_w, const float *d_max_w,
+                                 float *d_data, float *d_kernels, float *scratch,
+                                 const unsigned *dmax, unsigned *bound,
+                                 int bs, int s, int c, int h, int w, int k, int top, int bot, void *stream);
+
 /*
  * Row-slab form of the all-samples splat: ONE frame sharded along H over several GPUs (new
  * functionality; the reference's closest analogue is the overlapped tiling
@@ -450,6 +463,16 @@ SBMC_API int sbmc_pointwise_bwd_scaled_f32(const float *gy, const unsigned *sign
                                   int s_mean, const unsigned *gmax, const unsigned *gmmax, const unsigned *xmax,
                                   unsigned *gxmax, int b, int s, int cin, int cout, long hw, int t_mode, int act,
                                   float slope, void *stream);
+/* The WHOLE backward of a wide linear layer (128 < cout <= 512: the 441-channel logits, reference sbmc/models.py:98-102)
+ * in one pass over the logit gradient gz [b, cout, hw]: gx [b, cin, hw] = w^T gz, and the partial sums of gw / gbias as
+ * sbmc_pointwise_gw_wide_f32 ([groups, cout, cin], [groups, cout], groups = sbmc_pointwise_gw_wide_groups(b, hw)), in
+ * the two-f16-plane form: gmax / xmax are device words holding the bit patterns of floats >= max |gz| / max |x| (gmax
+ * may be a loose bound: sbmc_splat_all_bwd_bound_f32); gxmax (or NULL): a zeroed word raised to max |gx|.
+ * ws: sbmc_pointwise_wide_bwd_ws_bytes() bytes of device scratch, 16-byte aligned (the weights' prepared planes). */
+SBMC_API size_t sbmc_pointwise_wide_bwd_ws_bytes(void);
+SBMC_API int sbmc_pointwise_wide_bwd_f32(const float *gz, const float *x, const float *w, float *gx, float *gw_partial,
+                                float *gb_partial, void *ws, const unsigned *gmax, const unsigned *xmax,
+                                unsigned *gxmax, int b, int cin, int cout, long hw, void *stream);
 /* the all-half layer (x, y _Float16) with the mean as a _Float16 tensor: the mean of the half values as stored */
 SBMC_API int sbmc_pointwise_fwd_mean_f16(const void *x, const float *w, const float *bias, const float *t, void *y,
                                 void *ymean, int s_mean, int b, int s, int cin, int cout, long hw, int t_mode,

@@ -66,6 +66,9 @@ SYMBOLS = (
     "sbmc_pointwise_fwd_mean_f16",
     "sbmc_pointwise_fwd_scaled_f32",
     "sbmc_pointwise_bwd_scaled_f32",
+    "sbmc_pointwise_wide_bwd_ws_bytes",
+    "sbmc_pointwise_wide_bwd_f32",
+    "sbmc_splat_all_bwd_bound_f32",
     "sbmc_upsample2x_cat_supported",
     "sbmc_upsample2x_cat_fwd_f32",
     "sbmc_upsample2x_cat_bwd_f32",
@@ -229,6 +232,9 @@ def lib():
     handle.sbmc_pointwise_fwd_mean_f32.argtypes = [p] * 7 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_fwd_scaled_f32.argtypes = [p] * 7 + [i, p, p, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_scaled_f32.argtypes = [p] * 9 + [i] + [p] * 4 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
+    handle.sbmc_pointwise_wide_bwd_ws_bytes.argtypes = []
+    handle.sbmc_pointwise_wide_bwd_f32.argtypes = [p] * 10 + [i, i, i, ctypes.c_long, p]
+    handle.sbmc_splat_all_bwd_bound_f32.argtypes = [p] * 15 + [i] * 8 + [p]
     handle.sbmc_pointwise_fwd_mean_f16.argtypes = [p] * 6 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_f16.argtypes = [p, p, p, i, p, p, p, p, p, p, i, i, i, i, i, ctypes.c_long, i, i,
                                               ctypes.c_float, p]
@@ -291,6 +297,7 @@ def lib():
     for name in SYMBOLS[2:]:
         getattr(handle, name).restype = i
     handle.sbmc_halo_bytes.restype = ctypes.c_size_t
+    handle.sbmc_pointwise_wide_bwd_ws_bytes.restype = ctypes.c_size_t
     handle.sbmc_conv3x3_weights_bytes.restype = ctypes.c_size_t
     handle.sbmc_conv3x3_workspace_bytes.restype = ctypes.c_size_t
     handle.sbmc_conv3x3_wgrad_scratch_bytes.restype = ctypes.c_size_t

@@ -1998,6 +1998,314 @@ __global__ __launch_bounds__(PW_THREADS) void pw_gw_wide_kernel(PwBwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The WHOLE backward of the wide linear layer (the 441-channel logits, reference sbmc/models.py:98-102) in ONE pass over the
+// logit gradient (round 5): gw, gbias AND gx = w^T gz, everything in the two-f16-plane format.  Until here the data gradient
+// was a library GEMM on the fp32 matrix pipe behind a second pass over the 13 GB gradient (7.6 of the layer's 14.3 ms).
+//
+// pw_gw_wide_kernel's structure -- the x tile staged once per 64-pixel tile, the gz tile 128 output channels at a time
+// (a "step") -- plus, per step, the gx product of pw_bwd_kernel's GXS form on the staged gz chunk: a wave owns 16 rows of
+// K over all 64 pixels and adds up its four 16 x 16 blocks over the steps of a tile.  Its A operand, this wave's 16 rows of
+// w^T for the step's 128 channels in two planes, does not fit the registers next to 128 of gw accumulators for all four
+// steps (128 more), nor the LDS for the whole layer (229 KB): the PREPARED planes (pw_wide_prep_kernel: split once per
+// launch, laid out per (step, wave, plane, 32-channel sub-step, lane) so that a wave's slice is eight 1 KB runs) stream
+// from L2 -- 8 KB per wave and step, requested at the step's start BEFORE the step's gz request (a wait for them must not
+// be a wait for the far slower HBM rows behind them: the vector-memory counter is in order), parked in 32 registers
+// through the step and written to the wave's PRIVATE LDS slice at the step's commit.  gz rows one step ahead (a step is
+// twice the work of pw_gw_wide_kernel's).
+struct PwWideParams {
+    PwBwdParams b;
+    const u32x4* wprep;      // [4 steps][8 waves][2 planes][4 sub-steps][64 lanes] entries of 8 halves
+    const float* wscale;     // the weights' power-of-two scale (written by pw_wide_prep_kernel)
+};
+
+// w [Cout, K] -> the planes above + the scale.  One workgroup.
+__global__ __launch_bounds__(512) void pw_wide_prep_kernel(const float* __restrict__ w, u32x4* __restrict__ wprep,
+                                                           float* __restrict__ wscale, int cout, int k) {
+    unsigned m = 0;
+    for (int i = threadIdx.x; i < cout * k; i += 512) {
+        const unsigned a = abits(w[i]);
+        m = m > a ? m : a;
+    }
+    __shared__ unsigned wmax[8];
+    m = wave_umax(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    for (int i = 0; i < 8; ++i) m = m > wmax[i] ? m : wmax[i];
+    const float cw = pow2_scale_of((unsigned)__builtin_amdgcn_readfirstlane((int)m));
+    if (threadIdx.x == 0) *wscale = cw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g4 = lane >> 4, kr = wave * 16 + (lane & 15);
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {              // (the row -> reduction index map of pw_bwd_kernel's GXS form)
+                const int co = 128 * ct + 32 * st + 16 * (g4 >> 1) + 8 * (g4 & 1) + 2 * (e & 3) + (e >> 2);
+                v[e] = (co < cout && kr < k) ? w[co * k + kr] : 0.f;
+            }
+            u32x4 h, l;
+            split2(v, cw, h, l);
+            wprep[(((ct * 8 + wave) * 2 + 0) * 4 + st) * 64 + lane] = h;
+            wprep[(((ct * 8 + wave) * 2 + 1) * 4 + st) * 64 + lane] = l;
+        }
+    }
+}
+
+template <int KP>
+__global__ __launch_bounds__(PW_THREADS) void pw_wide_bwd2_kernel(PwWideParams pp) {
+    const PwBwdParams& p = pp.b;
+    const float* gz_g = static_cast<const float*>(p.gy);
+    const float* x_g = static_cast<const float*>(p.x);
+    float* gx_g = static_cast<float*>(p.gx);
+    extern __shared__ float4 pw_lds[];
+    _Float16* gzn = reinterpret_cast<_Float16*>(pw_lds);              // [2][128][PBS_PITCH]
+    _Float16* xn = gzn + 2 * 128 * PBS_PITCH;                         // [2][KP][PBS_PITCH]
+    u32x4* wsl = reinterpret_cast<u32x4*>(xn + 2 * KP * PBS_PITCH);   // [8 waves][2][4][64]: a wave's own slice
+    float* bacc = reinterpret_cast<float*>(wsl + 8 * 8 * 64);         // [512]: row sums of gz (the bias gradient)
+    constexpr int NB = KP / 32, NX = KP / 32;
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int rb = wave & 3, ph = wave >> 2;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const unsigned hw = p.hw;
+    const unsigned g = blockIdx.x, G = gridDim.x;
+    const unsigned c4 = (threadIdx.x & 15) * 4, srow = threadIdx.x >> 4;
+    const int nct = (p.Cout + 127) / 128;                             // steps per pixel tile (<= 4)
+    const float cg = pow2_scale_of(*p.gmax), cx = pow2_scale_of(*p.xmax);
+    const float osx = (1.f / *pp.wscale) * (1.f / cg);
+
+    u32x4 pg[4], px[NX];
+    auto coords = [&](unsigned unit, unsigned& b, unsigned& p0) {
+        b = unit / p.tiles_per_plane;
+        p0 = (unit % p.tiles_per_plane) * PB_NT;
+    };
+    // this wave's slice of step ct: eight 1 KB runs, L2 -> LDS without touching a register (LDS-DMA: this kernel has none
+    // to spare).  The destination is the wave's PRIVATE region, which only its own gx product reads: the request needs
+    // this wave's LDS reads retired (lgkmcnt) and nothing else; its completion is the s_waitcnt vmcnt(0) before the
+    // step's closing barrier.  (hipcc does not count an asm load: its own waits for the ordinary loads only get more
+    // conservative by it, never less -- the counter is in order and these are the youngest requests.)
+    const rsrc_t rwp = make_rsrc_n(pp.wprep, 4u * 8u * 8u * 1024u);
+    auto issue_w = [&](int ct) {
+        using lptr = __attribute__((address_space(3))) void*;
+        char* dst = reinterpret_cast<char*>(wsl + (size_t)wave * 8 * 64);
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((ct * 8 + wave) * 8192);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwp, (lptr)(dst + i * 1024), 16, (unsigned)lane * 16u, so + (unsigned)i * 1024u, 0, 0);
+    };
+    auto issue_g = [&](unsigned unit, int ct) {
+        unsigned b, p0;
+        coords(unit, b, p0);
+        const rsrc_t rg = make_rsrc_n(gz_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
+        const bool colok = p0 + c4 < hw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned r = 128u * ct + srow + 32u * i;
+            pg[i] = load4<float>(rg, (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB);
+        }
+    };
+    auto issue_x = [&](unsigned unit) {
+        unsigned b, p0;
+        coords(unit, b, p0);
+        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
+        const bool colok = p0 + c4 < hw;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const unsigned r = srow + 32u * i;
+            px[i] = load4<float>(rx, (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * 4u : PW_OOB);
+        }
+    };
+    // (the row sums live in LDS, not in 16 registers of every thread: a row's 16 staging threads add up their 4 pixels
+    // each and one of them adds the sum to the row's word -- this kernel has no register to spare)
+    bacc[threadIdx.x] = 0.f;
+    auto commit_g = [&](int ct) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 gv = unpack4<float>(pg[i]);
+            float rs = (gv.x + gv.y) + (gv.z + gv.w);
+            rs += __shfl_xor(rs, 8, 16);
+            rs += __shfl_xor(rs, 4, 16);
+            rs += __shfl_xor(rs, 2, 16);
+            rs += __shfl_xor(rs, 1, 16);
+            if ((threadIdx.x & 15) == 0) bacc[128 * ct + srow + 32 * i] += rs;      // (the one thread that owns this word)
+            u32x2 h, l;
+            split2_4(gv, cg, h, l);
+            _Float16* e = gzn + (srow + 32 * i) * PBS_PITCH + c4;
+            *reinterpret_cast<u32x2*>(e) = h;
+            *reinterpret_cast<u32x2*>(e + 128 * PBS_PITCH) = l;
+        }
+    };
+    auto commit_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const float4 xv = unpack4<float>(px[i]);
+            u32x2 h, l;
+            split2_4(xv, cx, h, l);
+            _Float16* e = xn + (srow + 32 * i) * PBS_PITCH + c4;
+            *reinterpret_cast<u32x2*>(e) = h;
+            *reinterpret_cast<u32x2*>(e + KP * PBS_PITCH) = l;
+        }
+    };
+    f32x16 acc_w[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc_w[a][n][j] = 0.f;
+    f32x4 acc_n[4];
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) acc_n[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned gxmax_run = 0;
+    const bool want_gxmax = p.gxmax != nullptr;
+
+    unsigned unit = g;
+    bool valid = unit < p.nunits;
+    if (valid) {
+        issue_g(unit, 0);
+        issue_x(unit);
+        issue_w(0);
+        commit_g(0);
+        commit_x();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool two = 2 * ph + 1 < NB;
+    // this lane's B-operand address of the gx product (pw_bwd_kernel, GXS)
+    const _Float16* tb = gzn + (16 * (lane >> 5) + 8 * ((lane >> 4) & 1) + 2 * ((lane & 15) >> 2)) * PBS_PITCH + 4 * (lane & 3);
+    using v4s = short __attribute__((ext_vector_type(4)));
+    using v4sp = __attribute__((address_space(3))) v4s*;
+    auto tr8 = [&](const _Float16* q) -> u32x4 {
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4sp)q);
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4sp)(q + PBS_PITCH));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        return u32x4{l2[0], l2[1], h2[0], h2[1]};
+    };
+    auto step = [&](auto ctc) __attribute__((always_inline)) {
+        constexpr int CT = decltype(ctc)::value;
+        const bool last_ct = CT + 1 >= nct;
+        const unsigned un = last_ct ? unit + G : unit;              // the next step's pixel tile and chunk
+        const int cn = last_ct ? 0 : CT + 1;
+        const bool more = un < p.nunits;
+        // requests of the next step: the HBM rows now, the weight slice (L2) behind the gx product -- everything is consumed
+        // at the step's commit, so the in-order vector-memory counter costs nothing, and the slice's 32 registers are
+        // live through the gw product only
+        if (more) {
+            issue_g(un, cn);
+            if (last_ct) issue_x(un);
+        }
+        // ---- gx += w^T[:, chunk] gz[chunk]: rows 16 wave .. of K, four blocks of 16 pixels
+        {
+            const u32x4* wa = wsl + (size_t)wave * 8 * 64 + lane;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const u32x4 awh = wa[st * 64], awl = wa[(4 + st) * 64];
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) {
+                    const _Float16* q = tb + (32 * st) * PBS_PITCH + 16 * pb;
+                    const u32x4 bh = tr8(q), bl = tr8(q + 128 * PBS_PITCH);
+                    acc_n[pb] = mfma16_f16(awh, bl, acc_n[pb]);
+                    acc_n[pb] = mfma16_f16(awl, bh, acc_n[pb]);
+                    acc_n[pb] = mfma16_f16(awh, bh, acc_n[pb]);
+                    __builtin_amdgcn_sched_barrier(0);              // (one block of operands in flight, not all four: registers)
+                }
+            }
+        }
+        if (more) issue_w(cn);                          // (behind the wave's own reads of the region)
+        if (last_ct) {                                               // the tile's data gradient is complete
+            unsigned b, p0;
+            coords(unit, b, p0);
+            const int r0 = wave * 16;
+            const int nr = p.K - r0 < 16 ? (p.K - r0 > 0 ? p.K - r0 : 0) : 16;
+            const rsrc_t rgx = make_rsrc_n(gx_g + ((size_t)b * p.K + r0) * hw, (unsigned)nr * hw * 4u);
+            // one lane offset per accumulator register (its row: rows beyond K fall outside the descriptor), the pixel
+            // block as a scalar offset; columns beyond the plane through the offset's select
+            const unsigned c0 = p0 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned vo = ((4u * (lane >> 4) + j) * hw + c0) * 4u;
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) {
+                    const bool in = c0 + 16u * pb < hw && nr > 0;
+                    const float v = acc_n[pb][j] * osx;
+                    if (want_gxmax) {
+                        const unsigned a = (in && 4 * (lane >> 4) + j < nr) ? abits(v) : 0u;
+                        gxmax_run = gxmax_run > a ? gxmax_run : a;
+                    }
+                    buf_store(v, rgx, in ? vo : PW_OOB, 64u * pb);
+                }
+            }
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) acc_n[pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- gw[chunk] += gz[chunk] x^T: rows 32 rb .. of the chunk, column blocks 2 ph, 2 ph + 1 of K
+        if (2 * ph < NB) {
+            const _Float16* ga = gzn + (rb * 32 + l31) * PBS_PITCH + 8 * lhi;
+            const _Float16* xb0 = xn + ((2 * ph) * 32 + l31) * PBS_PITCH + 8 * lhi;
+            const _Float16* xb1 = xn + ((2 * ph + 1) * 32 + l31) * PBS_PITCH + 8 * lhi;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {               // 16 pixels per step
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(ga + 16 * s);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(ga + 16 * s + 128 * PBS_PITCH);
+                {
+                    const u32x4 bh = *reinterpret_cast<const u32x4*>(xb0 + 16 * s);
+                    const u32x4 bl = *reinterpret_cast<const u32x4*>(xb0 + 16 * s + KP * PBS_PITCH);
+                    acc_w[CT][0] = mfma_f16(ah, bl, acc_w[CT][0]);
+                    acc_w[CT][0] = mfma_f16(al, bh, acc_w[CT][0]);
+                    acc_w[CT][0] = mfma_f16(ah, bh, acc_w[CT][0]);
+                }
+                if (two) {
+                    const u32x4 bh = *reinterpret_cast<const u32x4*>(xb1 + 16 * s);
+                    const u32x4 bl = *reinterpret_cast<const u32x4*>(xb1 + 16 * s + KP * PBS_PITCH);
+                    acc_w[CT][1] = mfma_f16(ah, bl, acc_w[CT][1]);
+                    acc_w[CT][1] = mfma_f16(al, bh, acc_w[CT][1]);
+                    acc_w[CT][1] = mfma_f16(ah, bh, acc_w[CT][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        lds_barrier();                                  // every wave is through with the stage before it is refilled
+        if (more) {
+            commit_g(cn);
+            if (last_ct) commit_x();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the slice has landed)
+        __syncthreads();
+        if (last_ct) {
+            unit += G;
+            valid = unit < p.nunits;
+        }
+    };
+    while (valid) {
+        step(std::integral_constant<int, 0>{});
+        if (nct > 1) step(std::integral_constant<int, 1>{});
+        if (nct > 2) step(std::integral_constant<int, 2>{});
+        if (nct > 3) step(std::integral_constant<int, 3>{});
+    }
+
+    // ---- this workgroup's partial sums: gbias, gw (scaled back)
+    if (threadIdx.x < (unsigned)p.Cout) p.gbp[(size_t)g * p.Cout + threadIdx.x] = bacc[threadIdx.x];     // (behind the loop's barrier)
+    const float osw = (1.f / cg) * (1.f / cx);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int r0 = a * 128 + rb * 32;
+        const int nrows = p.Cout - r0 < 32 ? (p.Cout - r0 > 0 ? p.Cout - r0 : 0) : 32;
+        const rsrc_t rgw = make_rsrc_n(p.gwp + ((size_t)g * p.Cout + r0) * p.K, (unsigned)(nrows * p.K) * 4u);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = (2 * ph + n) * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int rl = (j & 3) + 8 * (j >> 2) + 4 * lhi;
+                buf_store(acc_w[a][n][j] * osw, rgw, (col < p.K && nrows > 0 && rl < nrows) ? (unsigned)(rl * p.K + col) * 4u : PW_OOB, 0);
+            }
+        }
+    }
+    if (want_gxmax) amax_publish(gxmax_run, p.gxmax);
+}
+
+// ---------------------------------------------------------------------------------------------
 // The backward for half activations on the f16 matrix pipe (training under torch.autocast(float16)): gy, y, x
 // and gx are _Float16 in HBM, gz = gy * act'(y) is formed in fp32 and rounded to half once (what autocast's
 // activation backward hands to its convolution backward), the weights are rounded to half, every product is
@@ -2716,6 +3024,54 @@ static int pw_gw_wide_launch(const void* gz, const void* x, float* gw_partial, f
         default: SBMC_GWW(128); break;
     }
 #undef SBMC_GWW
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    return (int)hipGetLastError();
+}
+
+// The wide linear layer's whole backward in one pass (ABI 6; pw_wide_bwd2_kernel): gx [b, cin, hw], gw / gbias partial sums
+// as sbmc_pointwise_gw_wide_f32.  gmax / xmax: device words holding the bit patterns of floats >= max |gz| / max |x|;
+// gxmax (or NULL): a zeroed word raised to max |gx|; ws: sbmc_pointwise_wide_bwd_ws_bytes() bytes of scratch (the
+// weights' prepared planes; written and read by this call only).
+extern "C" size_t sbmc_pointwise_wide_bwd_ws_bytes(void) { return (size_t)4 * 8 * 2 * 4 * 64 * 16 + 256; }
+extern "C" int sbmc_pointwise_wide_bwd_f32(const float* gz, const float* x, const float* w, float* gx, float* gw_partial,
+                                           float* gb_partial, void* ws, const unsigned* gmax, const unsigned* xmax,
+                                           unsigned* gxmax, int b, int cin, int cout, long hw, void* stream) {
+    if (b < 0) return SBMC_HIP_EINVAL;
+    if (b == 0) return 0;
+    if (!sbmc_pointwise_gw_wide_supported(cin, cout, hw) || !gz || !x || !w || !gx || !gw_partial || !gb_partial || !ws ||
+        !gmax || !xmax || (double)cin * (double)hw * 4.0 >= 4294967000.0)
+        return SBMC_HIP_EINVAL;
+    if ((uintptr_t)gz % 16 || (uintptr_t)x % 16 || (uintptr_t)gx % 16 || (uintptr_t)ws % 16) return SBMC_HIP_EINVAL;
+    PwWideParams pp;
+    memset(&pp, 0, sizeof(pp));
+    PwBwdParams& p = pp.b;
+    p.gy = gz; p.x = x; p.w = w; p.gx = gx; p.gwp = gw_partial; p.gbp = gb_partial;
+    p.gmax = gmax; p.xmax = xmax; p.gxmax = gxmax;
+    p.B = b; p.S = 1; p.K = cin; p.Cout = cout; p.Bq = 1;
+    p.hw = (unsigned)hw;
+    p.tiles_per_plane = (unsigned)((hw + PB_NT - 1) / PB_NT);
+    p.slope = 1.f;
+    u32x4* wprep = static_cast<u32x4*>(ws);
+    float* wscale = reinterpret_cast<float*>(static_cast<char*>(ws) + (size_t)4 * 8 * 2 * 4 * 64 * 16);
+    pp.wprep = wprep; pp.wscale = wscale;
+    hipLaunchKernelGGL(pw_wide_prep_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, w, wprep, wscale, cout, cin);
+    const unsigned grid = pw_bwd_grid(b, 1, hw, &p.nunits);
+    const int kp = (cin + 31) / 32 * 32;
+    const size_t lds = (size_t)2 * (128 + kp) * PBS_PITCH * 2 + (size_t)8 * 8 * 64 * 16 + 512 * 4;
+    hipError_t e = hipSuccess;
+#define SBMC_WB2(KPV)                                                                                    \
+    do {                                                                                                 \
+        auto kern = pw_wide_bwd2_kernel<KPV>;                                                            \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(grid), dim3(PW_THREADS), lds, (hipStream_t)stream, pp); \
+    } while (0)
+    switch (kp) {
+        case 32: SBMC_WB2(32); break;
+        case 64: SBMC_WB2(64); break;
+        case 96: SBMC_WB2(96); break;
+        default: SBMC_WB2(128); break;
+    }
+#undef SBMC_WB2
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     return (int)hipGetLastError();
 }

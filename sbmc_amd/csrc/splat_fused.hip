@@ -877,6 +877,13 @@ struct SplatChainParams {
     const float* d_max_w;      // [bs, h, w]
     float* records;            // [bs, S, h, w, 8]
     int bs, s, h, w;
+    // An upper bound of |d_kernels| without a pass over it (or both nullptr): with e = exp(S - M) <= 1 the strip kernel's
+    // dS = e (dW + sum_c dR_c D_c) + [arg-max tap] d_kmax is at most |dW| + |d_kmax| + max|D| sum_c |dR_c| -- per-pixel
+    // quantities this kernel holds.  `bound` (a word the caller zeroed) is raised to the bit pattern of the largest
+    // over all records; `dmax`: the word of max |data|.  The wide 1x1 layer that consumes d_kernels takes its
+    // power-of-two scale from it (csrc/pointwise.hip pw_wide_bwd2_kernel).
+    const unsigned* dmax;
+    unsigned* bound;
 };
 
 template <int C>
@@ -884,6 +891,8 @@ __global__ __launch_bounds__(256) void splat_chain_bwd_kernel(SplatChainParams p
     static_assert(C <= 4, "records hold up to 4 channels");
     const size_t hw = (size_t)p.h * p.w;
     const size_t total = (size_t)p.bs * hw;
+    const float dmax = p.dmax ? __builtin_bit_cast(float, *p.dmax) : 0.f;
+    float bnd = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const size_t n = i / hw, pix = i % hw;
@@ -921,6 +930,10 @@ __global__ __launch_bounds__(256) void splat_chain_bwd_kernel(SplatChainParams p
             float4* rec = reinterpret_cast<float4*>(p.records) + o * 2;
             rec[0] = r0;
             rec[1] = r1;
+            {
+                const float b = fabsf(r0.y) + fabsf(r0.z) + dmax * ((fabsf(r1.x) + fabsf(r1.y)) + (fabsf(r1.z) + fabsf(r1.w)));
+                bnd = b > bnd ? b : bnd;               // (a NaN leaves it: the word then says nothing about NaN inputs, nor need it)
+            }
             // adjoint of the incoming state of this step = outgoing state of the previous one
             dM = sigma * dot_in + dMtot * sel_prev;
             dW *= sigma;
@@ -928,6 +941,7 @@ __global__ __launch_bounds__(256) void splat_chain_bwd_kernel(SplatChainParams p
             for (int c = 0; c < C; ++c) dR[c] *= sigma;
         }
     }
+    if (p.bound != nullptr) amax_publish(__builtin_bit_cast(unsigned, bnd), p.bound);
 }
 
 static inline size_t fwd_tile_lds_bytes(int c, int k) {
@@ -1126,8 +1140,10 @@ static int splat_all_bwd_impl(const float* data, const void* kernels,
                               const float* run_r, const float* run_w, const float* run_m,
                               const float* d_sum_r, const float* d_sum_w, const float* d_max_w,
                               float* d_data, void* d_kernels, float* scratch,
-                              int bs, int s, int c, int h, int w, int k, void* stream, int top = 0, int bot = 0) {
+                              int bs, int s, int c, int h, int w, int k, void* stream, int top = 0, int bot = 0,
+                              const unsigned* dmax = nullptr, unsigned* bound = nullptr) {
     if (top < 0 || bot < 0 || h < 0 || top > (k - 1) / 2 || bot > (k - 1) / 2) return SBMC_HIP_EINVAL;
+    if ((dmax == nullptr) != (bound == nullptr)) return SBMC_HIP_EINVAL;
     const int hd = top + h + bot;   // the per-pixel quantities (state, records) live on the destination rows
     if (bs < 0 || s < 1 || w < 0 || c < 1 || !strip_ok(c, k, hd, w, sizeof(LT) != 4)) return SBMC_HIP_EINVAL;
     if (bs == 0 || h == 0 || w == 0) return 0;
@@ -1135,7 +1151,7 @@ static int splat_all_bwd_impl(const float* data, const void* kernels,
         !d_max_w || !d_data || !d_kernels || !scratch)
         return SBMC_HIP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    SplatChainParams cp{part_m, atap, run_r, run_w, run_m, d_sum_r, d_sum_w, d_max_w, scratch, bs, s, hd, w};
+    SplatChainParams cp{part_m, atap, run_r, run_w, run_m, d_sum_r, d_sum_w, d_max_w, scratch, bs, s, hd, w, dmax, bound};
     const size_t total = (size_t)bs * hd * w;
     unsigned egrid = (unsigned)((total + 255) / 256);
     if (egrid > 8192) egrid = 8192;
@@ -1256,6 +1272,16 @@ extern "C" int sbmc_splat_all_bwd_f16(const float* data, const void* kernels, SP
                                       void* d_kernels, float* scratch, int bs, int s, int c, int h, int w,
                                       int k, void* stream) {
     return splat_all_bwd_impl<_Float16>(data, kernels, SPLAT_ALL_PASS, d_data, d_kernels, scratch, bs, s, c, h, w, k, stream);
+}
+
+// ABI 6: the same backward that also leaves an upper bound of |d_kernels| in a device word (SplatChainParams::bound);
+// top = bot = 0: the whole frame (sbmc_splat_all_bwd_f32), else the row-slab form (sbmc_splat_slab_bwd_f32).
+extern "C" int sbmc_splat_all_bwd_bound_f32(const float* data, const float* kernels, SPLAT_ALL_ARGS, float* d_data,
+                                            float* d_kernels, float* scratch, const unsigned* dmax, unsigned* bound,
+                                            int bs, int s, int c, int h, int w, int k, int top, int bot, void* stream) {
+    if (!dmax || !bound) return SBMC_HIP_EINVAL;
+    return splat_all_bwd_impl<float>(data, kernels, SPLAT_ALL_PASS, d_data, d_kernels, scratch, bs, s, c, h, w, k, stream,
+                                     top, bot, dmax, bound);
 }
 
 // ---- row-slab form (one frame sharded along H over several GPUs)

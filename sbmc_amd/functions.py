@@ -679,6 +679,24 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
         # bias sums + a library GEMM on the fp32 pipe; the data gradient (its reduction runs over the 441 channels: the
         # weights do not fit a CU in split form) stays a library GEMM
         gx = gw = gbias = None
+        gmax, xmax = known_amax(gy), getattr(ctx, "xmax", None)
+        if (ctx.needs_input_grad[0] and gmax is not None and xmax is not None and _pw_split_enabled()
+                and knob("SBMC_HIP_PW_F16") != 0 and knob("SBMC_HIP_PW_WIDE_FUSED") != 0):
+            # the whole backward in ONE pass over the logit gradient (pw_wide_bwd2_kernel: two f16 planes; the scale of gy
+            # from the bound the splat's backward left, of x from the forward's word): no second 13 GB read, no library GEMM
+            groups = L.sbmc_pointwise_gw_wide_groups(B, hw)
+            gwp = w.new_empty(groups, cout, cin)
+            gbp = w.new_empty(groups, cout)
+            gx = th.empty_like(x)
+            ws = th.empty(L.sbmc_pointwise_wide_bwd_ws_bytes(), dtype=th.uint8, device=dev)
+            gxmax = amax_word(dev)
+            with th.cuda.device(dev), _timed("pointwise_wide_bwd %dx%d" % (cout, cin), dev):
+                _lib.check(L.sbmc_pointwise_wide_bwd_f32(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(w), _lib.ptr(gx), _lib.ptr(gwp),
+                                                         _lib.ptr(gbp), _lib.ptr(ws), _lib.ptr(gmax), _lib.ptr(xmax),
+                                                         _lib.ptr(gxmax), B, cin, cout, hw, _lib.current_stream(dev)),
+                           "pointwise_wide_bwd")
+            tag_amax(gx, gxmax)
+            return gx, gwp.sum(0), gbp.sum(0), None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             groups = L.sbmc_pointwise_gw_wide_groups(B, hw)
             gwp = w.new_empty(groups, cout, cin)
@@ -1633,12 +1651,22 @@ class SplatAll(th.autograd.Function):
                 _lib.ptr(run_r), _lib.ptr(run_w), _lib.ptr(run_m),
                 _lib.ptr(d_r), _lib.ptr(d_w), _lib.ptr(d_m),
                 _lib.ptr(d_data), _lib.ptr(d_kernels), _lib.ptr(scratch), bs, S, c, h, w, ctx.k)
+        # fp32: the per-pixel chain also leaves an upper bound of |d_kernels| in a device word (the scale of the 441-channel
+        # layer's backward, which reads d_kernels next: no pass over 13 GB for it); it needs max |data|
+        bound = None
+        if not half and knob("SBMC_HIP_PW_F16") != 0 and knob("SBMC_AMAX_TAGS") != 0:
+            dmax, bound = ensure_amax(data), amax_word(dev)
         with th.cuda.device(dev), _timed("splat_update_bwd_all_f16" if half else "splat_update_bwd_all", dev):
-            if top or bot:
+            if bound is not None:
+                rc = L.sbmc_splat_all_bwd_bound_f32(*args[:13], _lib.ptr(dmax), _lib.ptr(bound), *args[13:], top, bot,
+                                                    _lib.current_stream(dev))
+            elif top or bot:
                 rc = (L.sbmc_splat_slab_bwd_f16 if half else L.sbmc_splat_slab_bwd_f32)(
                     *args, top, bot, _lib.current_stream(dev))
             else:
                 rc = (L.sbmc_splat_all_bwd_f16 if half else L.sbmc_splat_all_bwd_f32)(
                     *args, _lib.current_stream(dev))
         _lib.check(rc, "splat_all_bwd")
+        if bound is not None:
+            tag_amax(d_kernels, bound)
         return d_data, d_kernels, None, None, None, None

@@ -186,7 +186,7 @@ class Multisteps(nn.Module):
                 ctx = context.unsqueeze(1).expand(bs, spp, context.shape[1], h, w)
                 flat = th.cat([features, ctx], 2).reshape(bs * spp, -1, h, w)
                 kernels = self.kernel_regressor(flat)
-            kernels = kernels.view(bs, spp, kernels.shape[1], h, w)
+            kernels = funcs.tagged_view(kernels, bs, spp, kernels.shape[1], h, w)     # (d_kernels' word travels back)
             supported = (lambda kk: funcs.splat_slab_supported(radiance, kk, top, bot)) if slab else \
                 (lambda kk: funcs.splat_all_supported(radiance, kk))
             if kernels.dtype != th.float32 and not supported(kernels):

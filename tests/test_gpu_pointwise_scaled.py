@@ -238,3 +238,96 @@ def test_words_travel_through_a_chain_and_its_backward():
     bwd_gy = [ok for shape, ok in seen if len(shape) == 3]
     assert sum(bwd_gy) >= 4, seen
     assert per.grad is not None and th.isfinite(per.grad).all()
+
+
+@pytest.mark.parametrize("loose", [1.0, 37.0])
+@pytest.mark.parametrize("B,cin,cout,hw", [(2, 128, 441, 64 * 37 + 20), (1, 128, 441, 48), (3, 96, 200, 1000), (2, 128, 512, 4096),
+                                          (1, 64, 129, 260), (9, 128, 441, 64 * 300)])
+def test_wide_layer_whole_backward_vs_float64(B, cin, cout, hw, loose):
+    """sbmc_pointwise_wide_bwd_f32 (pw_wide_bwd2_kernel): gx, gw and gbias of the 441-channel layer in one pass over the
+    logit gradient, against float64.  loose: the word of gz may be a BOUND (the splat's backward leaves one, tens of
+    times the true maximum at worst)."""
+    from sbmc_amd import _lib
+    L = _lib.lib()
+    dev = th.device("cuda")
+    th.manual_seed(B * 31 + cout)
+    gz = th.randn(B, cout, hw, device=dev) * 1e-3
+    gz[:, :, ::7] *= 30.0                              # a wide spread of magnitudes, as logit gradients have
+    x = th.randn(B, cin, hw, device=dev).relu_()
+    w = th.randn(cout, cin, device=dev) / cin ** 0.5
+    groups = L.sbmc_pointwise_gw_wide_groups(B, hw)
+    gwp = th.full((groups, cout, cin), float("nan"), device=dev)
+    gbp = th.full((groups, cout), float("nan"), device=dev)
+    gx = th.full((B, cin, hw), float("nan"), device=dev)
+    ws = th.empty(L.sbmc_pointwise_wide_bwd_ws_bytes(), dtype=th.uint8, device=dev)
+    gxmax = th.zeros(1, dtype=th.int32, device=dev)
+    gword = (gz.abs().max() * loose).reshape(1).view(th.int32).clone()
+    _lib.check(L.sbmc_pointwise_wide_bwd_f32(_lib.ptr(gz), _lib.ptr(x), _lib.ptr(w), _lib.ptr(gx), _lib.ptr(gwp), _lib.ptr(gbp),
+                                             _lib.ptr(ws), _lib.ptr(gword), _lib.ptr(_word(x)), _lib.ptr(gxmax), B, cin, cout, hw,
+                                             _lib.current_stream(dev)), "wide_bwd")
+    gx64 = th.matmul(w.double().t(), gz.double())
+    gw64 = th.einsum("bop,bkp->ok", gz.double(), x.double())
+    gb64 = gz.double().sum((0, 2))
+    assert (gx.double() - gx64).abs().max().item() <= 1e-5 * gx64.abs().max().item()
+    assert (gwp.double().sum(0) - gw64).abs().max().item() <= 1e-5 * gw64.abs().max().item()
+    assert (gbp.double().sum(0) - gb64).abs().max().item() <= 1e-5 * gb64.abs().max().item()
+    assert gxmax.item() == _word(gx).item()
+
+
+def test_splat_backward_leaves_a_bound_of_the_logit_gradient():
+    """functions.SplatAll.backward tags d_kernels with a word >= max |d_kernels| (from per-pixel quantities, no pass over the
+    gradient), and not absurdly loose: within 2^6 of the true maximum on this input."""
+    from sbmc_amd import functions as F
+    th.manual_seed(9)
+    bs, S, c, h, w, k = 1, 3, 3, 30, 150, 21
+    data = (th.rand(bs, S, c, h, w) * 4).cuda().requires_grad_()
+    kern = (th.randn(bs, S, k * k, h, w) * 2).cuda().requires_grad_()
+    sr, sw, mw = F.SplatAll.apply(data, kern)
+    grads = th.autograd.grad([sr, sw, mw], [kern], [th.randn_like(sr), th.randn_like(sw), th.randn_like(mw) * 0.1])
+    word = F.known_amax(grads[0])
+    assert word is not None
+    bound = word.view(th.float32).item()
+    true = grads[0].abs().max().item()
+    assert true <= bound <= 64.0 * true, (true, bound)
+
+
+def test_regressor_backward_runs_in_one_pass():
+    """Multisteps' kernel regressor at the production width: the 441-channel layer's backward is the fused kernel (no
+    library GEMM, no second pass), reached through the words of the splat's bound and the forward's magnitude."""
+    from sbmc_amd import functions as F, modules
+    th.manual_seed(4)
+    bs, S, h, w = 1, 2, 24, 40
+    chain = modules.ConvChain(256, 441, ksize=1, width=128, depth=3, pad=False, activation="leaky_relu", output_type="linear").cuda()
+    chain.pointwise_as_gemm = True
+    per = th.randn(bs, S, 128, h, w, device="cuda").requires_grad_()
+    ctx = th.randn(bs, 128, h, w, device="cuda")
+    # (the per-sample input carries a word, as an embedding's output does)
+    F.tag_amax(per, per.detach().abs().max().reshape(1).view(th.int32).clone())
+    rad = th.rand(bs, S, 3, h, w, device="cuda")
+    calls = []
+    F.enable_kernel_timing(calls)
+    try:
+        kernels = modules.pointwise_chain_with_context(chain, per, ctx)
+        kernels = F.tagged_view(kernels, bs, S, 441, h, w)
+        sr, sw, _ = F.SplatAll.apply(rad, kernels)
+        (sr / (sw + 1e-8)).sum().backward()
+    finally:
+        F.enable_kernel_timing(None)
+    names = [c[0] for c in calls]
+    assert any(n.startswith("pointwise_wide_bwd") for n in names), names
+    assert not any(n.startswith("pointwise_gw_wide") for n in names), names
+    # against float64 of the same graph
+    ref = modules.ConvChain(256, 441, ksize=1, width=128, depth=3, pad=False, activation="leaky_relu", output_type="linear").double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in chain.state_dict().items()})
+    pd = per.detach().double().cpu().requires_grad_()
+    xin = th.cat([pd, ctx.double().cpu().unsqueeze(1).expand(bs, S, 128, h, w)], 2).reshape(bs * S, 256, h, w)
+    k64 = ref(xin).view(bs, S, 441, h, w)
+    from helpers import ProgressiveFP64
+    upd = ProgressiveFP64()
+    st = (None, None, None)
+    for s in range(S):
+        st = upd(rad[:, s].double().cpu(), k64[:, s], *st)
+    (st[0] / (st[1] + 1e-8)).sum().backward()
+    assert (per.grad.double().cpu() - pd.grad).abs().max().item() <= 1e-5 * pd.grad.abs().max().item()
+    for (n, a), (_, b) in zip(chain.named_parameters(), ref.named_parameters()):
+        assert (a.grad.double().cpu() - b.grad).abs().max().item() <= 1e-5 * b.grad.abs().max().item(), n
