@@ -58,27 +58,40 @@ def bwd_bytes_per_pixel(k, c=3):
     return 8 * k * k + 8 * c + 40
 
 
+def splat_source_hash():
+    """sha256 of what the splat kernels are built from (tools/pmc_summary.py records the same with every PMC pass)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sbmc_amd/csrc/splat_fused.hip", "sbmc_amd/csrc/common.hpp"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()
+
+
 def measured_traffic(kernel_substr):
-    """HBM bytes per launch from the newest committed PMC summary (profiles/r*_pmc.json,
-    produced by tools/prof.sh: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
+    """HBM bytes per launch from the newest committed PMC summary (profiles/r*_pmc.json, produced by tools/prof.sh:
+    separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950) -- a figure of ANOTHER run (PMC counters cannot be read from inside a run), quoted only while the kernel
+    sources are the ones that were profiled.  -> (bytes or None, source, note)"""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
-        return None, None
+        return None, None, "no committed PMC summary"
     try:
         d = json.load(open(files[-1]))
     except Exception:
-        return None, None
-    tot = 0
-    for k, v in d.items():
-        if k != "_meta" and any(sub in k for sub in kernel_substr):
-            tot += int(v["hbm_bytes_per_launch"])
+        return None, None, "unreadable PMC summary"
     meta = d.get("_meta") or {}
     src = os.path.basename(files[-1])
     if meta.get("commit") or meta.get("date"):
         src += " (tree %s, %s)" % ((meta.get("commit") or "?")[:10], meta.get("date") or "?")
-    return (tot or None), src
+    if meta.get("kernel_source_sha256") != splat_source_hash():
+        return None, src, ("profiles/%s was taken on other kernel sources than this tree's (splat_fused.hip / common.hpp "
+                           "differ): not quoted; re-run tools/prof.sh" % os.path.basename(files[-1]))
+    tot = 0
+    for k, v in d.items():
+        if k != "_meta" and any(sub in k for sub in kernel_substr):
+            tot += int(v["hbm_bytes_per_launch"])
+    return (tot or None), src, None
 
 
 def model_flops(model, h, w, spp, train):
@@ -753,7 +766,9 @@ def main():
             # products are formed from exact low-precision pieces of the fp32 operands
             "arith": None if (not is_model or args.fp16_activations) else
                      "fp32 storage and accumulation; 3x3 convolutions: operands as 2 f16 planes, 3 of 4 partial products "
-                     "(error <= 2^-22 per term); 1x1 layers: 3 bf16 planes, 6 of 9 partial products (<= 2^-23 per term); "
+                     "(error <= 2^-22 per term); 1x1 layers: the same two-plane form wherever the producer left the tensor's "
+                     "largest magnitude in a device word (all but each network input's first layer, which runs 3 bf16 planes, "
+                     "6 of 9 partial products, <= 2^-23 per term); "
                      "splat, losses, optimizer: plain fp32",
             "data": "synthetic",
             "world_size": world if world == 1 else dist.get_world_size(),
@@ -821,9 +836,9 @@ def main():
         rk = "splat_update_bwd_all" if "splat_update_bwd_all" in kern else "splat_update_bwd"
         if rk in kern:
             kb = kern[rk]
-            traffic, src = (None, None)
+            traffic, src, tnote = (None, None, "PMC passes exist for 1280x720, k = 21 on one GPU only")
             if (H, W, K) == (720, 1280, 21) and world == 1:   # the PMC summary was taken at this size
-                traffic, src = measured_traffic(("splat_bwd_strip_kernel",))
+                traffic, src, tnote = measured_traffic(("splat_bwd_strip_kernel",))
                 if traffic is not None:
                     traffic *= kb["samples_per_launch"]        # PMC figure is per 1-sample launch
             res["roofline"] = {
@@ -835,6 +850,8 @@ def main():
                 # comes from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate passes, gfx950
                 # correction) of this kernel at this size, named in `traffic_source` with the tree they were taken on
                 "traffic": traffic,
+                "traffic_measured_in_this_run": False,
+                "traffic_note": tnote,
                 "traffic_source": None if traffic is None else "profiles/" + src + ": per 1-sample launch x samples per "
                                   "launch; tools/prof.sh",
                 "traffic_over_algorithmic": None if traffic is None else round(traffic / kb["alg_bytes"], 3),
@@ -850,9 +867,9 @@ def main():
         fk = "splat_update_fwd_all" if "splat_update_fwd_all" in kern else "splat_update_fwd"
         if fk in kern and "roofline" in res:
             kf = kern[fk]
-            ftraffic, fsrc = (None, None)
+            ftraffic, fsrc, fnote = (None, None, "PMC passes exist for 1280x720, k = 21 on one GPU only")
             if (H, W, K) == (720, 1280, 21) and world == 1:
-                ftraffic, fsrc = measured_traffic(("splat_fwd_strip_kernel",))
+                ftraffic, fsrc, fnote = measured_traffic(("splat_fwd_strip_kernel",))
                 if ftraffic is not None:
                     ftraffic *= kf["samples_per_launch"]
             res["roofline_fwd"] = {
@@ -860,6 +877,7 @@ def main():
                           "the per-pixel fold of the samples' partial states)" % kf["samples_per_launch"],
                 "bound": "hbm", "achieved": kf["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(kf["GBps"] / HBM_PEAK_GBPS, 4), "traffic": ftraffic,
+                "traffic_measured_in_this_run": False, "traffic_note": fnote,
                 "traffic_source": None if ftraffic is None else "profiles/" + fsrc + ": per 1-sample launch x samples per "
                                   "launch; tools/prof.sh",
                 "traffic_over_algorithmic": None if ftraffic is None else round(ftraffic / kf["alg_bytes"], 3),

@@ -894,9 +894,6 @@ __device__ __forceinline__ unsigned cv_pack_hh(_Float16 a, _Float16 b) {
 
 // HF: half activations -- gy and x are _Float16 tensors: the staging is a pure 8 x 4 transposition (no split, no scale,
 // one plane), one matrix product per term; gw stays fp32.
-#ifndef WG_INTERLEAVE
-#define WG_INTERLEAVE 1      // development: 0 = leave the order of a stage's instructions to the compiler
-#endif
 template <bool HF>
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     constexpr unsigned ES = HF ? 2u : 4u;
@@ -1110,7 +1107,6 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         // not moved above LDS stores, so a commit in one piece would hold back the fetches -- and the MFMAs behind
         // them -- until all of its conversions were through)
         auto deal = [&](auto nv) {
-#if WG_INTERLEAVE
             constexpr int nvalu = decltype(nv)::value;
 #pragma unroll
             for (int i = 0; i < (HF ? 4 : 12); ++i) {
@@ -1119,7 +1115,6 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);             // DS write
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
             }
-#endif
         };
         load_b(b1, k, 0, 1);
         commit(done, k + 1, 0, 1);
@@ -1145,7 +1140,6 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         load_a(a0, k + 1, 0);
         load_b(b0, k + 1, 0, 0);
         mfmas(a1, b1, 2);
-#if WG_INTERLEAVE
 #pragma unroll
         for (int i = 0; i < (HF ? 6 : 18); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
@@ -1158,7 +1152,6 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
             __builtin_amdgcn_sched_group_barrier(0x020, HF ? 2 : 1, 0);        // VMEM read (its loads)
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // DS read
         }
-#endif
         cv_lds_barrier();
     };
     unsigned k = 0;

@@ -362,9 +362,6 @@ __device__ __forceinline__ unsigned wave_umax(unsigned m) {
 }
 
 constexpr int PS_NT = 64;           // pixels per tile of the split-precision kernels
-#ifndef PW_ABL
-#define PW_ABL 0                    // development: 1 = pw_fwd_s without its y stores, 2 = without its MFMAs, 3 = without the split
-#endif
 
 // WAVES: 8 (two waves per SIMD, 256 registers each; a wave owns 32 channels x 32 pixels) or 4 (one wave per
 // SIMD with the whole 512-entry register file -- accumulators in AccVGPRs --; a wave owns 32 channels x 64
@@ -643,10 +640,6 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
                     bm = xb[(KO + 2 * s) * PS_NT + 32 * h];
                     if constexpr (!F2) bl = xb[(2 * KO + 2 * s) * PS_NT + 32 * h];
                 }
-#if PW_ABL == 2
-                asm volatile("" :: "v"(bh), "v"(bm), "v"(bl));
-                continue;
-#endif
                 if constexpr (F2) {
                     acc[h] = mfma_f16(ah[s], bh, acc[h]);          // (bm / am: the LOW planes)
                     small[h] = mfma_f16(ah[s], bm, small[h]);
@@ -680,18 +673,9 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
                     if (TMODE == 1) add[j] += buf_load(rt1, ro, 0);
                 }
             }
-#if PW_ABL == 3
-            if (live(next) && s == KS - 1) {
-#pragma unroll
-                for (int i = 0; i < NOCT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) asm volatile("" :: "v"(cur[i][r]));
-            }
-#else
             // (no branch on `more`: behind the last tile this stages stale registers into the stage nobody reads)
 #pragma unroll
             for (int u = 4 * NOCT * s / KS; u < 4 * NOCT * (s + 1) / KS; ++u) commit_unit(cur, u, buf ^ 1);   // in order
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -723,11 +707,7 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
                     amax_run = amax_run > a ? amax_run : a;
                 }
                 const unsigned ro = (unsigned)((j & 3) + 8 * (j >> 2)) * hw * 4u;
-#if PW_ABL == 1
-                asm volatile("" :: "v"(v));
-#else
                 logit_store<TO>(v, ry, o0[h] != PW_OOB ? (o0[h] + ro) / (4u / SO) : PW_OOB, 0);
-#endif
                 if constexpr (MEAN) {
                     float* mp = macc + (rb * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhi) * PS_NT + (ph0 + h) * 32 + l31;
                     const float m = (first_s ? 0.f : *mp) + v;
@@ -1248,13 +1228,17 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     // k-step.  1536 instead of 4096 matrix-pipe cycles per wave and tile, and no fp32 gz tile in LDS.
     constexpr bool GXS = GWS && DX && PW_BWD_GXS;
     constexpr bool NARROW = GWS && DX && (TPIX || GM) && !GXS;
-    constexpr int GP = GXS ? 0 : (NARROW ? PB_PITCH_N : PB_PITCH);   // floats per row of the fp32 gz tile
+    constexpr bool GZF = !GWS || (DX && !GXS);          // an fp32 gz tile in LDS: the fp32-MFMA products only
+    constexpr int GP = GZF ? (NARROW ? PB_PITCH_N : PB_PITCH) : 0;   // floats per row of the fp32 gz tile
     extern __shared__ float4 pw_lds[];
     float* lds = reinterpret_cast<float*>(pw_lds);
     constexpr int BUF = (128 + KP) * PB_PITCH;          // floats per pipeline stage: gz tile, then x tile
     // GWS: one stage -- fp32 gz tile, then the bf16 images of gz and x ([3][128][PBS_PITCH], [3][KP][PBS_PITCH] halves)
-    _Float16* gzn = reinterpret_cast<_Float16*>(lds + 128 * GP);
-    _Float16* xn = gzn + NP * 128 * PBS_PITCH;
+    _Float16* gzn0 = reinterpret_cast<_Float16*>(lds + 128 * GP);
+    // DB (the two-plane form: its images are two thirds the size): TWO LDS stages -- a wave commits the next tile as soon
+    // as it is through with this one, without waiting for the others (one barrier per tile instead of two: -1 %)
+    constexpr bool DB = F2;
+    constexpr int STG = NP * (128 + KP) * PBS_PITCH;    // halves per stage
     constexpr int NB = KP / 32;                         // 32-column blocks of gw
     constexpr int NX = KP / 32;                         // staging passes of the x tile
     const int lane = threadIdx.x & 63, wave = wave_id();
@@ -1431,6 +1415,8 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         coords(c, b, bq, p0);
         float* gzs = lds + (GWS ? 0 : buf) * BUF;
         float* xst = gzs + 128 * PB_PITCH;
+        _Float16* gzn = gzn0 + (DB ? buf : 0) * STG;
+        _Float16* xn = gzn + NP * 128 * PBS_PITCH;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 gv = unpack4<TA>(pg[i]);
@@ -1457,7 +1443,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             if (TPIX) {
                 gts[i].x += gv.x; gts[i].y += gv.y; gts[i].z += gv.z; gts[i].w += gv.w;
             }
-            if constexpr (!GXS) {
+            if constexpr (GZF) {
                 float2* d = reinterpret_cast<float2*>(gzs + (srow + 32 * i) * GP + c4);
                 d[0] = make_float2(gv.x, gv.y);
                 d[1] = make_float2(gv.z, gv.w);
@@ -1558,6 +1544,8 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         coords(cur, b, bq, p0);
         const float* gzs = lds + (GWS ? 0 : buf) * BUF;
         const float* xst = gzs + 128 * PB_PITCH;
+        const _Float16* gzn = gzn0 + (DB ? buf : 0) * STG;
+        const _Float16* xn = gzn + NP * 128 * PBS_PITCH;
 
         // ---- gx tile: rows 32 rb .. of K, pixels 32 ph ..; reduction over cout
         f32x16 acc_x;
@@ -1742,7 +1730,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         }
         if constexpr (!GWS) store_gx();
 
-        if constexpr (GWS) lds_barrier();            // one stage: every wave is through with it before it is refilled
+        if constexpr (GWS && !DB) lds_barrier();     // one stage: every wave is through with it before it is refilled
                                                      // (LDS ordering only: the x loads stay in flight)
         if (nvalid) commit(nxt, buf ^ 1);
         __syncthreads();
@@ -2927,8 +2915,8 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
         f2 = gws && gmax != nullptr && xmax != nullptr && (!gmean || gmmax != nullptr) && (y_is_signs || act == 0) &&
              (PW_BWD_GXS || !gx);
         if (gws)
-            lds = (size_t)128 * ((PW_BWD_GXS && gx) ? 0 : ((side && gx) ? PB_PITCH_N : PB_PITCH)) * sizeof(float) +
-                  (size_t)(f2 ? 2 : 3) * (128 + kp) * PBS_PITCH * 2;
+            lds = (size_t)128 * ((PW_BWD_GXS || !gx) ? 0 : (side ? PB_PITCH_N : PB_PITCH)) * sizeof(float) +
+                  (size_t)(f2 ? 4 : 3) * (128 + kp) * PBS_PITCH * 2;      // (two planes in two stages, or three in one)
     }
 #define SBMC_PWB_PICK(KPV, DXV, TPV, SGV, GWSV)                                                          \
     ((gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, float, float, SGV, GWSV>                     \

@@ -1655,7 +1655,11 @@ class SplatAll(th.autograd.Function):
         # layer's backward, which reads d_kernels next: no pass over 13 GB for it); it needs max |data|
         bound = None
         if not half and knob("SBMC_HIP_PW_F16") != 0 and knob("SBMC_AMAX_TAGS") != 0:
-            dmax, bound = ensure_amax(data), amax_word(dev)
+            # (max |data|: its tag if a pass left one -- never tagged here: the radiance is a network INPUT, a new
+            # tensor every step of a real run, and a bench that reuses its batch must not skip the pass)
+            dmax, bound = known_amax(data), amax_word(dev)
+            if dmax is None:
+                dmax = Conv3x3NHWC._absmax(data)
         with th.cuda.device(dev), _timed("splat_update_bwd_all_f16" if half else "splat_update_bwd_all", dev):
             if bound is not None:
                 rc = L.sbmc_splat_all_bwd_bound_f32(*args[:13], _lib.ptr(dmax), _lib.ptr(bound), *args[13:], top, bot,

@@ -82,7 +82,36 @@ def bwd(cin, cout, t_mode, act, gm, dx, scaled):
     return ms, by
 
 
+def wide_bwd():
+    cin, cout = 128, 441
+    gz = th.randn(B, cout, HW, device=dev) * 1e-3
+    x = th.randn(B, cin, HW, device=dev)
+    w = th.randn(cout, cin, device=dev) / cin ** 0.5
+    groups = L.sbmc_pointwise_gw_wide_groups(B, HW)
+    gwp = th.empty(groups, cout, cin, device=dev)
+    gbp = th.empty(groups, cout, device=dev)
+    gx = th.empty(B, cin, HW, device=dev)
+    ws = th.empty(L.sbmc_pointwise_wide_bwd_ws_bytes(), dtype=th.uint8, device=dev)
+    gm, xm, gxm = word(gz), word(x), th.zeros(1, dtype=th.int32, device=dev)
+
+    def fused():
+        _lib.check(L.sbmc_pointwise_wide_bwd_f32(_lib.ptr(gz), _lib.ptr(x), _lib.ptr(w), _lib.ptr(gx), _lib.ptr(gwp), _lib.ptr(gbp),
+                                                 _lib.ptr(ws), _lib.ptr(gm), _lib.ptr(xm), _lib.ptr(gxm), B, cin, cout, HW,
+                                                 _lib.current_stream(dev)), "wide")
+
+    def two_pass():
+        _lib.check(L.sbmc_pointwise_gw_wide_f32(_lib.ptr(gz), _lib.ptr(x), _lib.ptr(gwp), _lib.ptr(gbp), B, cin, cout, HW,
+                                                _lib.current_stream(dev)), "gw_wide")
+        return th.bmm(w.t().unsqueeze(0).expand(B, -1, -1), gz)
+    by = 4.0 * B * HW * (cout + 2 * cin)
+    a, b_ = timeit(fused), timeit(two_pass)
+    print("%-40s one pass %.3f ms %.2f TB/s | wide gw kernel + library GEMM %.3f ms" % ("bwd 128->441 (gx, gw, gbias)", a, by / a / 1e9, b_), flush=True)
+
+
 if __name__ == "__main__":
+    if "--wide" in sys.argv:
+        wide_bwd()
+        sys.exit(0)
     rows = [("fwd 128->128 relu", lambda sc: fwd(128, 128, 0, 1, False, sc)),
             ("fwd 128->128 linear + mean", lambda sc: fwd(128, 128, 0, 0, True, sc)),
             ("fwd 128->128 per-pixel context", lambda sc: fwd(128, 128, 2, 1, False, sc)),
@@ -99,3 +128,4 @@ if __name__ == "__main__":
             out.append("%s %.3f ms %.2f TB/s" % ("two f16 planes" if sc else "three bf16 planes", ms, by / ms / 1e9))
             th.cuda.empty_cache()
         print("%-40s %s | %s" % (name, out[0], out[1]), flush=True)
+    wide_bwd()

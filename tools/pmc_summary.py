@@ -61,7 +61,13 @@ commit = None
 for cand in (os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), ".commit_for_profiles"),):
     if os.path.exists(cand):
         commit = open(cand).read().strip()
-traffic["_meta"] = {"commit": commit, "date": datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"),
+# what the profiled kernels were built from: bench.py quotes these figures only while the sources are the same
+import hashlib
+repo = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+src_hash = hashlib.sha256()
+for f in ("sbmc_amd/csrc/splat_fused.hip", "sbmc_amd/csrc/common.hpp"):
+    src_hash.update(open(os.path.join(repo, f), "rb").read())
+traffic["_meta"] = {"kernel_source_sha256": src_hash.hexdigest(), "commit": commit, "date": datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"),
                     "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python bench.py "
                                "--workload splat --steps 1 --warmup 1 (tools/prof.sh)",
                     "correction": "bytes = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024 (gfx950: FETCH_SIZE counts 128-byte "

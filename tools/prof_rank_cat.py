@@ -8,7 +8,7 @@ CATS = [
     ("conv3x3 wgrad", r"conv3_wgrad"),
     ("conv3x3 weight prep / absmax", r"prep_weights|absmax"),
     ("1x1 fwd", r"pw_fwd"),
-    ("1x1 bwd", r"pw_bwd|pw_gw_wide"),
+    ("1x1 bwd", r"pw_bwd|pw_gw_wide|pw_wide_bwd|pw_wide_prep"),
     ("hipBLASLt / rocBLAS", r"Cijk_|rocblas|gemm"),
     ("MIOpen", r"igemm|miopen|naive_conv|batched_transpose"),
     ("splat", r"splat_|gather_|s2g_|kw_"),
