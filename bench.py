@@ -295,10 +295,11 @@ def cpu_baseline(args, device=None):
     h, w = max(2 * k + 2, (args.height // 16) // 4 * 4), args.width
 
     # op level: S progressive updates + normalise + backward on the oracle (C operators + torch-CPU glue)
-    def splat_cpu_once():
-        rad = [th.empty(1, 3, h, w).exponential_(1.0).requires_grad_() for _ in range(spp)]
-        logits = [th.randn(1, k * k, h, w).requires_grad_() for _ in range(spp)]
-        d_out = th.randn(1, 3, h, w)
+    def splat_cpu_once(hh=None):
+        hh = hh or h
+        rad = [th.empty(1, 3, hh, w).exponential_(1.0).requires_grad_() for _ in range(spp)]
+        logits = [th.randn(1, k * k, hh, w).requires_grad_() for _ in range(spp)]
+        d_out = th.randn(1, 3, hh, w)
         t0 = time.perf_counter()
         splat_step(lambda d, kk, a, b, m: orc.progressive_kernel_apply(d, kk, a, b, m, splat=True),
                    rad, logits, d_out)
@@ -309,6 +310,17 @@ def cpu_baseline(args, device=None):
     op = {"value": round(spp * h * w / splat_dt / 1e6, 4), "unit": "Msamples/s",
           "sample": "oracle splat fwd+bwd (%d x progressive_kernel_apply + normalise + backward) on %dx%d, "
                     "%d spp, k=%d: median of 3 after 1 warm-up = %.2f s" % (spp, w, h, spp, k, splat_dt)}
+    # the same op on a QUARTER of the height (SURVEY.md 8d's crop: the sixteenth above has a larger share of border rows
+    # and sits better in the host's caches) -- one run behind a warm-up, bounded to what fits ~48 GB of host memory
+    hq = (args.height // 4) // 4 * 4
+    if hq > h and 4.0 * spp * k * k * hq * w * 6 < 48e9:
+        try:
+            splat_cpu_once(hq)
+            qdt = splat_cpu_once(hq)
+            op["quarter_height"] = {"value": round(spp * hq * w / qdt / 1e6, 4), "unit": "Msamples/s",
+                                    "sample": "the same on %dx%d (a quarter of the height): 1 run after 1 warm-up = %.2f s" % (w, hq, qdt)}
+        except Exception as e:          # (informational: a host short of memory must not sink the line)
+            op["quarter_height"] = {"error": repr(e)}
     if args.workload != "model":
         base = dict(op)
         base.update({"cores": threads, "kind": "port"})

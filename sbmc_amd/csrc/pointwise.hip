@@ -519,7 +519,11 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     // the memory latency at full bandwidth.  The two register sets swap roles from tile to tile (an in-flight
     // load is never copied: a copy would wait for it), and the barrier orders LDS traffic only.  The split of
     // the next tile (registers -> LDS) is dealt out between the MFMAs of the k-steps.
-    float preA[NOCT][8], preB[NOCT][8];
+    // DEEP (the two-plane form: 32 weight registers fewer): THREE tiles in flight -- the two-plane kernels wait (s_waitcnt /
+    // barrier: 34-39 % of a wave's cycles, PMC) where the three-plane ones were busy with twice the matrix work.
+    // 1.78 -> 1.71 ms (128 -> 128), 1.91 -> 1.75 with the mean, 5.65 -> 5.22 at 441 channels.
+    constexpr bool DEEP = F2 && WAVES == 8;
+    float preA[NOCT][8], preB[NOCT][8], preC[DEEP ? NOCT : 1][8];
     Cur tile;
     tile.s = 0;
     tile.unit = first;
@@ -530,7 +534,11 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
         issue_loads(tile, preA);
         commit(0, preA);
         if (live(next)) issue_loads(next, preA);
+        if constexpr (DEEP) {
+            if (live(next2)) issue_loads(next2, preB);
+        }
     }
+    Cur next3 = advance(next2);                        // (DEEP: the tile whose loads a step issues)
     __syncthreads();
     // the mean over a pixel's samples: every wave accumulates its own 32 x 32 block of outputs in LDS
     float* macc = reinterpret_cast<float*>(xs + 2 * NP * KO * PS_NT);       // [128][PS_NT]
@@ -578,7 +586,11 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     // one tile; `cur` holds the NEXT tile's values (split and written to LDS stage buf ^ 1 during this one),
     // `fill` receives the loads of the tile after that
     auto step = [&](const float (&cur)[NOCT][8], float (&fill)[NOCT][8], const int buf) {
-        if (live(next2)) issue_loads(next2, fill);
+        if constexpr (DEEP) {
+            if (live(next3)) issue_loads(next3, fill);
+        } else {
+            if (live(next2)) issue_loads(next2, fill);
+        }
 
         unsigned b, bq, p0;
         tile_coords(tile, b, bq, p0);
@@ -728,14 +740,32 @@ __global__ __launch_bounds__(64 * WAVES) void pw_fwd_s_kernel(PwFwdParams p) {
     auto roll = [&]() {
         tile = next;
         next = next2;
-        next2 = advance(next2);
+        if constexpr (DEEP) {
+            next2 = next3;
+            next3 = advance(next3);
+        } else {
+            next2 = advance(next2);
+        }
     };
-    while (live(tile)) {
-        step(preA, preB, 0);
-        roll();
-        if (!live(tile)) break;
-        step(preB, preA, 1);
-        roll();
+    if constexpr (DEEP) {
+        // step i: the next tile's values sit in set (i + 1) % 3, the loads of tile i + 3 go to set i % 3 (whose tile is in
+        // LDS); LDS stage i % 2
+        while (live(tile)) {
+            step(preA, preC, 0); roll(); if (!live(tile)) break;
+            step(preB, preA, 1); roll(); if (!live(tile)) break;
+            step(preC, preB, 0); roll(); if (!live(tile)) break;
+            step(preA, preC, 1); roll(); if (!live(tile)) break;
+            step(preB, preA, 0); roll(); if (!live(tile)) break;
+            step(preC, preB, 1); roll();
+        }
+    } else {
+        while (live(tile)) {
+            step(preA, preB, 0);
+            roll();
+            if (!live(tile)) break;
+            step(preB, preA, 1);
+            roll();
+        }
     }
     if (want_amax) amax_publish(amax_run, p.amax);
 }
@@ -1539,6 +1569,13 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         const Cursor nxt = advance(cur);
         const bool nvalid = nxt.unit < p.nunits;
         if (nvalid) issue(nxt);
+        // XE (the two-plane form without a context / mean gradient: 21 registers to spare): the x rows requested up front
+        // too -- the two-plane kernels WAIT for their loads (60 % of a wave's cycles, PMC) where the three-plane ones
+        // were busy
+        constexpr bool XE = F2 && !TPIX && !GM;
+        if constexpr (XE) {
+            if (nvalid) issue_x(nxt);
+        }
 
         unsigned b, bq, p0;
         coords(cur, b, bq, p0);
@@ -1584,7 +1621,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                         acc_n[pb] = mfma16_bf16(awh[st], bh, acc_n[pb]);
                     }
                 }
-                if (st == 1 && nvalid) issue_x(nxt);
+                if (!XE && st == 1 && nvalid) issue_x(nxt);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if constexpr (NARROW) {
@@ -1655,7 +1692,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         };
         // ---- gw: rows 32 rb .. of cout, column blocks 2 ph, 2 ph + 1 of K; reduction over the 64 pixels
         if constexpr (GWS) {
-            if (!DX && nvalid) issue_x(nxt);
+            if (!XE && !DX && nvalid) issue_x(nxt);
             store_gx();                                // (its 16 accumulator registers are free for the gw product)
             const bool two = 2 * ph + 1 < NB;
             if (2 * ph < NB) {
