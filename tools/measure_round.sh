@@ -1,10 +1,10 @@
 #!/bin/bash
-# A round's measurements on one MI355X box:   tools/grun --timeout 3300 bash tools/measure_round.sh r04
+# A round's measurements on one MI355X box:   tools/grun --timeout 3300 bash tools/measure_round.sh r05
 # bench lines (fp32 with the fp32-pipe A/B, fp16 activations), rocprofv3 kernel statistics of the model step and of an
 # interior rank of 8 with their per-category splits, PMC passes (splat traffic, 1x1 and 3x3 kernels), per-rank cost of the
 # sharded step in every transport, the 8-rank partition as communicating processes on this one GPU, fuzz sweeps.
 # Everything lands in gpurun_out/<tag>/ ; copy what is to be kept into profiles/.
-tag=${1:-r04}
+tag=${1:-r05}
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/$tag
 mkdir -p $o
@@ -39,7 +39,9 @@ rm -rf gpurun_out/prof_$tag gpurun_out/profiles_$tag        # (raw traces: gpuru
 # an interior rank of 8, every exchange running: kernel statistics + categories
 bash tools/prof_rank.sh 8 --ipc-self > $o/prof_rank.log 2>&1; cp gpurun_out/q/rank8_stats.csv $o/${tag}_rank8_kernel_stats.csv; rm -rf gpurun_out/q
 python tools/prof_rank_cat.py $o/${tag}_rank8_kernel_stats.csv 5 > $o/${tag}_rank8_categories.txt; head -18 $o/${tag}_rank8_categories.txt
-bash tools/prof_pointwise.sh > $o/prof_pw.log 2>&1; cp gpurun_out/profiles_pw/r02_pointwise_pmc.txt $o/${tag}_pointwise_pmc.txt; tail -5 $o/${tag}_pointwise_pmc.txt; rm -rf gpurun_out/prof_pw gpurun_out/profiles_pw
+bash tools/prof_pointwise.sh > $o/prof_pw.log 2>&1; cp gpurun_out/profiles_pw/r02_pointwise_pmc.txt $o/${tag}_pointwise_pmc.txt; grep -v raw $o/${tag}_pointwise_pmc.txt | tail -5 | cut -c1-260; rm -rf gpurun_out/prof_pw gpurun_out/profiles_pw
+timeout 300 python tools/bench_pw_scaled.py > $o/${tag}_pointwise_launches.txt 2>&1; tail -3 $o/${tag}_pointwise_launches.txt
+bash tools/calibrate_fetch.sh > /dev/null 2>&1; cp gpurun_out/fetch_calibration.txt $o/${tag}_fetch_calibration.txt
 bash tools/prof_conv_stack.sh > $o/prof_conv.log 2>&1; cp gpurun_out/conv_stack/r02_conv_stack_mfma.txt $o/${tag}_conv_stack_mfma.txt; tail -3 $o/${tag}_conv_stack_mfma.txt; rm -rf gpurun_out/conv_stack
 ( timeout 300 python tools/fuzz_gpu.py --seconds 100 2>&1 | tail -2; timeout 300 python tools/fuzz_slab.py --seconds 100 2>&1 | tail -1; timeout 200 python tools/fuzz_pointwise.py --seconds 60 2>&1 | tail -1 ) > $o/${tag}_fuzz.txt; cat $o/${tag}_fuzz.txt | cut -c1-300
 timeout 400 python tools/conv3x3_experiment.py --shapes all > $o/${tag}_conv3x3_experiment.txt 2>&1; tail -2 $o/${tag}_conv3x3_experiment.txt
