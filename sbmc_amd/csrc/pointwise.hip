@@ -1144,6 +1144,9 @@ __global__ __launch_bounds__(512) void pw_fwd_hw_kernel(PwFwdParams p) {
 #define PW_BWD_PIPE 0     // 1 = keep a tile's gx in registers and store it between the next tile's MFMAs: 16 more
                           // live registers = 10-12 spilled VGPRs at 2 waves/SIMD; measured 4.98 ms vs 4.66 ms without
 #endif
+#ifndef PW_BWD_RAW
+#define PW_BWD_RAW 1      // two-plane split kernels: the gy and x tiles travel L2/HBM -> LDS by LDS-DMA, a whole iteration ahead
+#endif
 #ifndef PW_BWD_GXS
 #define PW_BWD_GXS 1      // split-gw kernels with a data gradient: gx on the bf16 pipe too (transposing LDS reads)
 #endif
@@ -1267,8 +1270,17 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     _Float16* gzn0 = reinterpret_cast<_Float16*>(lds + 128 * GP);
     // DB (the two-plane form: its images are two thirds the size): TWO LDS stages -- a wave commits the next tile as soon
     // as it is through with this one, without waiting for the others (one barrier per tile instead of two: -1 %)
-    constexpr bool DB = F2;
+    // RAW (the two-plane form, instead of DB): these kernels WAIT for their loads (39-60 % of a wave's cycles, PMC) with one
+    // tile of requests in flight, held in registers from the top of an iteration to its end.  The fp32 gy and x tiles
+    // now travel by LDS-DMA into a raw LDS slot each (no register in between: pg / px are gone), requested right after
+    // the commit that emptied the slot -- a WHOLE iteration before they are needed instead of one product phase.  A
+    // thread reads back exactly the 16-byte pieces its own wave requested (same row / column roles as the register
+    // path), so the only ordering needed is the wave's own vmcnt.
+    constexpr bool RAW = F2 && PW_BWD_RAW;
+    constexpr bool DB = F2 && !RAW;
     constexpr int STG = NP * (128 + KP) * PBS_PITCH;    // halves per stage
+    float* rawg = reinterpret_cast<float*>(gzn0 + STG);               // RAW: [128][64] gy, [KP][64] x
+    float* rawx = rawg + 128 * PB_NT;
     constexpr int NB = KP / 32;                         // 32-column blocks of gw
     constexpr int NX = KP / 32;                         // staging passes of the x tile
     const int lane = threadIdx.x & 63, wave = wave_id();
@@ -1385,7 +1397,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         for (int i = 0; i < 4; ++i) {
             const unsigned r = srow + 32u * i;
             const unsigned off = (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * SA : PW_OOB;
-            pg[i] = load4<TA>(rg, off);
+            if constexpr (!RAW) pg[i] = load4<TA>(rg, off);
             if constexpr (SG) {
                 // (rows / columns beyond the tensor read 0: their gradient is 0 as well)
                 psg[i] = __builtin_amdgcn_raw_buffer_load_b32(
@@ -1402,6 +1414,28 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                 const unsigned off = (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * SX : PW_OOB;
                 px[i] = load4<TXT>(rx, off);
             }
+        }
+    };
+    // RAW: the requests of a tile's gy and x rows, straight into the raw LDS slots (this wave's rows: 4 w + lane / 16 + 32 i)
+    auto issue_raw = [&](Cursor c) {
+        using lptr = __attribute__((address_space(3))) void*;
+        unsigned b, bq, p0;
+        coords(c, b, bq, p0);
+        const rsrc_t rg = make_rsrc_n(gy_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * SA);
+        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * SX);
+        const bool colok = p0 + c4 < hw;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (this wave's reads of the slots have retired)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned r = srow + 32u * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lptr)(rawg + (32 * i + 4 * wave) * PB_NT), 16,
+                                                     (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const unsigned r = srow + 32u * i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr)(rawx + (32 * i + 4 * wave) * PB_NT), 16,
+                                                     (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * 4u : PW_OOB, 0, 0, 0);
         }
     };
     // GWS: the x tile is wanted by the weight-gradient product only -- its loads are issued after the gx
@@ -1447,9 +1481,16 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         float* xst = gzs + 128 * PB_PITCH;
         _Float16* gzn = gzn0 + (DB ? buf : 0) * STG;
         _Float16* xn = gzn + NP * 128 * PBS_PITCH;
+        const bool colok_c = p0 + c4 < hw;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float4 gv = unpack4<TA>(pg[i]);
+            float4 gv;
+            if constexpr (RAW) {                       // (rows / columns beyond the tensor: zeros, whatever the DMA left there)
+                gv = *reinterpret_cast<const float4*>(rawg + (srow + 32 * i) * PB_NT + c4);
+                if (!(colok_c && srow + 32u * i < (unsigned)p.Cout)) gv = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                gv = unpack4<TA>(pg[i]);
+            }
             if (GM) {
                 const float4 m = unpack4<TA>(pm[i]);
                 gv.x += m.x * inv_sm; gv.y += m.y * inv_sm; gv.z += m.z * inv_sm; gv.w += m.w * inv_sm;
@@ -1495,7 +1536,13 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const float4 xv = unpack4<TXT>(px[i]);
+            float4 xv;
+            if constexpr (RAW) {
+                xv = *reinterpret_cast<const float4*>(rawx + (srow + 32 * i) * PB_NT + c4);
+                if (!(colok_c && srow + 32u * i < (unsigned)p.K)) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                xv = unpack4<TXT>(px[i]);
+            }
             if constexpr (F2) {
                 u32x2 h, l;
                 split2_4(xv, cx, h, l);
@@ -1536,8 +1583,17 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
     bool valid = cur.unit < p.nunits;
     if (valid) {
         issue(cur);
-        if constexpr (GWS) issue_x(cur);
+        if constexpr (RAW) {
+            issue_raw(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (GWS) {
+            issue_x(cur);
+        }
         commit(cur, 0);
+        if constexpr (RAW) {
+            const Cursor n1 = advance(cur);
+            if (n1.unit < p.nunits) issue_raw(n1);
+        }
     }
     __syncthreads();
 
@@ -1572,7 +1628,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         // XE (the two-plane form without a context / mean gradient: 21 registers to spare): the x rows requested up front
         // too -- the two-plane kernels WAIT for their loads (60 % of a wave's cycles, PMC) where the three-plane ones
         // were busy
-        constexpr bool XE = F2 && !TPIX && !GM;
+        constexpr bool XE = F2 && !TPIX && !GM && !RAW;
         if constexpr (XE) {
             if (nvalid) issue_x(nxt);
         }
@@ -1621,7 +1677,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                         acc_n[pb] = mfma16_bf16(awh[st], bh, acc_n[pb]);
                     }
                 }
-                if (!XE && st == 1 && nvalid) issue_x(nxt);
+                if (!XE && !RAW && st == 1 && nvalid) issue_x(nxt);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if constexpr (NARROW) {
@@ -1692,7 +1748,7 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         };
         // ---- gw: rows 32 rb .. of cout, column blocks 2 ph, 2 ph + 1 of K; reduction over the 64 pixels
         if constexpr (GWS) {
-            if (!XE && !DX && nvalid) issue_x(nxt);
+            if (!XE && !RAW && !DX && nvalid) issue_x(nxt);
             store_gx();                                // (its 16 accumulator registers are free for the gw product)
             const bool two = 2 * ph + 1 < NB;
             if (2 * ph < NB) {
@@ -1769,7 +1825,18 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
 
         if constexpr (GWS && !DB) lds_barrier();     // one stage: every wave is through with it before it is refilled
                                                      // (LDS ordering only: the x loads stay in flight)
-        if (nvalid) commit(nxt, buf ^ 1);
+        if constexpr (RAW) {
+            if (nvalid) {
+                // the next tile's rows have landed (requested a whole iteration ago; this also waits for the iteration's gx
+                // stores, which have had the gw product to drain)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                commit(nxt, buf ^ 1);
+                const Cursor n2 = advance(nxt);
+                if (n2.unit < p.nunits) issue_raw(n2);
+            }
+        } else {
+            if (nvalid) commit(nxt, buf ^ 1);
+        }
         __syncthreads();
         cur = nxt;
         valid = nvalid;
@@ -2953,7 +3020,9 @@ static int pw_bwd_launch(const void* gy, const void* y, const void* x, const flo
              (PW_BWD_GXS || !gx);
         if (gws)
             lds = (size_t)128 * ((PW_BWD_GXS || !gx) ? 0 : (side ? PB_PITCH_N : PB_PITCH)) * sizeof(float) +
-                  (size_t)(f2 ? 4 : 3) * (128 + kp) * PBS_PITCH * 2;      // (two planes in two stages, or three in one)
+                  (f2 ? (PW_BWD_RAW ? (size_t)2 * (128 + kp) * PBS_PITCH * 2 + (size_t)(128 + kp) * PB_NT * 4      // + the raw slots
+                                    : (size_t)4 * (128 + kp) * PBS_PITCH * 2)                                    // two stages
+                      : (size_t)3 * (128 + kp) * PBS_PITCH * 2);
     }
 #define SBMC_PWB_PICK(KPV, DXV, TPV, SGV, GWSV)                                                          \
     ((gmean && !TPV) ? pw_bwd_kernel<KPV, DXV, false, true, float, float, SGV, GWSV>                     \
