@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
     rng = np.random.RandomState(args.seed)
-    t0, n, fused_bwd, halves, half_trains = time.time(), 0, 0, 0, 0
+    t0, n, fused_bwd, halves, half_trains, scaled, scaled_bwd, wide_fused = time.time(), 0, 0, 0, 0, 0, 0, 0
+    calls = []
+    F.enable_kernel_timing(calls)
     while time.time() - t0 < args.seconds:
         S = int(rng.choice([1, 1, 2, 3, 8]))
         B = S * int(rng.choice([1, 1, 2, 3]))
@@ -43,8 +45,15 @@ def main():
         slope = float(rng.choice([0.01, 0.2])) if act == 2 else 0.0
         tag = "B%d S%d cin%d cout%d hw%d t%d act%d dx%d" % (B, S, cin, cout, hw, tm, act, needx)
         th.manual_seed(int(rng.randint(1 << 30)))
-        x0 = th.randn(B, cin, hw, device="cuda")
-        w0 = th.randn(cout, cin, device="cuda") / max(cin, 1) ** 0.5
+        # round 5: half of the cases carry MAGNITUDE WORDS (as tensors inside a chain do): the two-plane kernels run -- and,
+        # for a wide linear layer with a data gradient, the one-pass backward -- at random magnitudes, with words that are
+        # the exact maxima or bounds up to 50 x too large
+        words = bool(rng.randint(2))
+        xmag = 10.0 ** rng.uniform(-4, 3) if words else 1.0
+        gmag = 10.0 ** rng.uniform(-6, 2) if words else 1.0
+        tag += " words%d" % words
+        x0 = th.randn(B, cin, hw, device="cuda") * xmag
+        w0 = th.randn(cout, cin, device="cuda") / max(cin, 1) ** 0.5 / xmag
         b0 = th.randn(cout, device="cuda")
         t0_ = None if tm == 0 else (th.randn(B // S, cout, device="cuda") if tm == 1
                                     else th.randn(B // S, cout, hw, device="cuda"))
@@ -61,11 +70,32 @@ def main():
             elif tm == 2:
                 pre = pre + t.repeat_interleave(S, 0)
             ref = pre if act == 0 else th.nn.functional.leaky_relu(pre, slope)
-            g = th.randn(B, cout, hw, device="cuda") * (pre.detach().abs() > 1e-4).float()
+            g = th.randn(B, cout, hw, device="cuda") * (pre.detach().abs() > 1e-4).float() * gmag
             ref.backward(g.double())
             x2, w2, b2, t2 = leaves(th.float32)
+            del calls[:]
+            if words:
+                def word(v):
+                    return (v.detach().abs().max() * float(rng.choice([1.0, 1.0, 3.0, 50.0]))).reshape(1).view(th.int32).clone()
+                F.tag_amax(x2, word(x2))
+                F.tag_amax(g, word(g))
             out = F.PointwiseLayer.apply(x2, w2, b2, t2, S, act, slope)
+            if words:
+                yw = F.known_amax(out)
+                assert yw is not None and yw.item() == out.detach().abs().max().reshape(1).view(th.int32).item(), "word of y"
             out.backward(g)
+            if words:
+                scaled += 1
+                names = [c[0] for c in calls]
+                if any(nm.startswith("pointwise_wide_bwd") for nm in names):
+                    wide_fused += 1
+                if cout <= 128:
+                    scaled_bwd += 1
+                if needx and (cout <= 128 or any(nm.startswith("pointwise_wide_bwd") for nm in names)) and not (
+                        cout <= 128 and tm == 2 and False):
+                    gw_ = F.known_amax(x2.grad)
+                    if gw_ is not None:
+                        assert gw_.item() == x2.grad.abs().max().reshape(1).view(th.int32).item(), "word of gx"
             close(out, ref.float(), rtol=1e-5)
             if needx:
                 close(x2.grad, x.grad.float(), rtol=1e-5)
@@ -73,13 +103,13 @@ def main():
             # ~|g| |x|: compare them relative to that sum's natural scale sqrt(#terms) as well, or a
             # [1, 1] gradient that happens to cancel to ~0 fails on fp32 summation noise alone
             red = (B * hw) ** 0.5
-            close_sum(w2.grad, w.grad, 3e-5, 1e-6 * red)
-            close_sum(b2.grad, b.grad, 3e-5, 1e-6 * red)
+            close_sum(w2.grad, w.grad, 3e-5, 1e-6 * red * gmag * xmag)
+            close_sum(b2.grad, b.grad, 3e-5, 1e-6 * red * gmag)
             if tm == 1:
-                close_sum(t2.grad, t.grad, 3e-5, 1e-6 * (S * hw) ** 0.5)
+                close_sum(t2.grad, t.grad, 3e-5, 1e-6 * (S * hw) ** 0.5 * gmag)
             elif tm == 2:
                 close(t2.grad, t.grad.float(), rtol=1e-5)
-            if n % 3 == 0:            # half-storage forward (inference) on the same case
+            if n % 3 == 0 and not words:            # half-storage forward (inference) on the same case
                 xin = x0.half() if n % 2 else x0
                 refh = F.PointwiseLayer.apply(xin.float(), w0, b0, t0_, S, act, slope)
                 with th.no_grad(), th.autocast("cuda", dtype=th.float16):
@@ -88,7 +118,7 @@ def main():
                 errh = (yh.float() - refh).abs().max().item()
                 assert errh <= 1e-3 * refh.abs().max().item() + 1e-3, "half forward: %.3e" % errh
                 halves += 1
-            if n % 3 == 1 and cout <= 128:      # half-storage training (autocast): forward + backward on half tensors
+            if n % 3 == 1 and cout <= 128 and not words:      # half-storage training (autocast): forward + backward on half tensors
                 half_training_case(x0, w0, b0, t0_, S, tm, act, slope, x_half=bool(n % 2))
                 half_trains += 1
         except Exception:
@@ -96,8 +126,11 @@ def main():
             raise
         n += 1
         fused_bwd += int(cout <= 128)
+    F.enable_kernel_timing(None)
     print("fuzz ok: %d random layers (%d with the fused backward, %d half-storage forwards, %d half-storage "
-          "forward+backward) in %.0f s" % (n, fused_bwd, halves, half_trains, time.time() - t0))
+          "forward+backward; %d with magnitude words = the two-plane kernels, %d of them through the fused two-plane "
+          "backward, %d through the wide layer's one-pass backward) in %.0f s" % (
+              n, fused_bwd, halves, half_trains, scaled, scaled_bwd, wide_fused, time.time() - t0))
 
 
 def half_training_case(x0, w0, b0, t0, S, tm, act, slope, x_half):
