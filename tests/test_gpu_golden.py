@@ -165,7 +165,8 @@ def test_multisteps_production_width_on_gpu_matches_reference_fixture(case):
     assert count("conv3x3_bwd_weight") == 45 and count("conv3x3_bwd_data") == 45
     assert count("pointwise_fwd ") == 2 * 12, count("pointwise_fwd ")
     assert count("pointwise_bwd ") == 11 + (1 if case == "k5" else 0), names
-    assert count("pointwise_gw_wide") == (1 if case == "k21" else 0)
+    # k = 21: the 441-channel layer's backward is the ONE-PASS kernel (round 5), reached through the splat's bound word
+    assert count("pointwise_wide_bwd") == (1 if case == "k21" else 0) and count("pointwise_gw_wide") == 0, names
     assert any(n.startswith("splat") for n in names), set(names)
     worst = max(report.items(), key=lambda kv: kv[1][0])
     print("%s: worst gradient %s at %.2e of its scale from float64 (reference %.2e)" % (case, worst[0], *worst[1]))
