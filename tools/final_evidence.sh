@@ -1,3 +1,6 @@
+#!/bin/bash
+# The round-end evidence in ONE GPU call (same box): the whole GPU suite + smoke(), the default bench line, tools/prof.sh (rocprofv3
+# kernel statistics of the same commands + the PMC passes) and the step's categories:   tools/grun --timeout 3300 "bash tools/final_evidence.sh"
 cd $GRAFT_REPO_ROOT
 bash tools/gpu_suite.sh
 mkdir -p gpurun_out/final
