@@ -166,3 +166,65 @@ def test_4k_pointwise_layer_indexing():
     assert x.grad.abs().sum().item() == pytest.approx(x.grad[0][:, idx].abs().sum().item(), rel=1e-6)
     close(w.grad, (gz @ xs.t()).float(), rtol=2e-5)
     close(b.grad, gz.sum(1).float(), rtol=2e-5)
+
+
+def test_fullsize_regressor_output_layer_backward_in_one_pass():
+    """BASELINE configs[2] size: the 441-channel layer's backward over 8 x 1280 x 720 sample-pixels (13 GB of logit gradient)
+    through pw_wide_bwd2_kernel, behind the real chain splat backward -> bound word -> one-pass kernel.  No oracle at
+    this size; properties instead:
+      * gx against the library's fp32 product w^T gz (two fp32 evaluations of a 441-term sum): 1e-5 of the tensor's scale;
+      * gw and gbias -- sums over 7.4 M terms -- against float64 sums of the same products on the device;
+      * LINEARITY: the gradients for 3 gz are 3 x the gradients for gz to the last bit but one (a power-of-two-free
+        factor changes every rounding: 4e-7 relative), and the words scale with it;
+      * the splat's bound word really bounds the logit gradient it was made for."""
+    from sbmc_amd import _lib, functions as F
+    L = _lib.lib()
+    dev = th.device("cuda")
+    g = th.Generator(device="cuda").manual_seed(5)
+    B, cin, cout, hw = 8, 128, 441, H * W
+    # a real logit gradient: the splat's backward of random upstream gradients (its magnitudes span many binades)
+    rad = th.rand(1, B, 3, H, W, device=dev, generator=g)
+    ker = (th.randn(1, B, cout, H, W, device=dev, generator=g) * 2).requires_grad_()
+    sr, sw, mw = F.SplatAll.apply(rad, ker)
+    gz5, = th.autograd.grad([sr, sw], [ker], [th.randn(sr.shape, device=dev, generator=g), th.randn(sw.shape, device=dev, generator=g)])
+    word = F.known_amax(gz5)
+    assert word is not None
+    true_max = gz5.abs().max().item()
+    assert true_max <= word.view(th.float32).item() <= 256.0 * true_max
+    del sr, sw, mw, ker, rad
+    gz = gz5.view(B, cout, hw)
+    x = th.randn(B, cin, hw, device=dev, generator=g).relu_()
+    w = th.randn(cout, cin, device=dev, generator=g) / cin ** 0.5
+    xword = x.abs().max().reshape(1).view(th.int32).clone()
+
+    def run(gzt, gword):
+        groups = L.sbmc_pointwise_gw_wide_groups(B, hw)
+        gwp = th.empty(groups, cout, cin, device=dev)
+        gbp = th.empty(groups, cout, device=dev)
+        gx = th.empty(B, cin, hw, device=dev)
+        ws = th.empty(L.sbmc_pointwise_wide_bwd_ws_bytes(), dtype=th.uint8, device=dev)
+        gxmax = th.zeros(1, dtype=th.int32, device=dev)
+        _lib.check(L.sbmc_pointwise_wide_bwd_f32(_lib.ptr(gzt), _lib.ptr(x), _lib.ptr(w), _lib.ptr(gx), _lib.ptr(gwp), _lib.ptr(gbp),
+                                                 _lib.ptr(ws), _lib.ptr(gword), _lib.ptr(xword), _lib.ptr(gxmax), B, cin, cout, hw,
+                                                 _lib.current_stream(dev)), "wide_bwd")
+        return gx, gwp.double().sum(0), gbp.double().sum(0), gxmax
+    gx, gw, gb, gxmax = run(gz, word)
+    assert gxmax.item() == gx.abs().max().reshape(1).view(th.int32).item()
+    lib = th.bmm(w.t().unsqueeze(0).expand(B, -1, -1), gz)
+    assert (gx - lib).abs().max().item() <= 1e-5 * lib.abs().max().item()
+    del lib
+    gw64 = th.zeros(cout, cin, dtype=th.float64, device=dev)
+    gb64 = th.zeros(cout, dtype=th.float64, device=dev)
+    for b in range(B):                                   # (float64 on the device, image by image: 13 GB at a time would not fit twice)
+        gzd = gz[b].double()
+        gw64 += gzd @ x[b].double().t()
+        gb64 += gzd.sum(1)
+        del gzd
+    assert (gw - gw64).abs().max().item() <= 1e-5 * gw64.abs().max().item()
+    assert (gb - gb64).abs().max().item() <= 1e-5 * gb64.abs().max().item()
+    gz3 = gz * 3.0
+    word3 = (word.view(th.float32) * 3.0).view(th.int32)
+    gx3, gw3, gb3, _ = run(gz3, word3)
+    assert (gx3 - 3.0 * gx).abs().max().item() <= 4e-6 * gx3.abs().max().item()
+    assert (gw3 - 3.0 * gw).abs().max().item() <= 4e-6 * gw3.abs().max().item()
+    assert (gb3 - 3.0 * gb).abs().max().item() <= 4e-6 * gb3.abs().max().item()
