@@ -793,7 +793,6 @@ template <int KP, int TMODE, bool MEAN = false>
 __global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
     constexpr int NT = 128;                            // pixels per tile
     constexpr int KQ = KP / 4;                         // channel quads
-    constexpr int KS = KP / 8;                         // MFMA k-steps
     constexpr int NPASS = (KQ + 15) / 16;              // staging passes: 16 quads x 32 pixel groups per pass
     const _Float16* xg = static_cast<const _Float16*>(p.x);
     _Float16* yg = static_cast<_Float16*>(p.y);
@@ -854,16 +853,18 @@ __global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
         }
     };
 
-    // weight rows of this wave as f16 A-operands: a[kk][i] = W[r0 + lane % 32][8 kk + 4 (lane / 32) + i]
-    h4 a[KS];
+    // weight rows of this wave as f16 A-operands of v_mfma_f32_32x32x16_f16 (gfx950: twice the K per issue of the
+    // 32x32x8 form these kernels were written on): a[s][i] = W[r0 + lane % 32][16 s + 8 (lane / 32) + i]
+    constexpr int KS16 = KP / 16;
+    hf8 a[KS16];
     {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
         const int row = r0 + l31;
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
+        for (int kk = 0; kk < KS16; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = 8 * kk + 4 * lhi + i;
+            for (int i = 0; i < 8; ++i) {
+                const int k = 16 * kk + 8 * lhi + i;
                 const bool ok = row < p.Cout && k < p.K;
                 a[kk][i] = (_Float16)buf_load(rw, ok ? (unsigned)(row * p.K + k) * 4u : PW_OOB, 0);
             }
@@ -939,17 +940,19 @@ __global__ __launch_bounds__(512) void pw_fwd_h_kernel(PwFwdParams p) {
             }
         }
 
-        const u32x2* xb = xs + buf * (KQ * NT) + lhi * NT + ph * 64 + l31;
+        // B operand of a 16-step: this lane's pixel, channels 16 s + 8 lhi .. + 7 = the quads 4 s + 2 lhi and the next
+        const u32x2* xb = xs + buf * (KQ * NT) + 2 * lhi * NT + ph * 64 + l31;
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const h4 b0 = __builtin_bit_cast(h4, xb[(2 * kk) * NT]);
-            const h4 b1 = __builtin_bit_cast(h4, xb[(2 * kk) * NT + 32]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(a[kk], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(a[kk], b1, acc1, 0, 0, 0);
-            if (kk < 16) store_prev(kk);
+        for (int kk = 0; kk < KS16; ++kk) {
+            const u32x2 q0 = xb[(4 * kk) * NT], q1 = xb[(4 * kk + 1) * NT];
+            const u32x2 r0q = xb[(4 * kk) * NT + 32], r1q = xb[(4 * kk + 1) * NT + 32];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], __builtin_bit_cast(hf8, u32x4{q0[0], q0[1], q1[0], q1[1]}), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], __builtin_bit_cast(hf8, u32x4{r0q[0], r0q[1], r1q[0], r1q[1]}), acc1, 0, 0, 0);
+            store_prev(2 * kk);
+            store_prev(2 * kk + 1);
         }
 #pragma unroll
-        for (int j = KS; j < 16; ++j) store_prev(j);
+        for (int j = 2 * KS16; j < 16; ++j) store_prev(j);
 
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -1003,7 +1006,6 @@ template <int KP>
 __global__ __launch_bounds__(512) void pw_fwd_hw_kernel(PwFwdParams p) {
     constexpr int NT = 128;
     constexpr int KQ = KP / 4;
-    constexpr int KS = KP / 8;
     constexpr int NPASS = (KQ + 15) / 16;
     constexpr int NR = 4;                              // row tiles of 128 output channels
     const _Float16* xg = static_cast<const _Float16*>(p.x);
@@ -1051,21 +1053,23 @@ __global__ __launch_bounds__(512) void pw_fwd_hw_kernel(PwFwdParams p) {
 
     // weight rows of this wave for every row tile: a[rt][kk][i] = W[128 rt + 32 rb + lane % 32][8 kk + 4 (lane / 32) + i]
     // (kept as packed words: as _Float16 vectors the compiler holds one half per register)
-    u32x2 a[NR][KS];
+    // (v_mfma_f32_32x32x16_f16 operands, as in pw_fwd_h_kernel: a[rt][s] = W[..][16 s + 8 (lane / 32) + 0..7])
+    constexpr int KS16 = KP / 16;
+    u32x4 a[NR][KS16];
     {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
 #pragma unroll
         for (int rt = 0; rt < NR; ++rt) {
             const int row = rt * 128 + rb * 32 + l31;
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                h4 v;
+            for (int kk = 0; kk < KS16; ++kk) {
+                hf8 v;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = 8 * kk + 4 * lhi + i;
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 16 * kk + 8 * lhi + i;
                     v[i] = (_Float16)buf_load(rw, (row < p.Cout && k < p.K) ? (unsigned)(row * p.K + k) * 4u : PW_OOB, 0);
                 }
-                a[rt][kk] = __builtin_bit_cast(u32x2, v);
+                a[rt][kk] = __builtin_bit_cast(u32x4, v);
             }
         }
     }
@@ -1085,7 +1089,7 @@ __global__ __launch_bounds__(512) void pw_fwd_hw_kernel(PwFwdParams p) {
         if (next < p.ntiles) issue_loads(next, pre);
         const unsigned b = tile / p.tiles_per_plane, p0 = (tile % p.tiles_per_plane) * NT;
         const unsigned col = p0 + ph * 64 + l31;
-        const u32x2* xb = xs + buf * (KQ * NT) + lhi * NT + ph * 64 + l31;
+        const u32x2* xb = xs + buf * (KQ * NT) + 2 * lhi * NT + ph * 64 + l31;
 #pragma unroll
         for (int rt = 0; rt < NR; ++rt) {
             if (rt < nr) {
@@ -1105,11 +1109,13 @@ __global__ __launch_bounds__(512) void pw_fwd_hw_kernel(PwFwdParams p) {
                     acc1[j] = v;
                 }
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) {
-                    const h4 b0 = __builtin_bit_cast(h4, xb[(2 * kk) * NT]);
-                    const h4 b1 = __builtin_bit_cast(h4, xb[(2 * kk) * NT + 32]);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(h4, a[rt][kk]), b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(h4, a[rt][kk]), b1, acc1, 0, 0, 0);
+                for (int kk = 0; kk < KS16; ++kk) {
+                    const u32x2 q0 = xb[(4 * kk) * NT], q1 = xb[(4 * kk + 1) * NT];
+                    const u32x2 r0q = xb[(4 * kk) * NT + 32], r1q = xb[(4 * kk + 1) * NT + 32];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[rt][kk]),
+                                                                  __builtin_bit_cast(hf8, u32x4{q0[0], q0[1], q1[0], q1[1]}), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf8, a[rt][kk]),
+                                                                  __builtin_bit_cast(hf8, u32x4{r0q[0], r0q[1], r1q[0], r1q[1]}), acc1, 0, 0, 0);
                 }
                 // (stored right away: the workgroup's other waves and the CU's second wave per SIMD keep the matrix pipe
                 // busy meanwhile; holding a unit's outputs back for the next unit's MFMAs costs 32 registers = spills here)
