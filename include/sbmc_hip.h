@@ -41,7 +41,7 @@ extern "C" {
 #define SBMC_API
 #endif
 
-#define SBMC_HIP_ABI_VERSION 6
+#define SBMC_HIP_ABI_VERSION 7
 #define SBMC_HIP_EINVAL (-1)
 /* largest channel count the fused/plain kernels take in one call */
 #define SBMC_HIP_MAX_CHANNELS 8
@@ -681,6 +681,23 @@ SBMC_API int sbmc_conv3x3_nhwc_f32(const float *x, const unsigned *xmax, const v
 SBMC_API int sbmc_conv3x3_bias_act_nhwc_f32(const float *x, const unsigned *xmax, const void *wp, const float *bias,
                                    float *y, unsigned *signs, unsigned *amax, int n, int h, int w, int cin,
                                    int cout, int act, float slope, void *ws, void *stream);
+/* ABI 7 -- the DATA GRADIENT of such a layer whose input is the activated output of another one that nothing else reads
+ * (a chain of convolutions: reference sbmc/modules.py:195-320, ttools ConvChain), with that producing layer's
+ * activation adjoint + bias gradient pass (sbmc_bias_act_nhwc_bwd_amax_f32) in the kernel's epilogue -- the gradient
+ * is written once instead of written, read and rewritten:
+ *     gz[n][h][w][cout] = (sum gy[n][h + ky - 1][w + kx - 1][ci] wT[co][ci][ky][kx]) * (z > 0 ? 1 : slope)
+ *   gy [n, h, w, cin] with its magnitude word gmax; wp: the adjoint's prepared weights (prepare_weights flip = 1 / the
+ *   bank's wp_bwd); cout = the producing layer's output channels (adj_supported: conv3x3_supported and cout <= 512);
+ *   signs: the words that layer's forward left (sbmc_conv3x3_bias_act_nhwc_f32); slope 0: ReLU;
+ *   partial [sbmc_conv3x3_adj_partial_rows()][cout], ZEROED by the caller: partial sums of the bias gradient, sum over
+ *   pixels of gz (which rows a launch writes is its own business; fixed order: the result does not depend on the run);
+ *   the caller adds the rows up, e.g. as bias_partial of sbmc_conv3x3_wgrad_bias_f32;
+ *   amax: raised to the bit pattern of max |gz| (a word the caller zeroed). */
+SBMC_API int sbmc_conv3x3_adj_supported(int n, int h, int w, int cin, int cout);
+SBMC_API int sbmc_conv3x3_adj_partial_rows(void);
+SBMC_API int sbmc_conv3x3_adj_nhwc_f32(const float *gy, const unsigned *gmax, const void *wp, const unsigned *signs,
+                              float slope, float *gz, float *partial, unsigned *amax, int n, int h, int w, int cin,
+                              int cout, void *ws, void *stream);
 /* Half activations (torch.autocast(float16) semantics: half inputs, weights rounded to half once, fp32 accumulation,
  * half outputs): x, y _Float16 channels-last; wp the prepared weights of prepare_weights_f32 / the weight bank (their
  * high plane is f16 of the power-of-two-scaled weight, the scale is divided out); bias fp32; no magnitude words. */

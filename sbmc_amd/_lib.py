@@ -113,6 +113,9 @@ SYMBOLS = (
     "sbmc_conv3x3_workspace_bytes",
     "sbmc_conv3x3_nhwc_f32",
     "sbmc_conv3x3_bias_act_nhwc_f32",
+    "sbmc_conv3x3_adj_supported",
+    "sbmc_conv3x3_adj_partial_rows",
+    "sbmc_conv3x3_adj_nhwc_f32",
     "sbmc_conv3x3_wgrad_supported",
     "sbmc_conv3x3_wgrad_scratch_bytes",
     "sbmc_conv3x3_wgrad_f32",
@@ -124,7 +127,7 @@ SYMBOLS = (
     "sbmc_wbank_forward_f32",
     "sbmc_wbank_backward_f32",
 )
-ABI_VERSION = 6
+ABI_VERSION = 7
 WBANK_MAX = 24
 
 
@@ -286,6 +289,9 @@ def lib():
     handle.sbmc_conv3x3_workspace_bytes.argtypes = []
     handle.sbmc_conv3x3_nhwc_f32.argtypes = [p, p, p, p, i, i, i, i, i, p, p]
     handle.sbmc_conv3x3_bias_act_nhwc_f32.argtypes = [p] * 7 + [i] * 6 + [ctypes.c_float, p, p]
+    handle.sbmc_conv3x3_adj_supported.argtypes = [i] * 5
+    handle.sbmc_conv3x3_adj_partial_rows.argtypes = []
+    handle.sbmc_conv3x3_adj_nhwc_f32.argtypes = [p, p, p, p, ctypes.c_float, p, p, p, i, i, i, i, i, p, p]
     handle.sbmc_conv3x3_wgrad_supported.argtypes = [i] * 5
     handle.sbmc_conv3x3_wgrad_scratch_bytes.argtypes = [i] * 5
     handle.sbmc_conv3x3_wgrad_f32.argtypes = [p, p, p, p, p, lg, lg, lg, lg, p, i, i, i, i, i, p]

@@ -113,7 +113,15 @@ struct Conv3Params {
     // stream-K (or nullptr: whole tiles dealt round-robin): [4 KB unused][partial slabs: gridDim.x x 32768 floats][parked
     // slabs: the same]
     void* ws;
+    // ADJ (the data gradient of a convolution whose INPUT is the activated output of another one, which nothing else
+    // reads): y = conv * act'(z), the adjoint of that layer's bias + activation pass in this kernel's epilogue -- sign
+    // bits in (the words the producer's forward left), the bias gradient's partial sums and max |y| out (amax above)
+    const unsigned* adj_signs;   // [N H W Cout / 32]
+    float adj_slope;             // 0: ReLU, else LeakyReLU
+    float* adj_partial;          // [rows][Cout], zeroed by the caller: rows 2 g + (wave & 1) of the main kernel, 2 G + 2 g + .. of the fix-up's
 };
+constexpr int CV_ADJ_MAXC = 512;                                   // output channels of an ADJ launch (LDS: 2 x Cout floats)
+constexpr unsigned CV_ADJ_LDS_BYTES = 2u * CV_ADJ_MAXC * 4u;
 constexpr int CV_SLAB = 256 * 128;           // floats of one workgroup's accumulators
 constexpr int CV_WS_HDR = 4096;
 
@@ -147,11 +155,16 @@ __device__ __forceinline__ void cv_unrolled(F&& f) { cv_unrolled_impl(f, std::ma
 // and an immediate per channel block; rows beyond the image select an empty descriptor per row pair; the sign words
 // of 16 registers are gathered in a register (lane r / r + 32 <- the ballot's halves) and leave in ONE store; the
 // largest magnitude is a masked max.  ~12 instructions per accumulator register instead of ~35.
-template <bool EPI, bool HF, bool SK>
+template <bool EPI, bool HF, bool SK, bool ADJ = false>
 __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4][2], const CvTile& t, const bool park,
-                                          float* park_slab, const float oscale, unsigned& amax_run) {
+                                          float* park_slab, const float oscale, unsigned& amax_run, float* bacc = nullptr) {
+    static_assert(!(EPI && ADJ) && !(HF && ADJ), "ADJ: the fp32 data gradient");
     constexpr unsigned ES = HF ? 2u : 4u;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    int tid_e = threadIdx.x;
+    // (ADJ: the lane's offsets are derived HERE, per tile -- hoisted out of the persistent loop they are four registers more
+    // than the main loop has, i.e. spills)
+    if constexpr (ADJ) asm volatile("" : "+v"(tid_e));
+    const int tid = tid_e, lane = tid & 63, wave = wave_id();
     const int l31 = lane & 31, lhi = lane >> 5;
     const int mh = wave & 1, nh = wave >> 1;
     const bool sign_lane = l31 == 0;
@@ -168,6 +181,20 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
         rs = cv_rsrc(p.signs + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)(p.Cout / 32) + t.ct * 4,
                      (p.signs && !parking) ? 0x7FFFFFF0u : 0u);
     }
+    float bsum[2] = {0.f, 0.f};
+    if constexpr (ADJ)
+        rs = cv_rsrc(p.adj_signs + (((long)t.n * p.H + t.y0) * (long)p.W + t.x0) * (long)(p.Cout / 32) + t.ct * 4, 0x7FFFFFF0u);
+    // ADJ: the tile's bias sums (this wave's 64 channels, both half-waves added) join the workgroup's in LDS
+    auto adj_commit = [&]() {
+        if constexpr (ADJ) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const float o = __shfl_xor(bsum[ni], 32, 64);
+                float* d = bacc + mh * p.Cout + t.ct * 128 + nh * 64 + ni * 32 + l31;      // (this wave's own entries)
+                if (lhi == 0) *d += bsum[ni] + o;
+            }
+        }
+    };
     if constexpr (SK) {
         // stream-K: a parked tile's accumulators go to the slab raw (its epilogue runs in the fix-up kernel)
         if (park) {
@@ -191,7 +218,7 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
         const int rows_in = p.H - t.y0 - mh * 8;                               // rows of this wave's 8 inside the image
         // sign words: lane j (j < 16) / 32 + j holds register j's word: pixel (j / 8, column of register j)
         unsigned sgl = CV_OOB;
-        if constexpr (EPI) {
+        if constexpr (EPI || ADJ) {
             const int cj = (l31 & 3) + 8 * ((l31 >> 2) & 1) + 14 * ((l31 >> 3) & 1);
             const int colj = (cj + 4 * lhi) & 15;
             sgl = (unsigned)(((((l31 >> 3) & 1) * p.W + colj) * (p.Cout / 32) + nh * 2) * 4);
@@ -200,6 +227,16 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             unsigned sw[2] = {0u, 0u};
+            if constexpr (ADJ) {
+                __builtin_amdgcn_sched_barrier(0);       // (one row pair's words at a time: registers)
+                // the sign words of this row pair's 16 registers, where the forward's epilogue put them: lane r / r + 32 <-
+                // register r's word of the lower / upper half-wave's pixel
+                const bool ok = l31 < 16 && mi * 2 + ((l31 >> 3) & 1) < rows_in;
+                const unsigned so = (unsigned)(((mh * 8 + mi * 2) * p.W) * (p.Cout / 32)) * 4u;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    sw[ni] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? sgl + (unsigned)ni * 4u : CV_OOB, so, 0);
+            }
 #pragma unroll
             for (int rh = 0; rh < 2; ++rh) {
                 const bool gok = mi * 2 + rh < rows_in;                       // wave-uniform
@@ -228,6 +265,16 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
                                 amax_run = amax_run > a ? amax_run : a;
                             }
                         }
+                        if constexpr (ADJ) {
+                            // the 64 lanes' sign bits are the two words as they stand: a lane mask
+                            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)sw[ni], r);
+                            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)sw[ni], r + 32);
+                            const bool pos = __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
+                            v = pos ? v : v * p.adj_slope;
+                            const unsigned a = __builtin_bit_cast(unsigned, v) & amask;
+                            amax_run = amax_run > a ? amax_run : a;
+                            bsum[ni] += gok ? v : 0.f;
+                        }
                         if constexpr (HF)
                             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rg,
                                                                   vb + (unsigned)(ni * 32) * ES, so, 0);
@@ -246,6 +293,7 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
                     __builtin_amdgcn_raw_buffer_store_b32(sw[ni], rs, ok ? sgl + (unsigned)ni * 4u : CV_OOB, so, 0);
             }
         }
+        adj_commit();
         return;
     }
 #pragma unroll
@@ -278,6 +326,17 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
                         amax_run = amax_run > a ? amax_run : a;
                     }
                 }
+                if constexpr (ADJ) {
+                    // (the 32 lanes of a half-wave are the 32 channels of one sign word)
+                    const unsigned so = ok ? (unsigned)((row * p.W + col) * (p.Cout / 32) + nh * 2 + ni) * 4u : CV_OOB;
+                    const unsigned word = __builtin_amdgcn_raw_buffer_load_b32(rs, so, 0, 0);
+                    v = ((word >> l31) & 1u) ? v : v * p.adj_slope;
+                    if (ok) {
+                        const unsigned a = abits(v);
+                        amax_run = amax_run > a ? amax_run : a;
+                        bsum[ni] += v;
+                    }
+                }
                 if constexpr (HF)
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), ry, voff, 0, 0);
                 else
@@ -287,6 +346,7 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
             if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);      // (one register's ballots and stores at a time)
         }
     }
+    adj_commit();
 }
 
 // a workgroup's accumulators <-> a slab of the stream-K workspace (element e of thread t at e * 256 + t; buffer
@@ -323,13 +383,18 @@ __device__ __forceinline__ void cv_slab_load(f32x16 (&acc)[4][2], const float* b
 // tail of its first tile if its range of (tile, chunk) units began inside that tile and reached the tile's end; the
 // workgroups before it left the tile's head (and middle) in their partial slabs.  Tail + partials in a FIXED order
 // (g - 1, g - 2, ... back to the workgroup whose range holds the tile's first unit), then the tile's epilogue.
-template <bool EPI, bool HF>
+template <bool EPI, bool HF, bool ADJ = false>
 __global__ __launch_bounds__(256) void conv3_fixup_kernel(Conv3Params p, unsigned G) {
     const unsigned g = blockIdx.x, nchunks = (unsigned)p.Cin / 32u;
     const unsigned long long U = (unsigned long long)p.ntiles * nchunks;
     const unsigned long long u0 = U * g / G, u1 = U * (g + 1) / G;
     const unsigned first = (unsigned)(u0 / nchunks), c0 = (unsigned)(u0 % nchunks);
+    __shared__ float bacc[ADJ ? 2 * CV_ADJ_MAXC : 1];
     if (c0 == 0 || u0 + (nchunks - c0) > u1) return;      // began on a tile boundary, or never reached its tile's end
+    if constexpr (ADJ) {
+        for (int i = threadIdx.x; i < 2 * p.Cout; i += 256) bacc[i] = 0.f;
+        __syncthreads();
+    }
     float* const slabs = reinterpret_cast<float*>(static_cast<char*>(p.ws) + CV_WS_HDR);
     // (a slab's 128 loads per thread all in flight -- this kernel has the registers --: issued 16 at a time it took 20 us,
     // on latency alone, where the convolution it completes takes 120)
@@ -354,9 +419,13 @@ __global__ __launch_bounds__(256) void conv3_fixup_kernel(Conv3Params p, unsigne
     const float cx = HF ? 1.f : cv_scale_of(*p.xmax);
     const float oscale = (1.f / cx) * (1.f / *p.wscale);
     unsigned amax_run = 0;
-    cv_finish<EPI, HF, false>(p, acc, t, false, nullptr, oscale, amax_run);
-    if constexpr (EPI) {
-        if (p.amax) amax_publish(amax_run, p.amax);
+    cv_finish<EPI, HF, false, ADJ>(p, acc, t, false, nullptr, oscale, amax_run, bacc);
+    if constexpr (EPI || ADJ) {
+        if (p.amax) amax_publish(amax_run, p.amax);         // (a barrier inside)
+    }
+    if constexpr (ADJ) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * p.Cout; i += 256) p.adj_partial[(size_t)(2 * G + 2 * g) * p.Cout + i] = bacc[i];
     }
 }
 
@@ -365,7 +434,7 @@ __global__ __launch_bounds__(256) void conv3_fixup_kernel(Conv3Params p, unsigne
 // as it is (one plane, no split, no scale), the weights are the prepared weights' HIGH plane (f16 of the scaled
 // weight: the rounding autocast applies, with a power-of-two scale that is divided out again), ONE matrix product per
 // term instead of three.
-template <bool EPI, bool HF = false, bool SK = false>
+template <bool EPI, bool HF = false, bool SK = false, bool ADJ = false>
 __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     constexpr unsigned ES = HF ? 2u : 4u;              // bytes of an activation element
     extern __shared__ float4 cv_lds[];
@@ -505,6 +574,11 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     unsigned amax_run = 0;
+    // ADJ: the workgroup's bias sums [wave & 1][Cout], in LDS behind the weight stages
+    float* const bacc = reinterpret_cast<float*>(Ws + 3 * CV_WSTAGE);
+    if constexpr (ADJ) {
+        for (int i = tid; i < 2 * p.Cout; i += 256) bacc[i] = 0.f;      // (visible after the prologue's barrier)
+    }
     if (total == 0) return;
 
     // operands of one tap: A 4 m-blocks x 2 planes, B 2 n-blocks x 2 planes
@@ -612,7 +686,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         if (last) {
             // (stream-K: the tail of a tile whose head other workgroups hold is parked until this one's range is through)
             const bool park = sk && ti == 0 && c0 > 0;
-            cv_finish<EPI, HF, SK>(p, acc, tcur, park, park ? slabs + (size_t)(G + g) * CV_SLAB : nullptr, oscale, amax_run);
+            cv_finish<EPI, HF, SK, ADJ>(p, acc, tcur, park, park ? slabs + (size_t)(G + g) * CV_SLAB : nullptr, oscale, amax_run, bacc);
         }
         if (last) {
             tcur = tnext;
@@ -628,8 +702,12 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
         // (the next launch: no flags, no waiting) adds it to the tail its neighbour parked and runs that tile's epilogue
         cv_slab_store(acc, slabs + (size_t)g * CV_SLAB);
     }
-    if constexpr (EPI) {
-        if (p.amax) amax_publish(amax_run, p.amax);
+    if constexpr (EPI || ADJ) {
+        if (p.amax) amax_publish(amax_run, p.amax);          // (a barrier inside)
+    }
+    if constexpr (ADJ) {
+        __syncthreads();
+        for (int i = tid; i < 2 * p.Cout; i += 256) p.adj_partial[(size_t)(2 * g) * p.Cout + i] = bacc[i];
     }
 }
 
@@ -772,10 +850,13 @@ extern "C" int sbmc_conv3x3_prepare_weights_f32(const float* w, long s_co, long 
     return (int)hipGetLastError();
 }
 
+struct Conv3Adj { const unsigned* signs; float slope; float* partial; };
+
 static int conv3_launch(const void* x, const unsigned* xmax, const void* wp, void* y, int n, int h, int w, int cin,
                         int cout, const float* bias, int act, float slope, unsigned* signs, unsigned* amax, bool epi,
-                        void* ws, void* stream, bool hf = false) {
+                        void* ws, void* stream, bool hf = false, const Conv3Adj* adj = nullptr) {
     if (!conv3_dims_ok(n, h, w, cin, cout) || !x || (!xmax && !hf) || !wp || !y) return SBMC_HIP_EINVAL;
+    if (adj && (epi || hf || cout > CV_ADJ_MAXC || !adj->signs || !adj->partial || !amax)) return SBMC_HIP_EINVAL;
     if ((uintptr_t)x % 16 || (uintptr_t)wp % 16) return SBMC_HIP_EINVAL;
     Conv3Params p;
     p.x = x; p.wp = static_cast<const u32x4*>(wp); p.y = y; p.xmax = xmax;
@@ -784,17 +865,29 @@ static int conv3_launch(const void* x, const unsigned* xmax, const void* wp, voi
     p.tiles_x = (w + CV_TS - 1) / CV_TS; p.tiles_y = (h + CV_TS - 1) / CV_TS; p.ncot = cout / 128;
     p.ntiles = (unsigned)((long long)n * p.tiles_y * p.tiles_x * p.ncot);
     p.bias = bias; p.slope = act == 0 ? 1.f : (act == 1 ? 0.f : slope); p.signs = signs; p.amax = amax;
+    p.adj_signs = adj ? adj->signs : nullptr; p.adj_slope = adj ? adj->slope : 1.f; p.adj_partial = adj ? adj->partial : nullptr;
     const int cus = cu_count();
     unsigned grid = p.ntiles < (unsigned)cus ? p.ntiles : (unsigned)cus;
     p.ws = nullptr;
     const unsigned rounds = (p.ntiles + (unsigned)cus - 1) / (unsigned)cus;
-    if (ws != nullptr && (unsigned long long)p.ntiles * 100 < (unsigned long long)rounds * (unsigned)cus * 85) {
-        // stream-K: (tile, chunk) units in equal ranges over ALL compute units -- where whole tiles dealt round-robin
-        // would leave more than 15 % of the chip idle in their last round (320 or 160 tiles on 256 CUs: the slabs of a
-        // sharded frame at the U-net's coarser levels).  Nearly every workgroup then holds a split tile, and the slabs
-        // they meet in are as many bytes as a small convolution's own tensors: not worth it for a few per cent.
+    // stream-K: (tile, chunk) units in equal ranges over ALL compute units, where whole tiles dealt round-robin
+    //   * would leave more than 15 % of the chip idle in their last round (320 or 160 tiles on 256 CUs: the slabs of a
+    //     sharded frame at the U-net's coarser levels), or
+    //   * would take at least SBMC_CONV3X3_SK_SAVED (default 3) chunk times longer: a chunk (32 input channels of a
+    //     tile) takes ~12 us whatever the layer, the slabs and the fix-up launch of a split launch ~30 us whatever its
+    //     size -- so what decides is the ABSOLUTE time the last round wastes: 1800 tiles of 8 chunks (the whole frame
+    //     at the U-net's second level) waste 7 chunk times of 64, the 480 tiles of a rank of 8 none (round 5 tried
+    //     stream-K everywhere: -2.4 ms on the whole frame, +1-3 ms on a rank of 8).  0: this rule off.
+    // Nearly every workgroup of a split launch holds a split tile, and the slabs they meet in are as many bytes as a
+    // small convolution's own tensors.
+    const unsigned long long units_all = (unsigned long long)p.ntiles * (unsigned)(cin / 32);
+    const unsigned long long sk_chunks = (units_all + (unsigned)cus - 1) / (unsigned)cus;
+    const unsigned long long rr_chunks = (unsigned long long)rounds * (unsigned)(cin / 32);
+    const int sk_saved = env_knob("SBMC_CONV3X3_SK_SAVED", 3);
+    const bool sk_pays = sk_saved > 0 && rr_chunks >= sk_chunks + (unsigned long long)sk_saved;
+    if (ws != nullptr && (sk_pays || (unsigned long long)p.ntiles * 100 < (unsigned long long)rounds * (unsigned)cus * 85)) {
         if ((uintptr_t)ws % 16) return SBMC_HIP_EINVAL;
-        const unsigned long long units = (unsigned long long)p.ntiles * (unsigned)(cin / 32);
+        const unsigned long long units = units_all;
         grid = units < (unsigned long long)cus ? (unsigned)units : (unsigned)cus;
         p.ws = ws;
     }
@@ -803,17 +896,25 @@ static int conv3_launch(const void* x, const unsigned* xmax, const void* wp, voi
     if (p.ws != nullptr)
         kern = hf ? (epi ? conv3_kernel<true, true, true> : conv3_kernel<false, true, true>)
                   : (epi ? conv3_kernel<true, false, true> : conv3_kernel<false, false, true>);
+    if (adj) kern = p.ws != nullptr ? conv3_kernel<false, false, true, true> : conv3_kernel<false, false, false, true>;
+    const unsigned lds = CV_LDS_BYTES + (adj ? CV_ADJ_LDS_BYTES : 0u);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CV_LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     e = hipGetLastError();
     if (e != hipSuccess || p.ws == nullptr) return (int)e;
     auto fix = hf ? (epi ? conv3_fixup_kernel<true, true> : conv3_fixup_kernel<false, true>)
                   : (epi ? conv3_fixup_kernel<true, false> : conv3_fixup_kernel<false, false>);
+    if (adj) fix = conv3_fixup_kernel<false, false, true>;
     hipLaunchKernelGGL(fix, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, grid);
     return (int)hipGetLastError();
 }
+
+// rows of the bias gradient's partial sums an ADJ launch may write (the caller hands them in zeroed): two per workgroup
+// of the main kernel, and as many again for the fix-up launch of a split (stream-K) launch -- which the launcher decides,
+// so the caller sizes for it
+extern "C" int sbmc_conv3x3_adj_partial_rows(void) { return 4 * cu_count(); }
 
 extern "C" size_t sbmc_conv3x3_workspace_bytes(void) {
     return (size_t)CV_WS_HDR + (size_t)2 * cu_count() * CV_SLAB * sizeof(float);
@@ -831,6 +932,23 @@ extern "C" int sbmc_conv3x3_bias_act_nhwc_f32(const float* x, const unsigned* xm
     // (*amax is RAISED to max |y|: the caller hands in a zeroed word -- one memset launch per convolution was a
     // cost that does not shrink with the slab of a sharded frame)
     return conv3_launch(x, xmax, wp, y, n, h, w, cin, cout, bias, act, slope, signs, amax, true, ws, stream);
+}
+
+// The data gradient of a convolution whose input is another convolution's activated output that nothing else reads,
+// with that layer's activation adjoint in the epilogue (csrc: ADJ):  gz = (gy * w^T) . act'(z),  act' from the sign words
+// the producing layer's forward left (sbmc_conv3x3_bias_act_nhwc_f32), partial[rows][cout]: the bias gradient's partial
+// sums (sbmc_conv3x3_adj_partial_rows() rows, zeroed by the caller, who also adds them up -- e.g. through
+// sbmc_conv3x3_wgrad_bias_f32), *amax raised to max |gz|.  x = gy [n, h, w, cin], wp: the adjoint's
+// prepared weights, cout = the producing layer's output channels (<= 512).
+extern "C" int sbmc_conv3x3_adj_nhwc_f32(const float* x, const unsigned* xmax, const void* wp, const unsigned* signs,
+                                          float slope, float* y, float* partial, unsigned* amax, int n, int h, int w,
+                                          int cin, int cout, void* ws, void* stream) {
+    if ((uintptr_t)signs % 4) return SBMC_HIP_EINVAL;
+    const Conv3Adj adj{signs, slope, partial};
+    return conv3_launch(x, xmax, wp, y, n, h, w, cin, cout, nullptr, 0, 1.f, nullptr, amax, false, ws, stream, false, &adj);
+}
+extern "C" int sbmc_conv3x3_adj_supported(int n, int h, int w, int cin, int cout) {
+    return (conv3_dims_ok(n, h, w, cin, cout) && cout <= sbmc::CV_ADJ_MAXC) ? 1 : 0;
 }
 
 // Half activations (torch.autocast(float16) semantics): x, y _Float16 channels-last; wp: the SAME prepared weights

@@ -1253,10 +1253,12 @@ class Conv3x3NHWC(th.autograd.Function):
                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wp)
 
     @staticmethod
-    def _backward(x, w, xmax, gy, want_gx, want_gw, wp=None, bias_partial=None):
+    def _backward(x, w, xmax, gy, want_gx, want_gw, wp=None, bias_partial=None, adj=None):
         """bias_partial: the bias gradient's per-workgroup partial sums [chunks, cout] (bias_act_nhwc_bwd); where the
         weight-gradient kernel runs, its reduction launch adds them up as well and a third value, the bias gradient,
-        is returned (else None: the caller sums)."""
+        is returned (else None: the caller sums).
+        adj (an `_AdjLink`): x is the activated output of the chain's previous layer and nothing else reads it -- the
+        data gradient comes out with that layer's activation adjoint applied (csrc ADJ), and the link tells it so."""
         b, cin, h, wd = x.shape
         cout = w.shape[0]
         gx = gw = gbias = None
@@ -1266,7 +1268,18 @@ class Conv3x3NHWC(th.autograd.Function):
             gmax = known_amax(gy)
             if gmax is None:
                 gmax = Conv3x3NHWC._absmax(gy)
-            if want_gx:
+            if want_gx and adj is not None:
+                with _timed("conv3x3_bwd_data_adj %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
+                    gx = th.empty((b, cin, h, wd), dtype=th.float32, device=dev, memory_format=th.channels_last)
+                    apartial = th.zeros((L.sbmc_conv3x3_adj_partial_rows(), cin), dtype=th.float32, device=dev)
+                    amax = amax_word(dev)
+                    _lib.check(L.sbmc_conv3x3_adj_nhwc_f32(
+                        _lib.ptr(gy), _lib.ptr(gmax), _lib.ptr(wp[1] if wp is not None else Conv3x3NHWC._prepare(w, True)),
+                        _lib.ptr(adj.signs), adj.slope, _lib.ptr(gx), _lib.ptr(apartial), _lib.ptr(amax), b, h, wd, cout, cin,
+                        _STREAMK.take(dev), _lib.current_stream(dev)), "conv3x3_adj_nhwc")
+                    tag_amax(gx, amax)
+                    adj.done = (apartial, amax, gx.data_ptr())
+            elif want_gx:
                 with _timed("conv3x3_bwd_data %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
                     gx = Conv3x3NHWC._conv(gy, gmax, wp[1] if wp is not None else Conv3x3NHWC._prepare(w, True), cin)
             if want_gw:
@@ -1305,7 +1318,19 @@ class Conv3x3BiasActNHWC(th.autograd.Function):
         return conv.bias is not None and bool(_lib.lib().sbmc_bias_act_nhwc_supported(int(conv.out_channels)))
 
     @staticmethod
-    def forward(ctx, x, w, bias, act, slope):
+    def adj_link_for(y):
+        """The link `forward(..., want_link=True)` left on its output (or None): hand it to the ONE layer that
+        consumes that output as `adj_in`."""
+        return getattr(y, "_sbmc_adj_link", None)
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act, slope, adj_in=None, want_link=False):
+        """adj_in / want_link (ABI 7, csrc ADJ): two layers of a CHAIN -- `x` is the activated output of another
+        Conv3x3BiasActNHWC that NOTHING ELSE reads (the caller's guarantee: modules.ConvChain._run between its own
+        layers) -- share an `_AdjLink`: the producer's forward leaves it on its output (want_link), the consumer takes
+        it (adj_in) and its backward runs the data gradient with the producer's activation adjoint + bias sums in the
+        epilogue; the producer's backward then finds its gradient finished and skips its `bias_act_nhwc_bwd` pass (one
+        read and one write of the gradient less per layer)."""
         _require_f32("Conv3x3BiasActNHWC", x=x, w=w, bias=bias)
         L = _lib.lib()
         b, cin, h, wd = x.shape
@@ -1330,32 +1355,74 @@ class Conv3x3BiasActNHWC(th.autograd.Function):
         ctx.save_for_backward(x, w, xmax, signs if signs is not None else xmax)
         ctx.mark_non_differentiable(amax)
         ctx.set_materialize_grads(False)         # (else autograd zero-fills a "gradient" for the amax word every step)
+        # the chain: what this layer's data gradient does for the layer before it (adj_in), and what the layer behind it
+        # will do for this one (link_out)
+        ctx.adj_in = adj_in if (adj_in is not None and ctx.needs_input_grad[0] and adj_in.fits(x, L, cout)) else None
+        if ctx.adj_in is not None:
+            ctx.adj_in.taken = True
+        ctx.link_out = None
+        if want_link and signs is not None and act in (1, 2) and knob("SBMC_CONV3X3_ADJ") != 0:
+            ctx.link_out = y._sbmc_adj_link = _AdjLink(signs, 0.0 if act == 1 else float(slope), y)
         return y, amax
 
     @staticmethod
     def backward(ctx, gy, _gamax):
         if gy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None, None
         x, w, xmax, signs = ctx.saved_tensors
         gy = gy.contiguous(memory_format=th.channels_last)
         b, cout, h, wd = gy.shape
         L = _lib.lib()
         dev = gy.device
-        gz = th.empty_like(gy, memory_format=th.channels_last)
-        partial = gy.new_empty(L.sbmc_bias_act_nhwc_chunks(b * h * wd, cout), cout)
-        gmax = amax_word(dev)
-        with th.cuda.device(dev):
-            _lib.check(L.sbmc_bias_act_nhwc_bwd_amax_f32(_lib.ptr(gy), _lib.ptr(signs) if ctx.act != 0 else None, _lib.ptr(gz),
-                                                         _lib.ptr(partial), _lib.ptr(gmax), b * h * wd, cout, ctx.act, ctx.slope,
-                                                         _lib.current_stream(dev)), "bias_act_nhwc_bwd")
+        done = ctx.link_out.collect(gy) if ctx.link_out is not None else None
+        if done is not None:
+            # the layer behind this one has applied the adjoint in its data gradient's epilogue: gy IS gz
+            gz, partial, gmax = gy, done[0], done[1]
+        else:
+            gz = th.empty_like(gy, memory_format=th.channels_last)
+            partial = gy.new_empty(L.sbmc_bias_act_nhwc_chunks(b * h * wd, cout), cout)
+            gmax = amax_word(dev)
+            with th.cuda.device(dev):
+                _lib.check(L.sbmc_bias_act_nhwc_bwd_amax_f32(_lib.ptr(gy), _lib.ptr(signs) if ctx.act != 0 else None, _lib.ptr(gz),
+                                                             _lib.ptr(partial), _lib.ptr(gmax), b * h * wd, cout, ctx.act, ctx.slope,
+                                                             _lib.current_stream(dev)), "bias_act_nhwc_bwd")
         tag_amax(gz, gmax)
         want_bias = ctx.needs_input_grad[2]
         res = Conv3x3NHWC._backward(x, w, xmax, gz, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.wp,
-                                    partial if want_bias else None)
+                                    partial if want_bias else None, ctx.adj_in)
         gbias = res[2] if want_bias else None
         if want_bias and gbias is None:
             gbias = partial.sum(0)               # (the weight-gradient kernel did not run: its reduction adds them up)
-        return res[0], res[1], gbias, None, None
+        return res[0], res[1], gbias, None, None, None, None
+
+
+class _AdjLink(object):
+    """What two consecutive layers of a convolution chain share (Conv3x3BiasActNHWC.forward, adj_in / want_link): the
+    producer's sign words and slope for the consumer's data-gradient epilogue, and -- in the backward pass -- the
+    consumer's word that the producer's gradient arrives finished, with the bias gradient's partial sums and the
+    gradient's magnitude word."""
+
+    def __init__(self, signs, slope, y):
+        self.signs, self.slope = signs, slope
+        self.shape, self.ptr = tuple(y.shape), y.data_ptr()
+        self.taken = False            # a consumer's forward has taken the link
+        self.done = None              # (partial, gmax, gz pointer) between the consumer's backward and the producer's
+
+    def fits(self, x, L, cout_consumer):
+        """The consumer's input IS the producer's output, once, and the ADJ kernel takes the shape."""
+        b, c, h, w = x.shape
+        return (not self.taken and tuple(x.shape) == self.shape and x.data_ptr() == self.ptr
+                and bool(L.sbmc_conv3x3_adj_supported(b, h, w, cout_consumer, c)))
+
+    def collect(self, gy):
+        """Producer's backward: (partial, gmax) if `gy` is the finished gradient the consumer's backward left."""
+        done, self.done = self.done, None
+        if done is None:
+            return None
+        if done[2] != gy.data_ptr():
+            raise RuntimeError("Conv3x3BiasActNHWC: the gradient of a chained layer's output was replaced on its way "
+                               "(another consumer of that output, or a hook): the caller's guarantee does not hold")
+        return done[0], done[1]
 
 
 class Conv3x3BiasActHalfNHWC(th.autograd.Function):

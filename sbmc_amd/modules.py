@@ -345,9 +345,11 @@ class ConvChain(nn.Module):
         return self._run(list(self.children()), x)
 
     @staticmethod
-    def _conv_bias_act(conv, x, activation):
+    def _conv_bias_act(conv, x, activation, adj_in=None, want_link=False):
         """conv(x) without bias, then bias + activation by the fused pass.  Returns (y, activation
-        was applied), or (None, False) when the fused pass does not apply."""
+        was applied), or (None, False) when the fused pass does not apply.
+        adj_in / want_link: see functions.Conv3x3BiasActNHWC.forward -- `_run` passes them between the layers of ONE
+        chain, whose intermediate maps nothing else reads."""
         if conv.bias is None or conv.padding_mode != "zeros" or not isinstance(conv.padding, tuple):
             return None, False
         act, slope = 0, 0.0
@@ -369,7 +371,7 @@ class ConvChain(nn.Module):
             # change around them, bias + activation by the NHWC pass
             if funcs.Conv3x3NHWC.supported(x, conv) and funcs.Conv3x3BiasActNHWC.supported(conv):
                 # csrc/conv3x3.hip: fp32 values on the f16 matrix pipe, bias + activation in the kernel's epilogue
-                y, amax = funcs.Conv3x3BiasActNHWC.apply(x, w, conv.bias, act, slope)
+                y, amax = funcs.Conv3x3BiasActNHWC.apply(x, w, conv.bias, act, slope, adj_in, want_link)
                 return funcs.tag_amax(y, amax), act != 0
             elif funcs.Conv3x3NHWC.supported(x, conv):
                 y = funcs.Conv3x3NHWC.apply(x, w)             # (a channel count the bias / activation adjoint does not take)
@@ -398,9 +400,16 @@ class ConvChain(nn.Module):
         gemm = self.pointwise_as_gemm and x.is_cuda
         pending = 0                                                # halo rows still to be dropped
         i = 0
+        # (two consecutive fused 3 x 3 layers of the chain on a whole frame: the second one's data gradient applies the
+        # first one's activation adjoint -- functions._AdjLink; a sharded frame's halo rows travel between them)
+        link = None
+        fusable = lambda q: halo is None and (
+            (isinstance(q, ConvChain._ConvBNRelu) and len(q.layer) == 2 and isinstance(q.layer[0], nn.Conv2d)
+             and q.layer[0].kernel_size == (3, 3)) or (isinstance(q, nn.Conv2d) and q.kernel_size == (3, 3)))
         while i < len(mods):
             m = mods[i]
             i += 1
+            link_in, link = link, None
             if halo is not None:
                 conv = m.layer[0] if isinstance(m, ConvChain._ConvBNRelu) else m
                 if isinstance(conv, nn.Conv2d) and conv.kernel_size[0] > 1:
@@ -429,11 +438,13 @@ class ConvChain(nn.Module):
             elif (self.fuse_bias_act and x.is_cuda and x.dtype in (th.float32, th.float16)
                   and isinstance(m, ConvChain._ConvBNRelu) and len(m.layer) == 2
                   and isinstance(m.layer[0], nn.Conv2d)):
-                y, fused = ConvChain._conv_bias_act(m.layer[0], x, m.layer[1])
+                y, fused = ConvChain._conv_bias_act(m.layer[0], x, m.layer[1], link_in,
+                                                    fusable(m) and i < len(mods) and fusable(mods[i]))
                 x = m(x) if y is None else (y if fused else m.layer[1](y))
+                link = funcs.Conv3x3BiasActNHWC.adj_link_for(x) if (y is not None and fused) else None
             elif self.fuse_bias_act and x.is_cuda and x.dtype in (th.float32, th.float16) and isinstance(m, nn.Conv2d):
                 nxt = mods[i] if i < len(mods) else None
-                y, fused = ConvChain._conv_bias_act(m, x, nxt)
+                y, fused = ConvChain._conv_bias_act(m, x, nxt, link_in)      # (the chain's last layer: nothing behind it)
                 if y is None:
                     x = m(x)
                 else:

@@ -291,3 +291,143 @@ def test_stream_k_equals_whole_tiles(shape, monkeypatch):
     assert (ys["1"] - ys["0"]).abs().max().item() <= 2e-6 * scale
     ref = F.leaky_relu(F.conv2d(x.double(), wt.double(), bias.double(), padding=1), 0.01)
     assert _err(ys["1"], ref) <= 1e-5
+
+
+# ---- ABI 7: the data gradient with the producing layer's activation adjoint in its epilogue (csrc ADJ) ----
+
+def _two_layers(x, w1, b1, w2, b2, gy, act, slope, chained):
+    """y2 = act(conv(act(conv(x, w1) + b1), w2) + b2) through Conv3x3BiasActNHWC, with (chained) or without the link between
+    the layers; returns y2 and every gradient."""
+    leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    xs, w1s, b1s, w2s, b2s = leaves
+    y1, a1 = funcs.Conv3x3BiasActNHWC.apply(xs, w1s, b1s, act, slope, None, chained)
+    funcs.tag_amax(y1, a1)
+    link = funcs.Conv3x3BiasActNHWC.adj_link_for(y1)
+    assert (link is not None) == chained
+    y2, _ = funcs.Conv3x3BiasActNHWC.apply(y1, w2s, b2s, act, slope, link, False)
+    return (y2.detach().clone(),) + th.autograd.grad(y2, leaves, gy) + (y1.detach().clone(),)
+
+
+@pytest.mark.parametrize("b,c0,c1,c2,h,w", [
+    (1, 128, 128, 128, 37, 53),       # ragged: the general epilogue on the right edge, rows beyond the image below
+    (1, 128, 256, 128, 48, 64),       # lean epilogue everywhere, two channel tiles of the adjoint's output
+    (2, 384, 128, 256, 24, 40),
+    (1, 256, 512, 512, 26, 320),      # a stream-K launch (160 tiles): the fix-up kernel's epilogue and its rows of sums
+    (1, 128, 128, 128, 94, 1280),     # 480 tiles: two rounds of whole tiles
+    (1, 128, 128, 128, 1, 1),
+])
+@pytest.mark.parametrize("act,slope", [(2, 0.01), (1, 0.0)])
+def test_chained_layers_equal_the_unchained_and_float64(b, c0, c1, c2, h, w, act, slope):
+    """The second layer's data gradient applies the first one's activation adjoint, sums its bias gradient and leaves the
+    gradient's magnitude word: same values as the pass of its own (one product per element in either form; the bias sums
+    in another fixed order), and both against float64."""
+    dev = _dev()
+    g = th.Generator(device="cpu").manual_seed(c0 + c1 + h * w + act)
+    x = _cl((th.randn(b, c0, h, w, generator=g) * 2.0).to(dev))
+    w1 = (th.randn(c1, c0, 3, 3, generator=g) * (2.0 / (9 * c0)) ** 0.5).to(dev)
+    w2 = (th.randn(c2, c1, 3, 3, generator=g) * (2.0 / (9 * c1)) ** 0.5).to(dev)
+    b1, b2 = th.randn(c1, generator=g).to(dev) * 0.5, th.randn(c2, generator=g).to(dev) * 0.5
+    gy = _cl(th.randn(b, c2, h, w, generator=g).to(dev))
+    launches = []
+    funcs.enable_kernel_timing(launches)
+    try:
+        plain = _two_layers(x, w1, b1, w2, b2, gy, act, slope, False)
+        n_plain = sum(n.startswith("conv3x3_bwd_data_adj") for n, _, _ in launches)
+        chained = _two_layers(x, w1, b1, w2, b2, gy, act, slope, True)
+        n_chained = sum(n.startswith("conv3x3_bwd_data_adj") for n, _, _ in launches)
+        again = _two_layers(x, w1, b1, w2, b2, gy, act, slope, True)
+    finally:
+        funcs.enable_kernel_timing(None)
+    assert n_plain == 0 and n_chained == 1                       # the fused epilogue ran, once
+    for a, c in zip(chained, again):
+        assert th.equal(a, c)                                     # the same to the bit from run to run
+    names = ("y", "gx", "gw1", "gb1", "gw2", "gb2")
+    for name, a, c in zip(names, plain, chained):
+        scale = a.abs().max().item()
+        # gz1 is the same product in both forms; what follows it differs by fp32 rounding of other sums' order only where
+        # a sum's order differs: gb1 (partial sums per workgroup instead of per chunk of pixels)
+        tol = 1e-5 if name == "gb1" else 0.0
+        assert (a - c).abs().max().item() <= tol * scale, name
+    # float64 with the activations' branches as the kernels took them: a pre-activation within fp32 rounding of zero (one or
+    # two of a million here) may fall on the other side in float64 -- the function's own discontinuity, worth a whole
+    # element of the gradient, and nothing the comparison is about
+    xd, w1d, b1d, w2d, b2d = (t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+    m1 = th.where(chained[6] > 0, 1.0, slope).double()
+    m2 = th.where(chained[0] > 0, 1.0, slope).double()
+    yd = (F.conv2d(F.conv2d(xd, w1d, b1d, padding=1) * m1, w2d, b2d, padding=1)) * m2
+    ref = (yd.detach(),) + th.autograd.grad(yd, (xd, w1d, b1d, w2d, b2d), gy.double())
+    for name, a, r in zip(names, chained, ref):
+        assert _err(a, r) <= 1e-5, name
+
+
+def test_adj_entry_point_through_the_abi_and_its_words():
+    """sbmc_conv3x3_adj_nhwc_f32 by itself: gz against float64, the bias sums, the magnitude word; argument errors."""
+    dev = _dev()
+    L = _lib.lib()
+    b, cin, cout, h, w = 1, 256, 128, 20, 48          # gy has cin channels; the producing layer cout
+    g = th.Generator(device="cpu").manual_seed(77)
+    gy = _cl(th.randn(b, cin, h, w, generator=g).to(dev))
+    wt = (th.randn(cin, cout, 3, 3, generator=g) * 0.02).to(dev)          # the consumer's weight [its cout = cin here][cout]
+    z = _cl(th.randn(b, cout, h, w, generator=g).to(dev))                 # the producer's pre-activation
+    bits = (z.permute(0, 2, 3, 1).reshape(-1, 32) > 0).to(th.int64)
+    words = (bits << th.arange(32, device=dev)).sum(1)
+    signs = th.where(words >= 2 ** 31, words - 2 ** 32, words).to(th.int32).contiguous()
+    gmax = funcs.Conv3x3NHWC._absmax(gy)
+    wp = funcs.Conv3x3NHWC._prepare(wt, True)
+    gz = th.empty((b, cout, h, w), device=dev).contiguous(memory_format=th.channels_last)
+    rows = L.sbmc_conv3x3_adj_partial_rows()
+    partial = th.zeros(rows, cout, device=dev)
+    amax = th.zeros(1, dtype=th.int32, device=dev)
+    st = _lib.current_stream(dev)
+    args = lambda signs_ptr, co: (_lib.ptr(gy), _lib.ptr(gmax), _lib.ptr(wp), signs_ptr, 0.01, _lib.ptr(gz), _lib.ptr(partial),
+                                  _lib.ptr(amax), b, h, w, cin, co, None, st)
+    assert L.sbmc_conv3x3_adj_supported(b, h, w, cin, cout) == 1 and L.sbmc_conv3x3_adj_supported(b, h, w, cin, 1024) == 0
+    assert L.sbmc_conv3x3_adj_nhwc_f32(*args(None, cout)) == -1
+    assert L.sbmc_conv3x3_adj_nhwc_f32(*args(_lib.ptr(signs), cout)) == 0
+    gxd = th.nn.grad.conv2d_input((b, cout, h, w), wt.double(), gy.double(), padding=1)
+    ref = gxd * th.where(z > 0, 1.0, 0.01).double()
+    assert _err(gz, ref) <= 1e-5
+    assert _err(partial.sum(0), ref.sum((0, 2, 3))) <= 1e-5
+    assert amax.view(th.float32).item() == gz.abs().max().item()
+
+
+def test_unet_chains_with_and_without_the_fused_adjoint(monkeypatch):
+    """One U-net of the model (5 chains of 3 convolutions): with the links (the default) the second and third convolution
+    of every chain apply the adjoint of the one before them -- 10 data gradients in the ADJ form, 10 `bias_act_nhwc_bwd` passes
+    less -- and every gradient is what the passes of their own give: to the bit, except the 10 bias gradients whose partial
+    sums are added up in another order."""
+    from sbmc_amd import modules as ops
+    dev = _dev()
+    th.manual_seed(5)
+    net = ops.Autoencoder(128, 128, num_levels=3, increase_factor=2.0, num_convs=3, width=128, ksize=3,
+                          output_type="leaky_relu", pooling="max").to(dev)
+    for m in net.modules():
+        if isinstance(m, ops.ConvChain):
+            m.fuse_bias_act = True
+    x = th.randn(1, 128, 48, 80, device=dev)
+    gy = th.randn(1, 128, 48, 80, device=dev)
+    names = [n for n, _ in net.named_parameters()]
+
+    def run(flag):
+        monkeypatch.setenv("SBMC_CONV3X3_ADJ", flag)
+        launches = []
+        funcs.enable_kernel_timing(launches)
+        try:
+            xi = x.clone().requires_grad_(True)
+            y = net(xi)
+            gs = th.autograd.grad(y, [xi] + list(net.parameters()), gy)
+        finally:
+            funcs.enable_kernel_timing(None)
+        return [y.detach()] + list(gs), sum(n.startswith("conv3x3_bwd_data_adj") for n, _, _ in launches)
+
+    with_links, n1 = run("1")
+    without, n0 = run("0")
+    assert (n1, n0) == (10, 0), (n1, n0)
+    differing = 0
+    for name, a, b in zip(["y", "gx"] + names, with_links, without):
+        if th.equal(a, b):
+            continue
+        assert name.endswith("bias"), name
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item(), name
+        differing += 1
+    assert differing <= 10
