@@ -536,6 +536,14 @@ SBMC_API int sbmc_transpose2d_f32(const float *src, float *dst, int b, int rows,
 SBMC_API int sbmc_maxpool2_nhwc_fwd(const void *x, void *y, int b, int hc, int wc, int c, int elem, void *stream);
 SBMC_API int sbmc_maxpool2_nhwc_bwd_add(const void *x, const void *gpool, const void *gskip, void *gx, int b, int hc,
                                int wc, int c, int elem, void *stream);
+/* ABI 7: the same routing with the adjoint of the bias + activation pass that PRODUCED x in the same pass (fp32; x is a
+ * convolution chain's activated output and the pooling + skip node its only reader): gx = (gskip + routed gpool) *
+ * (z > 0 ? 1 : slope) from the producer's sign words (sbmc_conv3x3_bias_act_nhwc_f32), partial
+ * [sbmc_bias_act_nhwc_chunks(b hc wc, c)][c]: the bias gradient's partial sums, *amax (a zeroed word) raised to max |gx|.
+ * c as sbmc_bias_act_nhwc_supported. */
+SBMC_API int sbmc_maxpool2_nhwc_bwd_add_adj_f32(const float *x, const float *gpool, const float *gskip, float *gx,
+                                       const unsigned *signs, float slope, float *partial, unsigned *amax, int b, int hc,
+                                       int wc, int c, void *stream);
 /* the same batched 2-d transpose of _Float16 tensors (rows, cols multiples of 4; 8-byte aligned) */
 SBMC_API int sbmc_transpose2d_f16(const void *src, void *dst, int b, int rows, int cols, void *stream);
 /* ... and *amax raised to the bit pattern of the largest magnitude of the tensor (see sbmc_bias_act_nhwc_fwd_amax_f32). */
@@ -573,6 +581,13 @@ SBMC_API int sbmc_upsample2x_cat_nhwc_slab_fwd_f32(const float *coarse, const fl
                                           int cu, int cl, int hc, int w, int top, int bot, void *stream);
 SBMC_API int sbmc_upsample2x_cat_nhwc_slab_bwd_f32(const float *gout, float *gcoarse, float *gleft, int b,
                                           int cu, int cl, int hc, int w, int top, int bot, void *stream);
+/* ABI 7: the whole frame's adjoint (top = bot = 0) with the activation adjoint of the layer that PRODUCED the coarse map in
+ * the same pass (a convolution chain's activated output that only the upsampling reads): gcoarse = gather(gout) *
+ * (z > 0 ? 1 : slope) from that layer's sign words, partial [sbmc_bias_act_nhwc_chunks(b h w, cu)][cu]: the bias gradient's
+ * partial sums, *amax (a zeroed word) raised to max |gcoarse|; gleft or NULL.  cu as sbmc_bias_act_nhwc_supported. */
+SBMC_API int sbmc_upsample2x_cat_nhwc_bwd_adj_f32(const float *gout, float *gcoarse, float *gleft, const unsigned *signs,
+                                         float slope, float *partial, unsigned *amax, int b, int cu, int cl, int h,
+                                         int w, void *stream);
 /* the same on _Float16 tensors (fp16 activations under torch.autocast): half storage, fp32 interpolation */
 SBMC_API int sbmc_upsample2x_cat_nhwc_slab_fwd_f16(const void *coarse, const void *left, void *out, int b,
                                           int cu, int cl, int hc, int w, int top, int bot, void *stream);

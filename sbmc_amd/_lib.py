@@ -78,6 +78,7 @@ SYMBOLS = (
     "sbmc_transpose2d_f16",
     "sbmc_maxpool2_nhwc_fwd",
     "sbmc_maxpool2_nhwc_bwd_add",
+    "sbmc_maxpool2_nhwc_bwd_add_adj_f32",
     "sbmc_bias_act_nhwc_supported",
     "sbmc_bias_act_nhwc_chunks",
     "sbmc_bias_act_nhwc_fwd_f32",
@@ -89,6 +90,7 @@ SYMBOLS = (
     "sbmc_upsample2x_cat_nhwc_bwd_f32",
     "sbmc_upsample2x_cat_nhwc_slab_fwd_f32",
     "sbmc_upsample2x_cat_nhwc_slab_bwd_f32",
+    "sbmc_upsample2x_cat_nhwc_bwd_adj_f32",
     "sbmc_upsample2x_cat_nhwc_slab_fwd_f16",
     "sbmc_upsample2x_cat_nhwc_slab_bwd_f16",
     "sbmc_halo_bytes",
@@ -250,6 +252,7 @@ def lib():
     handle.sbmc_transpose2d_f16.argtypes = [p, p, i, i, i, p]
     handle.sbmc_maxpool2_nhwc_fwd.argtypes = [p, p, i, i, i, i, i, p]
     handle.sbmc_maxpool2_nhwc_bwd_add.argtypes = [p, p, p, p, i, i, i, i, i, p]
+    handle.sbmc_maxpool2_nhwc_bwd_add_adj_f32.argtypes = [p, p, p, p, p, ctypes.c_float, p, p, i, i, i, i, p]
     handle.sbmc_bias_act_nhwc_supported.argtypes = [i]
     handle.sbmc_bias_act_nhwc_chunks.argtypes = [ctypes.c_long, i]
     handle.sbmc_bias_act_nhwc_fwd_f32.argtypes = [p, p, ctypes.c_long, i, i, ctypes.c_float, p]
@@ -261,6 +264,7 @@ def lib():
     handle.sbmc_upsample2x_cat_nhwc_bwd_f32.argtypes = [p, p, p, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_nhwc_slab_fwd_f32.argtypes = [p, p, p, i, i, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_nhwc_slab_bwd_f32.argtypes = [p, p, p, i, i, i, i, i, i, i, p]
+    handle.sbmc_upsample2x_cat_nhwc_bwd_adj_f32.argtypes = [p, p, p, p, ctypes.c_float, p, p, i, i, i, i, i, p]
     handle.sbmc_upsample2x_cat_nhwc_slab_fwd_f16.argtypes = handle.sbmc_upsample2x_cat_nhwc_slab_fwd_f32.argtypes
     handle.sbmc_upsample2x_cat_nhwc_slab_bwd_f16.argtypes = handle.sbmc_upsample2x_cat_nhwc_slab_bwd_f32.argtypes
     ll, u = ctypes.c_longlong, ctypes.c_uint

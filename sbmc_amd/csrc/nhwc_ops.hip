@@ -217,6 +217,68 @@ __global__ __launch_bounds__(256) void upcat_nhwc_bwd_kernel(const T* __restrict
     }
 }
 
+// The coarse half of the same adjoint (whole frames: no slab rows) with the adjoint of the bias + activation pass that
+// PRODUCED the coarse map behind it (a convolution chain's activated output that only the upsampling reads): gcoarse =
+// gather * act'(z) from the producer's sign words, the bias gradient's per-workgroup partial sums, max |gcoarse|.
+// 256 threads = (256 / cu4) lanes of coarse pixels x cu4 channel quads; cu4 divides 256.
+__global__ __launch_bounds__(256) void upcat_nhwc_bwd_adj_kernel(const float* __restrict__ gout, float* __restrict__ gcoarse,
+                                                                const unsigned* __restrict__ signs, float slope,
+                                                                float* __restrict__ partial, unsigned* __restrict__ amax,
+                                                                int cu4, int cl4, int hc, int w, size_t pixels) {
+    __shared__ float4 red[256];
+    unsigned m = 0;
+    const int W = 2 * w, H = 2 * hc, ct4 = cu4 + cl4;
+    const int q = threadIdx.x % cu4, pl = threadIdx.x / cu4, npl = 256 / cu4;
+    const size_t per = (pixels + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per;
+    const size_t p1 = p0 + per < pixels ? p0 + per : pixels;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t px = p0 + pl; px < p1; px += npl) {
+        const int j = (int)(px % w);
+        const size_t rest = px / w;
+        const int i = (int)(rest % hc);
+        const size_t b = rest / hc;
+        float wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wx[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+        if (i == 0) { wy[0] = 0.f; wy[1] = 1.f; }
+        if (i == hc - 1) { wy[3] = 0.f; wy[2] = 1.f; }
+        if (j == 0) { wx[0] = 0.f; wx[1] = 1.f; }
+        if (j == w - 1) { wx[3] = 0.f; wx[2] = 1.f; }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t g = (b * H) * (size_t)W * ct4 + q;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            if (wy[dy] == 0.f) continue;
+            const int yy = 2 * i - 1 + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                if (wx[dx] == 0.f) continue;
+                const int xx = 2 * j - 1 + dx;
+                const float4 v = Quad<float>::load(gout, g + ((size_t)yy * W + xx) * ct4);
+                const float wt = wy[dy] * wx[dx];
+                acc.x += wt * v.x; acc.y += wt * v.y; acc.z += wt * v.z; acc.w += wt * v.w;
+            }
+        }
+        const size_t e4 = px * cu4 + q;
+        const unsigned bits = signs[e4 >> 3] >> (4 * (unsigned)(e4 & 7));
+        acc.x = (bits & 1u) ? acc.x : acc.x * slope; acc.y = (bits & 2u) ? acc.y : acc.y * slope;
+        acc.z = (bits & 4u) ? acc.z : acc.z * slope; acc.w = (bits & 8u) ? acc.w : acc.w * slope;
+        Quad<float>::store(gcoarse, e4, acc);
+        sum.x += acc.x; sum.y += acc.y; sum.z += acc.z; sum.w += acc.w;
+        m = amax4(m, acc);
+    }
+    amax_publish(m, amax);
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    if (pl == 0) {
+        for (int k = 1; k < npl; ++k) {
+            const float4 o = red[k * cu4 + q];
+            sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+        }
+        reinterpret_cast<float4*>(partial)[(size_t)blockIdx.x * cu4 + q] = sum;
+    }
+}
+
 // 2 x 2 / stride 2 max-pooling of a channels-last map (the U-nets' `pooling="max"`, reference sbmc/modules.py:262-263,
 // 300-302) and its adjoint FUSED with the addition of the skip connection's gradient: the pooled map's input also feeds
 // the up path's concatenation, so autograd ran max_pool_backward, wrote a full-size gradient, and added the skip's to it
@@ -286,6 +348,60 @@ __global__ __launch_bounds__(256) void maxpool2_nhwc_bwd_add_kernel(const T* __r
             o.x += kx == k ? g.x : 0.f; o.y += ky == k ? g.y : 0.f; o.z += kz == k ? g.z : 0.f; o.w += kw == k ? g.w : 0.f;
             Quad<T>::store(gx, at[k], o);
         }
+    }
+}
+
+// The same routing with the adjoint of the bias + activation pass that PRODUCED x behind it (x is a convolution chain's
+// activated output and this node its only reader: functions.PoolSkip with an `_AdjLink`): gx = (gskip + routed gpool) *
+// act'(z) from the producer's sign words, per-workgroup partial sums of gx per channel (the bias gradient) and max |gx| --
+// what bias_act_nhwc_bwd_kernel<true> would do in a pass of its own over the map just written.
+// 256 threads = (256 / c4n) lanes of POOLED pixels x c4n channel quads; c4n divides 256.
+__global__ __launch_bounds__(256) void maxpool2_nhwc_bwd_add_adj_kernel(const float* __restrict__ x, const float* __restrict__ gpool,
+                                                                       const float* __restrict__ gskip, float* __restrict__ gx,
+                                                                       const unsigned* __restrict__ signs, float slope,
+                                                                       float* __restrict__ partial, unsigned* __restrict__ amax,
+                                                                       int c4n, int hc, int wc, size_t ppixels) {
+    __shared__ float4 red[256];
+    unsigned m = 0;
+    const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n, npl = 256 / c4n;
+    const size_t per = (ppixels + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per;
+    const size_t p1 = p0 + per < ppixels ? p0 + per : ppixels;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t pp = p0 + pl; pp < p1; pp += npl) {
+        const int j = (int)(pp % wc);
+        size_t rest = pp / wc;
+        const int i = (int)(rest % hc);
+        const size_t b = rest / hc;
+        const size_t f = ((b * 2 * hc + 2 * i) * (size_t)(2 * wc) + 2 * j) * c4n + cq;
+        const size_t row = (size_t)(2 * wc) * c4n;
+        const size_t at[4] = {f, f + c4n, f + row, f + row + c4n};
+        const float4 a = Quad<float>::load(x, at[0]), bq = Quad<float>::load(x, at[1]), c = Quad<float>::load(x, at[2]),
+                     d = Quad<float>::load(x, at[3]);
+        const float4 g = Quad<float>::load(gpool, pp * c4n + cq);
+        const int kx = first_max4(a.x, bq.x, c.x, d.x), ky = first_max4(a.y, bq.y, c.y, d.y);
+        const int kz = first_max4(a.z, bq.z, c.z, d.z), kw = first_max4(a.w, bq.w, c.w, d.w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 o = gskip ? Quad<float>::load(gskip, at[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            o.x += kx == k ? g.x : 0.f; o.y += ky == k ? g.y : 0.f; o.z += kz == k ? g.z : 0.f; o.w += kw == k ? g.w : 0.f;
+            const unsigned bits = signs[at[k] >> 3] >> (4 * (unsigned)(at[k] & 7));
+            o.x = (bits & 1u) ? o.x : o.x * slope; o.y = (bits & 2u) ? o.y : o.y * slope;
+            o.z = (bits & 4u) ? o.z : o.z * slope; o.w = (bits & 8u) ? o.w : o.w * slope;
+            Quad<float>::store(gx, at[k], o);
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+            m = amax4(m, o);
+        }
+    }
+    amax_publish(m, amax);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (pl == 0) {
+        for (int j = 1; j < npl; ++j) {
+            const float4 o = red[j * c4n + cq];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        reinterpret_cast<float4*>(partial)[(size_t)blockIdx.x * c4n + cq] = acc;
     }
 }
 
@@ -508,6 +624,27 @@ static int upcat_nhwc_bwd_impl(const T* gout, T* gcoarse, T* gleft, int b, int c
     return (int)hipGetLastError();
 }
 
+// (ABI 7) the whole frame's adjoint with the activation adjoint of the layer that produced the coarse map in the same
+// pass over gcoarse: gcoarse = gather(gout) * (z > 0 ? 1 : slope), partial [sbmc_bias_act_nhwc_chunks(b h w, cu)][cu], *amax
+// raised to max |gcoarse|; gleft (or NULL) as sbmc_upsample2x_cat_nhwc_bwd_f32.  cu as sbmc_bias_act_nhwc_supported.
+extern "C" int sbmc_upsample2x_cat_nhwc_bwd_adj_f32(const float* gout, float* gcoarse, float* gleft, const unsigned* signs,
+                                                    float slope, float* partial, unsigned* amax, int b, int cu, int cl,
+                                                    int h, int w, void* stream) {
+    if (b < 0 || !sbmc_upsample2x_cat_nhwc_supported(cu, cl, h, w) || !sbmc_bias_act_nhwc_supported(cu)) return SBMC_HIP_EINVAL;
+    if (b == 0) return 0;
+    if (!gout || !gcoarse || !signs || !partial || !amax || (uintptr_t)gout % 16 || (uintptr_t)gcoarse % 16 ||
+        (uintptr_t)gleft % 16 || (uintptr_t)signs % 4 || (uintptr_t)partial % 16) return SBMC_HIP_EINVAL;
+    const size_t pixels = (size_t)b * h * w;
+    hipLaunchKernelGGL(upcat_nhwc_bwd_adj_kernel, dim3((unsigned)sbmc_bias_act_nhwc_chunks((long)pixels, cu)), dim3(256), 0,
+                       (hipStream_t)stream, gout, gcoarse, signs, slope, partial, amax, cu / 4, cl / 4, h, w, pixels);
+    const int err = (int)hipGetLastError();
+    if (err || !gleft || cl == 0) return err;
+    const size_t total4 = (size_t)b * (2 * (size_t)h) * (2 * (size_t)w) * (cl / 4);
+    hipLaunchKernelGGL((slice_channels_nhwc_kernel<float>), dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, gout,
+                       gleft, (cu + cl) / 4, cu / 4, cl / 4, total4);
+    return (int)hipGetLastError();
+}
+
 extern "C" int sbmc_upsample2x_cat_nhwc_fwd_f32(const float* coarse, const float* left, float* out, int b, int cu,
                                                 int cl, int h, int w, void* stream) {
     return upcat_nhwc_fwd_impl(coarse, left, out, b, cu, cl, h, w, 0, 0, stream);
@@ -600,6 +737,23 @@ extern "C" int sbmc_maxpool2_nhwc_bwd_add(const void* x, const void* gpool, cons
         hipLaunchKernelGGL(maxpool2_nhwc_bwd_add_kernel<_Float16>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream,
                            static_cast<const _Float16*>(x), static_cast<const _Float16*>(gpool),
                            static_cast<const _Float16*>(gskip), static_cast<_Float16*>(gx), c / 4, hc, wc, total4);
+    return (int)hipGetLastError();
+}
+
+// ... fp32, with the adjoint of the bias + activation pass that produced x in the same pass (ABI 7): gx = (gskip + routed
+// gpool) * (z > 0 ? 1 : slope) from the producer's sign words (one bit per element of x, as sbmc_conv3x3_bias_act_nhwc_f32
+// leaves them), partial [sbmc_bias_act_nhwc_chunks(b hc wc, c)][c]: the bias gradient's partial sums, *amax raised to max |gx|
+extern "C" int sbmc_maxpool2_nhwc_bwd_add_adj_f32(const float* x, const float* gpool, const float* gskip, float* gx,
+                                                  const unsigned* signs, float slope, float* partial, unsigned* amax, int b,
+                                                  int hc, int wc, int c, void* stream) {
+    if (b < 0 || hc < 0 || wc < 0 || c < 0) return SBMC_HIP_EINVAL;
+    if (b == 0 || hc == 0 || wc == 0 || c == 0) return 0;
+    if (!x || !gpool || !gx || !signs || !partial || !amax || !sbmc_bias_act_nhwc_supported(c) || (uintptr_t)x % 16 ||
+        (uintptr_t)gpool % 16 || (uintptr_t)gskip % 16 || (uintptr_t)gx % 16 || (uintptr_t)signs % 4 || (uintptr_t)partial % 16)
+        return SBMC_HIP_EINVAL;
+    const size_t ppixels = (size_t)b * hc * wc;
+    hipLaunchKernelGGL(maxpool2_nhwc_bwd_add_adj_kernel, dim3((unsigned)sbmc_bias_act_nhwc_chunks((long)ppixels, c)), dim3(256), 0,
+                       (hipStream_t)stream, x, gpool, gskip, gx, signs, slope, partial, amax, c / 4, hc, wc, ppixels);
     return (int)hipGetLastError();
 }
 

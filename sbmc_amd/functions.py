@@ -880,8 +880,17 @@ class PoolSkip(th.autograd.Function):
                 and knob("SBMC_POOL_SKIP") != 0)
 
     @staticmethod
-    def forward(ctx, left):
+    def forward(ctx, left, adj_in=None):
+        """adj_in: the `_AdjLink` of the convolution that produced `left`, whose only reader this node then is
+        (Conv3x3BiasActNHWC.forward, want_link): the backward pass applies that layer's activation adjoint, sums its bias
+        gradient and leaves the gradient's magnitude word -- the `bias_act_nhwc_bwd` pass over the map it has just written."""
         b, c, h, w = left.shape
+        ctx.adj_in = None
+        if (adj_in is not None and left.dtype == th.float32 and ctx.needs_input_grad[0] and not adj_in.taken
+                and tuple(left.shape) == adj_in.shape and left.data_ptr() == adj_in.ptr
+                and _lib.lib().sbmc_bias_act_nhwc_supported(c)):
+            ctx.adj_in = adj_in
+            adj_in.taken = True
         pooled = th.empty((b, c, h // 2, w // 2), dtype=left.dtype, device=left.device, memory_format=th.channels_last)
         dev = left.device
         with th.cuda.device(dev):
@@ -896,19 +905,33 @@ class PoolSkip(th.autograd.Function):
     @staticmethod
     def backward(ctx, g_pooled, g_skip):
         (left,) = ctx.saved_tensors
-        if g_pooled is None:
-            return g_skip
+        adj = ctx.adj_in
+        if g_pooled is None and adj is None:
+            return g_skip, None
         b, c, h, w = left.shape
+        L = _lib.lib()
+        if g_pooled is None:
+            g_pooled = left.new_zeros((b, c, h // 2, w // 2)).contiguous(memory_format=th.channels_last)
         g_pooled = g_pooled.to(left.dtype).contiguous(memory_format=th.channels_last)
         if g_skip is not None:
             g_skip = g_skip.to(left.dtype).contiguous(memory_format=th.channels_last)
         gx = th.empty_like(left, memory_format=th.channels_last)
         dev = left.device
         with th.cuda.device(dev):
-            _lib.check(_lib.lib().sbmc_maxpool2_nhwc_bwd_add(_lib.ptr(left), _lib.ptr(g_pooled), _lib.ptr(g_skip), _lib.ptr(gx),
-                                                             b, h // 2, w // 2, c, left.element_size(),
-                                                             _lib.current_stream(dev)), "maxpool2_nhwc_bwd_add")
-        return gx
+            if adj is not None:
+                partial = left.new_empty(L.sbmc_bias_act_nhwc_chunks(b * (h // 2) * (w // 2), c), c)
+                amax = amax_word(dev)
+                _lib.check(L.sbmc_maxpool2_nhwc_bwd_add_adj_f32(_lib.ptr(left), _lib.ptr(g_pooled), _lib.ptr(g_skip), _lib.ptr(gx),
+                                                                _lib.ptr(adj.signs), adj.slope, _lib.ptr(partial), _lib.ptr(amax),
+                                                                b, h // 2, w // 2, c, _lib.current_stream(dev)),
+                           "maxpool2_nhwc_bwd_add_adj")
+                tag_amax(gx, amax)
+                adj.done = (partial, amax, gx.data_ptr())
+            else:
+                _lib.check(L.sbmc_maxpool2_nhwc_bwd_add(_lib.ptr(left), _lib.ptr(g_pooled), _lib.ptr(g_skip), _lib.ptr(gx),
+                                                        b, h // 2, w // 2, c, left.element_size(),
+                                                        _lib.current_stream(dev)), "maxpool2_nhwc_bwd_add")
+        return gx, None
 
 
 class ContextProductNHWC(th.autograd.Function):
@@ -1539,10 +1562,19 @@ class UpsampleCatNHWC(th.autograd.Function):
     top, bot: row-slab form, as for `UpsampleCat`."""
 
     @staticmethod
-    def forward(ctx, coarse, left, top=0, bot=0):
+    def forward(ctx, coarse, left, top=0, bot=0, adj_in=None):
+        """adj_in: the `_AdjLink` of the convolution that produced `coarse`, whose only reader this node then is: the
+        backward pass applies that layer's activation adjoint to the coarse map's gradient as it writes it (whole frames,
+        fp32)."""
         if not (coarse.is_cuda and coarse.dtype in (th.float32, th.float16) and left.dtype == coarse.dtype):
             raise TypeError("UpsampleCatNHWC: float32 or float16 GPU tensors of one dtype expected")
         b, cu, hc, w = coarse.shape
+        ctx.adj_in = None
+        if (adj_in is not None and coarse.dtype == th.float32 and top == 0 and bot == 0 and ctx.needs_input_grad[0]
+                and not adj_in.taken and tuple(coarse.shape) == adj_in.shape and coarse.data_ptr() == adj_in.ptr
+                and _lib.lib().sbmc_bias_act_nhwc_supported(cu)):
+            ctx.adj_in = adj_in
+            adj_in.taken = True
         cl = left.shape[1]
         h = hc - top - bot
         out = th.empty(b, cu + cl, 2 * h, 2 * w, dtype=coarse.dtype, device=coarse.device,
@@ -1571,11 +1603,21 @@ class UpsampleCatNHWC(th.autograd.Function):
             dev = g.device
             L = _lib.lib()
             bwd = L.sbmc_upsample2x_cat_nhwc_slab_bwd_f16 if g.dtype == th.float16 else L.sbmc_upsample2x_cat_nhwc_slab_bwd_f32
+            adj = ctx.adj_in if (gcoarse is not None and g.dtype == th.float32) else None
             with th.cuda.device(dev):
-                rc = bwd(_lib.ptr(g), _lib.ptr(gcoarse), _lib.ptr(gleft), b, cu, cl, hc, w, top, bot,
-                         _lib.current_stream(dev))
+                if adj is not None:
+                    partial = g.new_empty(L.sbmc_bias_act_nhwc_chunks(b * hc * w, cu), cu)
+                    amax = amax_word(dev)
+                    rc = L.sbmc_upsample2x_cat_nhwc_bwd_adj_f32(_lib.ptr(g), _lib.ptr(gcoarse), _lib.ptr(gleft), _lib.ptr(adj.signs),
+                                                                adj.slope, _lib.ptr(partial), _lib.ptr(amax), b, cu, cl, hc, w,
+                                                                _lib.current_stream(dev))
+                    tag_amax(gcoarse, amax)
+                    adj.done = (partial, amax, gcoarse.data_ptr())
+                else:
+                    rc = bwd(_lib.ptr(g), _lib.ptr(gcoarse), _lib.ptr(gleft), b, cu, cl, hc, w, top, bot,
+                             _lib.current_stream(dev))
             _lib.check(rc, "upsample2x_cat_nhwc_bwd")
-        return gcoarse, gleft, None, None
+        return gcoarse, gleft, None, None, None
 
 
 def gather_update_supported(data, kernels):

@@ -341,8 +341,11 @@ class ConvChain(nn.Module):
     #: bias-gradient reduction; set per instance by Multisteps for its U-nets.
     fuse_bias_act = False
 
-    def forward(self, x):
-        return self._run(list(self.children()), x)
+    def forward(self, x, want_link=False):
+        """want_link: the caller is the ONLY reader of the result and takes the chain's last layer's `_AdjLink`
+        (functions.Conv3x3BiasActNHWC.adj_link_for) -- a U-net level whose pooling + skip node applies that layer's
+        activation adjoint in its own backward pass."""
+        return self._run(list(self.children()), x, want_link=want_link)
 
     @staticmethod
     def _conv_bias_act(conv, x, activation, adj_in=None, want_link=False):
@@ -390,7 +393,7 @@ class ConvChain(nn.Module):
             return y + conv.bias.view(1, -1, 1, 1), False
         return funcs.BiasAct.apply(y, conv.bias, act, slope), act != 0
 
-    def _run(self, mods, x, mean_s=0, mean_out=None, halo=None):
+    def _run(self, mods, x, mean_s=0, mean_out=None, halo=None, want_link=False):
         """halo: the chain runs on a row slab of a frame sharded over several GPUs (sbmc_amd.dist) -- a tuple
         (pad, crop[, refresh]): before every padded k x k convolution `pad(x, k // 2)` attaches the neighbouring
         slabs' k // 2 edge rows, and `crop(y, k // 2)` drops the rows of its result that saw the artificial zero
@@ -444,7 +447,9 @@ class ConvChain(nn.Module):
                 link = funcs.Conv3x3BiasActNHWC.adj_link_for(x) if (y is not None and fused) else None
             elif self.fuse_bias_act and x.is_cuda and x.dtype in (th.float32, th.float16) and isinstance(m, nn.Conv2d):
                 nxt = mods[i] if i < len(mods) else None
-                y, fused = ConvChain._conv_bias_act(m, x, nxt, link_in)      # (the chain's last layer: nothing behind it)
+                # (the chain's last layer: what is behind it is the caller's business)
+                y, fused = ConvChain._conv_bias_act(m, x, nxt, link_in, want_link and halo is None
+                                                    and i + (1 if nxt is not None else 0) >= len(mods))
                 if y is None:
                     x = m(x)
                 else:
@@ -571,30 +576,34 @@ class Autoencoder(nn.Module):
             self.next_level = next_level
             self.right = ConvChain(num_us + width, num_outputs, output_type=output_type, **common)
 
-        def forward(self, x):
-            left = self.left(x)
+        def forward(self, x, want_link=False):
+            """want_link: the caller (the level above) is the only reader of the result and takes the `_AdjLink` of this
+            level's last convolution (ConvChain.forward)."""
             if self.is_last:
-                return left
+                return self.left(x, want_link=want_link)
+            left = self.left(x, want_link=isinstance(self.downsample, nn.MaxPool2d))
             if funcs.PoolSkip.supported(left, self.downsample):
-                # down path and skip connection as one autograd node: their gradients meet in ONE pass
+                # down path and skip connection as one autograd node: their gradients meet in ONE pass -- which is also
+                # the adjoint pass of the chain's last activation where that layer left a link
                 known = funcs.known_amax(left)
-                pooled, left = funcs.PoolSkip.apply(left)
+                pooled, left = funcs.PoolSkip.apply(left, funcs.Conv3x3BiasActNHWC.adj_link_for(left))
                 if known is not None:
                     funcs.tag_amax(left, known)
             else:
                 pooled = self.downsample(left)
             if isinstance(self.downsample, (nn.MaxPool2d, nn.AvgPool2d)) and funcs.known_amax(left) is not None:
                 funcs.tag_amax(pooled, funcs.known_amax(left))        # pooling grows no magnitude
-            coarse = self.next_level(pooled)
+            coarse = self.next_level(pooled, want_link=True)
             if funcs.upsample_cat_nhwc_supported(coarse, left):
-                cat = funcs.UpsampleCatNHWC.apply(coarse, left)
+                # (the upsampling's backward pass is also the adjoint pass of the coarser level's last activation)
+                cat = funcs.UpsampleCatNHWC.apply(coarse, left, 0, 0, funcs.Conv3x3BiasActNHWC.adj_link_for(coarse))
                 bound = funcs.bound_amax(funcs.known_amax(coarse), funcs.known_amax(left))
-                return self.right(cat if bound is None else funcs.tag_amax(cat, bound))
+                return self.right(cat if bound is None else funcs.tag_amax(cat, bound), want_link=want_link)
             if funcs.upsample_cat_supported(coarse, left):
-                return self.right(funcs.UpsampleCat.apply(coarse, left))   # one pass, same values
+                return self.right(funcs.UpsampleCat.apply(coarse, left), want_link=want_link)   # one pass, same values
             up = F.interpolate(coarse, size=left.shape[-2:], mode="bilinear",
                                align_corners=False)
-            return self.right(th.cat([up, left], 1))
+            return self.right(th.cat([up, left], 1), want_link=want_link)
 
 
 def _ksize_of(kernels):

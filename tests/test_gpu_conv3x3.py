@@ -430,4 +430,67 @@ def test_unet_chains_with_and_without_the_fused_adjoint(monkeypatch):
         assert name.endswith("bias"), name
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item(), name
         differing += 1
-    assert differing <= 10
+    assert differing <= 14            # (+ two pooling + skip nodes and two upsamplings that apply the adjoint of the chain before them)
+
+
+@pytest.mark.parametrize("b,c0,c1,h,w", [(1, 128, 128, 36, 52), (2, 128, 256, 16, 32), (1, 256, 512, 6, 10)])
+def test_pool_skip_applies_the_adjoint_of_the_chain_before_it(b, c0, c1, h, w):
+    """A U-net level's pooling + skip node behind a chain's last convolution: with the link its backward pass is also
+    that layer's `bias_act_nhwc_bwd` pass (sbmc_maxpool2_nhwc_bwd_add_adj_f32) -- same gradients to the bit, the bias gradient
+    up to the order of its partial sums."""
+    dev = _dev()
+    g = th.Generator(device="cpu").manual_seed(b + c1 + h)
+    x = _cl(th.randn(b, c0, h, w, generator=g).to(dev))
+    wt = (th.randn(c1, c0, 3, 3, generator=g) * (2.0 / (9 * c0)) ** 0.5).to(dev)
+    bias = (th.randn(c1, generator=g) * 0.3).to(dev)
+    gp = _cl(th.randn(b, c1, h // 2, w // 2, generator=g).to(dev))
+    gs = _cl(th.randn(b, c1, h, w, generator=g).to(dev))
+
+    def run(linked):
+        leaves = [t.clone().requires_grad_(True) for t in (x, wt, bias)]
+        y, amax = funcs.Conv3x3BiasActNHWC.apply(leaves[0], leaves[1], leaves[2], 2, 0.01, None, linked)
+        funcs.tag_amax(y, amax)
+        link = funcs.Conv3x3BiasActNHWC.adj_link_for(y)
+        assert (link is not None) == linked
+        pooled, skip = funcs.PoolSkip.apply(y, link)
+        out = th.autograd.grad((pooled, skip), leaves, (gp, gs))
+        assert link is None or (link.taken and link.done is None)
+        return (pooled.detach().clone(),) + out
+
+    plain, linked = run(False), run(True)
+    for name, a, c in zip(("pooled", "gx", "gw", "gb"), plain, linked):
+        if name == "gb":
+            assert (a - c).abs().max().item() <= 1e-5 * a.abs().max().item()
+        else:
+            assert th.equal(a, c), name
+
+
+@pytest.mark.parametrize("b,c0,cu,cl,h,w", [(1, 128, 256, 128, 18, 26), (2, 256, 512, 256, 6, 10), (1, 128, 128, 128, 1, 1)])
+def test_upsampling_applies_the_adjoint_of_the_chain_before_it(b, c0, cu, cl, h, w):
+    """The bilinear x2 + concatenation behind a coarser level's last convolution: with the link the coarse map's gradient
+    comes out of the upsampling's backward pass with that layer's activation adjoint applied
+    (sbmc_upsample2x_cat_nhwc_bwd_adj_f32) -- same gradients to the bit, the bias gradient up to its partial sums' order."""
+    dev = _dev()
+    g = th.Generator(device="cpu").manual_seed(b + cu + h)
+    x = _cl(th.randn(b, c0, h, w, generator=g).to(dev))
+    wt = (th.randn(cu, c0, 3, 3, generator=g) * (2.0 / (9 * c0)) ** 0.5).to(dev)
+    bias = (th.randn(cu, generator=g) * 0.3).to(dev)
+    left = _cl(th.randn(b, cl, 2 * h, 2 * w, generator=g).to(dev))
+    gout = _cl(th.randn(b, cu + cl, 2 * h, 2 * w, generator=g).to(dev))
+
+    def run(linked):
+        leaves = [t.clone().requires_grad_(True) for t in (x, wt, bias, left)]
+        y, amax = funcs.Conv3x3BiasActNHWC.apply(leaves[0], leaves[1], leaves[2], 2, 0.01, None, linked)
+        funcs.tag_amax(y, amax)
+        link = funcs.Conv3x3BiasActNHWC.adj_link_for(y)
+        cat = funcs.UpsampleCatNHWC.apply(y, leaves[3], 0, 0, link)
+        out = th.autograd.grad(cat, leaves, gout)
+        assert link is None or (link.taken and link.done is None)
+        return (cat.detach().clone(),) + out
+
+    plain, linked = run(False), run(True)
+    for name, a, c in zip(("cat", "gx", "gw", "gb", "gleft"), plain, linked):
+        if name == "gb":
+            assert (a - c).abs().max().item() <= 1e-5 * a.abs().max().item()
+        else:
+            assert th.equal(a, c), name
