@@ -434,24 +434,31 @@ def main():
             dist.barrier()
             th.cuda.synchronize(device)
 
-    def timed(step_fn, nwarm, nsteps, store=None, events_inside=True):
+    def timed(step_fn, nwarm, nsteps, store=None, events_inside=True, inside=None):
         """Wall time of `nsteps` steps.  `store` collects (name, start, end) HIP-event triples of the
         fused operators: inside the timed steps when `events_inside`, else in two extra, untimed
         steps: with ~50 event pairs per step switched on at the start of the 3 timed model steps they
         read 579 instead of 554 ms per step (not so when the events are already on during the warm-up,
         nor in the splat workload -- a start-up effect, not isolated further), which must not leak
-        into the model workload's `value`."""
+        into the model workload's `value`.  `inside` = (list, name prefixes): with `events_inside` off, the operators of
+        these names (the splat kernels: two event pairs per step) are timed INSIDE the timed steps all the same -- into
+        that list, warm-up steps included so that nothing switches on at the start of the timed region."""
         if os.environ.get("SBMC_BENCH_EVENTS_OUTSIDE"):   # debugging aid: never any event in a timed step
             events_inside = False
+        if inside is not None and not events_inside:
+            functions.enable_kernel_timing(inside[0], inside[1])
         for _ in range(nwarm):
             step_fn()
         sync()
+        if inside is not None:
+            del inside[0][:]                               # (the warm-up steps' launches)
         # as interfaces.train does after its first step: what is alive now stays alive, keep the
         # cyclic collector from walking it (a full collection costs ~50 ms of host time here and
         # lands right after a step's loss.item() sync, where the GPU waits for the host)
         gc.collect()
         gc.freeze()
-        functions.enable_kernel_timing(store if events_inside else None)
+        if events_inside or inside is None:
+            functions.enable_kernel_timing(store if events_inside else None)
         marks = [th.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]   # one per step boundary
         stream = th.cuda.current_stream(device)
         t0 = time.perf_counter()
@@ -487,6 +494,7 @@ def main():
     part = sdist.SlabPartition(H, world, rank)
     timings = []
     model_timings = []
+    in_step = []          # the splat operators' launches INSIDE the training step's timed region (N = 1)
     validation = None
 
     # ---------------------------------------------------------------- main timed region
@@ -531,7 +539,8 @@ def main():
                     # (raised on every rank together; the ranks have left the IPC transport: the step is repeated
                     # over torch.distributed P2P and the line says so in `transport` / `transport_note`)
                     runner.train_step(opt, loss_fn, batch)
-        dt = timed(step, warmup, steps, timings if world == 1 else None, events_inside=False)
+        dt = timed(step, warmup, steps, timings if world == 1 else None, events_inside=False,
+                   inside=(in_step, ("splat_update_",)) if (world == 1 and not infer) else None)
         med_s, spread = timed.median, timed.spread
         model_timings = timings
         if world > 1:
@@ -664,6 +673,9 @@ def main():
     if is_model and not infer and world == 1 and not args.no_stages:
         del model, opt
         th.cuda.empty_cache()
+        if os.environ.get("SBMC_BENCH_SPLAT_COOLDOWN"):      # measurement aid: seconds of idle device before the splat stages
+            sync()
+            time.sleep(float(os.environ["SBMC_BENCH_SPLAT_COOLDOWN"]))
         timings = []
         update = modules.ProgressiveKernelApply(splat=True)
         rad, logits, d_out = make_splat_inputs(H, W, S, K, device, seed=1234)
@@ -721,10 +733,31 @@ def main():
                                  ("splat_update_fwd_all", fwd_bytes_per_pixel(K), S),
                                  ("splat_update_bwd_all", bwd_bytes_per_pixel(K), S)):
             if name in per:
+                if os.environ.get("SBMC_BENCH_DUMP_KERNELS"):          # measurement aid: every launch's time
+                    print(name, " ".join("%.3f" % t for t in per[name]), file=sys.stderr, flush=True)
                 avg_ms = sum(per[name]) / len(per[name])
                 kern[name] = {"calls": len(per[name]), "samples_per_launch": nsamp,
                               "avg_ms": round(avg_ms, 4), "alg_bytes": local_px * bpp * nsamp,
                               "GBps": round(local_px * bpp * nsamp / (avg_ms * 1e-3) / 1e9, 1)}
+
+    # the same two operators INSIDE the training step's timed region (every timed step; the tensors are the step's own:
+    # allocated once at the start of the process.  The isolated stages above run on 13 GB tensors allocated after the
+    # model's memory went back to the driver, and their 8-sample launches read 4.4 or 5.0-5.4 ms from run to run on
+    # the same box -- every launch of a run alike: where the pages land, not the kernel, profiles/HISTORY.md)
+    kern_step = {}
+    per_s = {}
+    for name, a, b in in_step:
+        per_s.setdefault(name, []).append(a.elapsed_time(b))
+    for name, bpp in (("splat_update_fwd_all", fwd_bytes_per_pixel(K)), ("splat_update_bwd_all", bwd_bytes_per_pixel(K))):
+        if name in per_s:
+            if os.environ.get("SBMC_BENCH_DUMP_KERNELS"):
+                print("in step:", name, " ".join("%.3f" % t for t in per_s[name]), file=sys.stderr, flush=True)
+            avg_ms = sum(per_s[name]) / len(per_s[name])
+            kern_step[name] = {"calls": len(per_s[name]), "samples_per_launch": S, "avg_ms": round(avg_ms, 4),
+                               "alg_bytes": local_px * bpp * S,
+                               "GBps": round(local_px * bpp * S / (avg_ms * 1e-3) / 1e9, 1),
+                               "where": "inside the timed steps of the training step (HIP events on the launch stream "
+                                        "around the operator call, every timed step)"}
 
     # the fused 1x1-convolution layers (fp32 MFMA kernels), from two instrumented steps after the timed ones
     layers = {}
@@ -831,6 +864,8 @@ def main():
                 res["stages"]["splat_all_samples_fp16_storage"] = stage_f16
         if kern:
             res["kernels"] = kern
+        if kern_step:
+            res["kernels_in_step"] = kern_step
         if layers:
             res["pointwise_layers"] = layers
         if convs:
@@ -846,8 +881,10 @@ def main():
                         "the fp32 matrix pipe is bounded by %d TFLOP/s" % int(FP32_MFMA_PEAK_TFLOPS),
                 "ms_per_step": round(tot_ms, 2)}
         rk = "splat_update_bwd_all" if "splat_update_bwd_all" in kern else "splat_update_bwd"
-        if rk in kern:
-            kb = kern[rk]
+        if "splat_update_bwd_all" in kern_step:       # the training step's own launches, inside its timed region
+            rk = "splat_update_bwd_all"
+        if rk in kern or rk in kern_step:
+            kb = kern_step[rk] if rk in kern_step else kern[rk]
             traffic, src, tnote = (None, None, "PMC passes exist for 1280x720, k = 21 on one GPU only")
             if (H, W, K) == (720, 1280, 21) and world == 1:   # the PMC summary was taken at this size
                 traffic, src, tnote = measured_traffic(("splat_bwd_strip_kernel",))
@@ -869,7 +906,15 @@ def main():
                 "traffic_over_algorithmic": None if traffic is None else round(traffic / kb["alg_bytes"], 3),
                 "alg_bytes_per_launch": kb["alg_bytes"],
                 "avg_launch_ms": kb["avg_ms"],
+                "launches": kb["calls"],
+                "timed": kb.get("where", "the splat-only stage of this run (HIP events on the launch stream around the "
+                                         "operator call, every timed step of that stage)"),
             }
+            if rk in kern_step and rk in kern:
+                # the same launch in the splat-only stage of this run (its tensors: allocated after the model's memory was freed)
+                res["roofline"]["isolated_stage"] = {"avg_launch_ms": kern[rk]["avg_ms"], "achieved": kern[rk]["GBps"],
+                                                     "frac": round(kern[rk]["GBps"] / HBM_PEAK_GBPS, 4),
+                                                     "launches": kern[rk]["calls"]}
             if "splat_update_bwd" in kern and rk != "splat_update_bwd":
                 # the same kernel launched per sample (the reference's module API, `stages.splat`): shorter launches
                 # reach a lower rate -- ramp-up and tail of a 0.65 ms launch against a 4.5 ms one
@@ -877,8 +922,10 @@ def main():
                 res["roofline"]["one_sample_launches"] = {"avg_launch_ms": k1["avg_ms"], "achieved": k1["GBps"],
                                                           "frac": round(k1["GBps"] / HBM_PEAK_GBPS, 4)}
         fk = "splat_update_fwd_all" if "splat_update_fwd_all" in kern else "splat_update_fwd"
-        if fk in kern and "roofline" in res:
-            kf = kern[fk]
+        if "splat_update_fwd_all" in kern_step:
+            fk = "splat_update_fwd_all"
+        if (fk in kern or fk in kern_step) and "roofline" in res:
+            kf = kern_step[fk] if fk in kern_step else kern[fk]
             ftraffic, fsrc, fnote = (None, None, "PMC passes exist for 1280x720, k = 21 on one GPU only")
             if (H, W, K) == (720, 1280, 21) and world == 1:
                 ftraffic, fsrc, fnote = measured_traffic(("splat_fwd_strip_kernel",))
@@ -893,8 +940,13 @@ def main():
                 "traffic_source": None if ftraffic is None else "profiles/" + fsrc + ": per 1-sample launch x samples per "
                                   "launch; tools/prof.sh",
                 "traffic_over_algorithmic": None if ftraffic is None else round(ftraffic / kf["alg_bytes"], 3),
-                "alg_bytes_per_launch": kf["alg_bytes"], "avg_launch_ms": kf["avg_ms"],
+                "alg_bytes_per_launch": kf["alg_bytes"], "avg_launch_ms": kf["avg_ms"], "launches": kf["calls"],
+                "timed": kf.get("where", "the splat-only stage of this run"),
             }
+            if fk in kern_step and fk in kern:
+                res["roofline_fwd"]["isolated_stage"] = {"avg_launch_ms": kern[fk]["avg_ms"], "achieved": kern[fk]["GBps"],
+                                                         "frac": round(kern[fk]["GBps"] / HBM_PEAK_GBPS, 4),
+                                                         "launches": kern[fk]["calls"]}
             if "splat_update_fwd" in kern and fk != "splat_update_fwd":
                 k1 = kern["splat_update_fwd"]
                 res["roofline_fwd"]["one_sample_launches"] = {"avg_launch_ms": k1["avg_ms"], "achieved": k1["GBps"],

@@ -23,28 +23,36 @@ __all__ = ["Scatter2Gather", "KernelWeighting", "SplatUpdate", "splat_update_sup
 # is installed, every fused call appends (name, start_event, end_event), recorded on the
 # stream the kernels are launched on (torch's current stream).
 _KERNEL_TIMINGS = None
+_KERNEL_TIMINGS_ONLY = None
 
 
-def enable_kernel_timing(store):
-    """store: a list to append (name, start, end) event triples to, or None to disable."""
-    global _KERNEL_TIMINGS
+def enable_kernel_timing(store, only=None):
+    """store: a list to append (name, start, end) event triples to, or None to disable.  only: a tuple of name
+    prefixes -- calls of other names record nothing (bench.py keeps the splat operators' two event pairs per step on
+    INSIDE its timed steps, and the few hundred pairs of everything else out of them)."""
+    global _KERNEL_TIMINGS, _KERNEL_TIMINGS_ONLY
     _KERNEL_TIMINGS = store
+    _KERNEL_TIMINGS_ONLY = None if (store is None or only is None) else tuple(only)
 
 
 class _timed(object):
     def __init__(self, name, device):
         self.name, self.device = name, device
+        self.store = None
 
     def __enter__(self):
-        if _KERNEL_TIMINGS is not None:
+        store = _KERNEL_TIMINGS
+        if store is not None and (_KERNEL_TIMINGS_ONLY is None or self.name.startswith(_KERNEL_TIMINGS_ONLY)):
+            self.store = store
             self.start = th.cuda.Event(enable_timing=True)
             self.end = th.cuda.Event(enable_timing=True)
             self.start.record(th.cuda.current_stream(self.device))
 
     def __exit__(self, *exc):
-        if _KERNEL_TIMINGS is not None:
+        if self.store is not None:
             self.end.record(th.cuda.current_stream(self.device))
-            _KERNEL_TIMINGS.append((self.name, self.start, self.end))
+            self.store.append((self.name, self.start, self.end))
+            self.store = None
         return False
 
 

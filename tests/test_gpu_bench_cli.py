@@ -41,6 +41,11 @@ def test_bench_single_gpu_line():
     assert d["n_gpus"] == 1 and d["world_size"] == 1 and d["value"] > 0 and d["unit"] == "Msamples/s"
     assert d["steps"] == 2 and d["higher_is_better"] is True and d["dtype"] == "f32"
     assert d["ms_per_step_median"] > 0 and len(d["ms_per_step_min_max"]) == 2
+    # the roofline kernel is timed INSIDE the training step's timed region: one launch of each splat operator per timed step
+    ks = d["kernels_in_step"]
+    assert ks["splat_update_bwd_all"]["calls"] == 2 and ks["splat_update_fwd_all"]["calls"] == 2
+    assert d["roofline"]["launches"] == 2 and "inside the timed steps" in d["roofline"]["timed"]
+    assert d["roofline"]["avg_launch_ms"] == ks["splat_update_bwd_all"]["avg_ms"]
 
 
 @pytest.mark.parametrize("workload", ["model", "splat", "infer"])

@@ -66,3 +66,22 @@ def test_state_close_rules():
     state_close((sr, off, mw), (sr, sw, mw), truth=lambda: truth)
     with pytest.raises(AssertionError):
         state_close((sr, off, mw), (sr, sw, mw), truth=lambda: (sr.double(), sw.double(), mw.double()))
+
+
+def test_kernel_timing_filter_skips_other_names_without_touching_the_device():
+    """bench.py keeps the splat operators' event pairs on inside its timed steps (`only`): every other fused call must
+    record nothing -- on the host that also means no CUDA event is ever created."""
+    from sbmc_amd import functions as F
+    store = []
+    F.enable_kernel_timing(store, only=("splat_update_",))
+    try:
+        with F._timed("conv3x3_fwd 128x128@1x8x8", th.device("cpu")):
+            pass
+        with F._timed("pointwise_fwd 128x128", th.device("cpu")):
+            pass
+        assert store == []
+    finally:
+        F.enable_kernel_timing(None)
+    assert F._KERNEL_TIMINGS is None and F._KERNEL_TIMINGS_ONLY is None
+    with F._timed("splat_update_fwd_all", th.device("cpu")):        # nothing installed: nothing recorded, nothing created
+        pass

@@ -36,6 +36,7 @@ def main():
         kinds[kind] += 1
         c0, c1, c2 = (128 * [1, 2, 3, 4][ri(0, 3)] for _ in range(3))
         c1 = min(c1, 512) if c1 != 384 else 256
+        c2 = c2 if c2 != 384 else 256            # (output channels: what sbmc_bias_act_nhwc_supported takes, as Conv3x3BiasActNHWC.supported asks)
         b = ri(1, 2)
         h, w = (ri(1, 70), ri(2, 90)) if kind == 0 else ((2 * ri(1, 30), 2 * ri(1, 40)) if kind == 1 else (ri(1, 30), ri(1, 40)))
         act, slope = [(1, 0.0), (2, 0.01), (2, 0.2)][ri(0, 2)]
