@@ -86,6 +86,19 @@ def _object_hash(src):
     return h.hexdigest()
 
 
+def cached_remarks(src):
+    """The resource remarks hipcc printed when .obj/<src>.o was built, if that object is the current source's; else None."""
+    obj = os.path.join(OBJ_DIR, src + ".o")
+    try:
+        with open(obj + ".hash") as f:
+            if f.read().strip() != _object_hash(src):
+                return None
+        with open(obj + ".remarks") as f:
+            return f.read()
+    except OSError:
+        return None
+
+
 def _compile(src, verbose):
     """csrc/<src> -> .obj/<src>.o unless an object of the same content hash is there (the objects are a local
     cache: only the linked library travels with a snapshot)."""
@@ -94,20 +107,33 @@ def _compile(src, verbose):
     digest = _object_hash(src)
     try:
         with open(stamp) as f:
-            if f.read().strip() == digest and os.path.exists(obj):
+            if f.read().strip() == digest and os.path.exists(obj) and os.path.exists(obj + ".remarks"):
                 return obj
     except OSError:
         pass
     tmp = "%s.%d.tmp" % (obj, os.getpid())
-    cmd = [_hipcc()] + FLAGS + ["-c", "-o", tmp, os.path.join(CSRC, src)]
+    # (the compiler's per-kernel resource remarks -- registers, spills, scratch, occupancy -- are kept next to the object:
+    # tools/kernel_resources.py and tests/test_kernel_resources.py read them instead of compiling the file once more)
+    cmd = [_hipcc()] + FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", "-o", tmp, os.path.join(CSRC, src)]
     if verbose:
         print(" ".join(cmd), flush=True)
     try:
-        subprocess.check_call(cmd)
+        res = subprocess.run(cmd, stderr=subprocess.PIPE)
+        err = res.stderr.decode("utf-8", "replace")
+        if res.returncode != 0:
+            sys.stderr.write(err)
+            raise subprocess.CalledProcessError(res.returncode, cmd)
+        other = [ln for ln in err.splitlines() if "remark:" not in ln and "[-Rpass-analysis" not in ln]
+        if verbose and any(ln.strip() for ln in other):
+            sys.stderr.write("\n".join(other) + "\n")                  # (warnings)
+        with open(tmp + ".remarks", "w") as f:
+            f.write(err)
+        os.replace(tmp + ".remarks", obj + ".remarks")
         os.replace(tmp, obj)
     finally:
-        if os.path.exists(tmp):
-            os.remove(tmp)
+        for t in (tmp, tmp + ".remarks"):
+            if os.path.exists(t):
+                os.remove(t)
     with open(tmp + ".hash", "w") as f:
         f.write(digest + "\n")
     os.replace(tmp + ".hash", stamp)
@@ -121,7 +147,7 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     if force:
         for f in os.listdir(OBJ_DIR):          # the cached objects and their stamps only: another rank that is
-            if f.endswith((".o", ".hash")):    # building right now owns the "<obj>.<pid>.tmp" files
+            if f.endswith((".o", ".hash", ".remarks")):    # building right now owns the "<obj>.<pid>.tmp" files
                 try:
                     os.remove(os.path.join(OBJ_DIR, f))
                 except OSError:

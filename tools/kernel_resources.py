@@ -29,14 +29,28 @@ def _demangle(names):
 
 def resources(path):
     """-> list of dicts {name, vgprs, agprs, spill, scratch, occupancy, lds} for the kernels of one .hip file."""
-    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    with tempfile.TemporaryDirectory() as tmp:
-        res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", path, "-o",
-                              os.path.join(tmp, "o.o"), "-Rpass-analysis=kernel-resource-usage"],
-                             capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(res.stderr[-2000:])
-    blocks = re.split(r"remark: Function Name: ", res.stderr)[1:]
+    text = None
+    if os.path.dirname(os.path.abspath(path)) == CSRC and not os.environ.get("SBMC_KERNEL_RESOURCES_COMPILE"):
+        # the library's own build keeps the remarks of every object it compiles (sbmc_amd/build.py: same flags, same
+        # compiler, keyed on the source + header hash): no second three-minute compile of pointwise.hip
+        sys.path.insert(0, ROOT)
+        try:
+            from sbmc_amd import build as _build
+            text = _build.cached_remarks(os.path.basename(path))
+        except Exception:      # noqa: BLE001 -- any trouble with the cache: compile
+            text = None
+        finally:
+            sys.path.pop(0)
+    if text is None:
+        hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        with tempfile.TemporaryDirectory() as tmp:
+            res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-c", path,
+                                  "-o", os.path.join(tmp, "o.o"), "-Rpass-analysis=kernel-resource-usage"],
+                                 capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(res.stderr[-2000:])
+        text = res.stderr
+    blocks = re.split(r"remark: Function Name: ", text)[1:]
     names = [b.split(" ")[0] for b in blocks]
     dem = _demangle(names)
     out = []
