@@ -2407,15 +2407,16 @@ __global__ __launch_bounds__(PW_THREADS) void pw_wide_bwd2_kernel(PwWideParams p
 // The backward for half activations on the f16 matrix pipe (training under torch.autocast(float16)): gy, y, x
 // and gx are _Float16 in HBM, gz = gy * act'(y) is formed in fp32 and rounded to half once (what autocast's
 // activation backward hands to its convolution backward), the weights are rounded to half, every product is
-// exact and accumulates in fp32 (v_mfma_f32_32x32x8_f16); gw / gbias partial sums and gt stay fp32.  The fp32-MFMA
+// exact and accumulates in fp32 (v_mfma_f32_32x32x16_f16); gw / gbias partial sums and gt stay fp32.  The fp32-MFMA
 // kernel above is matrix-pipe bound on half tensors (4.2 ms per 128 -> 128 layer at 720p x 8 spp, for 7.5 GB of
 // traffic); at 8x the MFMA rate this one is HBM-bound.
 //
-// Operand layouts.  gw[co][k] = sum over pixels of gz[co][px] x[k][px] wants, per lane, 4 consecutive PIXELS of a
-// row of gz / x: the natural planar order (row pitch 68 halves = 34 words: the 8-byte operand reads of 16 lanes
-// cover the 32 banks exactly once).  gx[k][px] = sum over co of w[co][k] gz[co][px] wants 4 consecutive ROWS of gz
-// per pixel: a second, quad-transposed image of the gz tile ([Cout/4][64] entries of 4 halves, as in
-// pw_fwd_h_kernel), written by the same staging thread that holds a 4 x 4 block of gz in registers.
+// Operand layouts.  gw[co][k] = sum over pixels of gz[co][px] x[k][px] wants, per lane, 8 consecutive PIXELS of a
+// row of gz / x: the natural planar order, read as two 8-byte words (row pitch 68 halves = 34 words, chosen for the
+// 32x32x8 form's 8-byte reads; the 16-step form's pairs of them conflict two ways -- nothing these HBM-bound kernels
+// notice).  gx[k][px] = sum over co of w[co][k] gz[co][px] wants 8 consecutive ROWS of gz per pixel: two adjacent entries
+// of a second, quad-transposed image of the gz tile ([Cout/4][64] entries of 4 halves, as in pw_fwd_h_kernel), written by
+// the same staging thread that holds a 4 x 4 block of gz in registers.
 constexpr int PBH_PITCH = 68;
 
 template <int KP, bool DX, bool TPIX, bool GM>
@@ -2443,16 +2444,17 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_h_kernel(PwBwdParams p) {
     // staging role: pixels 4 pgp .. 4 pgp + 3 of the rows 4 q .. 4 q + 3 (of gy / y / gm, and of x)
     const unsigned pgp = threadIdx.x & 15, q = threadIdx.x >> 4;
 
-    // w^T rows of this wave as f16 A-operands for gx: a2[kk][i] = w[8 kk + 4 (lane / 32) + i][32 rb + lane % 32]
-    h4 a2[DX ? 16 : 1];
+    // w^T rows of this wave as f16 A-operands for gx (v_mfma_f32_32x32x16_f16: 8 values of the reduction index per lane):
+    // a2[kk][i] = w[16 kk + 8 (lane / 32) + i][32 rb + lane % 32]
+    hf8 a2[DX ? 8 : 1];
     if (DX) {
         const rsrc_t rw = make_rsrc_n(p.w, (unsigned)(p.Cout * p.K) * 4u);
         const int k = rb * 32 + l31;
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
+        for (int kk = 0; kk < 8; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int co = 8 * kk + 4 * lhi + i;
+            for (int i = 0; i < 8; ++i) {
+                const int co = 16 * kk + 8 * lhi + i;
                 a2[kk][i] = (H)buf_load(rw, (co < p.Cout && k < p.K) ? (unsigned)(co * p.K + k) * 4u : PW_OOB, 0);
             }
         }
@@ -2612,10 +2614,14 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_h_kernel(PwBwdParams p) {
             f32x16 acc_x;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc_x[j] = 0.f;
-            const u32x2* gb = gzt + lhi * PB_NT + ph * 32 + l31;
+            // (a lane's 8 output channels 16 kk + 8 lhi ..: two adjacent quad entries of its pixel)
+            const u32x2* gb = gzt + 2 * lhi * PB_NT + ph * 32 + l31;
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
-                acc_x = __builtin_amdgcn_mfma_f32_32x32x8f16(a2[kk], __builtin_bit_cast(h4, gb[(2 * kk) * PB_NT]), acc_x, 0, 0, 0);
+            for (int kk = 0; kk < 8; ++kk) {
+                const u32x2 q0 = gb[(4 * kk) * PB_NT], q1 = gb[(4 * kk + 1) * PB_NT];
+                acc_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[kk], __builtin_bit_cast(hf8, u32x4{q0[0], q0[1], q1[0], q1[1]}),
+                                                               acc_x, 0, 0, 0);
+            }
             const unsigned col = p0 + ph * 32 + l31;
             const unsigned o = (col < hw && nkrows > 0) ? (4u * lhi * hw + col) * 2u : PW_OOB;
             const rsrc_t rgx = make_rsrc_n(gx_g + ((size_t)b * p.K + kr0) * hw, (unsigned)nkrows * hw * 2u);
@@ -2627,18 +2633,21 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_h_kernel(PwBwdParams p) {
         }
         // ---- gw: rows 32 rb .. of cout, column blocks 2 ph, 2 ph + 1 of K; reduction over the 64 pixels
         if (2 * ph < NB) {
-            const H* ga = gzn + (rb * 32 + l31) * PBH_PITCH + 4 * lhi;
-            const H* xb0 = xn + ((2 * ph) * 32 + l31) * PBH_PITCH + 4 * lhi;
-            const H* xb1 = xn + ((2 * ph + 1 < NB ? 2 * ph + 1 : 2 * ph) * 32 + l31) * PBH_PITCH + 4 * lhi;
+            // (v_mfma_f32_32x32x16_f16: a lane's 8 consecutive pixels 16 kk + 8 lhi .. of its row -- two 8-byte words of
+            // the natural image, whose 136-byte row pitch keeps them 8-byte aligned)
+            const H* ga = gzn + (rb * 32 + l31) * PBH_PITCH + 8 * lhi;
+            const H* xb0 = xn + ((2 * ph) * 32 + l31) * PBH_PITCH + 8 * lhi;
+            const H* xb1 = xn + ((2 * ph + 1 < NB ? 2 * ph + 1 : 2 * ph) * 32 + l31) * PBH_PITCH + 8 * lhi;
             const bool two = 2 * ph + 1 < NB;
+            auto oct = [](const H* q) -> hf8 {
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(q), hi = *reinterpret_cast<const u32x2*>(q + 4);
+                return __builtin_bit_cast(hf8, u32x4{lo[0], lo[1], hi[0], hi[1]});
+            };
 #pragma unroll
-            for (int kk = 0; kk < PB_NT / 8; ++kk) {
-                const h4 av = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(ga + 8 * kk));
-                acc_w[0] = __builtin_amdgcn_mfma_f32_32x32x8f16(
-                    av, __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(xb0 + 8 * kk)), acc_w[0], 0, 0, 0);
-                if (two)
-                    acc_w[1] = __builtin_amdgcn_mfma_f32_32x32x8f16(
-                        av, __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(xb1 + 8 * kk)), acc_w[1], 0, 0, 0);
+            for (int kk = 0; kk < PB_NT / 16; ++kk) {
+                const hf8 av = oct(ga + 16 * kk);
+                acc_w[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, oct(xb0 + 16 * kk), acc_w[0], 0, 0, 0);
+                if (two) acc_w[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, oct(xb1 + 16 * kk), acc_w[1], 0, 0, 0);
             }
         }
 
