@@ -819,8 +819,10 @@ def test_pointwise_half_training(cfg):
     # to half (exact products, fp32 sums); the side sums (gbias, gt) are taken before that rounding
     f16_pipe = x_half and cout <= 128
     gzq = gz.half().float() if f16_pipe else gz
-    close(w.grad, th.einsum("bop,bcp->oc", gzq, xr), rtol=2e-5 if cout <= 128 else 2e-3, what="gw")
-    close(b.grad, gz.sum((0, 2)), rtol=2e-5, what="gbias")
+    # (the sums against FLOAT64: torch's fp32 einsum over 1e4 terms is ten times further from it than the kernel's fp32
+    # accumulators are -- tools/dev/half_gw_check.py, profiles/HISTORY.md)
+    close(w.grad, th.einsum("bop,bcp->oc", gzq.double(), xr.double()), rtol=2e-5 if cout <= 128 else 2e-3, what="gw")
+    close(b.grad, gz.double().sum((0, 2)), rtol=2e-5, what="gbias")
     gxr = th.einsum("oc,bop->bcp", wq if f16_pipe else w.detach(), gzq)
     if cout <= 128:
         assert xg.grad.dtype == x.dtype
@@ -829,7 +831,7 @@ def test_pointwise_half_training(cfg):
     else:                                            # half GEMM operands (w rounded to half)
         assert (xg.grad.float() - gxr).abs().max().item() <= 4e-3 * gxr.abs().max().item()
     if tm == 1:
-        close(t.grad, gz.view(B // S, S, cout, hw).sum((1, 3)), rtol=2e-5, what="gt (per image)")
+        close(t.grad, gz.double().view(B // S, S, cout, hw).sum((1, 3)), rtol=2e-5, what="gt (per image)")
     elif tm == 2:
         close(t.grad, gz.view(B // S, S, cout, hw).sum(1), rtol=1e-5, what="gt (per pixel)")
 
