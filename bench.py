@@ -907,6 +907,9 @@ def main():
                 "alg_bytes_per_launch": kb["alg_bytes"],
                 "avg_launch_ms": kb["avg_ms"],
                 "launches": kb["calls"],
+                # (identical kernels read ~4.4 or ~5.35 ms per 8-sample launch depending on where the allocator put the two
+                # 13 GB tensors -- per placement, stable in time: tools/placement_experiment*.py, profiles/HISTORY.md)
+                "placement_note": "bimodal in where the logit / gradient tensors live: 0.74-0.75 or 0.62 on identical kernels",
                 "timed": kb.get("where", "the splat-only stage of this run (HIP events on the launch stream around the "
                                          "operator call, every timed step of that stage)"),
             }
