@@ -41,7 +41,7 @@ extern "C" {
 #define SBMC_API
 #endif
 
-#define SBMC_HIP_ABI_VERSION 7
+#define SBMC_HIP_ABI_VERSION 8
 #define SBMC_HIP_EINVAL (-1)
 /* largest channel count the fused/plain kernels take in one call */
 #define SBMC_HIP_MAX_CHANNELS 8
@@ -473,6 +473,28 @@ SBMC_API size_t sbmc_pointwise_wide_bwd_ws_bytes(void);
 SBMC_API int sbmc_pointwise_wide_bwd_f32(const float *gz, const float *x, const float *w, float *gx, float *gw_partial,
                                 float *gb_partial, void *ws, const unsigned *gmax, const unsigned *xmax,
                                 unsigned *gxmax, int b, int cin, int cout, long hw, void *stream);
+/* ABI 8 -- a CHAIN of 2 or 3 per-sample 1 x 1 layers in ONE pass (csrc/pointwise_chain.hip): the reference's per-sample
+ * embeddings and the first two layers of its kernel regressor (sbmc/modules.py:154-175 as built at sbmc/models.py:79-102
+ * and run at :147-153, 171-177, 196-199), y_l = act_l(w_l y_{l-1} + bias_l (+ t for l = 0)), y_{-1} = x [b, cin, hw].
+ * A 64-pixel tile stays in LDS through all layers: x is read once, an intermediate y_l is WRITTEN only where y[l] is not
+ * NULL (training: the backward's input) and never read back.
+ *   w, bias, y, signs, amax   arrays of nl device pointers (host arrays; signs / amax may be NULL, and so may their
+ *         entries and y[l] for l < nl - 1).  signs[l] (needs y[l]): one bit per output, value > 0, [b, cout_l, ceil(hw / 32)]
+ *         words as sbmc_pointwise_fwd_signs_f32; amax[l]: a zeroed device word raised to the bit pattern of max |y_l|.
+ *   t / t_mode   the FIRST layer's context term as in sbmc_pointwise_fwd_f32 (s images share one); tmax (t_mode != 0): a
+ *         device word holding the bit pattern of a float >= max |t| (any bound: it only enters the scale below).
+ *   ymean   NULL or [b / s, cout_last, hw]: the mean of the last layer's output over groups of s consecutive images.
+ *   cout, act, slope   per layer (host arrays); cin, cout_l <= 128.
+ * Arithmetic: two f16 planes per operand under a power-of-two scale, three of the four partial products (<= 2^-22 per
+ * term dropped), fp32 accumulation -- the 3 x 3 kernels' format -- with the scale of an operand tile taken PER PIXEL: the input's
+ * from the tile itself (no magnitude word: network inputs are taken as they are), an intermediate activation's from a bound
+ * (its input's scale x the layer's largest absolute row sum + max |bias| (+ max |t|)), carried from layer to layer. */
+SBMC_API int sbmc_pointwise_chain_supported(int cin, int nl, const int *cout, long hw);
+SBMC_API int sbmc_pointwise_chain_fwd_f32(const float *x, const float *t, const unsigned *tmax, const float *const *w,
+                                 const float *const *bias,
+                                 float *const *y, unsigned *const *signs, unsigned *const *amax, float *ymean,
+                                 int nl, const int *cout, const int *act, const float *slope, int b, int s, int cin,
+                                 long hw, int t_mode, void *stream);
 /* the all-half layer (x, y _Float16) with the mean as a _Float16 tensor: the mean of the half values as stored */
 SBMC_API int sbmc_pointwise_fwd_mean_f16(const void *x, const float *w, const float *bias, const float *t, void *y,
                                 void *ymean, int s_mean, int b, int s, int cin, int cout, long hw, int t_mode,

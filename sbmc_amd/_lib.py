@@ -68,6 +68,8 @@ SYMBOLS = (
     "sbmc_pointwise_bwd_scaled_f32",
     "sbmc_pointwise_wide_bwd_ws_bytes",
     "sbmc_pointwise_wide_bwd_f32",
+    "sbmc_pointwise_chain_supported",
+    "sbmc_pointwise_chain_fwd_f32",
     "sbmc_splat_all_bwd_bound_f32",
     "sbmc_upsample2x_cat_supported",
     "sbmc_upsample2x_cat_fwd_f32",
@@ -129,7 +131,7 @@ SYMBOLS = (
     "sbmc_wbank_forward_f32",
     "sbmc_wbank_backward_f32",
 )
-ABI_VERSION = 7
+ABI_VERSION = 8
 WBANK_MAX = 24
 
 
@@ -239,6 +241,8 @@ def lib():
     handle.sbmc_pointwise_bwd_scaled_f32.argtypes = [p] * 9 + [i] + [p] * 4 + [i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_wide_bwd_ws_bytes.argtypes = []
     handle.sbmc_pointwise_wide_bwd_f32.argtypes = [p] * 10 + [i, i, i, ctypes.c_long, p]
+    handle.sbmc_pointwise_chain_supported.argtypes = [i, i, p, ctypes.c_long]
+    handle.sbmc_pointwise_chain_fwd_f32.argtypes = [p] * 9 + [i, p, p, p, i, i, i, ctypes.c_long, i, p]
     handle.sbmc_splat_all_bwd_bound_f32.argtypes = [p] * 15 + [i] * 8 + [p]
     handle.sbmc_pointwise_fwd_mean_f16.argtypes = [p] * 6 + [i, i, i, i, i, ctypes.c_long, i, i, ctypes.c_float, p]
     handle.sbmc_pointwise_bwd_f16.argtypes = [p, p, p, i, p, p, p, p, p, p, i, i, i, i, i, ctypes.c_long, i, i,

@@ -743,6 +743,154 @@ def _pointwise_backward(ctx, gy, gmean, mean_s):
     return gx, gw, gbias, gt
 
 
+def pointwise_chain_supported(x, couts):
+    """True when `PointwiseChain` applies: planar fp32 GPU activations x [B, cin, hw], 2 or 3 layers of at most 128
+    channels each, no autocast (csrc/pointwise_chain.hip)."""
+    import ctypes
+    if not (x.is_cuda and x.dtype == th.float32 and x.dim() == 3 and x.numel() > 0 and x.is_contiguous()):
+        return False
+    if knob("SBMC_PW_CHAIN") == 0 or not _pw_split_enabled() or th.is_autocast_enabled():
+        return False
+    n = len(couts)
+    arr = (ctypes.c_int * max(n, 1))(*couts)
+    return (x.data_ptr() % 16 == 0 and x.shape[0] <= 65535
+            and bool(_lib.lib().sbmc_pointwise_chain_supported(x.shape[1], n, arr, x.shape[2])))
+
+
+def pointwise_chain_forward(x, t, s, layers, store_mid=False, want_signs=False, mean=False, want_amax=True):
+    """The raw launch (no autograd): `layers` = [(w [cout, cin], bias [cout], act, slope), ...], 2 or 3 of them.
+    -> (ys, signs, amaxes, ymean): ys[l] = the l-th layer's output [B, cout_l, hw] (None for an intermediate layer
+    unless store_mid), signs[l] its sign words (want_signs, activated layers with a stored output), amaxes[l] the device
+    word of max |y_l|, ymean the mean of the last output over groups of s images (mean=True)."""
+    import ctypes
+    L = _lib.lib()
+    nl = len(layers)
+    B, cin, hw = x.shape
+    dev = x.device
+    t_mode = 0
+    if t is not None:
+        t = t.contiguous()
+        t_mode = 2 if (t.dim() == 3 and t.shape[2] == hw and hw > 1) else 1
+    ws = [w.contiguous() for (w, _, _, _) in layers]
+    bs = [b.contiguous() for (_, b, _, _) in layers]
+    _require_f32("PointwiseChain", x=x, t=t, **{"w%d" % i: w for i, w in enumerate(ws)})
+    couts = [w.shape[0] for w in ws]
+    ys, signs, amaxes = [], [], []
+    for l in range(nl):
+        last = l + 1 == nl
+        ys.append(th.empty(B, couts[l], hw, dtype=th.float32, device=dev) if (last or store_mid) else None)
+        signs.append(th.empty(B, couts[l], (hw + 31) // 32, dtype=th.int32, device=dev)
+                     if (want_signs and ys[l] is not None and layers[l][2] != 0) else None)
+        amaxes.append(amax_word(dev) if want_amax else None)
+    ymean = th.empty(B // s, couts[-1], hw, dtype=th.float32, device=dev) if mean else None
+    # the context term's largest magnitude (it enters the bound the intermediate activations are scaled by): the producer's
+    # word where it left one, else one pass over t (1 / S of an activation's bytes)
+    tmax = ensure_amax(t) if t is not None else None
+
+    def parr(ts):
+        return (ctypes.c_void_p * nl)(*[None if q is None else q.data_ptr() for q in ts])
+    with th.cuda.device(dev), _timed("pointwise_chain_fwd %s<-%d%s" % ("x".join(str(c) for c in couts), cin,
+                                                                        "" if store_mid else " (inference)"), dev):
+        rc = L.sbmc_pointwise_chain_fwd_f32(
+            _lib.ptr(x), _lib.ptr(t) if t is not None else None, _lib.ptr(tmax) if t is not None else None,
+            parr(ws), parr(bs), parr(ys), parr(signs), parr(amaxes),
+            _lib.ptr(ymean) if ymean is not None else None, nl, (ctypes.c_int * nl)(*couts),
+            (ctypes.c_int * nl)(*[a for (_, _, a, _) in layers]), (ctypes.c_float * nl)(*[float(sl) for (_, _, _, sl) in layers]),
+            B, s, cin, hw, t_mode, _lib.current_stream(dev))
+    _lib.check(rc, "pointwise_chain_fwd")
+    return ys, signs, amaxes, ymean
+
+
+class _LayerCtx(object):
+    """What `_pointwise_backward` reads of a `PointwiseLayer` context, for one layer of a `PointwiseChain`."""
+
+    def __init__(self, cfg, saved, has_signs, xmax, needs):
+        self.cfg, self.saved_tensors, self.has_signs, self.xmax, self.needs_input_grad = cfg, saved, has_signs, xmax, needs
+        self.half = False
+
+
+class PointwiseChain(th.autograd.Function):
+    """Two or three 1x1-convolution layers of at most 128 channels in ONE forward pass (csrc/pointwise_chain.hip):
+    y = act_n(w_n .. act_1(w_1 x + b_1 + t) .. + b_n) on planar activations x [B, cin, hw] -- the reference's per-sample
+    embeddings and the first two layers of its kernel regressor (sbmc/models.py:79-102, 147-153, 171-177, 196-199).  A
+    tile's intermediate activations stay in LDS; they are written to HBM only when a backward will want them and never
+    read back by the forward.  The backward runs layer by layer on the kernels of `PointwiseLayer`, from the tensors
+    this forward left exactly as the separate layers would have.
+
+    apply(x, t, s, mean, cfg, w_1, b_1, ..., w_n, b_n): t / s as `PointwiseLayer` (the FIRST layer's context term);
+    mean: also return the mean of the output over groups of s images (-> (y, ymean)); cfg = ((act, slope), ...).
+    """
+
+    @staticmethod
+    def forward(ctx, x, t, s, mean, cfg, *wb):
+        nl = len(cfg)
+        layers = [(wb[2 * l].contiguous(), wb[2 * l + 1].contiguous(), cfg[l][0], cfg[l][1]) for l in range(nl)]
+        train = any(ctx.needs_input_grad)
+        ctx.xmax = known_amax(x)
+        x = x.contiguous()
+        ys, signs, amaxes, ymean = pointwise_chain_forward(x, t, s, layers, store_mid=train, want_signs=train, mean=mean)
+        B, cin, hw = x.shape
+        t_mode = 0
+        if t is not None:
+            t_mode = 2 if (t.dim() == 3 and t.shape[2] == hw and hw > 1) else 1
+        ctx.nl, ctx.s, ctx.mean, ctx.cfg_layers, ctx.t_mode = nl, s, mean, cfg, t_mode
+        ctx.tshape = None if t is None else tuple(t.shape)
+        ctx.amaxes = amaxes
+        ctx.has_signs = [sg is not None for sg in signs]
+        if train:
+            # per layer: its input, its weight, its sign words (or -- a linear layer -- nothing)
+            saved = [x]
+            for l in range(nl):
+                saved += [layers[l][0], signs[l]]
+                if l + 1 < nl:
+                    saved.append(ys[l])
+            ctx.save_for_backward(*saved)
+        tag_amax(ys[-1], amaxes[-1])
+        if mean:
+            tag_amax(ymean, amaxes[-1])          # (a mean of values of y: the bound holds)
+            return ys[-1], ymean
+        return ys[-1]
+
+    @staticmethod
+    def backward(ctx, gy, gmean=None):
+        nl, s = ctx.nl, ctx.s
+        saved = ctx.saved_tensors
+        x = saved[0]
+        inputs, weights, sgs = [x], [], []
+        i = 1
+        for l in range(nl):
+            weights.append(saved[i])
+            sgs.append(saved[i + 1])
+            i += 2
+            if l + 1 < nl:
+                inputs.append(saved[i])
+                i += 1
+        if gy is None:                            # only the mean was used
+            gy = (gmean / s).repeat_interleave(s, 0)
+            gmean = None
+        grads = [None] * (2 * nl)
+        gt = None
+        g = gy
+        for l in range(nl - 1, -1, -1):
+            act, slope = ctx.cfg_layers[l]
+            first = l == 0
+            lctx = _LayerCtx((s if first else 1, act, slope, ctx.t_mode if first else 0, ctx.tshape if first else None),
+                             (inputs[l], weights[l], sgs[l]), ctx.has_signs[l],
+                             ctx.xmax if first else ctx.amaxes[l - 1],
+                             (True if not first else ctx.needs_input_grad[0], True, True, True))
+            if l + 1 < nl:
+                tag = ctx.amaxes[l]
+                if tag is not None and known_amax(inputs[l + 1]) is None:
+                    tag_amax(inputs[l + 1], tag)
+            gm = gmean if (l == nl - 1) else None
+            gx, gw, gb, gtl = _pointwise_backward(lctx, g, gm, s if gm is not None else 1)
+            grads[2 * l], grads[2 * l + 1] = gw, gb
+            if first:
+                gt = gtl
+            g = gx
+        return (g, gt, None, None, None) + tuple(grads)
+
+
 def upsample_cat_supported(coarse, left, top=0, bot=0):
     """True when `UpsampleCat` applies: fp32 GPU tensors, `left` exactly twice the size of `coarse` (minus
     its `top` + `bot` halo rows in the row-slab form)."""

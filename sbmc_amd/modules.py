@@ -168,6 +168,23 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     t = context_term(wt[:, cs:]).contiguous()
     if t.dtype == th.float32 and funcs.pointwise_supported(xs, cout):
         tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)
+        # two or three layers of the chain in ONE pass where they fit (functions.PointwiseChain: a tile's intermediate
+        # activations stay on the chip); what is behind them -- the regressor's 441-channel layer -- runs as before
+        plan, used = _pointwise_plan(mods)
+        if len(plan) >= 2 and funcs.pointwise_chain_supported(xs, [c.out_channels for c, _, _ in plan]):
+            wb = [wt[:, :cs], conv.bias]
+            for c, _, _ in plan[1:]:
+                wc = conv_weight(c)
+                wb += [wc.view(wc.shape[0], wc.shape[1]), c.bias]
+            rest = mods[used:]
+            mean = bool(mean_out is not None and not rest)
+            out = funcs.PointwiseChain.apply(xs, tt, S, mean, tuple((a, sl) for _, a, sl in plan), *wb)
+            y, m = out if mean else (out, None)
+            cl = plan[-1][0].out_channels
+            if mean:
+                mean_out.append(funcs.tagged_view(m, bs, cl, h, w))
+            y = funcs.tagged_view(y, bs * S, cl, h, w)
+            return chain._run(rest, y, mean_s=S, mean_out=mean_out) if rest else y
         y = funcs.PointwiseLayer.apply(xs, wt[:, :cs], conv.bias, tt, S, act[0], act[1])
         y = funcs.tagged_view(y, bs * S, cout, h, w)
     else:
@@ -179,6 +196,36 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     consumed = 1 if isinstance(first, ConvChain._ConvBNRelu) else (2 if act[0] != 0 else 1)
     rest = mods[consumed:]
     return chain._run(rest, y, mean_s=S, mean_out=mean_out) if rest else y
+
+
+def _pointwise_plan(mods, limit=3):
+    """The leading layers of a ConvChain's module list that `functions.PointwiseChain` can take in one pass: 1x1
+    convolutions of at most 128 output channels, each followed by ReLU / LeakyReLU or -- the last one of the list --
+    by nothing.  -> ([(conv, act, slope), ...], number of modules of `mods` they cover)."""
+    plan, i = [], 0
+    while i < len(mods) and len(plan) < limit:
+        m = mods[i]
+        if isinstance(m, ConvChain._ConvBNRelu):
+            if len(m.layer) != 2:
+                break
+            conv, act_mod, step = m.layer[0], m.layer[1], 1
+        elif isinstance(m, nn.Conv2d):
+            conv, act_mod, step = m, (mods[i + 1] if i + 1 < len(mods) else None), 2
+        else:
+            break
+        if not _is_pointwise(conv) or conv.out_channels > 128 or (plan and conv.in_channels != plan[-1][0].out_channels):
+            break
+        if isinstance(act_mod, nn.ReLU):
+            act = (1, 0.0)
+        elif isinstance(act_mod, nn.LeakyReLU):
+            act = (2, float(act_mod.negative_slope))
+        elif act_mod is None and isinstance(m, nn.Conv2d):
+            act, step = (0, 0.0), 1
+        else:
+            break
+        plan.append((conv, act[0], act[1]))
+        i += step
+    return plan, i
 
 
 _LAYOUT_DECISIONS = {}

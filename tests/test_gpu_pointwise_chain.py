@@ -1,0 +1,186 @@
+"""Two or three per-sample 1 x 1 layers in one pass (round 6; csrc/pointwise_chain.hip through the C ABI
+sbmc_pointwise_chain_fwd_f32 and functions.PointwiseChain) against float64 of the same chain (reference
+sbmc/modules.py:154-175 as built at sbmc/models.py:79-102), against the layer-by-layer kernels, and through autograd."""
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain64(x, t, s, layers, masks=None):
+    """float64 of the chain; -> [y_0, y_1, ...].  masks[l] (or None): the activation's decisions (pre-activation > 0) taken
+    from elsewhere instead of the float64 pre-activation's own sign -- a gradient is only comparable between two evaluations
+    that took the SAME decisions, and a pre-activation within fp32 rounding of the kink decides differently in float64."""
+    outs = []
+    cur = x.double()
+    for l, (w, bias, act, slope) in enumerate(layers):
+        pre = th.matmul(w.double(), cur) + bias.double().view(1, -1, 1)
+        if l == 0 and t is not None:
+            tt = t.double().repeat_interleave(s, 0)
+            pre = pre + (tt.unsqueeze(-1) if tt.dim() == 2 else tt)
+        pos = pre > 0 if (masks is None or masks[l] is None) else masks[l]
+        cur = th.where(pos, pre, pre * (0.0 if act == 1 else slope)) if act != 0 else pre
+        outs.append(cur)
+    return outs
+
+
+def _make(b, s, cin, couts, hw, t_mode, acts, spread, dev, seed):
+    th.manual_seed(seed)
+    x = th.randn(b, cin, hw, device=dev) * spread
+    layers = []
+    k = cin
+    for l, (c, a) in enumerate(zip(couts, acts)):
+        w = th.randn(c, k, device=dev) / k ** 0.5
+        if l == 0:
+            w = w / spread
+        layers.append((w, th.randn(c, device=dev) * 0.3, a, 0.01))
+        k = c
+    t = None
+    if t_mode == 1:
+        t = th.randn(b // s, couts[0], device=dev)
+    elif t_mode == 2:
+        t = th.randn(b // s, couts[0], hw, device=dev)
+    return x, t, layers
+
+
+CASES = [
+    # b, s, cin, couts, hw, t_mode, acts, mean
+    (8, 8, 128, (128, 128, 128), 64 * 9 + 20, 2, (1, 1, 0), True),     # a later embedding: per-pixel context, sample mean
+    (4, 2, 93, (128, 128, 128), 516, 1, (1, 1, 0), True),              # the first embedding: 93 features, per-image context
+    (6, 3, 128, (128, 128), 720, 2, (2, 2), False),                    # the regressor's first two layers
+    (3, 1, 32, (25, 40, 17), 100, 0, (2, 1, 2), False),                # narrow layers, ragged everything
+    (2, 1, 64, (96, 128), 260, 1, (1, 0), False),
+    (2, 2, 128, (128, 128, 128), 4, 0, (1, 2, 1), True),               # a plane of four pixels
+    (5, 1, 128, (128, 128, 128), 64 * 40, 0, (1, 1, 1), False),        # more tiles than one round of the grid at small b
+]
+
+
+@pytest.mark.parametrize("spread", [1.0, 1e-4])
+@pytest.mark.parametrize("store_mid", [False, True])
+@pytest.mark.parametrize("b,s,cin,couts,hw,t_mode,acts,mean", CASES)
+def test_chain_forward_vs_float64(b, s, cin, couts, hw, t_mode, acts, mean, store_mid, spread):
+    """Every output the pass writes -- intermediates (training form), the last layer, the mean, sign words, magnitude
+    words -- against float64 at 1e-5 of each tensor's scale; spread: nothing may depend on the input's magnitude."""
+    from sbmc_amd import functions as funcs
+    dev = th.device("cuda")
+    x, t, layers = _make(b, s, cin, couts, hw, t_mode, acts, spread, dev, b * 1000 + hw)
+    ref = _chain64(x, t, s, layers)
+    ys, signs, amaxes, ymean = funcs.pointwise_chain_forward(x, t, s, layers, store_mid=store_mid, want_signs=store_mid,
+                                                             mean=mean)
+    th.cuda.synchronize()
+    for l, r in enumerate(ref):
+        last = l + 1 == len(ref)
+        if not (last or store_mid):
+            assert ys[l] is None
+            continue
+        scale = r.abs().max().item()
+        err = (ys[l].double() - r).abs().max().item()
+        assert err <= 1e-5 * scale, (l, err / scale)
+        assert amaxes[l].item() == ys[l].abs().max().reshape(1).view(th.int32).item(), "magnitude word is not max |y|"
+        if signs[l] is not None:
+            # bit i of word j of a row = (y > 0) of pixel 32 j + i; elements within rounding of the kink may differ from float64
+            bits = ((signs[l].unsqueeze(-1) >> th.arange(32, device=dev)) & 1).reshape(b, couts[l], -1)[..., :hw].bool()
+            assert th.equal(bits, ys[l] > 0)
+    if mean:
+        m = ref[-1].view(b // s, s, couts[-1], hw).mean(1)
+        assert (ymean.double() - m).abs().max().item() <= 1e-5 * m.abs().max().item()
+
+
+def test_chain_equals_the_separate_layers_closely():
+    """The fused pass and the layer-by-layer kernels compute the same chain from the same weights: both within 1e-5 of
+    float64, and of each other within 2e-6 of the output's scale (different scales, same products)."""
+    from sbmc_amd import functions as funcs
+    dev = th.device("cuda")
+    b, s, cin, couts, hw = 8, 4, 128, (128, 128, 128), 64 * 30
+    x, t, layers = _make(b, s, cin, couts, hw, 2, (1, 1, 0), 1.0, dev, 5)
+    ys, _, _, ymean = funcs.pointwise_chain_forward(x, t, s, layers, mean=True)
+    cur = x
+    for l, (w, bias, act, slope) in enumerate(layers):
+        if l + 1 < len(layers):
+            cur = funcs.PointwiseLayer.apply(cur, w, bias, t if l == 0 else None, s if l == 0 else 1, act, slope)
+        else:
+            cur, m = funcs.PointwiseLayerMean.apply(cur, w, bias, None, 1, act, slope, s)
+    scale = cur.abs().max().item()
+    assert (ys[-1] - cur).abs().max().item() <= 2e-6 * scale
+    assert (ymean - m).abs().max().item() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("b,s,cin,couts,hw,t_mode,acts,mean", [
+    (4, 2, 128, (128, 128, 128), 64 * 3 + 12, 2, (1, 1, 0), True),
+    (4, 2, 93, (128, 128, 128), 200, 1, (1, 1, 0), True),
+    (3, 3, 128, (128, 128), 260, 2, (2, 2), False),
+])
+def test_chain_autograd_vs_float64(b, s, cin, couts, hw, t_mode, acts, mean):
+    """functions.PointwiseChain: outputs and EVERY gradient (input, context term, weights, biases) against float64 autograd of
+    the same chain, 1e-5 of each gradient's scale."""
+    from sbmc_amd import functions as funcs
+    dev = th.device("cuda")
+    x, t, layers = _make(b, s, cin, couts, hw, t_mode, acts, 1.0, dev, 77)
+    x.requires_grad_(True)
+    t.requires_grad_(True)
+    wb = []
+    for (w, bias, _, _) in layers:
+        wb += [w.requires_grad_(True), bias.requires_grad_(True)]
+    cfg = tuple((a, sl) for (_, _, a, sl) in layers)
+    out = funcs.PointwiseChain.apply(x, t, s, mean, cfg, *wb)
+    y, m = out if mean else (out, None)
+    gy = th.randn_like(y)
+    gm = th.randn_like(m) if mean else None
+    leaves = [x, t] + wb
+    got = th.autograd.grad([y] + ([m] if mean else []), leaves, [gy] + ([gm] if mean else []))
+
+    # the decisions the pass took (a raw launch of the same chain in its training form)
+    mids = funcs.pointwise_chain_forward(x.detach(), t.detach(), s, [(w.detach(), bb.detach(), a, sl) for (w, bb, a, sl) in layers],
+                                         store_mid=True)[0]
+    masks = [(m > 0) if a != 0 else None for m, (_, _, a, _) in zip(mids, layers)]
+    x64, t64 = x.detach().double().requires_grad_(True), t.detach().double().requires_grad_(True)
+    wb64 = [p.detach().double().requires_grad_(True) for p in wb]
+    l64 = [(wb64[2 * l], wb64[2 * l + 1], layers[l][2], layers[l][3]) for l in range(len(layers))]
+    y64 = _chain64(x64, t64, s, l64, masks)[-1]
+    outs64, gr64 = [y64], [gy.double()]
+    if mean:
+        outs64.append(y64.view(b // s, s, couts[-1], hw).mean(1))
+        gr64.append(gm.double())
+    ref = th.autograd.grad(outs64, [x64, t64] + wb64, gr64)
+    assert (y.double() - y64).abs().max().item() <= 1e-5 * y64.abs().max().item()
+    for i, (a, r) in enumerate(zip(got, ref)):
+        scale = r.abs().max().item()
+        assert a.shape == r.shape
+        assert (a.double() - r).abs().max().item() <= 1e-5 * scale, (i, (a.double() - r).abs().max().item() / scale)
+
+
+def test_chain_is_what_the_embedding_runs():
+    """modules.pointwise_chain_with_context hands a three-layer 1x1 ConvChain to ONE fused pass (and the regressor's first
+    two layers + its wide layer), with the same result as the layer-by-layer path (SBMC_PW_CHAIN=0)."""
+    import os
+    from sbmc_amd import functions as funcs, modules as ops
+    dev = th.device("cuda")
+    th.manual_seed(3)
+    chain = ops.ConvChain(128 + 128, 128, width=128, depth=3, ksize=1, pad=False).to(dev)
+    chain.pointwise_as_gemm = True
+    reg = ops.ConvChain(128 + 128, 441, width=128, depth=3, ksize=1, pad=False, activation="leaky_relu").to(dev)
+    reg.pointwise_as_gemm = True
+    per_sample = th.randn(1, 4, 128, 24, 40, device=dev)
+    context = th.randn(1, 128, 24, 40, device=dev)
+    store = []
+    funcs.enable_kernel_timing(store)
+    try:
+        mean_out = []
+        a = ops.pointwise_chain_with_context(chain, per_sample, context, mean_out)
+        k = ops.pointwise_chain_with_context(reg, per_sample, context)
+        th.cuda.synchronize()
+    finally:
+        funcs.enable_kernel_timing(None)
+    names = sorted(n for n, _, _ in store)
+    assert sum(n.startswith("pointwise_chain_fwd 128x128x128") for n in names) == 1, names
+    assert sum(n.startswith("pointwise_chain_fwd 128x128<") for n in names) == 1, names
+    os.environ["SBMC_PW_CHAIN"] = "0"
+    try:
+        mean_ref = []
+        a0 = ops.pointwise_chain_with_context(chain, per_sample, context, mean_ref)
+        k0 = ops.pointwise_chain_with_context(reg, per_sample, context)
+    finally:
+        del os.environ["SBMC_PW_CHAIN"]
+    for got, ref in ((a, a0), (mean_out[0], mean_ref[0]), (k, k0)):
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
