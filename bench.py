@@ -759,21 +759,34 @@ def main():
                                "where": "inside the timed steps of the training step (HIP events on the launch stream "
                                         "around the operator call, every timed step)"}
 
-    # the fused 1x1-convolution layers (fp32 MFMA kernels), from two instrumented steps after the timed ones
+    # the per-sample 1x1 layers (csrc/pointwise.hip, csrc/pointwise_chain.hip), from two instrumented steps after the timed
+    # ones.  They are HBM-bound: each is priced by its ALGORITHMIC bytes (every activation it must read or write once, 4 bytes
+    # per value) against the HBM peak -- not by its matrix work (a fraction of the fp32 matrix peak read > 1 for
+    # kernels that run on the f16 pipe).
     layers = {}
     for name, a, b in model_timings:
         if name.startswith("pointwise"):
             layers.setdefault(name, []).append(a.elapsed_time(b))
+    npx = S * (local_px if world > 1 else H * W)
     for name in list(layers):
         v = layers[name]
         kind, dims = name.split(" ")[0], name.split(" ")[1]
-        cout, cin = (int(t) for t in dims.split("x"))
-        nprod = 1 if kind.endswith("fwd") or "no gx" in name else 2
-        flop = 2.0 * cin * cout * S * (local_px if world > 1 else H * W) * nprod
+        if "<-" in dims:                                   # a fused chain: C0xC1(xC2)<-K
+            couts = [int(t) for t in dims.split("<-")[0].split("x")]
+            cin = int(dims.split("<-")[1])
+            chans = cin + (couts[-1] if "inference" in name else sum(couts))
+            flop = 2.0 * npx * sum(k * c for k, c in zip([cin] + couts[:-1], couts))
+        else:
+            cout, cin = (int(t) for t in dims.split("x"))
+            nprod = 1 if kind.endswith("fwd") or "no gx" in name else 2
+            flop = 2.0 * cin * cout * npx * nprod
+            # forward: x in, y out; backward: gy and x in (+ gx out)
+            chans = cin + cout + (cin if (not kind.endswith("fwd") and "no gx" not in name) else 0)
         avg = sum(v) / len(v)
-        layers[name] = {"calls_per_step": len(v) // 2, "avg_ms": round(avg, 3),
-                        "TFLOPs": round(flop / (avg * 1e-3) / 1e12, 1),
-                        "frac_of_fp32_mfma_peak": round(flop / (avg * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)}
+        gbps = 4.0 * chans * npx / (avg * 1e-3) / 1e9
+        layers[name] = {"calls_per_step": len(v) // 2, "avg_ms": round(avg, 3), "alg_bytes": int(4 * chans * npx),
+                        "GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 3),
+                        "TFLOPs_fp32_equivalent": round(flop / (avg * 1e-3) / 1e12, 1)}
 
     # the U-nets' 3 x 3 convolutions (csrc/conv3x3.hip: fp32 values from three f16 matrix products per term), as
     # the model issues them -- scale lookup and weight preparation included -- from the same two instrumented steps

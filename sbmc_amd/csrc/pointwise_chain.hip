@@ -379,8 +379,10 @@ __global__ __launch_bounds__(512) void pw_chain_fwd_kernel(PwChainParams p) {
     // that phase's stores (16 + the sign words' one, where layer 1 is stored) and -- three layers -- the last phase's 16: the
     // counter is in order, so "no more outstanding than those" means the rows have landed, without sitting out the stores.
     const int nyounger = (p.y[1] != nullptr ? 16 : 0) + (p.signs[1] != nullptr ? 1 : 0) + (NL == 3 ? 16 : 0);
+    bool primed = false;                                // (the first tile's successor was requested in the prologue: nothing younger)
     auto wait_rows = [&]() {
-        if (nyounger >= 33) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+        if (!primed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nyounger >= 33) asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
         else if (nyounger >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else if (nyounger >= 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
         else if (nyounger >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -592,6 +594,7 @@ __global__ __launch_bounds__(512) void pw_chain_fwd_kernel(PwChainParams p) {
             }
         });
         ttiles += 1;
+        primed = true;
 
         cur = nxt;
         nxt = advance(nxt);

@@ -122,13 +122,18 @@ def progressive_fp64_torch(datas, kerns, grads=None, splat=True):
 
 
 class ProgressiveFP64(th.nn.Module):
-    """ProgressiveKernelApply(splat=True) (reference sbmc/modules.py:422-471) in torch ops of any dtype."""
+    """ProgressiveKernelApply (reference sbmc/modules.py:422-471; splat=False: the gather ablation, no transposition) in
+    torch ops of any dtype."""
+
+    def __init__(self, splat=True):
+        super(ProgressiveFP64, self).__init__()
+        self.splat = splat
 
     def forward(self, data, kernels, sum_r, sum_w, max_w):
         bs, k2, h, w = kernels.shape
         k = int(round(k2 ** 0.5))
         p = (k - 1) // 2
-        g = gather_logits_fp64(kernels)
+        g = gather_logits_fp64(kernels) if self.splat else kernels
         kmax = g.max(1, keepdim=True)[0]
         new_max = kmax if sum_r is None else th.max(kmax, max_w)
         wts = th.exp(g - new_max)
@@ -152,8 +157,32 @@ def multisteps_fp64(model, ctor_args, ctor_kwargs):
     m64 = Multisteps(*ctor_args, pointwise_gemm=False, batch_samples=False, **ctor_kwargs)
     m64.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
     m64.double()
-    m64.kernel_update = ProgressiveFP64()
+    m64.kernel_update = ProgressiveFP64(splat=m64.splat)
     return m64
+
+
+class KernelApplyFP64(th.nn.Module):
+    """KernelApply(softmax=True, splat=False) (reference sbmc/modules.py:338-361) in torch ops of any dtype."""
+
+    def forward(self, data, kernels):
+        bs, k2, h, w = kernels.shape
+        k = int(round(k2 ** 0.5))
+        p = (k - 1) // 2
+        wts = th.softmax(kernels, 1)
+        dpad = th.nn.functional.pad(data, (p, p, p, p))
+        out = th.zeros_like(data)
+        for dy in range(k):
+            for dx in range(k):
+                out = out + wts[:, dy * k + dx:dy * k + dx + 1] * dpad[:, :, dy:dy + h, dx:dx + w]
+        return out, th.ones_like(out[:, :1])
+
+
+def float64_twin(net, factory):
+    """A float64 twin of a module on the CPU: `factory()` builds the same module anew (weight-normalised modules do not
+    deepcopy), the weights are `net`'s."""
+    twin = factory()
+    twin.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    return twin.double()
 
 
 def module_scales(named_grads):
@@ -167,7 +196,7 @@ def module_scales(named_grads):
     return {k: per[k.rsplit(".", 1)[0]] for k in named_grads}
 
 
-def no_worse_than(a, ref32, truth, rtol=1e-5, slack=2.0, what="", scale=None):
+def no_worse_than(a, ref32, truth, rtol=1e-5, slack=2.0, what="", scale=None, terms=None):
     """|a - truth| <= rtol-bound, OR no worse than `slack` x the error the reference-order fp32
     computation (`ref32`, the oracle) itself makes against the float64 truth, element by element max.
     For quantities whose fp32 value is a difference of two long sums: both implementations round, so
@@ -179,8 +208,55 @@ def no_worse_than(a, ref32, truth, rtol=1e-5, slack=2.0, what="", scale=None):
     err = (a - truth).abs().max().item()
     ref_err = (ref32 - truth).abs().max().item()
     bound = max(rtol * scale, slack * ref_err)
-    assert err <= bound, "%s: err vs fp64 %.3e > max(%.1e * scale = %.3e, %.1f x oracle's own fp32 error %.3e)" % (
-        what, err, rtol, rtol * scale, slack, ref_err)
+    if terms is not None:                      # `a` is an fp32 sum whose terms' magnitudes add up to `terms` (bias_term_sums)
+        bound = max(bound, SUM_ROUNDING * terms)
+    assert err <= bound, "%s: err vs fp64 %.3e > max(%.1e * scale = %.3e, %.1f x oracle's own fp32 error %.3e%s)" % (
+        what, err, rtol, rtol * scale, slack, ref_err, "" if terms is None else ", 2^-21 x sum |terms| = %.3e" % (SUM_ROUNDING * terms))
+
+
+SUM_ROUNDING = 2.0 ** -21
+
+
+def bias_term_sums(model64):
+    """Hooks on every biased convolution of a float64 model: after its backward, {"<module>.bias": the largest over the output
+    channels of sum |d loss / d output|} -- the sum of the MAGNITUDES of the terms a bias gradient adds up.  An fp32 sum
+    of n terms of mixed sign is good to a few ulp of THAT (SUM_ROUNDING = 8 ulp: partial sums per thread, a tree over
+    them), not of its own value: where a bias gradient cancels to a hundredth of its terms' magnitudes, two correct fp32
+    evaluations differ by 1e-5 of it and land on either side of any such bound by rounding luck."""
+    sums = {}
+
+    def forward_hook(name):
+        # (a hook on the output TENSOR, set in the forward: a module backward hook does not go with the in-place
+        # activations behind the convolutions; a tensor hook sees the gradient of the value it was set on)
+        def on_grad(g):
+            sums[name + ".bias"] = sums.get(name + ".bias", 0.0) + g.detach().abs().sum((0, 2, 3)).max().item()
+
+        def fn(mod, inp, out):
+            if out.requires_grad:
+                out.register_hook(on_grad)
+        return fn
+    for name, mod in model64.named_modules():
+        if isinstance(mod, th.nn.Conv2d) and mod.bias is not None:
+            mod.register_forward_hook(forward_hook(name))
+    return sums
+
+
+def close_sum(a, truth, abs_terms, rtol=1e-5, what="", extra=0.0):
+    """`a`: fp32 sums of many terms of mixed sign (a weight or bias gradient: a sum over every pixel), `truth` the float64
+    sums, `abs_terms` the sums of the terms' MAGNITUDES (same shape).  Each element is held to `close`'s bound (rtol of the
+    tensor's scale + rtol of itself) or to 8 ulp of its terms' magnitudes (SUM_ROUNDING), whichever is larger: what an fp32
+    accumulation warrants where the terms cancel.  extra: an absolute allowance on top (half-storage kernels: a few terms whose
+    rounding to half fell the other way)."""
+    a = a.detach().cpu().double()
+    b = truth.detach().cpu().double()
+    t_ = abs_terms.detach().cpu().double()
+    assert a.shape == b.shape == t_.shape, "%s: shapes %s %s %s" % (what, tuple(a.shape), tuple(b.shape), tuple(t_.shape))
+    scale = b.abs().max().item()
+    err = (a - b).abs()
+    bound = th.maximum(rtol * scale + rtol * b.abs(), SUM_ROUNDING * t_) + extra
+    bad = err > bound
+    assert not bad.any(), "%s: max err %.3e (scale %.3e), %d/%d beyond max(%.0e of scale, 2^-21 of sum |terms|)" % (
+        what, err.max().item(), scale, int(bad.sum()), b.numel(), rtol)
 
 
 def close_or_yardstick(a, ref32, truth_fn, rtol=1e-5, slack=2.0, what=""):

@@ -60,9 +60,10 @@ def _worker(rank, world, port, height, layout="auto", per_conv=True, transport="
         ref_loss.backward()
         ref_grads = {k: p.grad.clone() for k, p in model.named_parameters()}
         model.zero_grad()
-        from helpers import module_scales, multisteps_fp64, no_worse_than
+        from helpers import bias_term_sums, module_scales, multisteps_fp64, no_worse_than
         th.set_num_threads(8)
         m64 = multisteps_fp64(model, *ctor).train(True)
+        terms = bias_term_sums(m64)
         o64 = m64({k: v.cpu().double() for k, v in full.items()})["radiance"]
         l64 = loss_fn(o64, crop_like(full["target_image"].cpu().double(), o64))
         l64.backward()
@@ -83,14 +84,11 @@ def _worker(rank, world, port, height, layout="auto", per_conv=True, transport="
         no_worse_than(loss, ref_loss, l64, what="loss")
         scales = module_scales(g64)
         for k, q in model.named_parameters():
-            # weights: 1e-5 of the module's gradient scale from float64, or twice the single-process evaluation's own
-            # distance.  Biases with the weight bank on: 2e-5 / three times -- a bias gradient here is an fp32 sum over
-            # ~9000 pixel-samples of mixed sign, both evaluations sit at 0.3-1.2e-5 from the float64 one, and the bank's
-            # weight norm differs from torch's in the last bit, which moves them across 1e-5 (wbank=False below runs
-            # every parameter at the tight bound: the bank is the only source of that drift)
-            loose = wbank and k.endswith(".bias")
-            no_worse_than(q.grad, ref_grads[k], g64[k], rtol=2e-5 if loose else 1e-5, what="grad " + k, scale=scales[k],
-                          slack=3.0 if loose else 2.0)
+            # 1e-5 of the module's gradient scale from float64, or twice the single-process evaluation's own distance from it;
+            # a bias gradient -- an fp32 sum over ~9000 pixel-samples of mixed sign -- also to 8 ulp of the sum of its terms'
+            # magnitudes (helpers.bias_term_sums: what an fp32 sum warrants; until round 6 these ran at a blanket 2e-5 / 3 x)
+            no_worse_than(q.grad, ref_grads[k], g64[k], rtol=1e-5, what="grad " + k, scale=scales[k], slack=2.0,
+                          terms=terms.get(k) if k.endswith(".bias") else None)
         assert (part.channel is not None) == (transport == "ipc")
     finally:
         dist.destroy_process_group()
@@ -160,7 +158,9 @@ def _fallback_worker(rank, world, port):
         second = float(runner.train_step(opt, loss_fn, slab))    # ... and the frame goes on over torch.distributed
         assert abs(second - first) <= 1e-6 * abs(first)
         for k, q in model.named_parameters():
-            assert (q.grad - grads[k]).abs().max().item() <= 2e-5 * max(grads[k].abs().max().item(), 1e-30), k
+            # (two fp32 evaluations of the step -- halo rows through the mailboxes, then over torch.distributed --, each
+            # within 1e-5 of the exact gradient: their difference within twice that)
+            assert (q.grad - grads[k]).abs().max().item() <= 2 * 1e-5 * max(grads[k].abs().max().item(), 1e-30), k
     finally:
         dist.destroy_process_group()
 

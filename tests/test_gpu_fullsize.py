@@ -3,7 +3,7 @@ full size, plus a full-width band checked against the oracle."""
 import pytest
 import torch as th
 
-from helpers import close, run_progressive
+from helpers import close_sum, close, run_progressive
 
 pytestmark = pytest.mark.gpu
 
@@ -93,9 +93,10 @@ def test_fullsize_scatter2gather_involution_and_kw_linearity():
     o1, s1 = F.KernelWeighting.apply(d1, y)
     o2, s2 = F.KernelWeighting.apply(d2, y)
     o12, s12 = F.KernelWeighting.apply(d1 + 2 * d2, y)
-    close(o12, o1 + 2 * o2, rtol=2e-5)
+    # (linearity between THREE fp32 evaluations, each within 1e-5 of the exact operator: o12's error + o1's + twice o2's)
+    close(o12, o1 + 2 * o2, rtol=4 * 1e-5)
     assert th.equal(s1, s12)
-    close(s1, y.sum((1, 2)), rtol=2e-5)
+    close(s1, y.double().sum((1, 2)), rtol=1e-5)
 
 
 def test_4k_frame_indexing():
@@ -164,8 +165,8 @@ def test_4k_pointwise_layer_indexing():
     gz = gs.double() * (pre > 0).double()
     close(x.grad[0][:, idx], (w.detach().double().t() @ gz).float(), rtol=1e-5)
     assert x.grad.abs().sum().item() == pytest.approx(x.grad[0][:, idx].abs().sum().item(), rel=1e-6)
-    close(w.grad, (gz @ xs.t()).float(), rtol=2e-5)
-    close(b.grad, gz.sum(1).float(), rtol=2e-5)
+    close_sum(w.grad, gz @ xs.t(), gz.abs() @ xs.abs().t(), what="gw")
+    close_sum(b.grad, gz.sum(1), gz.abs().sum(1), what="gbias")
 
 
 def test_fullsize_regressor_output_layer_backward_in_one_pass():

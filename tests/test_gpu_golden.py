@@ -159,11 +159,15 @@ def test_multisteps_production_width_on_gpu_matches_reference_fixture(case):
 
     def count(prefix):
         return sum(1 for n in names if n.startswith(prefix))
-    # per forward pass: 3 U-nets x 15 convolutions, 3 embeddings x 3 + 3 regressor 1x1 layers; the fixture check
-    # runs an eval and a train forward and one backward
+    # per forward pass: 3 U-nets x 15 convolutions; the three embeddings' 1x1 chains in ONE fused pass each (round 6:
+    # csrc/pointwise_chain.hip) and the regressor's -- all three layers at k = 5 (25 logits), its first two + the
+    # 441-channel layer's own kernel at k = 21; the fixture check runs an eval and a train forward and one backward (layer
+    # by layer: 12 launches)
     assert count("conv3x3_fwd") == 2 * 45, count("conv3x3_fwd")
     assert count("conv3x3_bwd_weight") == 45 and count("conv3x3_bwd_data") == 45
-    assert count("pointwise_fwd ") == 2 * 12, count("pointwise_fwd ")
+    assert count("pointwise_chain_fwd 128x128x128<-") == 2 * 3, names
+    assert count("pointwise_chain_fwd 128x128x25<-" if case == "k5" else "pointwise_chain_fwd 128x128<-") == 2, names
+    assert count("pointwise_fwd ") == (0 if case == "k5" else 2), count("pointwise_fwd ")
     assert count("pointwise_bwd ") == 11 + (1 if case == "k5" else 0), names
     # k = 21: the 441-channel layer's backward is the ONE-PASS kernel (round 5), reached through the splat's bound word
     assert count("pointwise_wide_bwd") == (1 if case == "k21" else 0) and count("pointwise_gw_wide") == 0, names
@@ -194,8 +198,15 @@ def test_kpcn_on_gpu_matches_reference_fixture():
     from test_host_golden import _kpcn_from_golden
     g, model, data = _kpcn_from_golden("cuda")
     res = model(data)
+    # 1e-5 of a float64 evaluation of the same model, or no further from it than twice the reference's own fixture
+    from helpers import KernelApplyFP64
+    _, m64, d64 = _kpcn_from_golden("cpu")
+    m64.double()
+    m64.kernel_apply = KernelApplyFP64()
+    with th.no_grad():
+        r64 = m64({k: v.double() for k, v in d64.items()})
     for k in ("radiance", "diffuse", "specular"):
-        close(res[k], g["out." + k], rtol=2e-5, what=k)
+        no_worse_than(res[k], t(g["out." + k]), r64[k], what=k)
 
 
 @pytest.mark.parametrize("tag", ["splat", "gather", "pixel"])
@@ -204,4 +215,8 @@ def test_multisteps_odd_sizes_on_gpu(tag):
     g, model, batch = _multisteps_odd(tag, "cuda")
     with th.no_grad():
         out = model(batch)["radiance"]
-    close(out, g[tag + ".eval.radiance"], rtol=2e-5, what=tag)
+        # 1e-5 of a float64 evaluation of the same model, or no further from it than twice the reference's own fixture
+        m64 = multisteps_fp64(model, (5, 3), dict(width=4, embedding_width=4, ksize=3, nsteps=3, splat=(tag != "gather"),
+                                                  pixel=(tag == "pixel"))).train(False)
+        o64 = m64({k: v.cpu().double() for k, v in batch.items()})["radiance"]
+    no_worse_than(out, t(g[tag + ".eval.radiance"]), o64, what=tag)

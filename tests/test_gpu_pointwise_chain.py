@@ -184,3 +184,28 @@ def test_chain_is_what_the_embedding_runs():
     for got, ref in ((a, a0), (mean_out[0], mean_ref[0]), (k, k0)):
         assert got.shape == ref.shape
         assert (got - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+
+
+def test_chain_at_1280x720x4spp_equals_the_separate_layers_and_itself():
+    """BASELINE configs[2]'s size (every workgroup walks ~450 tiles: the prefetch of the tile after next, its waits and the
+    store traffic at full rate), training form: every output against the layer-by-layer kernels, and bit-equal between two
+    launches."""
+    from sbmc_amd import functions as funcs
+    dev = th.device("cuda")
+    b, s, cin, couts, hw = 4, 4, 128, (128, 128, 128), 1280 * 720
+    x, t, layers = _make(b, s, cin, couts, hw, 2, (1, 1, 0), 1.0, dev, 11)
+    ys, signs, amaxes, ymean = funcs.pointwise_chain_forward(x, t, s, layers, store_mid=True, want_signs=True, mean=True)
+    ys2, signs2, _, ymean2 = funcs.pointwise_chain_forward(x, t, s, layers, store_mid=True, want_signs=True, mean=True)
+    for a, c in zip(ys + signs[:2] + [ymean], ys2 + signs2[:2] + [ymean2]):
+        assert th.equal(a, c)
+    del ys2, signs2, ymean2
+    cur = x
+    for l, (w, bias, act, slope) in enumerate(layers):
+        if l + 1 < len(layers):
+            cur = funcs.PointwiseLayer.apply(cur, w, bias, t if l == 0 else None, s if l == 0 else 1, act, slope)
+        else:
+            cur, m = funcs.PointwiseLayerMean.apply(cur, w, bias, None, 1, act, slope, s)
+        scale = cur.abs().max().item()
+        assert th.isfinite(ys[l]).all()
+        assert (ys[l] - cur).abs().max().item() <= 3e-6 * scale, l
+    assert (ymean - m).abs().max().item() <= 3e-6 * scale

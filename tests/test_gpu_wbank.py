@@ -9,7 +9,7 @@ import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
 
-from helpers import close
+from helpers import bias_term_sums, close, module_scales, multisteps_fp64, no_worse_than
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -110,7 +110,8 @@ def test_model_with_and_without_banks_agrees(monkeypatch):
     from sbmc_amd import Multisteps, losses
     from sbmc_amd.utils import crop_like
     th.manual_seed(0)
-    model = Multisteps(12, 3, width=128, embedding_width=128, ksize=5, nsteps=2).to(DEV)
+    ctor = ((12, 3), dict(width=128, embedding_width=128, ksize=5, nsteps=2))
+    model = Multisteps(*ctor[0], **ctor[1]).to(DEV)
     batch = {"radiance": th.rand(1, 2, 3, 32, 48, device=DEV), "features": th.rand(1, 2, 12, 32, 48, device=DEV),
              "global_features": th.rand(1, 3, 1, 1, device=DEV)}
     target = th.rand(1, 3, 32, 48, device=DEV)
@@ -125,8 +126,18 @@ def test_model_with_and_without_banks_agrees(monkeypatch):
         for m in model.modules():
             assert "_sbmc_bank_w" not in m.__dict__          # nothing stale left on the modules
     assert abs(res["0"][0] - res["1"][0]) <= 1e-6 * abs(res["0"][0])
+    # against a float64 evaluation of the model: either way of taking the weight norm within 1e-5 of the module's gradient
+    # scale, or no further from it than twice the other (a bias gradient also to 8 ulp of its terms' magnitudes)
+    m64 = multisteps_fp64(model, *ctor).train(True)
+    terms = bias_term_sums(m64)
+    o64 = m64({k: v.cpu().double() for k, v in batch.items()})["radiance"]
+    losses.TonemappedRelativeMSE()(o64, crop_like(target.cpu().double(), o64)).backward()
+    g64 = {k: q.grad for k, q in m64.named_parameters()}
+    scales = module_scales(g64)
     for k in res["0"][1]:
-        close(res["1"][1][k], res["0"][1][k], 2e-5, k)
+        tk = terms.get(k) if k.endswith(".bias") else None
+        no_worse_than(res["1"][1][k], res["0"][1][k], g64[k], what=k + " (banks)", scale=scales[k], terms=tk)
+        no_worse_than(res["0"][1][k], res["1"][1][k], g64[k], what=k + " (torch)", scale=scales[k], terms=tk)
 
 
 def test_amax_words_come_zeroed_and_are_raised():
