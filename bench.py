@@ -270,15 +270,19 @@ def validate_sharded(model, runner, loss_fn, batch, part, H, W, S, device):
     return out
 
 
+def scale_ok(pm, H, W, S):
+    """Was a committed PMC pass taken at this run's frame size?"""
+    return pm.get("height") == H and pm.get("width") == W and pm.get("spp") == S
+
+
 def cpu_baseline(args, device=None):
     """Times the CPU port on a bounded sample of the same workload (rank 0, N=1 only).
 
     model workload: the same Python model code with torch-CPU convolutions and the oracle's splat
-    operators behind the `*_cpu_float32` names, on a full-width, eighth-height crop of the real frame
-    (all samples).  Warm-up: one whole training step on a narrow crop of the same height (Adam state,
-    thread pools, allocator -- at full crop size a warmed step measured 3 % faster than the first one,
-    71.2 s vs 73.5 s at 1280x180, which does not justify doubling the CPU time); then 1 timed step, or the
-    median of 3 if a step takes less than ~12 s on this host (about 30-40 s of CPU work).  The op-level figure
+    operators behind the `*_cpu_float32` names, on a full-width, QUARTER-height crop of the real frame
+    (all samples): one timed step, behind a warm-up step and a timed step on a sixteenth of the height (Adam
+    state, thread pools, allocator -- at full crop size a warmed step measured 3 % faster than the first one, 71.2 s vs
+    73.5 s at 1280x180, which does not justify doubling the CPU time).  The op-level figure
     (SURVEY.md 8d metric (i): the oracle's splat forward + backward alone, same crop) rides in the
     same object.  The same seeded model and inputs are also run on the GPU, which gives the parity
     figures of BASELINE.json's metric ("PSNR vs ref", SURVEY.md section 8d: 10*log10(1/MSE) after
@@ -339,16 +343,19 @@ def cpu_baseline(args, device=None):
             ref_out = model(batch)["radiance"]
         loss_fn = losses.TonemappedRelativeMSE()
         t0 = time.perf_counter()
-        train_step(model, opt, loss_fn, batch)           # warm-up on the SAME crop: Adam state, thread pools, allocator
+        train_step(model, opt, loss_fn, batch)           # warm-up: Adam state, thread pools, allocator
         warm = time.perf_counter() - t0
-        dts = []
-        # median of 3 timed steps; a host on which one step takes more than 45 s gets one timed step
-        while len(dts) < (1 if (dts and dts[0] > 45.0) else 3):
-            t0 = time.perf_counter()
-            train_step(model, opt, loss_fn, batch)
-            dts.append(time.perf_counter() - t0)
-        ntimed = len(dts)
-        dt = sorted(dts)[len(dts) // 2]
+        t0 = time.perf_counter()
+        train_step(model, opt, loss_fn, batch)
+        dt16 = time.perf_counter() - t0
+        # THE figure: one timed step on a QUARTER of the height (SURVEY.md 8d's crop; VERDICT r5: the sixteenth flatters
+        # neither side equally -- fewer border rows per output row on the larger crop), behind the two steps above
+        hq = max(h, (args.height // 4) // 4 * 4)
+        qbatch = make_model_inputs(hq, w, spp, "cpu", seed=1) if hq > h else batch
+        t0 = time.perf_counter()
+        train_step(model, opt, loss_fn, qbatch)
+        dt = time.perf_counter() - t0
+        del qbatch
         model.load_state_dict(state)                     # (the parity run below compares the seeded weights)
     finally:
         halide_ops.register_cpu_ops_for_testing(None)
@@ -376,12 +383,14 @@ def cpu_baseline(args, device=None):
                           "within 2x the MEASURED fp32 noise floor between two single-GPU evaluations, up to 4e-4 of a "
                           "gradient's scale -- not 1e-5"}
     base = {
-        "value": round(spp * h * w / dt / 1e6, 4), "unit": "Msamples/s",
+        "value": round(spp * hq * w / dt / 1e6, 4), "unit": "Msamples/s",
         "cores": threads, "kind": "port",
-        "sample": "Multisteps training step (torch-CPU convs + oracle splat ops) on a %dx%d crop (full width, "
-                  "a sixteenth of the height) of the frame, %d spp, k=%d: 1 warm-up step on the same crop (%.1f s)"
-                  " + %d timed, median %.1f s (all: %s), on %d threads (host has %d logical cpus)" % (
-                      w, h, spp, k, warm, ntimed, dt, ", ".join("%.1f" % d for d in dts), threads, os.cpu_count()),
+        "sample": "Multisteps training step (torch-CPU convs + oracle splat ops) on a %dx%d crop (full width, a QUARTER of "
+                  "the height: SURVEY.md 8d) of the frame, %d spp, k=%d: ONE timed step = %.1f s, behind a warm-up step (%.1f s) "
+                  "and a timed step (%.1f s) on a %dx%d crop (a sixteenth of the height), on %d threads (host has %d "
+                  "logical cpus)" % (w, hq, spp, k, dt, warm, dt16, w, h, threads, os.cpu_count()),
+        "sixteenth_height": {"value": round(spp * h * w / dt16 / 1e6, 4), "unit": "Msamples/s",
+                             "sample": "the same step on %dx%d: 1 timed step after 1 warm-up = %.1f s" % (w, h, dt16)},
         "splat_op": op,
     }
     return base, parity
@@ -849,7 +858,8 @@ def main():
             res["whole_step_tflops"] = round(step_flops / (dt / steps) / 1e12, 1)
             # (above 1 since round 3: the 3 x 3 convolutions and the fp32 1 x 1 layers run on the f16 / bf16 matrix pipe
             # at fp32 accuracy -- three resp. six low-precision products per fp32 multiply-add)
-            res["frac_of_fp32_mfma_peak"] = round(step_flops / (dt / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)
+            # (a multiple, not a fraction: most of the step's multiply-adds run on the f16 pipe)
+            res["multiples_of_fp32_mfma_peak"] = round(step_flops / (dt / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)
             res["unet_layout"] = layout
         if fp32_pipe is not None:
             res["ms_per_step_fp32_pipe"] = fp32_pipe.get("ms_per_step")
@@ -881,6 +891,23 @@ def main():
             res["kernels_in_step"] = kern_step
         if layers:
             res["pointwise_layers"] = layers
+            # the 1x1 kernel furthest below its (HBM) roof; PMC traffic where a committed pass of THIS tree's kernels holds it
+            worst = min(layers, key=lambda n: layers[n]["frac_of_hbm_peak"])
+            traffic, tsrc = None, None
+            try:
+                pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_pointwise_pmc.json")
+                with open(pj) as f:
+                    pm = json.load(f)
+                ent = pm.get("kernels", {}).get(worst)
+                if ent and scale_ok(pm, H, W, S):
+                    traffic, tsrc = ent.get("hbm_bytes_per_launch"), "profiles/r06_pointwise_pmc.json (another run of this command)"
+            except (OSError, ValueError):
+                pass
+            res["roofline_pointwise"] = {
+                "kernel": worst, "bound": "hbm", "achieved": layers[worst]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": layers[worst]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": tsrc,
+                "alg_bytes": layers[worst]["alg_bytes"], "avg_ms": layers[worst]["avg_ms"],
+                "note": "the per-sample 1x1 layer furthest below the HBM roof (two instrumented steps after the timed ones)"}
         if convs:
             res["conv3x3"] = convs
             tot_flop = sum(v["TFLOPs_fp32_equivalent"] * v["ms_per_step"] for v in convs.values())

@@ -124,8 +124,8 @@ def _compile(src, verbose):
             sys.stderr.write(err)
             raise subprocess.CalledProcessError(res.returncode, cmd)
         other = [ln for ln in err.splitlines() if "remark:" not in ln and "[-Rpass-analysis" not in ln]
-        if verbose and any(ln.strip() for ln in other):
-            sys.stderr.write("\n".join(other) + "\n")                  # (warnings)
+        if any(ln.strip() for ln in other):
+            sys.stderr.write("\n".join(other) + "\n")                  # (warnings: always shown)
         with open(tmp + ".remarks", "w") as f:
             f.write(err)
         os.replace(tmp + ".remarks", obj + ".remarks")

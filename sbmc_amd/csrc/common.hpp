@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <strings.h>
 
 namespace sbmc {
@@ -202,7 +203,10 @@ static inline int env_knob(const char* name, int fallback) {
     const char* v = getenv(name);
     if (!v) return fallback;
     while (*v == ' ' || *v == '\t') ++v;
-    if (!strncasecmp(v, "on", 2) || !strncasecmp(v, "yes", 3) || !strncasecmp(v, "true", 4)) return 1;
+    // whole tokens, as sbmc_amd/utils.py knob compares them ("only" is not "on"): trailing blanks do not count
+    size_t n = strlen(v);
+    while (n > 0 && (v[n - 1] == ' ' || v[n - 1] == '\t' || v[n - 1] == '\n')) --n;
+    if ((n == 2 && !strncasecmp(v, "on", 2)) || (n == 3 && !strncasecmp(v, "yes", 3)) || (n == 4 && !strncasecmp(v, "true", 4))) return 1;
     return atoi(v);
 }
 

@@ -518,7 +518,9 @@ __global__ __launch_bounds__(512) void pw_chain_fwd_kernel(PwChainParams p) {
                 // pixel block sits in the SCALAR offset: a constant added to the lane offset is not folded into the instruction
                 // -- the unsigned sum might wrap -- and cost 16 lane registers of offsets.  Tried and measured slower: the same
                 // stores dealt out between the NEXT phase's products from held registers -- a store blocks the wave that issues
-                // it wherever it sits, 4.46 -> 4.79 ms --, and an fp32 tile in LDS stored 16 bytes per lane, 4.46 <- 4.77.)
+                // it wherever it sits, 4.46 -> 4.79 ms --, an fp32 tile in LDS stored 16 bytes per lane, 4.46 <- 4.77, and 16 bytes
+                // per lane through a 4 x 4 transpose inside the lane quads (DPP; 16 pieces of 64 bytes per instruction), 4.62 -> 4.87:
+                // what a store costs is its 64-byte pieces, not the instruction.)
                 const rsrc_t ry = rsrc_n(p.y[L] + ((size_t)b * C + r0) * hw, (unsigned)nrows * hw * 4u);
                 if (!edge) {
 #pragma unroll

@@ -1082,7 +1082,7 @@ class PoolSkip(th.autograd.Function):
                                                                 b, h // 2, w // 2, c, _lib.current_stream(dev)),
                            "maxpool2_nhwc_bwd_add_adj")
                 tag_amax(gx, amax)
-                adj.done = (partial, amax, gx.data_ptr())
+                adj.done = (partial, amax, gx.data_ptr(), gx._version)
             else:
                 _lib.check(L.sbmc_maxpool2_nhwc_bwd_add(_lib.ptr(left), _lib.ptr(g_pooled), _lib.ptr(g_skip), _lib.ptr(gx),
                                                         b, h // 2, w // 2, c, left.element_size(),
@@ -1316,7 +1316,10 @@ class _TaggedView(th.autograd.Function):
 
 
 def tagged_view(x, *shape):
-    """x.view(*shape); through `_TaggedView` where a magnitude word could travel (contiguous fp32 GPU tensors)."""
+    """x.view(*shape); through `_TaggedView` where a magnitude word could travel (contiguous fp32 GPU tensors).
+    The result is then a view made inside a custom Function: torch refuses IN-PLACE operations on it (an
+    nn.ReLU(inplace=True) behind it raises).  Every caller in this package feeds it to one of its own Functions, which
+    apply activations themselves; a new caller that wants to modify the result in place must use x.view() and lose the tag."""
     if x.is_cuda and x.dtype == th.float32 and x.is_contiguous() and knob("SBMC_AMAX_TAGS") != 0:
         return _TaggedView.apply(x, tuple(shape))
     return x.reshape(*shape)
@@ -1457,7 +1460,7 @@ class Conv3x3NHWC(th.autograd.Function):
                         _lib.ptr(adj.signs), adj.slope, _lib.ptr(gx), _lib.ptr(apartial), _lib.ptr(amax), b, h, wd, cout, cin,
                         _STREAMK.take(dev), _lib.current_stream(dev)), "conv3x3_adj_nhwc")
                     tag_amax(gx, amax)
-                    adj.done = (apartial, amax, gx.data_ptr())
+                    adj.done = (apartial, amax, gx.data_ptr(), gx._version)
             elif want_gx:
                 with _timed("conv3x3_bwd_data %dx%d@%dx%dx%d" % (cout, cin, b, h, wd), dev):
                     gx = Conv3x3NHWC._conv(gy, gmax, wp[1] if wp is not None else Conv3x3NHWC._prepare(w, True), cin)
@@ -1585,7 +1588,7 @@ class _AdjLink(object):
         self.signs, self.slope = signs, slope
         self.shape, self.ptr = tuple(y.shape), y.data_ptr()
         self.taken = False            # a consumer's forward has taken the link
-        self.done = None              # (partial, gmax, gz pointer) between the consumer's backward and the producer's
+        self.done = None              # (partial, gmax, gz pointer, gz version) between the consumer's backward and the producer's
 
     def fits(self, x, L, cout_consumer):
         """The consumer's input IS the producer's output, once, and the ADJ kernel takes the shape."""
@@ -1598,7 +1601,9 @@ class _AdjLink(object):
         done, self.done = self.done, None
         if done is None:
             return None
-        if done[2] != gy.data_ptr():
+        # (the pointer alone is not enough: autograd may add a second reader's gradient into that very buffer in place --
+        # the version counter then moves)
+        if done[2] != gy.data_ptr() or done[3] != gy._version:
             raise RuntimeError("Conv3x3BiasActNHWC: the gradient of a chained layer's output was replaced on its way "
                                "(another consumer of that output, or a hook): the caller's guarantee does not hold")
         return done[0], done[1]
@@ -1768,7 +1773,7 @@ class UpsampleCatNHWC(th.autograd.Function):
                                                                 adj.slope, _lib.ptr(partial), _lib.ptr(amax), b, cu, cl, hc, w,
                                                                 _lib.current_stream(dev))
                     tag_amax(gcoarse, amax)
-                    adj.done = (partial, amax, gcoarse.data_ptr())
+                    adj.done = (partial, amax, gcoarse.data_ptr(), gcoarse._version)
                 else:
                     rc = bwd(_lib.ptr(g), _lib.ptr(gcoarse), _lib.ptr(gleft), b, cu, cl, hc, w, top, bot,
                              _lib.current_stream(dev))
@@ -1919,7 +1924,8 @@ class SplatAll(th.autograd.Function):
         # fp32: the per-pixel chain also leaves an upper bound of |d_kernels| in a device word (the scale of the 441-channel
         # layer's backward, which reads d_kernels next: no pass over 13 GB for it); it needs max |data|
         bound = None
-        if not half and knob("SBMC_HIP_PW_F16") != 0 and knob("SBMC_AMAX_TAGS") != 0:
+        if (not half and knob("SBMC_HIP_PW_F16") != 0 and knob("SBMC_AMAX_TAGS") != 0
+                and (known_amax(data) is not None or data.data_ptr() % 16 == 0)):    # (the absmax pass takes 16-byte-aligned pointers)
             # (max |data|: its tag if a pass left one -- never tagged here: the radiance is a network INPUT, a new
             # tensor every step of a real run, and a bench that reuses its batch must not skip the pass)
             dmax, bound = known_amax(data), amax_word(dev)

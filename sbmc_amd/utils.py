@@ -27,7 +27,8 @@ def crop_like(src, tgt):
 def knob(name, default=1):
     """An integer development knob from the environment, read by ONE rule on both sides of the C ABI
     (csrc/common.hpp `env_knob`): unset -> default; "on" / "yes" / "true" -> 1; otherwise the leading integer as C's
-    atoi reads it, i.e. "off" / "no" / "false" / anything else -> 0."""
+    atoi reads it, i.e. "off" / "no" / "false" / the empty string / anything else -> 0 (note: an EMPTY value switches a knob
+    off, it does not leave the default).  Whole tokens on both sides: "only" is not "on"."""
     v = os.environ.get(name)
     if v is None:
         return default
@@ -38,6 +39,6 @@ def knob(name, default=1):
     if i < n and v[i] in "+-":
         i += 1
     j = i
-    while j < n and v[j].isdigit():
+    while j < n and v[j] in "0123456789":         # (ASCII digits only: str.isdigit takes others that int() refuses)
         j += 1
     return int(v[:j]) if j > i else 0

@@ -12,7 +12,7 @@ from helpers import state_close
 def test_knob_rule(monkeypatch):
     from sbmc_amd.utils import knob
     for v, want in ((None, 1), ("0", 0), ("off", 0), ("no", 0), ("false", 0), ("1", 1), ("2", 2), ("on", 1), ("YES", 1),
-                    (" 3x", 3), ("", 0), ("-1", -1)):
+                    (" 3x", 3), ("", 0), ("-1", -1), ("only", 0), ("on ", 1), ("truest", 0), ("\u0663", 0)):
         if v is None:
             monkeypatch.delenv("SBMC_TEST_KNOB", raising=False)
         else:
