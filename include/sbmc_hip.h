@@ -495,6 +495,13 @@ SBMC_API int sbmc_pointwise_chain_fwd_f32(const float *x, const float *t, const 
                                  float *const *y, unsigned *const *signs, unsigned *const *amax, float *ymean,
                                  int nl, const int *cout, const int *act, const float *slope, int b, int s, int cin,
                                  long hw, int t_mode, void *stream);
+/* ABI 8 -- the forward of a WIDE layer without a context term (128 < cout <= 512: the 441-channel logits, reference
+ * sbmc/models.py:98-102) on the chain pass's machinery (csrc/pointwise_chain.hip pw_wide_fwd_kernel): the input tile staged once
+ * per 64 pixels for all row tiles, per-pixel scale (no magnitude word needed), the same arithmetic.  amax (or NULL): a zeroed
+ * device word raised to the bit pattern of max |y|.  No sign words (a wide layer's backward reads none). */
+SBMC_API int sbmc_pointwise_wide_fwd_supported(int cin, int cout, long hw);
+SBMC_API int sbmc_pointwise_wide_fwd_f32(const float *x, const float *w, const float *bias, float *y, unsigned *amax, int b,
+                                int cin, int cout, long hw, int act, float slope, void *stream);
 /* the all-half layer (x, y _Float16) with the mean as a _Float16 tensor: the mean of the half values as stored */
 SBMC_API int sbmc_pointwise_fwd_mean_f16(const void *x, const float *w, const float *bias, const float *t, void *y,
                                 void *ymean, int s_mean, int b, int s, int cin, int cout, long hw, int t_mode,

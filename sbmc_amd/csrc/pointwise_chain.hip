@@ -615,6 +615,284 @@ __global__ __launch_bounds__(512) void pw_chain_fwd_kernel(PwChainParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The WIDE layer's forward (128 < cout <= 512: the 441-channel logits, reference sbmc/models.py:98-102) on the chain
+// kernel's machinery: the input tile is staged ONCE per 64 pixels (LDS-DMA a tile ahead, per-pixel scale) for all row
+// tiles -- csrc/pointwise.hip pw_fwd_s_kernel gives every 128-row tile a workgroup of its own, each staging the tile again
+// through L2 and its own registers --, a wave owns 16 rows of EACH of the four row tiles (their weights in registers: 4 x 32),
+// and what is left is the 13 GB of stores: 16 per wave and row tile, issued behind the tile's products.
+struct PwWideFwdParams {
+    const float* x;              // [B, K0, hw]
+    const float* w;              // [C, K0]
+    const float* bias;           // [C]
+    float* y;                    // [B, C, hw]
+    unsigned* amax;              // raised to the bit pattern of max |y|, or nullptr
+    float slope;                 // 1: linear, 0: relu, else leaky relu
+    int B, K0, C;
+    unsigned hw, tiles_per_plane, nunits;
+};
+
+template <int KP0>
+__global__ __launch_bounds__(512) void pw_wide_fwd_kernel(PwWideFwdParams p) {
+    constexpr int NRT = 4;
+    constexpr int KO0 = KP0 / 8;
+    constexpr bool FIRST_ALL = KO0 >= 8, SECOND = KO0 > 8, SECOND_ALL = KO0 == 16;
+    constexpr int KS = KP0 / 32;
+    extern __shared__ float4 pc_lds[];
+    float* raw = reinterpret_cast<float*>(pc_lds);                            // [KP0][64]
+    u32x4* xp = reinterpret_cast<u32x4*>(raw + KP0 * PC_NT);                  // [2 stages][2 planes][KO0][64]
+    unsigned* pmx = reinterpret_cast<unsigned*>(xp + 2 * 2 * KO0 * PC_NT);    // [2][64]
+    float* btab = reinterpret_cast<float*>(pmx + 2 * PC_NT);                  // [512]
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int r = lane & 15, q = lane >> 4;
+    const unsigned hw = p.hw;
+    const unsigned G = gridDim.x;
+    const int r0 = 16 * wave;
+
+    // a*[t][s] = planes of W[128 t + 16 wave + lane % 16][32 s + 8 (lane / 16) + 0..7], under the scale of the wave's own rows
+    u32x4 ah[NRT][4], al[NRT][4];
+    float icw[NRT];
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+        const rsrc_t rw = rsrc_n(p.w, (unsigned)(p.C * p.K0) * 4u);
+        const int row = 128 * t + r0 + r;
+        float v[4][8];
+        float wm = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 32 * s + 8 * q + i;
+                v[s][i] = buf_load(rw, (row < p.C && k < p.K0) ? (unsigned)(row * p.K0 + k) * 4u : PC_OOB, 0);
+                wm = __builtin_fmaxf(wm, __builtin_fabsf(v[s][i]));
+            }
+        }
+        const unsigned ew = scale_exp((unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u(__builtin_bit_cast(unsigned, wm))));
+        const float cw = exp_scale(ew);
+        icw[t] = exp_inverse(ew);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned hp, lp;
+                f16_split_pair(v[s][2 * j], v[s][2 * j + 1], cw, hp, lp);
+                ah[t][s][j] = hp;
+                al[t][s][j] = lp;
+            }
+        }
+    }
+    {
+        const rsrc_t rb = rsrc_n(p.bias, (unsigned)p.C * 4u);
+        btab[threadIdx.x] = buf_load(rb, threadIdx.x * 4u, 0);                // (rows >= C: 0)
+    }
+
+    const unsigned sraw = (unsigned)((8 * wave * PC_NT + lane) * 4);
+    const unsigned sxp = (unsigned)((wave * PC_NT + lane) * 16);
+    const unsigned xv = ((unsigned)q * hw + 4u * r) * 4u;
+    const unsigned av = ((unsigned)(4 * q) * hw + (unsigned)r) * 4u;
+
+    struct Cur { unsigned unit, b, pt; };
+    const unsigned tpp = p.tiles_per_plane, Gd = G / tpp, Gm = G % tpp;
+    auto advance = [&](Cur c) -> Cur {
+        c.unit += G;
+        c.b += Gd;
+        c.pt += Gm;
+        if (c.pt >= tpp) {
+            c.pt -= tpp;
+            c.b += 1;
+        }
+        return c;
+    };
+    const unsigned xbytes = (unsigned)p.K0 * hw * 4u;
+    auto dma = [&](const Cur& c) {
+        const unsigned p0 = c.pt * PC_NT;
+        const uintptr_t xa = reinterpret_cast<uintptr_t>(p.x + (size_t)c.b * p.K0 * hw);
+        const u32x4 rxw = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa),
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(xa >> 32) & 0xffffu)),
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)xbytes), 0x00020000u};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 0 ? (FIRST_ALL || wave < KO0) : (SECOND_ALL || (SECOND && wave + 8 < KO0))) {
+                const int o = wave + 8 * i;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned dst = (unsigned)(uintptr_t)(raw + (8 * o + 4 * j) * PC_NT);
+                    const unsigned vo = xv + ((unsigned)(8 * o + 4 * j) * hw + p0) * 4u;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                                 :: "v"(vo), "s"(rxw), "s"(dst) : "memory");
+                }
+            }
+        }
+    };
+    auto read_raw = [&](float (&v)[2][8]) {
+        const char* src = reinterpret_cast<const char*>(raw) + sraw;
+        if (FIRST_ALL || wave < KO0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[0][j] = *reinterpret_cast<const float*>(src + j * PC_NT * 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[0][j] = 0.f;
+        }
+        if (SECOND_ALL || (SECOND && wave + 8 < KO0)) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[1][j] = *reinterpret_cast<const float*>(src + (64 + j) * PC_NT * 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[1][j] = 0.f;
+        }
+    };
+    auto x_max = [&](unsigned* pm) {
+        float v[2][8];
+        read_raw(v);
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = __builtin_fmaxf(m, __builtin_fabsf(v[i][j]));
+        atomicMax(pm + lane, __builtin_bit_cast(unsigned, m));
+    };
+    auto x_split = [&](const unsigned* pm, int stage) {
+        float v[2][8];
+        read_raw(v);
+        const float cx = exp_scale(scale_exp(pm[lane]));
+        char* dst = reinterpret_cast<char*>(xp + stage * 2 * KO0 * PC_NT) + sxp;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 0 ? (FIRST_ALL || wave < KO0) : (SECOND_ALL || (SECOND && wave + 8 < KO0))) {
+                u32x4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned hp, lp;
+                    split_pair_v(v[i][2 * j], v[i][2 * j + 1], cx, hp, lp);
+                    h[j] = hp;
+                    l[j] = lp;
+                }
+                *reinterpret_cast<u32x4*>(dst + (8 * i) * PC_NT * 16) = h;
+                *reinterpret_cast<u32x4*>(dst + (KO0 + 8 * i) * PC_NT * 16) = l;
+            }
+        }
+    };
+
+    if (threadIdx.x < 2 * PC_NT) pmx[threadIdx.x] = 0u;
+    for (int i = threadIdx.x; i < KP0 * PC_NT; i += 512) raw[i] = 0.f;
+    Cur cur;
+    cur.unit = blockIdx.x;
+    cur.b = cur.unit / tpp;
+    cur.pt = cur.unit % tpp;
+    bool valid = cur.unit < p.nunits;
+    __syncthreads();
+    if (valid) dma(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (valid) x_max(pmx);
+    lds_sync();
+    Cur nxt = advance(cur);
+    if (valid) {
+        x_split(pmx, 0);
+        if (nxt.unit < p.nunits) dma(nxt);
+    }
+    lds_sync();
+
+    float amax_run = 0.f;
+    int par = 0;
+    bool primed = false;
+    const float* const brow = btab + r0 + 4 * q;
+    const float slope = p.slope;
+    while (valid) {
+        const bool nvalid = nxt.unit < p.nunits;
+        const unsigned b = cur.b, p0 = cur.pt * PC_NT;
+        const bool edge = p0 + PC_NT > hw;
+        unsigned avi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) avi[i] = av + (unsigned)i * hw * 4u;
+        float ics[4];                                   // 1 / c_pixel of this lane's four pixel columns
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ics[k] = exp_inverse(scale_exp(pmx[par * PC_NT + 16 * k + r]));
+        const u32x4* bp = xp + par * 2 * KO0 * PC_NT + q * PC_NT + r;
+
+        unrolled<NRT>([&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            if (T == 0 && nvalid) {
+                // the next tile's rows (requested at row tile 2 of the tile before: the stores of row tiles 2 and 3 have been
+                // issued since, 16 each where the layer has those rows)
+                if (primed && p.C > 384) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                else if (primed && p.C > 256) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                x_max(pmx + (par ^ 1) * PC_NT);
+            }
+            if (T == 1) lds_sync();                     // (the next tile's words are complete)
+            if (T == 2 && nvalid) {
+                x_split(pmx + (par ^ 1) * PC_NT, par ^ 1);
+                const Cur n2 = advance(nxt);
+                if (n2.unit < p.nunits) dma(n2);
+            }
+            if (128 * T < p.C) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    u32x4 bh[4], bl[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        bh[k] = bp[(4 * s) * PC_NT + 16 * k];
+                        bl[k] = bp[(KO0 + 4 * s) * PC_NT + 16 * k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] = mfma16(ah[T][s], bl[k], acc[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] = mfma16(al[T][s], bh[k], acc[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] = mfma16(ah[T][s], bh[k], acc[k]);
+                }
+                const int rt0 = 128 * T + r0;
+                const int nrows = p.C - rt0 < 16 ? (p.C - rt0 > 0 ? p.C - rt0 : 0) : 16;
+                const rsrc_t ry = rsrc_n(p.y + ((size_t)b * p.C + rt0) * hw, (unsigned)nrows * hw * 4u);
+                float add[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) add[i] = brow[128 * T + i];
+                float m = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float io = ics[k] * icw[T];
+                    float mk = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = __builtin_fmaf(acc[k][i], io, add[i]);
+                        v = __builtin_fmaxf(v, v * slope);
+                        acc[k][i] = v;
+                        // (rows beyond the layer's width are zero weights and zero bias: 0)
+                        mk = __builtin_fmaxf(mk, __builtin_fabsf(v));
+                    }
+                    m = __builtin_fmaxf(m, (!edge || p0 + 16u * k + r < hw) ? mk : 0.f);
+                }
+                amax_run = __builtin_fmaxf(amax_run, m);
+                if (!edge) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) buf_store(acc[k][i], ry, avi[i], p0 * 4u + 64u * k);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool in_k = p0 + 16u * k + r < hw;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) buf_store(acc[k][i], ry, in_k ? avi[i] : PC_OOB, p0 * 4u + 64u * k);
+                    }
+                }
+            }
+        });
+        if (threadIdx.x < PC_NT) pmx[par * PC_NT + threadIdx.x] = 0u;      // (this tile's words: read above; the tile after next's)
+        lds_sync();                                     // (the next tile's planes are complete; this tile's are free)
+        primed = true;
+        cur = nxt;
+        nxt = advance(nxt);
+        valid = nvalid;
+        par ^= 1;
+    }
+    if (p.amax != nullptr) amax_publish(__builtin_bit_cast(unsigned, amax_run), p.amax);
+}
+
 }  // namespace sbmc
 
 using namespace sbmc;
@@ -684,6 +962,52 @@ extern "C" int sbmc_pointwise_chain_fwd_f32(const float* x, const float* t, cons
     if (nl == 2) { SBMC_PCH_K(2) } else { SBMC_PCH_K(3) }
 #undef SBMC_PCH_K
 #undef SBMC_PCH
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
+    return (int)hipGetLastError();
+}
+
+extern "C" int sbmc_pointwise_wide_fwd_supported(int cin, int cout, long hw) {
+    return (cin >= 1 && cin <= 128 && cout > 128 && cout <= 512 && hw >= 4 && hw % 4 == 0 && hw < (1L << 27) &&
+            (double)128 * (double)hw * 4.0 < 4294967000.0) ? 1 : 0;
+}
+
+// y[b] = act(w x[b] + bias), 128 < cout <= 512 (pw_wide_fwd_kernel); amax (or NULL): a zeroed word raised to max |y|.
+extern "C" int sbmc_pointwise_wide_fwd_f32(const float* x, const float* w, const float* bias, float* y, unsigned* amax, int b,
+                                           int cin, int cout, long hw, int act, float slope, void* stream) {
+    if (b < 0 || act < 0 || act > 2) return SBMC_HIP_EINVAL;
+    if (!sbmc_pointwise_wide_fwd_supported(cin, cout, hw)) return SBMC_HIP_EINVAL;
+    if (b == 0) return 0;
+    if (!x || !w || !bias || !y || (uintptr_t)x % 16 || (uintptr_t)y % 4) return SBMC_HIP_EINVAL;
+    PwWideFwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.amax = amax;
+    p.slope = act == 0 ? 1.f : (act == 1 ? 0.f : slope);
+    p.B = b; p.K0 = cin; p.C = cout;
+    p.hw = (unsigned)hw;
+    p.tiles_per_plane = (unsigned)((hw + PC_NT - 1) / PC_NT);
+    const unsigned long long nunits = (unsigned long long)p.tiles_per_plane * (unsigned)b;
+    if (nunits > 0xFFFFFFFFull - 65536) return SBMC_HIP_EINVAL;
+    p.nunits = (unsigned)nunits;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    const unsigned grid = nunits < (unsigned long long)cus ? (unsigned)nunits : (unsigned)cus;
+    const int kp = (cin + 31) / 32 * 32;
+    const size_t lds = (size_t)kp * PC_NT * 4 + (size_t)2 * 2 * (kp / 8) * PC_NT * 16 + (size_t)2 * PC_NT * 4 + (size_t)512 * 4;
+    hipError_t e = hipSuccess;
+#define SBMC_PWF(KPV)                                                                                    \
+    do {                                                                                                 \
+        auto kern = pw_wide_fwd_kernel<KPV>;                                                             \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, p); \
+    } while (0)
+    switch (kp) {
+        case 32: SBMC_PWF(32); break;
+        case 64: SBMC_PWF(64); break;
+        case 96: SBMC_PWF(96); break;
+        default: SBMC_PWF(128); break;
+    }
+#undef SBMC_PWF
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     return (int)hipGetLastError();
 }

@@ -527,8 +527,14 @@ def _pointwise_forward(ctx, x, w, bias, t, s, act, slope, half=False, mean_s=0):
                  and knob("SBMC_HIP_PW_F16MFMA") != 0)
     if half_mean:
         ymean = th.empty(B // mean_s, cout, hw, dtype=th.float16, device=dev)
+    wide = (scaled and t is None and signs is None and ymean is None and knob("SBMC_PW_WIDE_FWD") != 0
+            and bool(L.sbmc_pointwise_wide_fwd_supported(cin, cout, hw)))
     with th.cuda.device(dev), _timed("pointwise_fwd%s %dx%d" % ("_f16" if half else "", cout, cin), dev):
-        if scaled:
+        if wide:
+            # the 441-channel logits: the input tile staged once for all four row tiles (csrc/pointwise_chain.hip)
+            rc = L.sbmc_pointwise_wide_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(amax),
+                                               B, cin, cout, hw, act, slope, _lib.current_stream(dev))
+        elif scaled:
             rc = L.sbmc_pointwise_fwd_scaled_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(t) if t is not None else None,
                                                  _lib.ptr(y), _lib.ptr(signs) if signs is not None else None,
                                                  _lib.ptr(ymean) if ymean is not None else None, mean_s if ymean is not None else 1,

@@ -209,3 +209,47 @@ def test_chain_at_1280x720x4spp_equals_the_separate_layers_and_itself():
         assert th.isfinite(ys[l]).all()
         assert (ys[l] - cur).abs().max().item() <= 3e-6 * scale, l
     assert (ymean - m).abs().max().item() <= 3e-6 * scale
+
+
+@pytest.mark.parametrize("spread", [1.0, 1e-4])
+@pytest.mark.parametrize("b,cin,cout,hw,act", [(2, 128, 441, 64 * 37 + 20, 0), (1, 128, 441, 48, 2), (3, 96, 200, 1000, 1),
+                                               (2, 128, 512, 4096, 0), (1, 33, 129, 132, 0), (2, 64, 300, 64 * 600, 0)])
+def test_wide_forward_vs_float64(b, cin, cout, hw, act, spread):
+    """sbmc_pointwise_wide_fwd_f32 (pw_wide_fwd_kernel: the 441-channel logits layer, all row tiles from one staged tile)
+    against float64 at 1e-5 of the output's scale; the magnitude word; layers of 2, 3 and 4 row tiles, ragged planes."""
+    from sbmc_amd import _lib
+    L = _lib.lib()
+    dev = th.device("cuda")
+    th.manual_seed(b * 100 + cout)
+    x = th.randn(b, cin, hw, device=dev) * spread
+    w = th.randn(cout, cin, device=dev) / cin ** 0.5 / spread
+    bias = th.randn(cout, device=dev)
+    assert L.sbmc_pointwise_wide_fwd_supported(cin, cout, hw)
+    y = th.full((b, cout, hw), float("nan"), device=dev)
+    amax = th.zeros(1, dtype=th.int32, device=dev)
+    _lib.check(L.sbmc_pointwise_wide_fwd_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(amax), b, cin, cout,
+                                             hw, act, 0.01, _lib.current_stream(dev)), "wide_fwd")
+    ref = _chain64(x, None, 1, [(w, bias, act, 0.01)])[0]
+    assert (y.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert amax.item() == y.abs().max().reshape(1).view(th.int32).item()
+
+
+def test_wide_forward_at_full_size_equals_the_row_tile_kernel(monkeypatch):
+    """1280 x 720 x 4 samples, 128 -> 441: the staged-once kernel against csrc/pointwise.hip's row-tile kernel (SBMC_PW_WIDE_FWD=0),
+    and bit-equal between two launches."""
+    from sbmc_amd import functions as funcs
+    dev = th.device("cuda")
+    th.manual_seed(9)
+    x = th.randn(4, 128, 1280 * 720, device=dev)
+    funcs.ensure_amax(x)
+    w = th.randn(441, 128, device=dev) / 128 ** 0.5
+    bias = th.randn(441, device=dev)
+    with th.no_grad():
+        a = funcs.PointwiseLayer.apply(x, w, bias, None, 1, 0, 0.0)
+        a2 = funcs.PointwiseLayer.apply(x, w, bias, None, 1, 0, 0.0)
+        assert th.equal(a, a2)
+        del a2
+        monkeypatch.setenv("SBMC_PW_WIDE_FWD", "0")
+        c = funcs.PointwiseLayer.apply(x, w, bias, None, 1, 0, 0.0)
+    assert funcs.known_amax(a) is not None and funcs.known_amax(a).item() == funcs.known_amax(c).item()
+    assert (a - c).abs().max().item() <= 3e-6 * c.abs().max().item()
