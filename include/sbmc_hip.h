@@ -502,6 +502,25 @@ SBMC_API int sbmc_pointwise_chain_fwd_f32(const float *x, const float *t, const 
 SBMC_API int sbmc_pointwise_wide_fwd_supported(int cin, int cout, long hw);
 SBMC_API int sbmc_pointwise_wide_fwd_f32(const float *x, const float *w, const float *bias, float *y, unsigned *amax, int b,
                                 int cin, int cout, long hw, int act, float slope, void *stream);
+/* ABI 8 -- the backward of TWO consecutive 128-channel per-sample 1 x 1 layers in one pass (csrc/pointwise_chain_bwd.hip):
+ * y_a = act_a(w_a x_a + b_a + t), y_b = act_b(w_b y_a + b_b) (reference sbmc/modules.py:154-175; the embeddings' and the
+ * regressor's first two layers, sbmc/models.py:79-102).  The gradient of y_a never leaves the chip.
+ *   gy [b, 128, hw]: gradient of y_b; signs_b: y_b's sign words (sbmc_pointwise_fwd_signs_f32; NULL when act_b == 0);
+ *   xb = y_a [b, 128, hw] (layer a's activation decisions are taken from it: y_a > 0); xa [b, cin, hw], cin <= 128.
+ *   gxa [b, cin, hw] or NULL; gw_partial_b [groups, 128, 128], gb_partial_b [groups, 128], gw_partial_a [groups, 128, cin],
+ *   gb_partial_a [groups, bq, 128] (bq = b / s with t_mode 1, else 1), every element written; groups =
+ *   sbmc_pointwise_chain_bwd_groups(b, s, t_mode, hw).  gt [b / s, 128, hw] (t_mode 2: the per-pixel context gradient) or
+ *   NULL; with t_mode 1 the per-image context gradient is gb_partial_a summed over the groups.
+ *   gmax, xbmax, xamax: device words holding the bit patterns of floats >= max |gy|, max |xb|, max |xa| (the two-f16-plane
+ *   format's scales; gz_a's scale is a bound: the largest absolute column sum of w_b x the word of gy); gxmax (or NULL):
+ *   a zeroed word raised to max |gxa|. */
+SBMC_API int sbmc_pointwise_chain_bwd_supported(int cin, long hw);
+SBMC_API int sbmc_pointwise_chain_bwd_groups(int b, int s, int t_mode, long hw);
+SBMC_API int sbmc_pointwise_chain_bwd_f32(const float *gy, const unsigned *signs_b, const float *xb, const float *wb,
+                                 const float *xa, const float *wa, float *gxa, float *gw_partial_b, float *gb_partial_b,
+                                 float *gw_partial_a, float *gb_partial_a, float *gt, const unsigned *gmax,
+                                 const unsigned *xbmax, const unsigned *xamax, unsigned *gxmax, int b, int s, int cin,
+                                 long hw, int t_mode, int act_b, float slope_b, int act_a, float slope_a, void *stream);
 /* the all-half layer (x, y _Float16) with the mean as a _Float16 tensor: the mean of the half values as stored */
 SBMC_API int sbmc_pointwise_fwd_mean_f16(const void *x, const float *w, const float *bias, const float *t, void *y,
                                 void *ymean, int s_mean, int b, int s, int cin, int cout, long hw, int t_mode,

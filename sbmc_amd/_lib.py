@@ -72,6 +72,9 @@ SYMBOLS = (
     "sbmc_pointwise_chain_fwd_f32",
     "sbmc_pointwise_wide_fwd_supported",
     "sbmc_pointwise_wide_fwd_f32",
+    "sbmc_pointwise_chain_bwd_supported",
+    "sbmc_pointwise_chain_bwd_groups",
+    "sbmc_pointwise_chain_bwd_f32",
     "sbmc_splat_all_bwd_bound_f32",
     "sbmc_upsample2x_cat_supported",
     "sbmc_upsample2x_cat_fwd_f32",
@@ -245,6 +248,9 @@ def lib():
     handle.sbmc_pointwise_wide_bwd_f32.argtypes = [p] * 10 + [i, i, i, ctypes.c_long, p]
     handle.sbmc_pointwise_chain_supported.argtypes = [i, i, p, ctypes.c_long]
     handle.sbmc_pointwise_wide_fwd_supported.argtypes = [i, i, ctypes.c_long]
+    handle.sbmc_pointwise_chain_bwd_supported.argtypes = [i, ctypes.c_long]
+    handle.sbmc_pointwise_chain_bwd_groups.argtypes = [i, i, i, ctypes.c_long]
+    handle.sbmc_pointwise_chain_bwd_f32.argtypes = [p] * 16 + [i, i, i, ctypes.c_long, i, i, ctypes.c_float, i, ctypes.c_float, p]
     handle.sbmc_pointwise_wide_fwd_f32.argtypes = [p] * 5 + [i, i, i, ctypes.c_long, i, ctypes.c_float, p]
     handle.sbmc_pointwise_chain_fwd_f32.argtypes = [p] * 9 + [i, p, p, p, i, i, i, ctypes.c_long, i, p]
     handle.sbmc_splat_all_bwd_bound_f32.argtypes = [p] * 15 + [i] * 8 + [p]

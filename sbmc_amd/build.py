@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libsbmc_hip.so")
-SOURCES = ["plain_ops.hip", "splat_fused.hip", "bias_act.hip", "pointwise.hip", "pointwise_chain.hip", "resample.hip", "nhwc_ops.hip", "halo.hip", "conv3x3.hip"]
+SOURCES = ["plain_ops.hip", "splat_fused.hip", "bias_act.hip", "pointwise.hip", "pointwise_chain.hip", "pointwise_chain_bwd.hip", "resample.hip", "nhwc_ops.hip", "halo.hip", "conv3x3.hip"]
 ARCH = "gfx950"
 
 

@@ -878,6 +878,11 @@ class PointwiseChain(th.autograd.Function):
         gt = None
         g = gy
         for l in range(nl - 1, -1, -1):
+            if l == 1:
+                pair = _chain_pair_backward(ctx, g if gmean is None or nl > 2 else None, inputs, weights, sgs)
+                if pair is not None:
+                    g, gt, grads[2], grads[3], grads[0], grads[1] = pair
+                    break
             act, slope = ctx.cfg_layers[l]
             first = l == 0
             lctx = _LayerCtx((s if first else 1, act, slope, ctx.t_mode if first else 0, ctx.tshape if first else None),
@@ -895,6 +900,58 @@ class PointwiseChain(th.autograd.Function):
                 gt = gtl
             g = gx
         return (g, gt, None, None, None) + tuple(grads)
+
+
+def _chain_pair_backward(ctx, g, inputs, weights, sgs):
+    """Layers 1 and 0 of a `PointwiseChain` in ONE backward pass (csrc/pointwise_chain_bwd.hip: the gradient of layer 0's
+    output stays on the chip) -> (gx, gt, gw1, gb1, gw0, gb0), or None where the pass does not apply (then layer by layer):
+    both layers 128 wide, the magnitude words of the incoming gradient and of both layers' inputs known, layer 1's sign words
+    there (or it is linear)."""
+    # OFF by default (SBMC_PW_CHAIN_BWD=1 switches it on): correct, but at 720p x 8 spp the pass measures 7.2 ms against the two
+    # separate passes' 5.9 -- two layers' weight-gradient accumulators (64 registers) next to two layers' operand planes (64)
+    # leave a wave of an 8-wave workgroup ~60 registers short, and the spilled registers travel through the same
+    # vector-memory queue as the tile's requests and stores (profiles/HISTORY.md, round 6)
+    if g is None or knob("SBMC_PW_CHAIN_BWD", 0) == 0 or knob("SBMC_HIP_PW_F16") == 0 or not _pw_split_enabled():
+        return None
+    L = _lib.lib()
+    x, y0 = inputs[0], inputs[1]
+    w0, w1 = weights[0], weights[1]
+    B, cin, hw = x.shape
+    (act0, slope0), (act1, slope1) = ctx.cfg_layers[0], ctx.cfg_layers[1]
+    if not (w0.shape[0] == 128 and tuple(w1.shape) == (128, 128) and L.sbmc_pointwise_chain_bwd_supported(cin, hw)
+            and g.dtype == th.float32 and (act1 == 0 or sgs[1] is not None)):
+        return None
+    g = g.contiguous()
+    gmax, xbmax, xamax = known_amax(g), ctx.amaxes[0], ctx.xmax
+    if gmax is None or xbmax is None:
+        return None
+    if xamax is None:
+        if ctx.needs_input_grad[0]:
+            return None                           # (an input that wants a gradient and carries no word: not a network input)
+        xamax = ensure_amax(x)                    # a network input (the first embedding): one pass over it, tagged for the step
+    s, t_mode, dev = ctx.s, ctx.t_mode, g.device
+    dx = bool(ctx.needs_input_grad[0])
+    groups = L.sbmc_pointwise_chain_bwd_groups(B, s, t_mode, hw)
+    nb = B // s if t_mode == 1 else 1
+    gx = th.empty_like(x) if dx else None
+    gwp1, gbp1 = w1.new_empty(groups, 128, 128), w1.new_empty(groups, 128)
+    gwp0, gbp0 = w0.new_empty(groups, 128, cin), w0.new_empty(groups, nb, 128)
+    gt = w0.new_empty(ctx.tshape) if t_mode == 2 else None
+    gxmax = amax_word(dev) if dx else None
+    with th.cuda.device(dev), _timed("pointwise_chain_bwd 128x128<-%d%s" % (cin, "" if dx else " (no gx)"), dev):
+        rc = L.sbmc_pointwise_chain_bwd_f32(
+            _lib.ptr(g), _lib.ptr(sgs[1]) if act1 != 0 else None, _lib.ptr(y0), _lib.ptr(w1), _lib.ptr(x), _lib.ptr(w0),
+            _lib.ptr(gx) if dx else None, _lib.ptr(gwp1), _lib.ptr(gbp1), _lib.ptr(gwp0), _lib.ptr(gbp0),
+            _lib.ptr(gt) if gt is not None else None, _lib.ptr(gmax), _lib.ptr(xbmax), _lib.ptr(xamax),
+            _lib.ptr(gxmax) if gxmax is not None else None, B, s, cin, hw, t_mode, act1, slope1, act0, slope0,
+            _lib.current_stream(dev))
+    _lib.check(rc, "pointwise_chain_bwd")
+    per_image = gbp0.sum(0)                       # [nb, 128]
+    if t_mode == 1:
+        gt = per_image.view(ctx.tshape)
+    if gxmax is not None:
+        tag_amax(gx, gxmax)
+    return gx, gt, gwp1.sum(0), gbp1.sum(0), gwp0.sum(0), per_image.sum(0)
 
 
 def upsample_cat_supported(coarse, left, top=0, bot=0):

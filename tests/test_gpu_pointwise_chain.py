@@ -253,3 +253,102 @@ def test_wide_forward_at_full_size_equals_the_row_tile_kernel(monkeypatch):
         c = funcs.PointwiseLayer.apply(x, w, bias, None, 1, 0, 0.0)
     assert funcs.known_amax(a) is not None and funcs.known_amax(a).item() == funcs.known_amax(c).item()
     assert (a - c).abs().max().item() <= 3e-6 * c.abs().max().item()
+
+
+def _word(t):
+    return t.abs().max().reshape(1).view(th.int32).clone()
+
+
+@pytest.mark.parametrize("loose", [1.0, 23.0])
+@pytest.mark.parametrize("b,s,cin,hw,t_mode,act1,act0,dx", [
+    (4, 2, 128, 64 * 5 + 12, 2, 2, 2, True),      # the regressor's first two layers: per-pixel context gradient
+    (8, 8, 128, 64 * 3, 2, 1, 1, True),           # an embedding's first two layers
+    (4, 2, 93, 200, 1, 1, 1, False),              # the first embedding: network input (no data gradient), per-image context
+    (3, 1, 64, 64 * 40 + 4, 0, 1, 2, True),       # several tiles per workgroup at small b
+    (2, 1, 128, 4, 0, 0, 1, True),                # a plane of four pixels; the upper layer linear
+])
+def test_chain_pair_backward_vs_float64(b, s, cin, hw, t_mode, act1, act0, dx, loose):
+    """sbmc_pointwise_chain_bwd_f32 (pw_chain_bwd_kernel): the backward of two consecutive 128-channel layers in one pass --
+    gx, both weight and bias gradients, the context gradient -- against float64 autograd of the same two layers taking the
+    same activation decisions, 1e-5 of each gradient's scale (weight / bias sums: helpers.close_sum).  loose: the words may
+    be bounds."""
+    from helpers import close_sum
+    from sbmc_amd import _lib
+    L = _lib.lib()
+    dev = th.device("cuda")
+    x, t, layers = _make(b, s, cin, (128, 128), hw, t_mode, (act0, act1), 1.0, dev, b * 7 + hw)
+    (w0, b0, _, sl0), (w1, b1, _, sl1) = layers
+    y = _chain64(x, t, s, layers)
+    y0 = y[0].float()                                   # what the forward stored (its decisions: y0 > 0)
+    y1 = y[1].float()
+    wpr = (hw + 31) // 32
+    bits = (y1 > 0)
+    pad = th.zeros(b, 128, wpr * 32, dtype=th.bool, device=dev)
+    pad[..., :hw] = bits
+    signs1 = (pad.view(b, 128, wpr, 32).long() << th.arange(32, device=dev)).sum(-1)
+    signs1 = th.where(signs1 >= 2 ** 31, signs1 - 2 ** 32, signs1).to(th.int32).contiguous()
+    th.manual_seed(3)
+    gy = th.randn(b, 128, hw, device=dev) * 1e-2
+    gy[:, :, ::5] *= 20.0
+    groups = L.sbmc_pointwise_chain_bwd_groups(b, s, t_mode, hw)
+    nb = b // s if t_mode == 1 else 1
+    gx = th.full((b, cin, hw), float("nan"), device=dev) if dx else None
+    gwp1, gbp1 = th.full((groups, 128, 128), float("nan"), device=dev), th.full((groups, 128), float("nan"), device=dev)
+    gwp0, gbp0 = th.full((groups, 128, cin), float("nan"), device=dev), th.full((groups, nb, 128), float("nan"), device=dev)
+    gt = th.full((b // s, 128, hw), float("nan"), device=dev) if t_mode == 2 else None
+    words = [(_word(v).view(th.float32) * loose).view(th.int32) for v in (gy, y0, x)]
+    gxmax = th.zeros(1, dtype=th.int32, device=dev) if dx else None
+    _lib.check(L.sbmc_pointwise_chain_bwd_f32(
+        _lib.ptr(gy), _lib.ptr(signs1) if act1 else None, _lib.ptr(y0), _lib.ptr(w1), _lib.ptr(x), _lib.ptr(w0),
+        _lib.ptr(gx) if dx else None, _lib.ptr(gwp1), _lib.ptr(gbp1), _lib.ptr(gwp0), _lib.ptr(gbp0),
+        _lib.ptr(gt) if gt is not None else None, _lib.ptr(words[0]), _lib.ptr(words[1]), _lib.ptr(words[2]),
+        _lib.ptr(gxmax) if dx else None, b, s, cin, hw, t_mode, act1, sl1, act0, sl0, _lib.current_stream(dev)), "chain_bwd")
+    # float64 with the same decisions
+    gz1 = gy.double() * (th.where(bits, 1.0, 0.0 if act1 == 1 else sl1) if act1 else 1.0)
+    gy0 = th.einsum("ok,bop->bkp", w1.double(), gz1)
+    gz0 = gy0 * (th.where(y0 > 0, 1.0, 0.0 if act0 == 1 else sl0) if act0 else 1.0)
+    y0d, xd = y0.double(), x.double()
+    close_sum(gwp1.sum(0), th.einsum("bop,bkp->ok", gz1, y0d), th.einsum("bop,bkp->ok", gz1.abs(), y0d.abs()), what="gw1")
+    close_sum(gbp1.sum(0), gz1.sum((0, 2)), gz1.abs().sum((0, 2)), what="gb1")
+    close_sum(gwp0.sum(0), th.einsum("bop,bkp->ok", gz0, xd), th.einsum("bop,bkp->ok", gz0.abs(), xd.abs()), what="gw0")
+    close_sum(gbp0.sum((0, 1)), gz0.sum((0, 2)), gz0.abs().sum((0, 2)), what="gb0")
+    if t_mode == 1:
+        close_sum(gbp0.sum(0), gz0.view(b // s, s, 128, hw).sum((1, 3)), gz0.abs().view(b // s, s, 128, hw).sum((1, 3)), what="gt")
+    elif t_mode == 2:
+        r = gz0.view(b // s, s, 128, hw).sum(1)
+        assert (gt.double() - r).abs().max().item() <= 1e-5 * r.abs().max().item()
+    if dx:
+        r = th.einsum("ok,bop->bkp", w0.double(), gz0)
+        assert (gx.double() - r).abs().max().item() <= 1e-5 * r.abs().max().item()
+        assert gxmax.item() == _word(gx).item()
+
+
+def test_chain_autograd_with_the_fused_pair_backward(monkeypatch):
+    """SBMC_PW_CHAIN_BWD=1 (off by default: slower at full size, functions._chain_pair_backward): PointwiseChain's backward
+    takes layers 1 and 0 in one pass -- same gradients as layer by layer."""
+    from sbmc_amd import functions as funcs
+    dev = th.device("cuda")
+    b, s, cin, hw = 4, 2, 128, 64 * 6 + 8
+    x, t, layers = _make(b, s, cin, (128, 128), hw, 2, (2, 2), 1.0, dev, 21)
+    x.requires_grad_(True)
+    t.requires_grad_(True)
+    funcs.ensure_amax(x)
+    wb = []
+    for (w, bias, _, _) in layers:
+        wb += [w.requires_grad_(True), bias.requires_grad_(True)]
+    cfg = tuple((a, sl) for (_, _, a, sl) in layers)
+    gy = th.randn(b, 128, hw, device=dev)
+    funcs.ensure_amax(gy)
+    res = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("SBMC_PW_CHAIN_BWD", knob)
+        calls = []
+        funcs.enable_kernel_timing(calls)
+        try:
+            y = funcs.PointwiseChain.apply(x, t, s, False, cfg, *wb)
+            res[knob] = th.autograd.grad(y, [x, t] + wb, gy)
+        finally:
+            funcs.enable_kernel_timing(None)
+        assert any(n.startswith("pointwise_chain_bwd") for n, _, _ in calls) == (knob == "1")
+    for a, c in zip(res["1"], res["0"]):
+        assert (a - c).abs().max().item() <= 5e-6 * c.abs().max().item()

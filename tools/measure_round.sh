@@ -1,10 +1,10 @@
 #!/bin/bash
-# A round's measurements on one MI355X box:   tools/grun --timeout 3300 bash tools/measure_round.sh r05
+# A round's measurements on one MI355X box:   gpurun --timeout 3300 -- bash tools/measure_round.sh r06
 # bench lines (fp32 with the fp32-pipe A/B, fp16 activations), rocprofv3 kernel statistics of the model step and of an
 # interior rank of 8 with their per-category splits, PMC passes (splat traffic, 1x1 and 3x3 kernels), per-rank cost of the
 # sharded step in every transport, the 8-rank partition as communicating processes on this one GPU, fuzz sweeps.
 # Everything lands in gpurun_out/<tag>/ ; copy what is to be kept into profiles/.
-tag=${1:-r05}
+tag=${1:-r06}
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/$tag
 mkdir -p $o
@@ -41,6 +41,9 @@ bash tools/prof_rank.sh 8 --ipc-self > $o/prof_rank.log 2>&1; cp gpurun_out/q/ra
 python tools/prof_rank_cat.py $o/${tag}_rank8_kernel_stats.csv 5 > $o/${tag}_rank8_categories.txt; head -18 $o/${tag}_rank8_categories.txt
 bash tools/prof_pointwise.sh > $o/prof_pw.log 2>&1; cp gpurun_out/profiles_pw/r02_pointwise_pmc.txt $o/${tag}_pointwise_pmc.txt; grep -v raw $o/${tag}_pointwise_pmc.txt | tail -5 | cut -c1-260; rm -rf gpurun_out/prof_pw gpurun_out/profiles_pw
 timeout 300 python tools/bench_pw_scaled.py > $o/${tag}_pointwise_launches.txt 2>&1; tail -3 $o/${tag}_pointwise_launches.txt
+# round 6: the fused 1x1 chains beside the layers they replace (+ cycles per phase), the wide forward, the pair backward
+( SBMC_PC_TIMING=1 timeout 300 python tools/bench_pw_chain.py 2>&1 | grep -v amdgpu.ids; timeout 200 python tools/dev/bench_wide_fwd.py 2>&1 | grep SBMC; timeout 300 python tools/dev/bench_chain_bwd.py 2>&1 | grep -v amdgpu.ids ) > $o/${tag}_pointwise_chain.txt; cat $o/${tag}_pointwise_chain.txt
+SBMC_PW_CHAIN=0 SBMC_PW_WIDE_FWD=0 timeout 500 python bench.py --no-cpu-baseline --no-stages > $o/${tag}_bench_without_chains.json 2>/dev/null; head -c 200 $o/${tag}_bench_without_chains.json; echo
 bash tools/calibrate_fetch.sh > /dev/null 2>&1; cp gpurun_out/fetch_calibration.txt $o/${tag}_fetch_calibration.txt
 bash tools/prof_conv_stack.sh > $o/prof_conv.log 2>&1; cp gpurun_out/conv_stack/r02_conv_stack_mfma.txt $o/${tag}_conv_stack_mfma.txt; tail -3 $o/${tag}_conv_stack_mfma.txt; rm -rf gpurun_out/conv_stack
 ( timeout 300 python tools/fuzz_gpu.py --seconds 100 2>&1 | tail -2; timeout 300 python tools/fuzz_slab.py --seconds 100 2>&1 | tail -1; timeout 200 python tools/fuzz_pointwise.py --seconds 60 2>&1 | tail -1 ) > $o/${tag}_fuzz.txt; cat $o/${tag}_fuzz.txt | cut -c1-300
