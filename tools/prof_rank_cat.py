@@ -7,14 +7,15 @@ CATS = [
     ("conv3x3 fwd/dgrad", r"sbmc::conv3_kernel|conv3_fixup"),
     ("conv3x3 wgrad", r"conv3_wgrad"),
     ("conv3x3 weight prep / absmax", r"prep_weights|absmax"),
-    ("1x1 fwd", r"pw_fwd"),
-    ("1x1 bwd", r"pw_bwd|pw_gw_wide|pw_wide_bwd|pw_wide_prep"),
+    ("1x1 fwd", r"pw_fwd|pw_chain_fwd|pw_wide_fwd"),
+    ("1x1 bwd", r"pw_bwd|pw_chain_bwd|pw_gw_wide|pw_wide_bwd|pw_wide_prep"),
     ("hipBLASLt / rocBLAS", r"Cijk_|rocblas|gemm"),
     ("MIOpen", r"igemm|miopen|naive_conv|batched_transpose"),
     ("splat", r"splat_|gather_|s2g_|kw_"),
     ("halo put/get/merge", r"halo::|halo_"),
     ("bias/act", r"bias_act|ctx_act"),
-    ("resample/pool/transposes (own)", r"upcat|upsample|transpose2d|maxpool|pool"),
+    ("resample/pool/transposes (own)", r"upcat|upsample|transpose2d|maxpool|pool|slice_channels"),
+    ("weight bank", r"wbank_"),
     ("fill / memset", r"fillBuffer|FillFunctor|memset"),
     ("weight norm", r"weight_norm"),
     ("adam / optimizer", r"adam|multi_tensor|foreach"),
