@@ -55,6 +55,9 @@ constexpr int CV_WSTAGE = 3 * 2 * 2 * 128;   // 16-byte entries of one weight st
 constexpr unsigned CV_LDS_BYTES = (2 * CV_ABUF + 3 * CV_WSTAGE) * 16;   // 156672 of the CU's 163840
 constexpr int CV_AROUNDS = (2 * CV_PP + 255) / 256;                     // staging rounds: (pixel, 16 channels) units
 constexpr unsigned CV_OOB = 0xFFFFFFF0u;
+#ifndef CV_WS_PRIO
+#define CV_WS_PRIO 0
+#endif
 
 __device__ __forceinline__ rsrc_t cv_rsrc(const void* base, unsigned bytes) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(base);
@@ -155,7 +158,9 @@ __device__ __forceinline__ void cv_unrolled(F&& f) { cv_unrolled_impl(f, std::ma
 // and an immediate per channel block; rows beyond the image select an empty descriptor per row pair; the sign words
 // of 16 registers are gathered in a register (lane r / r + 32 <- the ballot's halves) and leave in ONE store; the
 // largest magnitude is a masked max.  ~12 instructions per accumulator register instead of ~35.
-template <bool EPI, bool HF, bool SK, bool ADJ = false>
+// CLR = false: the accumulators are left as they are (the caller clears them as whole registers tuples: element-wise clears
+// between the reads make the compiler copy tuples, which the 256-register waves of the WS form have no room for).
+template <bool EPI, bool HF, bool SK, bool ADJ = false, bool CLR = true>
 __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4][2], const CvTile& t, const bool park,
                                           float* park_slab, const float oscale, unsigned& amax_run, float* bacc = nullptr) {
     static_assert(!(EPI && ADJ) && !(HF && ADJ), "ADJ: the fp32 data gradient");
@@ -280,7 +285,7 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
                                                                   vb + (unsigned)(ni * 32) * ES, so, 0);
                         else
                             buf_store(v, rg, vb + (unsigned)(ni * 32) * ES, so);
-                        acc[mi][ni][r] = 0.f;
+                        if constexpr (CLR) acc[mi][ni][r] = 0.f;
                     }
                 });
             }
@@ -296,6 +301,10 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
         adj_commit();
         return;
     }
+    // (an opaque copy of the scale: with the same expression `acc * oscale` in both forms the compiler computes all 128
+    // products -- and the ADJ form's 128 more -- ABOVE the branch between them, in registers nobody has)
+    float oscale_g = oscale;
+    asm volatile("" : "+v"(oscale_g));
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -308,7 +317,7 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const unsigned voff = ok ? (unsigned)((row * p.W + col) * p.Cout + nh * 64 + ni * 32 + l31) * ES : CV_OOB;
-                float v = acc[mi][ni][r] * oscale;
+                float v = acc[mi][ni][r] * oscale_g;
                 if constexpr (EPI) {
                     v += bv[ni];
                     const bool pos = v > 0.f;
@@ -341,7 +350,7 @@ __device__ __forceinline__ void cv_finish(const Conv3Params& p, f32x16 (&acc)[4]
                     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), ry, voff, 0, 0);
                 else
                     buf_store(v, ry, voff, 0);
-                acc[mi][ni][r] = 0.f;
+                if constexpr (CLR) acc[mi][ni][r] = 0.f;
             }
             if constexpr (EPI) __builtin_amdgcn_sched_barrier(0);      // (one register's ballots and stores at a time)
         }
@@ -434,13 +443,21 @@ __global__ __launch_bounds__(256) void conv3_fixup_kernel(Conv3Params p, unsigne
 // as it is (one plane, no split, no scale), the weights are the prepared weights' HIGH plane (f16 of the scaled
 // weight: the rounding autocast applies, with a power-of-two scale that is divided out again), ONE matrix product per
 // term instead of three.
-template <bool EPI, bool HF = false, bool SK = false, bool ADJ = false>
-__global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
+//
+// WS ("wave-specialised", 512 threads): the same tiles, stages and LDS protocol with the two jobs of a stage in different
+// waves -- waves 0-3 (one per SIMD) issue nothing but operand reads and MFMAs, waves 4-7 (their SIMD partners) request,
+// split and write the patches and weight stages; one barrier per stage for all eight.  An in-order wave cannot overlap
+// its staging instructions with its MFMAs; two waves of one SIMD can (the matrix pipe beside the vector-memory and
+// LDS-write work).  256 registers per wave: 128 accumulators + the two taps' operands in the MFMA waves.
+template <bool EPI, bool HF = false, bool SK = false, bool ADJ = false, bool WS = false>
+__global__ __launch_bounds__(WS ? 512 : 256) void conv3_kernel(Conv3Params p) {
     constexpr unsigned ES = HF ? 2u : 4u;              // bytes of an activation element
     extern __shared__ float4 cv_lds[];
     u32x4* As = reinterpret_cast<u32x4*>(cv_lds);
     u32x4* Ws = As + 2 * CV_ABUF;
-    const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
+    static_assert(!(WS && HF), "WS: the fp32 form");
+    const int tid = WS ? (int)(threadIdx.x & 255u) : (int)threadIdx.x, lane = tid & 63, wave = WS ? (wave_id() & 3) : wave_id();
+    const bool producer = WS && wave_id() >= 4;       // (wave-uniform, scalar)
     const int l31 = lane & 31, lhi = lane >> 5;
     const int mh = wave & 1, nh = wave >> 1;
     // Row i of a 32 x 32 block is pixel (i / 16, column) of the block's 2 rows x 16 columns.  ds_read_b128 serves
@@ -583,34 +600,39 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
 
     // operands of one tap: A 4 m-blocks x 2 planes, B 2 n-blocks x 2 planes
     struct Ops { u32x4 ah[4], al[4], bh[2], bl[2]; };
+    // (in the order the tap's MFMAs want them -- high planes, then the weights' low plane, then the patch's: the reads go out
+    // in this order between the previous tap's MFMAs and return in order; with the weights last, every tap began by waiting
+    // for the reads issued two MFMAs earlier)
     auto load_ops = [&](Ops& o, const u32x4* Ab, const u32x4* Wb, int kx) {
+        o.bh[0] = Wb[kx * 512];
+        o.ah[0] = Ab[kx];
+        o.bh[1] = Wb[kx * 512 + 32];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            o.ah[mi] = Ab[mi * 2 * CV_PS + kx];
-            if constexpr (!HF) o.al[mi] = Ab[4 * CV_PR + mi * 2 * CV_PS + kx];
-        }
+        for (int mi = 1; mi < 4; ++mi) o.ah[mi] = Ab[mi * 2 * CV_PS + kx];
+        if constexpr (!HF) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            o.bh[ni] = Wb[kx * 512 + ni * 32];
-            if constexpr (!HF) o.bl[ni] = Wb[kx * 512 + 256 + ni * 32];
+            for (int ni = 0; ni < 2; ++ni) o.bl[ni] = Wb[kx * 512 + 256 + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) o.al[mi] = Ab[4 * CV_PR + mi * 2 * CV_PS + kx];
         }
     };
-    auto mfmas = [&](const Ops& o) {
+    auto mfmas_on = [&](f32x16 (&A)[4][2], const Ops& o) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.ah[mi], o.bh[ni], acc[mi][ni]);
+            for (int ni = 0; ni < 2; ++ni) A[mi][ni] = cv_mfma(o.ah[mi], o.bh[ni], A[mi][ni]);
         if constexpr (!HF) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.ah[mi], o.bl[ni], acc[mi][ni]);
+                for (int ni = 0; ni < 2; ++ni) A[mi][ni] = cv_mfma(o.ah[mi], o.bl[ni], A[mi][ni]);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = cv_mfma(o.al[mi], o.bh[ni], acc[mi][ni]);
+                for (int ni = 0; ni < 2; ++ni) A[mi][ni] = cv_mfma(o.al[mi], o.bh[ni], A[mi][ni]);
         }
     };
+    auto mfmas = [&](const Ops& o) { mfmas_on(acc, o); };
     // The next tap's 12 operand fetches go BETWEEN the current tap's 24 MFMAs (2 MFMAs, 1 fetch, ...): left to
     // itself the compiler sinks them to just before their first use and the matrix pipe waits for LDS every tap.
     auto interleave = [&]() {
@@ -634,80 +656,249 @@ __global__ __launch_bounds__(256) void conv3_kernel(Conv3Params p) {
     // barrier), so every stage finds its weights -- and its patch: written in stage 3 of the previous chunk --
     // in LDS one whole stage early, and the operands of its first tap are fetched during the last tap of the
     // stage before: after a barrier the matrix pipe continues at once.
-    issue_a(tcur, cc, true);
-    issue_w(wregA, tcur, cc, 0, true);
-    issue_w(wregB, tcur, cc, 1, true);
-    commit_a(0);
-    commit_w(wregA, 0);
-    commit_w(wregB, 1);
-    __syncthreads();
-    issue_w(wregA, tcur, cc, 2, true);
-    Ops o0, o1;
-    load_ops(o0, a_ptr(0, 0), w_ptr(0), 0);
-
-    for (unsigned h = 0; h < total; ++h) {
-        const bool more = h + 1 < total;
-        const bool last = cc + 1 == nchunks;               // the next chunk opens the next tile
-        const Tile tn = last ? tnext : tcur;
-        const unsigned ccn = last ? 0u : cc + 1;
-        // (the patch of the next chunk: requested in stage 2 AFTER that stage's weight request -- loads return in
-        // order, and no weight stage may have to wait for the patch's HBM burst -- and written, round by round
-        // between the taps' MFMAs, in stage 4: visible when stage 5 fetches the next chunk's first operands)
-        auto stage = [&](Ops& cur, Ops& other, u32x4 (&wfill)[6], const u32x4 (&wdone)[6], const int st) {
-            if (st < 3) issue_w(wfill, tcur, cc, st + 3, true);
-            else issue_w(wfill, tn, ccn, st - 3, more);
-            if (st == 2) issue_a(tn, ccn, more);
-            const bool ca = st == 4;
-            const int nbuf = (int)((h + 1) & 1u);
-            const u32x4* Ab = a_ptr(h, st);
-            const u32x4* Wb = w_ptr(st);
-            load_ops(other, Ab, Wb, 1);
-            mfmas(cur);
-            interleave();
-            if (ca) commit_a_round(nbuf, 0);
-            load_ops(cur, Ab, Wb, 2);
-            mfmas(other);
-            interleave();
-            if (ca) commit_a_round(nbuf, 1);
-            if (st < 5) load_ops(other, a_ptr(h, st + 1), w_ptr(st + 1), 0);
-            else load_ops(other, a_ptr(h + 1, 0), w_ptr(0), 0);
-            mfmas(cur);
-            interleave();
-            if (ca) commit_a_round(nbuf, 2);
-            commit_w(wdone, (st + 2) % 3);
-            cv_lds_barrier();
-        };
-        stage(o0, o1, wregB, wregA, 0);
-        stage(o1, o0, wregA, wregB, 1);
-        stage(o0, o1, wregB, wregA, 2);
-        stage(o1, o0, wregA, wregB, 3);
-        stage(o0, o1, wregB, wregA, 4);
-        stage(o1, o0, wregA, wregB, 5);
-        if (last) {
-            // (stream-K: the tail of a tile whose head other workgroups hold is parked until this one's range is through)
-            const bool park = sk && ti == 0 && c0 > 0;
-            cv_finish<EPI, HF, SK, ADJ>(p, acc, tcur, park, park ? slabs + (size_t)(G + g) * CV_SLAB : nullptr, oscale, amax_run, bacc);
-        }
-        if (last) {
-            tcur = tnext;
-            ++ti;
-            tnext = tile_at(ti + 1);
-            cc = 0;
+    if constexpr (WS) {
+        if (producer) {
+            issue_a(tcur, cc, true);
+            issue_w(wregA, tcur, cc, 0, true);
+            issue_w(wregB, tcur, cc, 1, true);
+            commit_a(0);
+            commit_w(wregA, 0);
+            commit_w(wregB, 1);
+            __syncthreads();
+            issue_w(wregA, tcur, cc, 2, true);
+            for (unsigned h = 0; h < total; ++h) {
+                const bool more = h + 1 < total;
+                const bool last = cc + 1 == nchunks;
+                const Tile tn = last ? tnext : tcur;
+                const unsigned ccn = last ? 0u : cc + 1;
+                const int nbuf = (int)((h + 1) & 1u);
+                auto pstage = [&](u32x4 (&wfill)[6], const u32x4 (&wdone)[6], const int st) {
+                    if (st < 3) issue_w(wfill, tcur, cc, st + 3, true);
+                    else issue_w(wfill, tn, ccn, st - 3, more);
+                    if (st == 2) issue_a(tn, ccn, more);
+                    if (st == 4) commit_a(nbuf);
+                    commit_w(wdone, (st + 2) % 3);
+                    cv_lds_barrier();
+                };
+                pstage(wregB, wregA, 0);
+                pstage(wregA, wregB, 1);
+                pstage(wregB, wregA, 2);
+                pstage(wregA, wregB, 3);
+                pstage(wregB, wregA, 4);
+                pstage(wregA, wregB, 5);
+                if (last) {
+                    tcur = tnext;
+                    ++ti;
+                    tnext = tile_at(ti + 1);
+                    cc = 0;
+                } else {
+                    ++cc;
+                }
+            }
         } else {
-            ++cc;
+            __syncthreads();
+            if constexpr (CV_WS_PRIO > 0) __builtin_amdgcn_s_setprio(CV_WS_PRIO);
+            // The MFMA waves' operand stream.  A GROUP = one 32-pixel block of one tap: its patch operand pair (high, low) against
+            // the tap's four weight operands, 6 MFMAs on two accumulators alternately.  72 groups per chunk (6 stages x 3 taps
+            // x 4 blocks).  The operands ROLL: a group's patch pair is fetched two groups (12 MFMAs) ahead into one of three
+            // slots, the next tap's weights one operand per group into the other of two sets -- 14 operands (56 registers) live
+            // instead of two whole taps' 24, the same 12 reads per tap.  Per accumulator the order of the products is the
+            // one-wave kernel's (high x high, high x low, low x high per tap): the same bits.
+            struct APair { u32x4 h, l; };
+            struct BSet { u32x4 h[2], l[2]; };
+            APair Ap[3];
+            BSet Bs[2];
+            // LDS addresses: ONE lane offset for the patches (+ the chunk's buffer), two for the weight stages (buffers 0-1 | 2:
+            // the instruction's offset field ends at 64 KB), everything else an immediate.  Opaque to the compiler, which
+            // otherwise keeps the sums' parts in five to ten registers and, short of registers, reloads them mid-stream.
+            unsigned a_lane = (unsigned)((lhi * CV_PR + (mh * 8 + (l31 >> 4)) * CV_PS + pcol) * 16);
+            unsigned w_lane01 = (unsigned)((2 * CV_ABUF + lhi * 128 + nh * 64 + l31) * 16);
+            unsigned w_lane2 = w_lane01 + (unsigned)(2 * CV_WSTAGE * 16);
+            asm volatile("" : "+v"(a_lane), "+v"(w_lane01), "+v"(w_lane2));
+            auto lds_at = [&](const unsigned off) -> u32x4 {
+                return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(cv_lds) + off);
+            };
+            auto a_base = [&](const unsigned h) -> unsigned { return a_lane + (h & 1u) * (unsigned)(CV_ABUF * 16); };
+            auto load_a = [&](APair& d, const unsigned ab, const int J) {    // group J of the chunk whose patch is at ab
+                const int st = J / 12, kx = (J / 4) % 3, mi = J % 4;
+                const unsigned off = (unsigned)((2 * (st / 3) * CV_PR + (st % 3) * CV_PS + mi * 2 * CV_PS + kx) * 16);
+                d.h = lds_at(ab + off);
+                d.l = lds_at(ab + off + (unsigned)(4 * CV_PR * 16));
+            };
+            auto load_b = [&](BSet& d, const int T, const int c) {          // operand c of tap T (weights: the same addresses in every chunk)
+                const int wb = (T / 3) % 3, kx = T % 3;
+                const unsigned base = wb == 2 ? w_lane2 : w_lane01;
+                const unsigned off = (unsigned)(((wb == 2 ? 0 : wb) * CV_WSTAGE + kx * 512 + (c & 1) * 32 + (c >> 1) * 256) * 16);
+                const u32x4 v = lds_at(base + off);
+                if (c == 0) d.h[0] = v;
+                else if (c == 1) d.h[1] = v;
+                else if (c == 2) d.l[0] = v;
+                else d.l[1] = v;
+            };
+            auto prime = [&](const unsigned h) {
+                const unsigned ab = a_base(h);
+                load_b(Bs[0], 0, 0);
+                load_a(Ap[0], ab, 0);
+                load_b(Bs[0], 0, 1);
+                load_b(Bs[0], 0, 2);
+                load_b(Bs[0], 0, 3);
+                load_a(Ap[1], ab, 1);
+            };
+            prime(0);
+            auto chunk = [&](const unsigned h, f32x16 (&A)[4][2]) {
+                const unsigned ab = a_base(h);
+                cv_unrolled<72>([&](auto jc) {
+                    constexpr int J = decltype(jc)::value;
+                    constexpr int T = J / 4, mi = J % 4;
+                    // fetches: the next tap's weight operand `mi`, the patch pair of the group after next
+                    if constexpr (T + 1 < 18) load_b(Bs[(T + 1) % 2], T + 1, mi);
+                    else load_b(Bs[0], 0, mi);
+                    if constexpr (J + 2 < 72) load_a(Ap[(J + 2) % 3], ab, J + 2);
+                    else load_a(Ap[(J + 2) % 3], a_base(h + 1), J + 2 - 72);
+                    const APair& a = Ap[J % 3];
+                    const BSet& b = Bs[T % 2];
+                    A[mi][0] = cv_mfma(a.h, b.h[0], A[mi][0]);
+                    A[mi][1] = cv_mfma(a.h, b.h[1], A[mi][1]);
+                    A[mi][0] = cv_mfma(a.h, b.l[0], A[mi][0]);
+                    A[mi][1] = cv_mfma(a.h, b.l[1], A[mi][1]);
+                    A[mi][0] = cv_mfma(a.l, b.h[0], A[mi][0]);
+                    A[mi][1] = cv_mfma(a.l, b.h[1], A[mi][1]);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // DS read
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);               // MFMA
+                    }
+                    // (no wait for the reads in flight at a stage's end: they are the NEXT stage's operands, from buffers nobody
+                    // writes in that stage; every read of this stage's buffers has fed an MFMA above)
+                    if constexpr (J % 12 == 11) asm volatile("s_barrier" ::: "memory");
+                });
+            };
+            // a tile is through: the next chunk's first operands are fetched AGAIN behind the epilogue (what the last groups
+            // fetched is dead then: 32 registers the epilogue may use)
+            auto next_tile = [&](const unsigned h) {
+                tcur = tnext;
+                ++ti;
+                tnext = tile_at(ti + 1);
+                cc = 0;
+                prime(h + 1);
+            };
+            unsigned h = 0;
+            if constexpr (SK) {
+                // stream-K: the range starts inside a tile -- that tile's tail, parked raw in this workgroup's second slab (its
+                // epilogue runs in the fix-up kernel).  A loop and ACCUMULATORS of its own: parking stores beside the epilogue in
+                // one loop body, or one set of accumulators through both loops, cost the 256-register wave spills.
+                if (c0 > 0) {
+                    f32x16 pacc[4][2];
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) pacc[mi][ni][r] = 0.f;
+                    for (; h < total && cc < nchunks; ++h, ++cc) chunk(h, pacc);
+                    if (cc == nchunks) {
+                        cv_slab_store(pacc, slabs + (size_t)(G + g) * CV_SLAB);
+                        next_tile(h - 1);
+                    } else {
+                        // (the range ends inside the tile it began in: a "middle", in the slab of heads)
+                        cv_slab_store(pacc, slabs + (size_t)g * CV_SLAB);
+                        cc = 0;
+                    }
+                }
+            }
+            for (; h < total; ++h) {
+                const bool last = cc + 1 == nchunks;
+                chunk(h, acc);
+                if (last) {
+                    cv_finish<EPI, HF, false, ADJ, false>(p, acc, tcur, false, nullptr, oscale, amax_run, bacc);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    next_tile(h);
+                } else {
+                    ++cc;
+                }
+            }
+            if (sk && cc != 0) cv_slab_store(acc, slabs + (size_t)g * CV_SLAB);
         }
-    }
-    if (sk && cc != 0) {
-        // the range ended inside a tile: its head (or middle) goes to this workgroup's "partial" slab; the fix-up kernel
-        // (the next launch: no flags, no waiting) adds it to the tail its neighbour parked and runs that tile's epilogue
-        cv_slab_store(acc, slabs + (size_t)g * CV_SLAB);
+    } else {
+        issue_a(tcur, cc, true);
+        issue_w(wregA, tcur, cc, 0, true);
+        issue_w(wregB, tcur, cc, 1, true);
+        commit_a(0);
+        commit_w(wregA, 0);
+        commit_w(wregB, 1);
+        __syncthreads();
+        issue_w(wregA, tcur, cc, 2, true);
+        Ops o0, o1;
+        load_ops(o0, a_ptr(0, 0), w_ptr(0), 0);
+
+        for (unsigned h = 0; h < total; ++h) {
+            const bool more = h + 1 < total;
+            const bool last = cc + 1 == nchunks;               // the next chunk opens the next tile
+            const Tile tn = last ? tnext : tcur;
+            const unsigned ccn = last ? 0u : cc + 1;
+            // (the patch of the next chunk: requested in stage 2 AFTER that stage's weight request -- loads return in
+            // order, and no weight stage may have to wait for the patch's HBM burst -- and written, round by round
+            // between the taps' MFMAs, in stage 4: visible when stage 5 fetches the next chunk's first operands)
+            auto stage = [&](Ops& cur, Ops& other, u32x4 (&wfill)[6], const u32x4 (&wdone)[6], const int st) {
+                if (st < 3) issue_w(wfill, tcur, cc, st + 3, true);
+                else issue_w(wfill, tn, ccn, st - 3, more);
+                if (st == 2) issue_a(tn, ccn, more);
+                const bool ca = st == 4;
+                const int nbuf = (int)((h + 1) & 1u);
+                const u32x4* Ab = a_ptr(h, st);
+                const u32x4* Wb = w_ptr(st);
+                load_ops(other, Ab, Wb, 1);
+                mfmas(cur);
+                interleave();
+                if (ca) commit_a_round(nbuf, 0);
+                load_ops(cur, Ab, Wb, 2);
+                mfmas(other);
+                interleave();
+                if (ca) commit_a_round(nbuf, 1);
+                if (st < 5) load_ops(other, a_ptr(h, st + 1), w_ptr(st + 1), 0);
+                else load_ops(other, a_ptr(h + 1, 0), w_ptr(0), 0);
+                mfmas(cur);
+                interleave();
+                if (ca) commit_a_round(nbuf, 2);
+                commit_w(wdone, (st + 2) % 3);
+                cv_lds_barrier();
+            };
+            stage(o0, o1, wregB, wregA, 0);
+            stage(o1, o0, wregA, wregB, 1);
+            stage(o0, o1, wregB, wregA, 2);
+            stage(o1, o0, wregA, wregB, 3);
+            stage(o0, o1, wregB, wregA, 4);
+            stage(o1, o0, wregA, wregB, 5);
+            if (last) {
+                // (stream-K: the tail of a tile whose head other workgroups hold is parked until this one's range is through)
+                const bool park = sk && ti == 0 && c0 > 0;
+                cv_finish<EPI, HF, SK, ADJ>(p, acc, tcur, park, park ? slabs + (size_t)(G + g) * CV_SLAB : nullptr, oscale, amax_run, bacc);
+            }
+            if (last) {
+                tcur = tnext;
+                ++ti;
+                tnext = tile_at(ti + 1);
+                cc = 0;
+            } else {
+                ++cc;
+            }
+        }
+        if (sk && cc != 0) {
+            // the range ended inside a tile: its head (or middle) goes to this workgroup's "partial" slab; the fix-up kernel
+            // (the next launch: no flags, no waiting) adds it to the tail its neighbour parked and runs that tile's epilogue
+            cv_slab_store(acc, slabs + (size_t)g * CV_SLAB);
+        }
     }
     if constexpr (EPI || ADJ) {
         if (p.amax) amax_publish(amax_run, p.amax);          // (a barrier inside)
     }
     if constexpr (ADJ) {
         __syncthreads();
-        for (int i = tid; i < 2 * p.Cout; i += 256) p.adj_partial[(size_t)(2 * g) * p.Cout + i] = bacc[i];
+        if (!producer)
+            for (int i = tid; i < 2 * p.Cout; i += 256) p.adj_partial[(size_t)(2 * g) * p.Cout + i] = bacc[i];
     }
 }
 
@@ -897,11 +1088,18 @@ static int conv3_launch(const void* x, const unsigned* xmax, const void* wp, voi
         kern = hf ? (epi ? conv3_kernel<true, true, true> : conv3_kernel<false, true, true>)
                   : (epi ? conv3_kernel<true, false, true> : conv3_kernel<false, false, true>);
     if (adj) kern = p.ws != nullptr ? conv3_kernel<false, false, true, true> : conv3_kernel<false, false, false, true>;
+    // wave-specialised form (fp32 activations): SBMC_CONV3X3_WS
+    const bool wsp = !hf && env_knob("SBMC_CONV3X3_WS", 0) != 0;
+    if (wsp) {
+        if (adj) kern = p.ws != nullptr ? conv3_kernel<false, false, true, true, true> : conv3_kernel<false, false, false, true, true>;
+        else if (p.ws != nullptr) kern = epi ? conv3_kernel<true, false, true, false, true> : conv3_kernel<false, false, true, false, true>;
+        else kern = epi ? conv3_kernel<true, false, false, false, true> : conv3_kernel<false, false, false, false, true>;
+    }
     const unsigned lds = CV_LDS_BYTES + (adj ? CV_ADJ_LDS_BYTES : 0u);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(wsp ? 512 : 256), lds, (hipStream_t)stream, p);
     e = hipGetLastError();
     if (e != hipSuccess || p.ws == nullptr) return (int)e;
     auto fix = hf ? (epi ? conv3_fixup_kernel<true, true> : conv3_fixup_kernel<false, true>)
