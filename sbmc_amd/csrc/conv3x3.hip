@@ -58,6 +58,9 @@ constexpr unsigned CV_OOB = 0xFFFFFFF0u;
 #ifndef CV_WS_PRIO
 #define CV_WS_PRIO 0
 #endif
+#ifndef CV_WS_AHEAD
+#define CV_WS_AHEAD 2          // groups (of 6 MFMAs) a patch operand pair is fetched ahead of its use
+#endif
 
 __device__ __forceinline__ rsrc_t cv_rsrc(const void* base, unsigned bytes) {
     const uintptr_t a = reinterpret_cast<uintptr_t>(base);
@@ -456,6 +459,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv3_kernel(Conv3Params p) {
     u32x4* As = reinterpret_cast<u32x4*>(cv_lds);
     u32x4* Ws = As + 2 * CV_ABUF;
     static_assert(!(WS && HF), "WS: the fp32 form");
+    static_assert(72 % (CV_WS_AHEAD + 1) == 0, "the slots of the rolling patch operands must come round with the chunk");
     const int tid = WS ? (int)(threadIdx.x & 255u) : (int)threadIdx.x, lane = tid & 63, wave = WS ? (wave_id() & 3) : wave_id();
     const bool producer = WS && wave_id() >= 4;       // (wave-uniform, scalar)
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -706,7 +710,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv3_kernel(Conv3Params p) {
             // one-wave kernel's (high x high, high x low, low x high per tap): the same bits.
             struct APair { u32x4 h, l; };
             struct BSet { u32x4 h[2], l[2]; };
-            APair Ap[3];
+            constexpr int NA = CV_WS_AHEAD + 1;
+            APair Ap[NA];
             BSet Bs[2];
             // LDS addresses: ONE lane offset for the patches (+ the chunk's buffer), two for the weight stages (buffers 0-1 | 2:
             // the instruction's offset field ends at 64 KB), everything else an immediate.  Opaque to the compiler, which
@@ -742,7 +747,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv3_kernel(Conv3Params p) {
                 load_b(Bs[0], 0, 1);
                 load_b(Bs[0], 0, 2);
                 load_b(Bs[0], 0, 3);
-                load_a(Ap[1], ab, 1);
+#pragma unroll
+                for (int j = 1; j < CV_WS_AHEAD; ++j) load_a(Ap[j], ab, j);
             };
             prime(0);
             auto chunk = [&](const unsigned h, f32x16 (&A)[4][2]) {
@@ -753,9 +759,9 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv3_kernel(Conv3Params p) {
                     // fetches: the next tap's weight operand `mi`, the patch pair of the group after next
                     if constexpr (T + 1 < 18) load_b(Bs[(T + 1) % 2], T + 1, mi);
                     else load_b(Bs[0], 0, mi);
-                    if constexpr (J + 2 < 72) load_a(Ap[(J + 2) % 3], ab, J + 2);
-                    else load_a(Ap[(J + 2) % 3], a_base(h + 1), J + 2 - 72);
-                    const APair& a = Ap[J % 3];
+                    if constexpr (J + CV_WS_AHEAD < 72) load_a(Ap[(J + CV_WS_AHEAD) % NA], ab, J + CV_WS_AHEAD);
+                    else load_a(Ap[(J + CV_WS_AHEAD) % NA], a_base(h + 1), J + CV_WS_AHEAD - 72);
+                    const APair& a = Ap[J % NA];
                     const BSet& b = Bs[T % 2];
                     A[mi][0] = cv_mfma(a.h, b.h[0], A[mi][0]);
                     A[mi][1] = cv_mfma(a.h, b.h[1], A[mi][1]);
@@ -780,6 +786,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv3_kernel(Conv3Params p) {
                 ++ti;
                 tnext = tile_at(ti + 1);
                 cc = 0;
+                __builtin_amdgcn_sched_barrier(0);        // (not above the epilogue, where the scheduler would like them)
                 prime(h + 1);
             };
             unsigned h = 0;
@@ -1089,7 +1096,7 @@ static int conv3_launch(const void* x, const unsigned* xmax, const void* wp, voi
                   : (epi ? conv3_kernel<true, false, true> : conv3_kernel<false, false, true>);
     if (adj) kern = p.ws != nullptr ? conv3_kernel<false, false, true, true> : conv3_kernel<false, false, false, true>;
     // wave-specialised form (fp32 activations): SBMC_CONV3X3_WS
-    const bool wsp = !hf && env_knob("SBMC_CONV3X3_WS", 0) != 0;
+    const bool wsp = !hf && env_knob("SBMC_CONV3X3_WS", 1) != 0;
     if (wsp) {
         if (adj) kern = p.ws != nullptr ? conv3_kernel<false, false, true, true, true> : conv3_kernel<false, false, false, true, true>;
         else if (p.ws != nullptr) kern = epi ? conv3_kernel<true, false, true, false, true> : conv3_kernel<false, false, true, false, true>;

@@ -605,6 +605,10 @@ __global__ __launch_bounds__(512) void pw_chain_fwd_kernel(PwChainParams p) {
     }
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
+        // (amax_publish gathers the waves' maxima in ONE shared array: the next layer's must not land in it while thread 0
+        // still reads this layer's -- without this barrier layer l's word now and then carried a wave's maximum of layer
+        // l + 1, larger or SMALLER than its own; tools/fuzz_pointwise_chain.py found it)
+        if (l > 0) __syncthreads();
         if (p.amax[l] != nullptr) amax_publish(__builtin_bit_cast(unsigned, amax_run[l]), p.amax[l]);
     }
     if (timing && lane == 0) {

@@ -52,6 +52,12 @@ CASES = [
     (2, 1, 64, (96, 128), 260, 1, (1, 0), False),
     (2, 2, 128, (128, 128, 128), 4, 0, (1, 2, 1), True),               # a plane of four pixels
     (5, 1, 128, (128, 128, 128), 64 * 40, 0, (1, 1, 1), False),        # more tiles than one round of the grid at small b
+    # (tools/fuzz_pointwise_chain.py's finds: layer 0's magnitude word carried a wave's maximum of layer 1 -- the words of
+    # consecutive layers went through one shared array without a barrier between them)
+    (6, 3, 113, (22, 74, 128), 1880, 0, (0, 1, 0), False),
+    (3, 1, 124, (19, 124, 102), 1704, 1, (2, 0, 2), False),
+    (9, 3, 106, (98, 28, 7), 592, 1, (1, 1, 0), False),
+    (3, 3, 101, (10, 51, 83), 872, 2, (1, 0, 0), False),
 ]
 
 

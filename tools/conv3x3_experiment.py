@@ -59,6 +59,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="720p")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--power", action="store_true", help="also time the forward kernel on all-zero and constant operands")
     args = ap.parse_args()
     dev = th.device("cuda")
     th.manual_seed(1)
@@ -95,6 +96,16 @@ def main():
         err = (y.permute(0, 3, 1, 2) - mi).abs().max().item() / mi.abs().max().item()
         t_mi = timed(lambda: F.conv2d(x, wt, padding=1), args.reps)
         t_us = timed(lambda: conv(xn, wp, cout, xmax), args.reps)
+        if args.power:
+            # the same launch on data that toggles fewer bits (the scale word stays: same instructions, same addresses): what
+            # the part's power limit has to do with the time.  One value in the tensor keeps the scale, everything else is zero
+            # / a constant.
+            for name, fill in (("zeros", 0.0), ("constant 1", 1.0)):
+                xz = th.full_like(xn, fill)
+                xz.view(-1)[0] = xn.abs().max()
+                wz = prepare(th.full_like(wt, fill * 0.05 if fill else 0.0).index_put_((th.tensor(0), th.tensor(0), th.tensor(0), th.tensor(0)), wt.abs().max()))
+                tz = timed(lambda: conv(xz, wz, cout, xmax), args.reps)
+                print("      %-10s operands: %.3f ms (random: %.3f)" % (name, tz, t_us))
         t_all = timed(lambda: conv(xn, prepare(wt), cout), args.reps)
         gf = 2.0 * h * w * cin * cout * 9 / 1e9
         # weight gradient: ours (C ABI) against MIOpen's
@@ -119,6 +130,13 @@ def main():
             ref_w = lib_w()
             werr = (gw - ref_w).abs().max().item() / ref_w.abs().max().item()
             print("      weight gradient: MIOpen %.3f ms  ours %.3f ms  diff %.2e" % (timed(lib_w, args.reps), timed(ours_w, args.reps), werr))
+            if args.power:
+                keep_gy, keep_x = gy.clone(), xn.clone()
+                for name, fill in (("zeros", 0.0), ("constant 1", 1.0)):
+                    gy.fill_(fill); xn.fill_(fill)
+                    gy[0, 0, 0, 0] = keep_gy.abs().max(); xn[0, 0, 0, 0] = keep_x.abs().max()
+                    print("      weight gradient, %-10s operands: %.3f ms" % (name, timed(ours_w, args.reps)))
+                gy.copy_(keep_gy); xn.copy_(keep_x)
         print("%4dx%4d %3d->%3d: MIOpen %.3f ms (%.0f TFLOP/s)  ours %.3f ms (%.0f TFLOP/s fp32-equivalent, %.0f f16)  "
               "with absmax+prepare %.3f ms   diff %.2e" % (h, w, cin, cout, t_mi, gf / t_mi, t_us, gf / t_us,
                                                           3 * gf / t_us, t_all, err))

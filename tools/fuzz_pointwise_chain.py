@@ -40,7 +40,8 @@ while time.time() - t0 < seconds:
         ref = _chain64(x, None, 1, [(w, bias, act, 0.01)])[0]
         e = ((y.double() - ref).abs().max() / ref.abs().max()).item()
         assert e <= 1e-5, ("wide", b, cin, cout, hw, act, e)
-        assert amax.item() == y.abs().max().reshape(1).view(th.int32).item()
+        assert amax.item() == y.abs().max().reshape(1).view(th.int32).item(), \
+            ("wide amax", b, cin, cout, hw, act, amax.view(th.float32).item(), y.abs().max().item())
         worst["wide"] = max(worst["wide"], e)
         n["wide"] += 1
         continue
@@ -62,7 +63,8 @@ while time.time() - t0 < seconds:
             continue
         e = ((ys[l].double() - ref[l]).abs().max() / ref[l].abs().max().clamp(min=1e-300)).item()
         assert e <= 1e-5, ("chain", b, s, cin, couts, hw, t_mode, acts, train, l, e)
-        assert amaxes[l].item() == ys[l].abs().max().reshape(1).view(th.int32).item()
+        assert amaxes[l].item() == ys[l].abs().max().reshape(1).view(th.int32).item(), \
+            ("chain amax", b, s, cin, couts, hw, t_mode, acts, train, mean, l, amaxes[l].view(th.float32).item(), ys[l].abs().max().item())
         worst["chain"] = max(worst["chain"], e)
         if signs[l] is not None:
             bits = ((signs[l].unsqueeze(-1) >> th.arange(32, device=dev)) & 1).reshape(b, couts[l], -1)[..., :hw].bool()
