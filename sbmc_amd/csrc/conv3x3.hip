@@ -1217,15 +1217,24 @@ __device__ __forceinline__ unsigned cv_pack_hh(_Float16 a, _Float16 b) {
 
 // HF: half activations -- gy and x are _Float16 tensors: the staging is a pure 8 x 4 transposition (no split, no scale,
 // one plane), one matrix product per term; gw stays fp32.
-template <bool HF>
-__global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
+// W8 (512 threads, fp32 activations): the same workgroup tile, LDS rows and pipeline on EIGHT waves of 64 x 32 channels x 3 taps
+// (6 accumulators, 256 registers): waves 0-3 stage the rows AND multiply as before, waves 4-7 -- their SIMD partners -- only
+// multiply: while a staging wave converts and writes, the matrix pipe of its SIMD runs its partner's MFMAs (one wave per SIMD
+// issues in order and cannot overlap the two).  The partial sums keep their layout: wave (wm, wn4) writes what wave
+// (wm, wn4 / 2) wrote as its block ni = wn4 % 2.
+template <bool HF, bool W8 = false>
+__global__ __launch_bounds__(W8 ? 512 : 256) void conv3_wgrad_kernel(WgradParams p) {
+    static_assert(!(HF && W8), "W8: the fp32 form");
+    constexpr int NI = W8 ? 1 : 2;                      // 32-channel blocks of x a wave multiplies
     constexpr unsigned ES = HF ? 2u : 4u;
     extern __shared__ float4 cv_lds[];
     u32x4* Gs = reinterpret_cast<u32x4*>(cv_lds);       // [2][WG_G]
     u32x4* Xs = Gs + 2 * WG_G;                          // [4][WG_XR]: ring of x rows
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_id();
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave & 1, wn = wave >> 1;            // (W8: wn = 0 .. 3, a block of 32 input channels)
+    const bool stager = !W8 || wave < 4;
+    constexpr int WNC = W8 ? 32 : 64;                   // input channels per wn
     const float cg = HF ? 1.f : cv_scale_of(*p.gmax), cx = HF ? 1.f : cv_scale_of(*p.xmax);
 
     const unsigned logical = logical_block_id();
@@ -1334,11 +1343,11 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     // where this lane's channel of a [128] row sits (the swizzle above), as a reader: channel w 64 + 32 i + l31
     const int rsw = (l31 & ~3) + ((l31 & 3) ^ ((l31 >> 3) & 3));
 
-    f32x16 acc[2][2][3];
+    f32x16 acc[2][NI][3];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1356,9 +1365,9 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         }
     };
     auto load_b = [&](OpB& o, unsigned k, int ks, int ky) {
-        const u32x4* Xb = Xs + ((k + (unsigned)ky + 3u) & 3u) * WG_XR + (2 * ks + lhi) * 128 + wn * 64 + rsw;
+        const u32x4* Xb = Xs + ((k + (unsigned)ky + 3u) & 3u) * WG_XR + (2 * ks + lhi) * 128 + wn * WNC + rsw;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             o.h[ni] = Xb[ni * 32];
             if constexpr (!HF) o.l[ni] = Xb[WG_OCT * 128 + ni * 32];
         }
@@ -1367,16 +1376,16 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.h[mi], b.h[ni], acc[mi][ni][ky]);
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni][ky] = cv_mfma(a.h[mi], b.h[ni], acc[mi][ni][ky]);
         if constexpr (!HF) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.h[mi], b.l[ni], acc[mi][ni][ky]);
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni][ky] = cv_mfma(a.h[mi], b.l[ni], acc[mi][ni][ky]);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni][ky] = cv_mfma(a.l[mi], b.h[ni], acc[mi][ni][ky]);
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni][ky] = cv_mfma(a.l[mi], b.h[ni], acc[mi][ni][ky]);
         }
     };
 
@@ -1388,10 +1397,6 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
     // the extra one reads zeros and adds nothing.
     const unsigned long long t1e = t1 + ((t1 - t0) & 1ull);
     Rows r0, r1;
-    issue(r0, t0 < t1);
-    commit(r0, 0);
-    issue(r1, t0 + 1 < t1);
-    issue(r0, t0 + 2 < t1);
     OpA a0, a1;
     OpB b0, b1;
     int sy, sx0, sn;                                    // the stage being computed
@@ -1401,15 +1406,19 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         sx0 = (int)(rest % (unsigned)p.nstrips) * WG_TW;
         sn = (int)(rest / (unsigned)p.nstrips);
     }
-    auto stage = [&](unsigned long long t, Rows& done, const unsigned k) {
+    // PURE (W8, waves 4-7): the stage without its staging -- the same barriers, operand fetches and MFMAs.
+    auto stage = [&](auto pure_c, unsigned long long t, Rows& done, const unsigned k) {
+        constexpr bool PURE = decltype(pure_c)::value;
         if (k == 0 || sy == 0) {
             // x rows sy - 1 and sy of a new strip
             cv_lds_barrier();
-            Rows pr;
-            load_row(pr, sn, sy - 1, sx0, xrole && t < t1);
-            if (xrole) write_row(pr, Xs + ((k + 3u) & 3u) * WG_XR, cx);
-            load_row(pr, sn, sy, sx0, xrole && t < t1);
-            if (xrole) write_row(pr, Xs + (k & 3u) * WG_XR, cx);
+            if constexpr (!PURE) {
+                Rows pr;
+                load_row(pr, sn, sy - 1, sx0, xrole && t < t1);
+                if (xrole) write_row(pr, Xs + ((k + 3u) & 3u) * WG_XR, cx);
+                load_row(pr, sn, sy, sx0, xrole && t < t1);
+                if (xrole) write_row(pr, Xs + (k & 3u) * WG_XR, cx);
+            }
             __syncthreads();
             load_a(a0, k, 0);
             load_b(b0, k, 0, 0);
@@ -1429,33 +1438,36 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         // (a channel's two LDS stores come BEFORE the next group's operand fetches in program order: LDS reads are
         // not moved above LDS stores, so a commit in one piece would hold back the fetches -- and the MFMAs behind
         // them -- until all of its conversions were through)
+        constexpr int SUB = HF ? 4 : (W8 ? 6 : 12);    // MFMAs of a sub-step (one k-step of one tap)
         auto deal = [&](auto nv) {
             constexpr int nvalu = decltype(nv)::value;
 #pragma unroll
-            for (int i = 0; i < (HF ? 4 : 12); ++i) {
+            for (int i = 0; i < SUB; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, nvalu, 0);         // VALU
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);             // DS write
+                if constexpr (!PURE) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, W8 ? 2 * nvalu : nvalu, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);         // DS write
+                }
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
             }
         };
         load_b(b1, k, 0, 1);
-        commit(done, k + 1, 0, 1);
+        if constexpr (!PURE) commit(done, k + 1, 0, 1);
         mfmas(a0, b0, 0);
         deal(std::integral_constant<int, 4>{});
         load_b(b0, k, 0, 2);
-        commit(done, k + 1, 1, 2);
+        if constexpr (!PURE) commit(done, k + 1, 1, 2);
         mfmas(a0, b1, 1);
         deal(std::integral_constant<int, 4>{});
         load_a(a1, k, 1);
         load_b(b1, k, 1, 0);
-        commit(done, k + 1, 2, 4);
+        if constexpr (!PURE) commit(done, k + 1, 2, 4);
         mfmas(a0, b0, 2);
         deal(std::integral_constant<int, HF ? 8 : 7>{});
         cv_lds_barrier();
         // (the next request's address arithmetic -- ~60 scalar instructions -- and its loads: behind the barrier, between
         // the second half's MFMAs)
-        issue(done, t + 3 < t1);
+        if constexpr (!PURE) issue(done, t + 3 < t1);
         load_b(b0, k, 1, 1);
         mfmas(a1, b1, 0);
         load_b(b1, k, 1, 2);
@@ -1463,36 +1475,59 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(WgradParams p) {
         load_a(a0, k + 1, 0);
         load_b(b0, k + 1, 0, 0);
         mfmas(a1, b1, 2);
+        constexpr int HALF = 3 * SUB / 2;              // MFMAs of half the second half
+        if constexpr (PURE) {
 #pragma unroll
-        for (int i = 0; i < (HF ? 6 : 18); ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x004, HF ? 12 : 4, 0);       // SALU (the request's descriptor first)
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // DS read
-        }
+            for (int i = 0; i < 2 * HALF; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < (HF ? 6 : 18); ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, HF ? 2 : 1, 0);        // VMEM read (its loads)
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // DS read
+            for (int i = 0; i < HALF; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x004, HF ? 12 : (W8 ? 8 : 4), 0);   // SALU (the request's descriptor first)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
+            }
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, HF ? 2 : 1, 0);    // VMEM read (its loads)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
+            }
         }
         cv_lds_barrier();
     };
-    unsigned k = 0;
-    for (unsigned long long t = t0; t < t1e; t += 2, k += 2) {
-        stage(t, r1, k);
-        stage(t + 1, r0, k + 1);
+    if (stager) {
+        issue(r0, t0 < t1);
+        commit(r0, 0);
+        issue(r1, t0 + 1 < t1);
+        issue(r0, t0 + 2 < t1);
+        unsigned k = 0;
+        for (unsigned long long t = t0; t < t1e; t += 2, k += 2) {
+            stage(std::false_type{}, t, r1, k);
+            stage(std::false_type{}, t + 1, r0, k + 1);
+        }
+    } else {
+        unsigned k = 0;
+        for (unsigned long long t = t0; t < t1e; t += 2, k += 2) {
+            stage(std::true_type{}, t, r1, k);
+            stage(std::true_type{}, t + 1, r0, k + 1);
+        }
     }
 
     // ---- partial sums of this pixel range: [wave][mi][ni][ky][r][lane] ----
-    float* out = p.partial + ((size_t)combo * p.nsplit + split) * WG_TILE + (size_t)wave * (12 * 16 * 64) + lane;
+    // (W8: wave (wm, wn) holds block ni = wn % 2 of what wave (wm, wn / 2) of the four-wave form holds)
+    const int wave4 = W8 ? wm + 2 * (wn >> 1) : wave, ni0 = W8 ? (wn & 1) : 0;
+    float* out = p.partial + ((size_t)combo * p.nsplit + split) * WG_TILE + (size_t)wave4 * (12 * 16 * 64) + lane;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) out[(((mi * 2 + ni) * 3 + ky) * 16 + r) * 64] = acc[mi][ni][ky][r];
+                for (int r = 0; r < 16; ++r) out[(((mi * 2 + ni0 + ni) * 3 + ky) * 16 + r) * 64] = acc[mi][ni][ky][r];
 }
 
 struct WreduceParams {
@@ -1616,11 +1651,12 @@ static int wgrad_launch(const void* gy, const unsigned* gmax, const void* x, con
     p.total = (unsigned long long)n * h * p.nstrips;
     p.nsplit = wgrad_splits(cin, cout, (long long)p.total);
     const int ncombo = p.ncot * p.ncit * 3;
-    auto kern = hf ? conv3_wgrad_kernel<true> : conv3_wgrad_kernel<false>;
+    const bool w8 = !hf && env_knob("SBMC_CONV3X3_WGRAD_W8", 1) != 0;
+    auto kern = hf ? conv3_wgrad_kernel<true> : (w8 ? conv3_wgrad_kernel<false, true> : conv3_wgrad_kernel<false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ncombo * p.nsplit)), dim3(256), WG_LDS_BYTES, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ncombo * p.nsplit)), dim3(w8 ? 512 : 256), WG_LDS_BYTES, (hipStream_t)stream, p);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     WreduceParams q;
