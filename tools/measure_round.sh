@@ -27,7 +27,12 @@ timeout 900 python scripts/bench_ops.py > $o/${tag}_bench_ops.jsonl 2>/dev/null
   SBMC_WBANK=0 timeout 400 python tools/rank_cost.py 1 2>&1 | grep "^world" | sed "s/$/ [SBMC_WBANK=0]/"
   SBMC_HIP_PW_GW_WIDE=0 timeout 400 python tools/rank_cost.py 1 2>&1 | grep "^world" | sed "s/$/ [SBMC_HIP_PW_GW_WIDE=0]/"
   SBMC_POOL_SKIP=0 timeout 400 python tools/rank_cost.py 1 2>&1 | grep "^world" | sed "s/$/ [SBMC_POOL_SKIP=0]/"
-  SBMC_CONV3X3_STREAMK=0 timeout 400 python tools/rank_cost.py --ipc-self 8 2>&1 | grep "^world" | sed "s/$/ [SBMC_CONV3X3_STREAMK=0]/" ) | tee $o/${tag}_rank_cost.txt
+  SBMC_CONV3X3_STREAMK=0 timeout 400 python tools/rank_cost.py --ipc-self 8 2>&1 | grep "^world" | sed "s/$/ [SBMC_CONV3X3_STREAMK=0]/"
+  # round 6's 3x3 forms off: the one-wave-per-SIMD forward / data gradient, the four-wave weight gradient
+  SBMC_CONV3X3_WS=0 timeout 400 python tools/rank_cost.py 1 2>&1 | grep "^world" | sed "s/$/ [SBMC_CONV3X3_WS=0]/"
+  SBMC_CONV3X3_WGRAD_W8=0 timeout 400 python tools/rank_cost.py 1 2>&1 | grep "^world" | sed "s/$/ [SBMC_CONV3X3_WGRAD_W8=0]/"
+  SBMC_CONV3X3_WS=0 SBMC_CONV3X3_WGRAD_W8=0 timeout 400 python tools/rank_cost.py 1 2>&1 | grep "^world" | sed "s/$/ [SBMC_CONV3X3_WS=0 SBMC_CONV3X3_WGRAD_W8=0]/"
+  timeout 400 python tools/rank_cost.py 1 2>&1 | grep "^world" ) | tee $o/${tag}_rank_cost.txt
 # the real 8-rank partition as 8 communicating processes on this one GPU (gloo collectives, IPC mailboxes)
 SBMC_BENCH_BACKEND=gloo SBMC_BENCH_SINGLE_DEVICE=1 OMP_NUM_THREADS=8 timeout 1200 python bench.py --gpus 8 --steps 3 --warmup 2 --no-cpu-baseline --no-stages > $o/${tag}_bench_8ranks_one_gpu.json 2> $o/bench8.err; echo "8 ranks on one GPU rc=$?"
 head -c 400 $o/${tag}_bench_8ranks_one_gpu.json; echo
@@ -46,8 +51,10 @@ timeout 300 python tools/bench_pw_scaled.py > $o/${tag}_pointwise_launches.txt 2
 SBMC_PW_CHAIN=0 SBMC_PW_WIDE_FWD=0 timeout 500 python bench.py --no-cpu-baseline --no-stages > $o/${tag}_bench_without_chains.json 2>/dev/null; head -c 200 $o/${tag}_bench_without_chains.json; echo
 bash tools/calibrate_fetch.sh > /dev/null 2>&1; cp gpurun_out/fetch_calibration.txt $o/${tag}_fetch_calibration.txt
 bash tools/prof_conv_stack.sh > $o/prof_conv.log 2>&1; cp gpurun_out/conv_stack/r02_conv_stack_mfma.txt $o/${tag}_conv_stack_mfma.txt; tail -3 $o/${tag}_conv_stack_mfma.txt; rm -rf gpurun_out/conv_stack
-( timeout 300 python tools/fuzz_gpu.py --seconds 100 2>&1 | tail -2; timeout 300 python tools/fuzz_slab.py --seconds 100 2>&1 | tail -1; timeout 200 python tools/fuzz_pointwise.py --seconds 60 2>&1 | tail -1 ) > $o/${tag}_fuzz.txt; cat $o/${tag}_fuzz.txt | cut -c1-300
+( timeout 300 python tools/fuzz_gpu.py --seconds 100 2>&1 | tail -2; timeout 300 python tools/fuzz_slab.py --seconds 100 2>&1 | tail -1; timeout 200 python tools/fuzz_pointwise.py --seconds 60 2>&1 | tail -1; timeout 200 python tools/fuzz_pointwise_chain.py --seconds 40 2>&1 | tail -1 ) > $o/${tag}_fuzz.txt; cat $o/${tag}_fuzz.txt | cut -c1-300
 timeout 400 python tools/conv3x3_experiment.py --shapes all > $o/${tag}_conv3x3_experiment.txt 2>&1; tail -2 $o/${tag}_conv3x3_experiment.txt
+# the same launches on operands that toggle no bits (what the power limit has to do with the time), both forms of each kernel
+( for ws in 1 0; do echo "SBMC_CONV3X3_WS=$ws SBMC_CONV3X3_WGRAD_W8=$ws"; SBMC_CONV3X3_WS=$ws SBMC_CONV3X3_WGRAD_W8=$ws timeout 300 python tools/conv3x3_experiment.py --power --reps 20 2>&1 | grep -v "values\|adjoint\|amdgpu.ids"; done ) > $o/${tag}_conv3x3_power.txt; cat $o/${tag}_conv3x3_power.txt
 bash tools/prof_conv3x3.sh all > $o/prof_conv3.log 2>&1; cp gpurun_out/conv3x3_pmc.txt $o/${tag}_conv3x3_pmc.txt; grep "sbmc::conv3" $o/${tag}_conv3x3_pmc.txt | cut -c1-200
 timeout 900 python tools/fuzz_conv3x3.py --cases 400 2>&1 | tail -1 > $o/${tag}_conv3x3_fuzz.txt; cat $o/${tag}_conv3x3_fuzz.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
