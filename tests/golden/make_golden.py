@@ -457,7 +457,152 @@ def gen_multisteps_wide(ref):
     save("multisteps_wide.npz", out)
 
 
+# The production-width case WITHOUT decisions near their kinks (round 6): the same model class and batch
+# recipe, the bias of every convolution that feeds a ReLU / LeakyReLU shifted so that each channel's pre-activations lie
+# to one side of zero, a quarter of their span away from it (three channels of four positive, the fourth negative: both states of every
+# activation are exercised, none within rounding of the kink).  Any fp32 evaluation then takes the same ~1e7 decisions, and
+# the gradients can be held to the tight bound for EVERY parameter.  The shifted biases travel in the fixture (a few KB).
+WIDE_CASES["k21c"] = dict(ksize=21, seed=33, h=48, w=64, spp=2, clear=True)
+CLEAR_K = 0.25       # the gap between zero and a channel's pre-activations, in units of their span
+
+
+def activation_sites(model):
+    """(name of the convolution's bias parameter, convolution, activation) for every convolution that feeds a ReLU /
+    LeakyReLU directly (reference sbmc/modules.py:66-118, 154-195: _ConvBNRelu.layer = [conv, act]; a chain's
+    `prediction` + `output_activation`)."""
+    import torch.nn as nn
+    sites = []
+    for name, m in model.named_modules():
+        if type(m).__name__ == "_ConvBNRelu":
+            sites.append((name + ".layer.0.bias", m.layer[0], m.layer[-1]))
+        elif hasattr(m, "output_activation") and isinstance(m.output_activation, (nn.ReLU, nn.LeakyReLU)):
+            sites.append((name + ".prediction.bias", m.prediction, m.output_activation))
+    return sites
+
+
+def clear_the_kinks(model, batch, k=CLEAR_K, verbose=True):
+    """Shifts the biases as described above, one activation after the other in execution order (each shift moves the
+    statistics of everything behind it).  -> {bias parameter name: new bias}, worst margin min |z| / max |z|."""
+    sites = activation_sites(model)
+    order = []
+
+    def note(i):
+        def fn(mod, inp):
+            if i not in order:
+                order.append(i)
+        return fn
+    hs = [act.register_forward_pre_hook(note(i)) for i, (_, _, act) in enumerate(sites)]
+    model.train(True)
+    with th.no_grad():
+        model({k_: v.clone() for k_, v in batch.items()})
+    for h in hs:
+        h.remove()
+    assert sorted(order) == list(range(len(sites))), "an activation that the forward never ran"
+    stats = {}
+
+    def gather(mod, inp):
+        z = inp[0].detach().double()
+        c = z.shape[1]
+        zz = z.transpose(0, 1).reshape(c, -1)
+        lo, hi = zz.min(1).values, zz.max(1).values
+        if "lo" in stats:
+            stats["lo"], stats["hi"] = th.minimum(stats["lo"], lo), th.maximum(stats["hi"], hi)
+        else:
+            stats["lo"], stats["hi"] = lo, hi
+    shifted = {}
+    for n, i in enumerate(order):
+        pname, conv, act = sites[i]
+        stats.clear()
+        h = act.register_forward_pre_hook(gather)
+        with th.no_grad():
+            model({k_: v.clone() for k_, v in batch.items()})
+        h.remove()
+        # a channel's pre-activations span [lo, hi]: moved to [d, d + span] (three channels of four) or [-d - span, -d] (the
+        # fourth), d = k x span: the smallest magnitude is k / (1 + k) of the largest, exactly, on this batch
+        lo, hi = stats["lo"], stats["hi"]
+        span = (hi - lo).clamp_min(1e-3 * (hi - lo).max().clamp_min(1e-30))
+        up = -lo + k * span
+        down = -hi - k * span
+        shift = up.clone()
+        shift[3::4] = down[3::4]
+        conv.bias.data += shift.to(conv.bias.dtype)
+        shifted[pname] = conv.bias.data.clone()
+        if verbose and n % 10 == 0:
+            print("  clear_the_kinks: %d / %d activations" % (n, len(order)), flush=True)
+    worst = 1e300
+    for pname, conv, act in sites:
+        stats.clear()
+        h = act.register_forward_pre_hook(gather)
+        with th.no_grad():
+            model({k_: v.clone() for k_, v in batch.items()})
+        h.remove()
+        lo, hi = stats["lo"], stats["hi"]
+        small = th.where(lo > 0, lo, th.where(hi < 0, -hi, th.zeros_like(lo)))
+        worst = min(worst, (small / th.maximum(lo.abs(), hi.abs())).min().item())
+    return shifted, worst
+
+
+def gen_multisteps_clear(ref):
+    """`multisteps_clear.npz`: gen_multisteps_wide's recipe for the case "k21c" (see WIDE_CASES above)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from helpers import module_scales, multisteps_fp64
+    from sbmc_amd import halide_ops
+    from oracle import sbmc_oracle
+    out = {}
+    case = "k21c"
+    c = WIDE_CASES[case]
+    th.manual_seed(c["seed"])
+    model = ref.models.Multisteps(93, 3, width=128, embedding_width=128, ksize=c["ksize"], nsteps=3)
+    batch, target = wide_inputs(case)
+    shifted, margin = clear_the_kinks(model, batch)
+    print("k21c: %d biases shifted; smallest |pre-activation| / largest of its layer: %.2e" % (len(shifted), margin))
+    assert margin >= 1e-3, margin
+    out[case + ".margin"] = np.float64(margin)
+    for k, v in shifted.items():
+        out["%s.bias.%s" % (case, k)] = npy(v)
+    for k, v in model.state_dict().items():
+        out["%s.sdsum.%s" % (case, k)] = bits_checksum(v)
+    for k, v in batch.items():
+        out["%s.insum.%s" % (case, k)] = bits_checksum(v)
+    out[case + ".insum.target_image"] = bits_checksum(target)
+    model.train(False)
+    with th.no_grad():
+        out[case + ".eval.radiance"] = npy(model({k: v.clone() for k, v in batch.items()})["radiance"])
+    model.train(True)
+    res = model({k: v.clone() for k, v in batch.items()})["radiance"]
+    out[case + ".train.radiance"] = npy(res)
+    crop = (target.shape[-1] - res.shape[-1]) // 2
+    tgt = target[..., crop:-crop, crop:-crop]
+    loss = ref.losses.TonemappedRelativeMSE()(res, tgt)
+    loss.backward()
+    out[case + ".train.loss"] = npy(loss)
+    halide_ops.register_cpu_ops_for_testing(sbmc_oracle)
+    m64 = multisteps_fp64(model, (93, 3), dict(width=128, embedding_width=128, ksize=c["ksize"], nsteps=3)).train(True)
+    o64 = m64({k: v.double() for k, v in batch.items()})["radiance"]
+    ref.losses.TonemappedRelativeMSE()(o64, tgt.double()).backward()
+    halide_ops.register_cpu_ops_for_testing(None)
+    g64 = {k: q.grad for k, q in m64.named_parameters()}
+    scales = module_scales(g64)
+    out[case + ".out_err64"] = np.float64((res.detach().double() - o64.detach()).abs().max().item() / o64.abs().max().item())
+    for k, p in model.named_parameters():
+        gflat = p.grad.reshape(-1)
+        out["%s.gmax.%s" % (case, k)] = np.float64(gflat.abs().max().item())
+        out["%s.gl2.%s" % (case, k)] = np.float64(gflat.double().norm().item())
+        if gflat.numel() <= 1024:
+            out["%s.gfull.%s" % (case, k)] = npy(gflat)
+        else:
+            out["%s.gsample.%s" % (case, k)] = npy(gflat[wide_sample_index(gflat.numel(), k)])
+        out["%s.gerr64.%s" % (case, k)] = np.float64((p.grad.double() - g64[k]).abs().max().item() / scales[k])
+    errs = sorted(float(out["%s.gerr64.%s" % (case, k)]) for k, _ in model.named_parameters())
+    print(case, "loss", float(loss.detach()), "out", tuple(res.shape), "reference vs float64: output %.2e, gradients median %.2e, worst %.2e"
+          % (float(out[case + ".out_err64"]), errs[len(errs) // 2], errs[-1]))
+    save("multisteps_clear.npz", out)
+
+
 def main():
+    if "--round6" in sys.argv:        # the production-width fixture without decisions near their kinks (round 6)
+        gen_multisteps_clear(refload.load_reference())
+        return
     if "--round5" in sys.argv:        # the production-width fixture (round 5)
         gen_multisteps_wide(refload.load_reference())
         return

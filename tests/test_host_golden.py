@@ -271,10 +271,14 @@ def wide_fixture_checks(case, device):
         assert abs(flat.norm().item() - n_ref) <= 1e-3 * n_ref + 2e-5 * scales[k] * flat.numel() ** 0.5, k
     # (one flipped decision in the FIRST U-net moves every parameter before it: a quarter of them, not a handful)
     assert len(loose) * 2 <= len(grads), "beyond their own yardstick: %s" % loose
+    if WIDE_CASES[case].get("clear"):
+        # no pre-activation of this case lies within 0.2 of its layer's largest from the kink: every evaluation takes the same
+        # decisions, and EVERY parameter is held to the tight clause
+        assert loose == [], "beyond max(1e-5, 2 x the reference's own distance from float64): %s" % loose
     return report
 
 
-@pytest.mark.parametrize("case", ["k5", "k21"])
+@pytest.mark.parametrize("case", ["k5", "k21", "k21c"])
 def test_multisteps_production_width_matches_reference_fixture(cpu_ops, case):
     """Host composition at the production widths (torch-CPU convolutions, the oracle behind the operators)."""
     wide_fixture_checks(case, "cpu")
