@@ -1153,6 +1153,9 @@ __global__ __launch_bounds__(512) void pw_fwd_hw_kernel(PwFwdParams p) {
 #ifndef PW_BWD_RAW
 #define PW_BWD_RAW 1      // two-plane split kernels: the gy and x tiles travel L2/HBM -> LDS by LDS-DMA, a whole iteration ahead
 #endif
+#ifndef PW_BWD_RAW_ASM
+#define PW_BWD_RAW_ASM 1  // the RAW requests as inline assembly with the kernel's own waits (0: the builtin + __syncthreads, for A/B builds)
+#endif
 #ifndef PW_BWD_GXS
 #define PW_BWD_GXS 1      // split-gw kernels with a data gradient: gx on the bf16 pipe too (transposing LDS reads)
 #endif
@@ -1423,25 +1426,50 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
         }
     };
     // RAW: the requests of a tile's gy and x rows, straight into the raw LDS slots (this wave's rows: 4 w + lane / 16 + 32 i)
+    // The requests are INLINE ASSEMBLY (round 6): behind the builtin the compiler orders every later LDS access -- and
+    // __syncthreads() every barrier -- with s_waitcnt vmcnt(0), i.e. the wave sat out the HBM latency of the rows it had just
+    // requested, every iteration, and the "whole iteration ahead" was none (48 % of a wave's cycles waiting, PMC).  The
+    // kernel's own waits: `vmcnt(16)` before the commit that reads the slots (the 16 gx stores are the only younger
+    // operations: the counter is in order), barriers that wait for LDS only.
     auto issue_raw = [&](Cursor c) {
-        using lptr = __attribute__((address_space(3))) void*;
         unsigned b, bq, p0;
         coords(c, b, bq, p0);
-        const rsrc_t rg = make_rsrc_n(gy_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * SA);
-        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * SX);
+        auto desc = [&](const void* base, unsigned bytes) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+            return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+        };
+        const u32x4 dg = desc(gy_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * SA);
+        const u32x4 dx = desc(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * SX);
         const bool colok = p0 + c4 < hw;
+        const unsigned lg = (unsigned)(uintptr_t)rawg, lx = (unsigned)(uintptr_t)rawx;     // LDS byte addresses
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (this wave's reads of the slots have retired)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned r = srow + 32u * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lptr)(rawg + (32 * i + 4 * wave) * PB_NT), 16,
-                                                     (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB, 0, 0, 0);
+            const unsigned vo = (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB;
+            const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(lg + (unsigned)((32 * i + 4 * wave) * PB_NT * 4)));
+#if PW_BWD_RAW_ASM
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(vo), "s"(dg), "s"(m0v) : "memory");
+#else
+            (void)m0v;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc_n(gy_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * SA),
+                                                     (__attribute__((address_space(3))) void*)(rawg + (32 * i + 4 * wave) * PB_NT), 16, vo, 0, 0, 0);
+#endif
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const unsigned r = srow + 32u * i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr)(rawx + (32 * i + 4 * wave) * PB_NT), 16,
-                                                     (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * 4u : PW_OOB, 0, 0, 0);
+            const unsigned vo = (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * 4u : PW_OOB;
+            const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(lx + (unsigned)((32 * i + 4 * wave) * PB_NT * 4)));
+#if PW_BWD_RAW_ASM
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(vo), "s"(dx), "s"(m0v) : "memory");
+#else
+            (void)m0v;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * SX),
+                                                     (__attribute__((address_space(3))) void*)(rawx + (32 * i + 4 * wave) * PB_NT), 16, vo, 0, 0, 0);
+#endif
         }
     };
     // GWS: the x tile is wanted by the weight-gradient product only -- its loads are issued after the gx
@@ -1601,7 +1629,8 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
             if (n1.unit < p.nunits) issue_raw(n1);
         }
     }
-    __syncthreads();
+    if constexpr (RAW && PW_BWD_RAW_ASM) lds_barrier();     // (LDS only: the second tile's rows stay in flight)
+    else __syncthreads();
 
     f32x16 acc_w[2];
 #pragma unroll
@@ -1833,17 +1862,20 @@ __global__ __launch_bounds__(PW_THREADS) void pw_bwd_kernel(PwBwdParams p) {
                                                      // (LDS ordering only: the x loads stay in flight)
         if constexpr (RAW) {
             if (nvalid) {
-                // the next tile's rows have landed (requested a whole iteration ago; this also waits for the iteration's gx
-                // stores, which have had the gw product to drain)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the next tile's rows have landed (requested a whole iteration ago): everything but this iteration's 16 gx
+                // stores, which are the youngest operations of the in-order counter, is through
+                if constexpr (DX && PW_BWD_RAW_ASM) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 commit(nxt, buf ^ 1);
                 const Cursor n2 = advance(nxt);
                 if (n2.unit < p.nunits) issue_raw(n2);
             }
+            if constexpr (PW_BWD_RAW_ASM) lds_barrier();      // (the planes are visible; the rows of the tile after next stay in flight)
+            else __syncthreads();
         } else {
             if (nvalid) commit(nxt, buf ^ 1);
+            __syncthreads();
         }
-        __syncthreads();
         cur = nxt;
         valid = nvalid;
         buf ^= 1;
