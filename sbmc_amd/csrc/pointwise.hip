@@ -2182,7 +2182,14 @@ __global__ __launch_bounds__(512) void pw_wide_prep_kernel(const float* __restri
     }
 }
 
-template <int KP>
+// G2 (round 6; an even number of steps per tile: the 441-channel layer's four): the gz rows are requested TWO steps ahead into
+// one of two register sets (the branch-free requests above freed 19 registers), BEHIND the weight slice's request, so that
+// "the slice has landed" is `s_waitcnt vmcnt(rows + stores issued since)` and a step's closing barrier leaves the next-but-one
+// step's HBM rows in flight -- with one step of lead (1600 cycles) every step sat out the rest of the HBM latency.  The
+// slice's requests are inline assembly: the compiler orders LDS reads behind a builtin LDS-DMA with vmcnt(0).
+// MEASURED (same box, 720p x 8 spp): correct (tests, fuzz) and SLOWER, 8.63-8.66 ms against 8.26-8.37 -- the step's exposed HBM
+// latency is not what bounds this kernel.  Off by default (SBMC_PW_WIDE_G2=1 selects it), kept for the next experiment.
+template <int KP, bool G2 = false>
 __global__ __launch_bounds__(PW_THREADS) void pw_wide_bwd2_kernel(PwWideParams pp) {
     const PwBwdParams& p = pp.b;
     const float* gz_g = static_cast<const float*>(p.gy);
@@ -2200,11 +2207,13 @@ __global__ __launch_bounds__(PW_THREADS) void pw_wide_bwd2_kernel(PwWideParams p
     const unsigned hw = p.hw;
     const unsigned g = blockIdx.x, G = gridDim.x;
     const unsigned c4 = (threadIdx.x & 15) * 4, srow = threadIdx.x >> 4;
-    const int nct = (p.Cout + 127) / 128;                             // steps per pixel tile (<= 4)
+    // steps per pixel tile (<= 4).  G2: FOUR, a constant -- a branch around a step is a join at which the compiler waits for
+    // every load in flight, the rows of the step after next among them
+    const int nct = G2 ? 4 : (p.Cout + 127) / 128;
     const float cg = pow2_scale_of(*p.gmax), cx = pow2_scale_of(*p.xmax);
     const float osx = (1.f / *pp.wscale) * (1.f / cg);
 
-    u32x4 pg[4], px[NX];
+    u32x4 pg[G2 ? 2 : 1][4], px[NX];
     auto coords = [&](unsigned unit, unsigned& b, unsigned& p0) {
         b = unit / p.tiles_per_plane;
         p0 = (unit % p.tiles_per_plane) * PB_NT;
@@ -2215,44 +2224,66 @@ __global__ __launch_bounds__(PW_THREADS) void pw_wide_bwd2_kernel(PwWideParams p
     // step's closing barrier.  (hipcc does not count an asm load: its own waits for the ordinary loads only get more
     // conservative by it, never less -- the counter is in order and these are the youngest requests.)
     const rsrc_t rwp = make_rsrc_n(pp.wprep, 4u * 8u * 8u * 1024u);
-    auto issue_w = [&](int ct) {
+    auto issue_w = [&](int ct, bool valid = true) {
         using lptr = __attribute__((address_space(3))) void*;
         char* dst = reinterpret_cast<char*>(wsl + (size_t)wave * 8 * 64);
         const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((ct * 8 + wave) * 8192);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (G2) {
+            const uintptr_t wa = reinterpret_cast<uintptr_t>(pp.wprep);
+            const u32x4 d{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wa),
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(wa >> 32) & 0xffffu)),
+                          valid ? 4u * 8u * 8u * 1024u : 0u, 0x00020000u};
+            const unsigned l0 = (unsigned)(uintptr_t)dst;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwp, (lptr)(dst + i * 1024), 16, (unsigned)lane * 16u, so + (unsigned)i * 1024u, 0, 0);
-    };
-    auto issue_g = [&](unsigned unit, int ct) {
-        unsigned b, p0;
-        coords(unit, b, p0);
-        const rsrc_t rg = make_rsrc_n(gz_g + (size_t)b * p.Cout * hw, (unsigned)p.Cout * hw * 4u);
-        const bool colok = p0 + c4 < hw;
+            for (int i = 0; i < 8; ++i) {
+                const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(l0 + (unsigned)i * 1024u));
+                const unsigned sv = so + (unsigned)i * 1024u;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                             :: "v"((unsigned)lane * 16u), "s"(d), "s"(m0v), "s"(sv) : "memory");
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned r = 128u * ct + srow + 32u * i;
-            pg[i] = load4<float>(rg, (colok && r < (unsigned)p.Cout) ? (r * hw + p0 + c4) * 4u : PW_OOB);
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rwp, (lptr)(dst + i * 1024), 16, (unsigned)lane * 16u, so + (unsigned)i * 1024u, 0, 0);
         }
     };
-    auto issue_x = [&](unsigned unit) {
+    // The rows' requests: ONE lane offset (row srow of a block of 32 rows, this thread's four pixels; beyond the plane: out
+    // of range) and a descriptor PER BLOCK OF ROWS that begins at the block and ends with the tensor -- rows beyond Cout / K
+    // fall outside it.  With a select per row in the lane offset the compiler built branches around the loads, and at their
+    // joins waited for every load in flight (`s_waitcnt vmcnt(0)`): two of the four row blocks' HBM latencies were sat
+    // out one after the other at the top of every step, before the first MFMA (round 6, found in the listing).
+    auto issue_g = [&](u32x4 (&dst)[4], unsigned unit, int ct, bool valid = true) {
         unsigned b, p0;
-        coords(unit, b, p0);
-        const rsrc_t rx = make_rsrc_n(x_g + (size_t)b * p.K * hw, (unsigned)p.K * hw * 4u);
-        const bool colok = p0 + c4 < hw;
+        coords(valid ? unit : 0u, b, p0);
+        const unsigned lo = (p0 + c4 < hw) ? (srow * hw + p0 + c4) * 4u : PW_OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row0 = 128 * ct + 32 * i, left = valid ? p.Cout - row0 : 0;
+            const rsrc_t rg = make_rsrc_n(gz_g + ((size_t)b * p.Cout + (left > 0 ? row0 : 0)) * hw,
+                                          left > 0 ? (unsigned)left * hw * 4u : 0u);
+            dst[i] = load4<float>(rg, lo);
+        }
+    };
+    auto issue_x = [&](unsigned unit, bool valid = true) {
+        unsigned b, p0;
+        coords(valid ? unit : 0u, b, p0);
+        const unsigned lo = (p0 + c4 < hw) ? (srow * hw + p0 + c4) * 4u : PW_OOB;
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            const unsigned r = srow + 32u * i;
-            px[i] = load4<float>(rx, (colok && r < (unsigned)p.K) ? (r * hw + p0 + c4) * 4u : PW_OOB);
+            const int row0 = 32 * i, left = valid ? p.K - row0 : 0;
+            const rsrc_t rx = make_rsrc_n(x_g + ((size_t)b * p.K + (left > 0 ? row0 : 0)) * hw,
+                                          left > 0 ? (unsigned)left * hw * 4u : 0u);
+            px[i] = load4<float>(rx, lo);
         }
     };
     // (the row sums live in LDS, not in 16 registers of every thread: a row's 16 staging threads add up their 4 pixels
     // each and one of them adds the sum to the row's word -- this kernel has no register to spare)
     bacc[threadIdx.x] = 0.f;
-    auto commit_g = [&](int ct) __attribute__((always_inline)) {
+    auto commit_g = [&](const u32x4 (&src)[4], int ct) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float4 gv = unpack4<float>(pg[i]);
+            const float4 gv = unpack4<float>(src[i]);
             float rs = (gv.x + gv.y) + (gv.z + gv.w);
             rs += __shfl_xor(rs, 8, 16);
             rs += __shfl_xor(rs, 4, 16);
@@ -2293,14 +2324,23 @@ __global__ __launch_bounds__(PW_THREADS) void pw_wide_bwd2_kernel(PwWideParams p
     unsigned unit = g;
     bool valid = unit < p.nunits;
     if (valid) {
-        issue_g(unit, 0);
+        issue_g(pg[0], unit, 0);
         issue_x(unit);
         issue_w(0);
-        commit_g(0);
+        commit_g(pg[0], 0);
         commit_x();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (G2) {
+        // the second step's rows (the first step commits them at its end)
+        const bool s1 = nct > 1;
+        const unsigned u1 = s1 ? unit : unit + G;
+        issue_g(pg[1], u1, s1 ? 1 : 0, valid && u1 < p.nunits);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // (everything but those four: the slice has landed)
+        lds_barrier();
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     const bool two = 2 * ph + 1 < NB;
     // this lane's B-operand address of the gx product (pw_bwd_kernel, GXS)
     const _Float16* tb = gzn + (16 * (lane >> 5) + 8 * ((lane >> 4) & 1) + 2 * ((lane & 15) >> 2)) * PBS_PITCH + 4 * (lane & 3);
@@ -2321,9 +2361,11 @@ __global__ __launch_bounds__(PW_THREADS) void pw_wide_bwd2_kernel(PwWideParams p
         // requests of the next step: the HBM rows now, the weight slice (L2) behind the gx product -- everything is consumed
         // at the step's commit, so the in-order vector-memory counter costs nothing, and the slice's 32 registers are
         // live through the gw product only
-        if (more) {
-            issue_g(un, cn);
-            if (last_ct) issue_x(un);
+        if constexpr (!G2) {
+            if (more) {
+                issue_g(pg[0], un, cn);
+                if (last_ct) issue_x(un);
+            }
         }
         // ---- gx += w^T[:, chunk] gz[chunk]: rows 16 wave .. of K, four blocks of 16 pixels
         {
@@ -2342,7 +2384,18 @@ __global__ __launch_bounds__(PW_THREADS) void pw_wide_bwd2_kernel(PwWideParams p
                 }
             }
         }
-        if (more) issue_w(cn);                          // (behind the wave's own reads of the region)
+        if constexpr (G2) {
+            // behind the wave's own reads of its slice: the next step's slice (L2), then the HBM rows -- the next tile's x rows
+            // (committed at this step's end) and the gz rows of the step after next.  Always the same NUMBER of requests (an
+            // empty descriptor where there is nothing to fetch): the waits below count them.
+            issue_w(more ? cn : 0, more);
+            if (last_ct) issue_x(un, more);
+            const bool wrap2 = CT + 2 >= nct;
+            const unsigned un2 = wrap2 ? unit + G : unit;
+            issue_g(pg[CT & 1], un2, wrap2 ? CT + 2 - nct : CT + 2, un2 < p.nunits);
+        } else {
+            if (more) issue_w(cn);                      // (behind the wave's own reads of the region)
+        }
         if (last_ct) {                                               // the tile's data gradient is complete
             unsigned b, p0;
             coords(unit, b, p0);
@@ -2397,11 +2450,18 @@ __global__ __launch_bounds__(PW_THREADS) void pw_wide_bwd2_kernel(PwWideParams p
         }
         lds_barrier();                                  // every wave is through with the stage before it is refilled
         if (more) {
-            commit_g(cn);
+            commit_g(pg[G2 ? (CT + 1) & 1 : 0], cn);
             if (last_ct) commit_x();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the slice has landed)
-        __syncthreads();
+        if constexpr (G2) {
+            // the slice has landed: all but the requests issued behind it (x rows, gz rows, the tile's 16 gx stores)
+            if (last_ct) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + 4 + 16) : "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            lds_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the slice has landed)
+            __syncthreads();
+        }
         if (last_ct) {
             unit += G;
             valid = unit < p.nunits;
@@ -3200,9 +3260,10 @@ extern "C" int sbmc_pointwise_wide_bwd_f32(const float* gz, const float* x, cons
     const int kp = (cin + 31) / 32 * 32;
     const size_t lds = (size_t)2 * (128 + kp) * PBS_PITCH * 2 + (size_t)8 * 8 * 64 * 16 + 512 * 4;
     hipError_t e = hipSuccess;
+    const bool g2 = kp == 128 && (cout + 127) / 128 == 4 && env_knob("SBMC_PW_WIDE_G2", 0) != 0;
 #define SBMC_WB2(KPV)                                                                                    \
     do {                                                                                                 \
-        auto kern = pw_wide_bwd2_kernel<KPV>;                                                            \
+        auto kern = (KPV == 128 && g2) ? pw_wide_bwd2_kernel<128, true> : pw_wide_bwd2_kernel<KPV>;      \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(grid), dim3(PW_THREADS), lds, (hipStream_t)stream, pp); \
     } while (0)
