@@ -62,7 +62,7 @@ def pointwise_kernels():
     "sbmc::pw_bwd_kernel<128, true, false, false, float, float, false, false, false>",
     "sbmc::pw_bwd_kernel<128, true, false, false, float, float, true, false, false>",     # with sign bits instead of y
     "float, float, true, true, true>",                       # round 5: every two-plane backward (context / mean gradient too)
-    "pw_wide_bwd2_kernel<128>",                              # the 441-channel layer's one-pass backward (255 registers)
+    "pw_wide_bwd2_kernel<128, ",                            # the 441-channel layer's one-pass backward, both forms (236 / 246 registers)
     "pw_fwd_h_kernel",                                       # the f16 matrix pipe (every instantiation)
     "pw_bwd_h_kernel",
 ])
