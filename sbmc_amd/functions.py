@@ -1070,6 +1070,17 @@ class FromChannelsLast(th.autograd.Function):
         b, c, h, w = x.shape
         out = th.empty(b, c, h, w, dtype=x.dtype, device=x.device)
         dev = x.device
+        if x.dtype == th.float32 and known_amax(x) is None:
+            # nobody left a magnitude word on x (a U-net's output, the data gradient of its first convolution): this pass
+            # finds it on its way -- the per-sample 1x1 layers behind it scale by it, and without a word each of them ran
+            # an absmax pass over the tensor (6 of a training step's 8)
+            amax = amax_word(dev)
+            with th.cuda.device(dev):
+                rc = _lib.lib().sbmc_transpose2d_amax_f32(_lib.ptr(x), _lib.ptr(out), _lib.ptr(amax), b, h * w, c,
+                                                          _lib.current_stream(dev))
+            _lib.check(rc, "transpose2d")
+            tag_amax(out, amax)
+            return out
         fn = _lib.lib().sbmc_transpose2d_f16 if x.dtype == th.float16 else _lib.lib().sbmc_transpose2d_f32
         with th.cuda.device(dev):
             rc = fn(_lib.ptr(x), _lib.ptr(out), b, h * w, c, _lib.current_stream(dev))

@@ -168,6 +168,14 @@ def pointwise_chain_with_context(chain, per_sample, context, mean_out=None):
     t = context_term(wt[:, cs:]).contiguous()
     if t.dtype == th.float32 and funcs.pointwise_supported(xs, cout):
         tt = t if t.shape[2] == h * w and h * w > 1 else t.reshape(bs, cout)
+        # the context term's magnitude word without a pass over it: the fused chain wants it only for the BOUND it scales
+        # its intermediate activations by, and max |context| x the largest absolute row sum of the context weights is one
+        # (a library GEMM made t: nobody left a word on it, and each chain ran an absmax pass over it -- 3 per step)
+        ca = funcs.known_amax(context) if tt is t else None
+        if ca is not None and funcs.known_amax(tt) is None:
+            with th.no_grad():
+                bound = ca.view(th.float32) * wt[:, cs:].detach().abs().sum(1).max()
+            funcs.tag_amax(tt, bound.view(th.int32))
         # two or three layers of the chain in ONE pass where they fit (functions.PointwiseChain: a tile's intermediate
         # activations stay on the chip); what is behind them -- the regressor's 441-channel layer -- runs as before
         plan, used = _pointwise_plan(mods)
